@@ -1,0 +1,763 @@
+/*
+ * storm_oracle.c — CPU ORACLE (test infrastructure only; see storm_oracle.h for the rules
+ * on who may load it and for the parity status: "parity unpinned" by the reference's own
+ * tests, pinned by two independent truths + SURVEY-recorded reference totals).
+ *
+ * Every function cites the reference lines (/root/reference/...) whose behaviour it restates.
+ * Nothing here is copied: the loops are re-derived from the reference's visiting order and
+ * written around one shared pair-visitor instead of the reference's per-entry-point copies.
+ * The four defects listed in SURVEY.md §8 a-note (D1 operator precedence in the
+ * bitmap-vs-list probes, D2/D3 list-pointer rebuild and memcpy size on regrow, D4 holes left
+ * by duplicate inputs) are deliberately NOT reproduced — intended semantics == truth.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "storm_oracle.h"
+
+#include <immintrin.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define ORC_BLOCK_BITS 65536u      /* storm.h:41-43  STORM_DEFAULT_BLOCK_SIZE        */
+#define ORC_SCALAR_THRESHOLD 4096u /* storm.h:45-47  STORM_DEFAULT_SCALAR_THRESHOLD  */
+#define ORC_CACHE_BLOCK 256e3      /* storm.h:37-39  STORM_CACHE_BLOCK_SIZE          */
+#define ORC_BLOCK_WORDS (ORC_BLOCK_BITS / 64u)
+
+/* ------------------------------------------------------------------------------------------
+ * Leaf: sum_k popcount(a[k] & b[k]).  Restates the libalgebra contract (see header); the
+ * SIMD variants follow the published Mula/Kurz/Lemire nibble-lookup popcount (README.md:30-31
+ * cites the paper) — any variant is the same integer function.
+ * ---------------------------------------------------------------------------------------- */
+__attribute__((target("popcnt")))
+uint64_t orc_intersect_count_scalar(const uint64_t* a, const uint64_t* b, size_t n) {
+    uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    size_t k = 0;
+    for (; k + 4 <= n; k += 4) {
+        c0 += (uint64_t)__builtin_popcountll(a[k + 0] & b[k + 0]);
+        c1 += (uint64_t)__builtin_popcountll(a[k + 1] & b[k + 1]);
+        c2 += (uint64_t)__builtin_popcountll(a[k + 2] & b[k + 2]);
+        c3 += (uint64_t)__builtin_popcountll(a[k + 3] & b[k + 3]);
+    }
+    for (; k < n; ++k) c0 += (uint64_t)__builtin_popcountll(a[k] & b[k]);
+    return c0 + c1 + c2 + c3;
+}
+
+__attribute__((target("avx2,popcnt")))
+uint64_t orc_intersect_count_avx2(const uint64_t* a, const uint64_t* b, size_t n) {
+    const __m256i lut = _mm256_setr_epi8(0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4,
+                                         0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4);
+    const __m256i low = _mm256_set1_epi8(0x0f);
+    __m256i acc = _mm256_setzero_si256();
+    size_t k = 0;
+    for (; k + 4 <= n; k += 4) {
+        __m256i x = _mm256_and_si256(_mm256_loadu_si256((const __m256i*)(a + k)),
+                                     _mm256_loadu_si256((const __m256i*)(b + k)));
+        __m256i lo = _mm256_shuffle_epi8(lut, _mm256_and_si256(x, low));
+        __m256i hi = _mm256_shuffle_epi8(lut, _mm256_and_si256(_mm256_srli_epi16(x, 4), low));
+        acc = _mm256_add_epi64(acc, _mm256_sad_epu8(_mm256_add_epi8(lo, hi),
+                                                    _mm256_setzero_si256()));
+    }
+    uint64_t lanes[4];
+    _mm256_storeu_si256((__m256i*)lanes, acc);
+    uint64_t total = lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    for (; k < n; ++k) total += (uint64_t)__builtin_popcountll(a[k] & b[k]);
+    return total;
+}
+
+__attribute__((target("avx512f,avx512bw,popcnt")))
+static uint64_t leaf_avx512_lut(const uint64_t* a, const uint64_t* b, size_t n) {
+    const __m512i lut = _mm512_broadcast_i32x4(
+        _mm_setr_epi8(0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4));
+    const __m512i low = _mm512_set1_epi8(0x0f);
+    __m512i acc = _mm512_setzero_si512();
+    size_t k = 0;
+    for (; k + 8 <= n; k += 8) {
+        __m512i x = _mm512_and_si512(_mm512_loadu_si512(a + k), _mm512_loadu_si512(b + k));
+        __m512i lo = _mm512_shuffle_epi8(lut, _mm512_and_si512(x, low));
+        __m512i hi = _mm512_shuffle_epi8(lut, _mm512_and_si512(_mm512_srli_epi16(x, 4), low));
+        acc = _mm512_add_epi64(acc, _mm512_sad_epu8(_mm512_add_epi8(lo, hi),
+                                                    _mm512_setzero_si512()));
+    }
+    uint64_t total = (uint64_t)_mm512_reduce_add_epi64(acc);
+    for (; k < n; ++k) total += (uint64_t)__builtin_popcountll(a[k] & b[k]);
+    return total;
+}
+
+__attribute__((target("avx512f,avx512vpopcntdq,popcnt")))
+static uint64_t leaf_avx512_vpopcnt(const uint64_t* a, const uint64_t* b, size_t n) {
+    __m512i acc0 = _mm512_setzero_si512(), acc1 = _mm512_setzero_si512();
+    size_t k = 0;
+    for (; k + 16 <= n; k += 16) {
+        __m512i x0 = _mm512_and_si512(_mm512_loadu_si512(a + k), _mm512_loadu_si512(b + k));
+        __m512i x1 =
+            _mm512_and_si512(_mm512_loadu_si512(a + k + 8), _mm512_loadu_si512(b + k + 8));
+        acc0 = _mm512_add_epi64(acc0, _mm512_popcnt_epi64(x0));
+        acc1 = _mm512_add_epi64(acc1, _mm512_popcnt_epi64(x1));
+    }
+    uint64_t total = (uint64_t)_mm512_reduce_add_epi64(_mm512_add_epi64(acc0, acc1));
+    for (; k < n; ++k) total += (uint64_t)__builtin_popcountll(a[k] & b[k]);
+    return total;
+}
+
+static int host_has(int kind) {
+    __builtin_cpu_init();
+    switch (kind) {
+        case 0: return 1;
+        case 1: return __builtin_cpu_supports("avx2");
+        case 2: return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+        case 3: return __builtin_cpu_supports("avx512f") &&
+                       __builtin_cpu_supports("avx512vpopcntdq");
+        default: return 0;
+    }
+}
+
+int orc_best_leaf_kind(void) {
+    for (int k = 3; k > 0; --k)
+        if (host_has(k)) return k;
+    return 0;
+}
+
+uint64_t orc_intersect_count_avx512(const uint64_t* a, const uint64_t* b, size_t n) {
+    return host_has(3) ? leaf_avx512_vpopcnt(a, b, n) : leaf_avx512_lut(a, b, n);
+}
+
+const char* orc_leaf_name(int kind) {
+    if (kind < 0) kind = orc_best_leaf_kind();
+    switch (kind) {
+        case 0: return "scalar-popcnt";
+        case 1: return "avx2-lut";
+        case 2: return "avx512bw-lut";
+        case 3: return "avx512-vpopcntdq";
+        default: return "unknown";
+    }
+}
+
+orc_compute_func orc_get_intersect_count_func_kind(int kind) {
+    if (kind < 0) kind = orc_best_leaf_kind();
+    if (!host_has(kind)) return NULL;
+    switch (kind) {
+        case 1: return orc_intersect_count_avx2;
+        case 2: return leaf_avx512_lut;
+        case 3: return leaf_avx512_vpopcnt;
+        default: return orc_intersect_count_scalar;
+    }
+}
+
+/* run-time selection of the widest leaf, as libalgebra's STORM_get_intersect_count_func does
+ * (call sites storm.c:609,777,881,901,1015). n_words is accepted for signature parity only. */
+orc_compute_func orc_get_intersect_count_func(size_t n_words) {
+    (void)n_words;
+    return orc_get_intersect_count_func_kind(-1);
+}
+
+uint32_t orc_get_alignment(void) { return 64; }
+
+/* alignment is the FIRST argument, as at storm.c:452 */
+void* orc_aligned_malloc(size_t alignment, size_t size) {
+    void* p = NULL;
+    if (size == 0) size = alignment;
+    if (posix_memalign(&p, alignment, size) != 0) return NULL;
+    return p;
+}
+void orc_aligned_free(void* p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------
+ * Generic list kernels
+ * ---------------------------------------------------------------------------------------- */
+
+/* |A ∩ B| for sorted, duplicate-free uint16 arrays. storm.c:4-73 does this with 8-wide
+ * pcmpestrm/pcmpistrm blocks plus the scalar tail of :59-71; the result is the plain merge
+ * count, which is what is computed here for every element. */
+uint64_t orc_intersect_vector16_cardinality(const uint16_t* v1, const uint16_t* v2,
+                                            uint32_t len1, uint32_t len2) {
+    uint64_t hits = 0;
+    uint32_t p = 0, q = 0;
+    while (p < len1 && q < len2) {
+        const uint16_t x = v1[p], y = v2[q];
+        hits += (x == y);
+        p += (x <= y);
+        q += (y <= x);
+    }
+    return hits;
+}
+
+/* Merge two sorted uint32 id lists; for each common id write (index in v1, index in v2) to
+ * out; return 2 * matches. storm.c:75-106 (early-outs :81-84). */
+uint64_t orc_intersect_vector32_unsafe(const uint32_t* v1, const uint32_t* v2, uint32_t len1,
+                                       uint32_t len2, uint32_t* out) {
+    if (!out || !v1 || !v2 || len1 == 0 || len2 == 0) return 0;
+    uint64_t w = 0;
+    uint32_t p = 0, q = 0;
+    while (p < len1 && q < len2) {
+        if (v1[p] < v2[q]) {
+            ++p;
+        } else if (v2[q] < v1[p]) {
+            ++q;
+        } else {
+            out[w++] = p++;
+            out[w++] = q++;
+        }
+    }
+    return w;
+}
+
+static inline uint64_t bit_test(const uint64_t* row, uint32_t pos) {
+    return (row[pos >> 6] >> (pos & 63u)) & 1u;
+}
+
+/* Walk the SHORTER position list and test its bits in the OTHER row's bitmap.
+ * storm.c:108-129; `1L << MOD(x)` there relies on x86 shift masking == bit (x & 63). */
+uint64_t orc_intersect_bitmaps_scalar_list(const uint64_t* b1, const uint64_t* b2,
+                                           const uint32_t* l1, const uint32_t* l2,
+                                           uint32_t n1, uint32_t n2) {
+    uint64_t hits = 0;
+    if (n1 < n2) {
+        for (uint32_t k = 0; k < n1; ++k) hits += bit_test(b2, l1[k]);
+    } else {
+        for (uint32_t k = 0; k < n2; ++k) hits += bit_test(b1, l2[k]);
+    }
+    return hits;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Pair visitors. Every pairwise entry point of the reference is one of two visiting orders
+ * over the strict upper triangle; the totals are order-independent, the orders are kept so
+ * the CPU baseline has the reference's cache behaviour.
+ * ---------------------------------------------------------------------------------------- */
+typedef uint64_t (*pair_eval)(const void* ctx, uint64_t i, uint64_t j);
+
+/* row-major i<j sweep: storm.c:141-147, :886-890, :1165-1170, :1251-1260 */
+static uint64_t sweep_naive(uint64_t n, pair_eval ev, const void* ctx) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t j = i + 1; j < n; ++j) total += ev(ctx, i, j);
+    return total;
+}
+
+/* cache-blocked sweep: for each full block of `bs` rows — its own triangle, then the full
+ * squares against every later full block, then the strip against the ragged remainder; the
+ * rows after the last full block finish with their own triangle.
+ * storm.c:236-276, :302-366, :921-956, :1199-1238, :1280-1344. */
+static uint64_t sweep_blocked(uint64_t n, uint64_t bs, pair_eval ev, const void* ctx) {
+    uint64_t total = 0;
+    uint64_t base = 0;
+    for (; base + bs <= n; base += bs) {
+        for (uint64_t p = 0; p < bs; ++p) /* diagonal block */
+            for (uint64_t q = p + 1; q < bs; ++q) total += ev(ctx, base + p, base + q);
+        uint64_t other = base + bs;
+        for (; other + bs <= n; other += bs) /* square blocks */
+            for (uint64_t p = 0; p < bs; ++p)
+                for (uint64_t q = 0; q < bs; ++q) total += ev(ctx, base + p, other + q);
+        for (; other < n; ++other) /* residual strip: later row outer, block rows inner */
+            for (uint64_t p = 0; p < bs; ++p) total += ev(ctx, base + p, other);
+    }
+    for (; base < n; ++base) /* tail triangle */
+        for (uint64_t j = base + 1; j < n; ++j) total += ev(ctx, base, j);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Raw-buffer wrappers (storm.c:132-369). 64-bit offsets throughout (the reference's uint32_t
+ * offsets at :238-239,:270 wrap once n_vectors*n_ints >= 2^32).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const uint64_t* vals;
+    uint64_t n_ints;
+    orc_compute_func f;
+    orc_compute_lfunc fl;
+    const uint32_t* n_alts;
+    const uint32_t* alt_positions;
+    const uint32_t* alt_offsets;
+    uint32_t cutoff;
+    int inclusive; /* diag_list uses <= cutoff (storm.c:207), list_blocked < cutoff (:309) */
+} raw_ctx;
+
+static uint64_t raw_pair(const void* c, uint64_t i, uint64_t j) {
+    const raw_ctx* r = (const raw_ctx*)c;
+    return r->f(r->vals + i * r->n_ints, r->vals + j * r->n_ints, r->n_ints);
+}
+
+static uint64_t raw_pair_list(const void* c, uint64_t i, uint64_t j) {
+    const raw_ctx* r = (const raw_ctx*)c;
+    const uint32_t ni = r->n_alts[i], nj = r->n_alts[j];
+    const int sparse = r->inclusive ? (ni <= r->cutoff || nj <= r->cutoff)
+                                    : (ni < r->cutoff || nj < r->cutoff);
+    if (sparse)
+        return r->fl(r->vals + i * r->n_ints, r->vals + j * r->n_ints,
+                     r->alt_positions + r->alt_offsets[i], r->alt_positions + r->alt_offsets[j],
+                     ni, nj);
+    return r->f(r->vals + i * r->n_ints, r->vals + j * r->n_ints, r->n_ints);
+}
+
+/* storm.c:132-150 */
+uint64_t orc_wrapper_diag(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints,
+                          orc_compute_func f) {
+    raw_ctx c = {vals, n_ints, f, NULL, NULL, NULL, NULL, 0, 0};
+    return sweep_naive(n_vectors, raw_pair, &c);
+}
+
+/* storm.c:222-279; block_size 0 means 3 (:230) */
+uint64_t orc_wrapper_diag_blocked(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints,
+                                  orc_compute_func f, uint32_t block_size) {
+    raw_ctx c = {vals, n_ints, f, NULL, NULL, NULL, NULL, 0, 0};
+    return sweep_blocked(n_vectors, block_size == 0 ? 3 : block_size, raw_pair, &c);
+}
+
+/* storm.c:153-171 — every row of buffer 1 against every row of buffer 2. The reference never
+ * rewinds its second offset per outer row (:164-168, latent bug, unused by its harness);
+ * the rectangle sum below is the documented intent (storm.h:72-77). */
+uint64_t orc_wrapper_square(uint32_t n_vectors1, const uint64_t* vals1, uint32_t n_vectors2,
+                            const uint64_t* vals2, uint32_t n_ints, orc_compute_func f) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n_vectors1; ++i)
+        for (uint64_t j = 0; j < n_vectors2; ++j)
+            total += f(vals1 + i * (uint64_t)n_ints, vals2 + j * (uint64_t)n_ints, n_ints);
+    return total;
+}
+
+/* storm.c:190-219 */
+uint64_t orc_wrapper_diag_list(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints,
+                               const uint32_t* n_alts, const uint32_t* alt_positions,
+                               const uint32_t* alt_offsets, orc_compute_func f,
+                               orc_compute_lfunc fl, uint32_t cutoff) {
+    raw_ctx c = {vals, n_ints, f, fl, n_alts, alt_positions, alt_offsets, cutoff, 1};
+    return sweep_naive(n_vectors, raw_pair_list, &c);
+}
+
+/* storm.c:282-369 */
+uint64_t orc_wrapper_diag_list_blocked(uint32_t n_vectors, const uint64_t* vals,
+                                       uint32_t n_ints, const uint32_t* n_alts,
+                                       const uint32_t* alt_positions,
+                                       const uint32_t* alt_offsets, orc_compute_func f,
+                                       orc_compute_lfunc fl, uint32_t cutoff,
+                                       uint32_t block_size) {
+    raw_ctx c = {vals, n_ints, f, fl, n_alts, alt_positions, alt_offsets, cutoff, 0};
+    return sweep_blocked(n_vectors, block_size == 0 ? 3 : block_size, raw_pair_list, &c);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_contiguous_t restatement (storm.h:181-200; storm.c:1001-1346)
+ * ---------------------------------------------------------------------------------------- */
+struct orc_contig_s {
+    uint64_t* data;       /* row-major [m_rows][n_words], zero-initialised           */
+    uint32_t* positions;  /* packed position lists of the sparse rows                */
+    uint64_t* pos_offset; /* per row: start of its list in `positions`               */
+    uint32_t* n_set;      /* per row: distinct set bits (n_scalar, storm.c:1132)     */
+    uint64_t n_rows, m_rows;
+    uint64_t n_pos, m_pos;
+    uint64_t vector_length;
+    uint32_t n_words;
+    uint32_t scalar_cutoff;
+    orc_compute_func leaf;
+};
+
+/* storm.c:1001-1018: W = ceil(M/64) (:1013); cutoff = min(200, M/200) (:1016) */
+orc_contig_t* orc_contig_new(size_t vector_length) {
+    orc_contig_t* h = (orc_contig_t*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->vector_length = vector_length;
+    h->n_words = (uint32_t)((vector_length + 63) / 64);
+    h->leaf = orc_get_intersect_count_func(h->n_words);
+    h->scalar_cutoff = (uint32_t)(vector_length / 200 > 200 ? 200 : vector_length / 200);
+    return h;
+}
+
+/* storm.c:1020-1029 (the reference leaks the handle itself; the oracle frees it) */
+void orc_contig_free(orc_contig_t* h) {
+    if (!h) return;
+    orc_aligned_free(h->data);
+    free(h->positions);
+    free(h->pos_offset);
+    free(h->n_set);
+    free(h);
+}
+
+void orc_contig_set_leaf(orc_contig_t* h, orc_compute_func f) {
+    if (h && f) h->leaf = f;
+}
+uint64_t orc_contig_n_rows(const orc_contig_t* h) { return h ? h->n_rows : 0; }
+uint32_t orc_contig_n_words(const orc_contig_t* h) { return h ? h->n_words : 0; }
+uint32_t orc_contig_scalar_cutoff(const orc_contig_t* h) { return h ? h->scalar_cutoff : 0; }
+const uint64_t* orc_contig_data(const orc_contig_t* h) { return h ? h->data : NULL; }
+
+/* storm.c:1031-1137. Returns n_values; 0 for an empty input WITHOUT appending a row (:1034);
+ * -1 / -2 for NULL handle / NULL values (:1032-1033). Rows grow in steps of 512 (:1046,:1082),
+ * the position pool starts at 16384 entries (:1038). Equal neighbours are skipped (:1106-1108)
+ * and the stored list is compacted (fixes D4); offsets instead of pointers (fixes D2/D3). */
+int orc_contig_add(orc_contig_t* h, const uint32_t* values, uint32_t n_values) {
+    if (!h) return -1;
+    if (!values) return -2;
+    if (n_values == 0) return 0;
+
+    if (h->n_rows >= h->m_rows) {
+        const uint64_t new_m = h->m_rows + 512;
+        uint64_t* nd = (uint64_t*)orc_aligned_malloc(64, new_m * h->n_words * sizeof(uint64_t));
+        if (!nd) return -3;
+        memset(nd, 0, new_m * h->n_words * sizeof(uint64_t));
+        if (h->data) memcpy(nd, h->data, h->n_rows * h->n_words * sizeof(uint64_t));
+        orc_aligned_free(h->data);
+        h->data = nd;
+        h->n_set = (uint32_t*)realloc(h->n_set, new_m * sizeof(uint32_t));
+        h->pos_offset = (uint64_t*)realloc(h->pos_offset, new_m * sizeof(uint64_t));
+        h->m_rows = new_m;
+    }
+    if (h->n_pos + n_values >= h->m_pos) {
+        const uint64_t grow = (uint64_t)5 * n_values < 65535 ? 65535 : (uint64_t)5 * n_values;
+        h->m_pos = (h->m_pos == 0 ? 16384 : h->m_pos) + grow;
+        h->positions = (uint32_t*)realloc(h->positions, h->m_pos * sizeof(uint32_t));
+    }
+
+    uint64_t* row = h->data + h->n_rows * h->n_words;
+    uint32_t distinct = 0;
+    for (uint32_t k = 0; k < n_values; ++k) {
+        if (k != 0 && values[k] == values[k - 1]) continue;
+        row[values[k] >> 6] |= 1ULL << (values[k] & 63u);
+        ++distinct;
+    }
+    h->pos_offset[h->n_rows] = h->n_pos;
+    if (distinct < h->scalar_cutoff) { /* storm.c:1119 */
+        for (uint32_t k = 0; k < n_values; ++k) {
+            if (k != 0 && values[k] == values[k - 1]) continue;
+            h->positions[h->n_pos++] = values[k];
+        }
+    }
+    h->n_set[h->n_rows] = distinct;
+    ++h->n_rows;
+    return (int)n_values;
+}
+
+/* storm.c:1139-1147 */
+int orc_contig_clear(orc_contig_t* h) {
+    if (!h) return -1;
+    if (!h->data) return 0;
+    memset(h->data, 0, h->m_rows * h->n_words * sizeof(uint64_t));
+    h->n_rows = 0;
+    h->n_pos = 0;
+    return 1;
+}
+
+static int contig_any_sparse(const orc_contig_t* h) { /* storm.c:1151-1156, :1178-1183 */
+    for (uint64_t i = 0; i < h->n_rows; ++i)
+        if (h->n_set[i] < h->scalar_cutoff) return 1;
+    return 0;
+}
+
+static uint64_t contig_pair(const void* c, uint64_t i, uint64_t j) {
+    const orc_contig_t* h = (const orc_contig_t*)c;
+    return h->leaf(h->data + i * h->n_words, h->data + j * h->n_words, h->n_words);
+}
+
+static uint64_t contig_pair_list(const void* c, uint64_t i, uint64_t j) {
+    const orc_contig_t* h = (const orc_contig_t*)c;
+    const uint64_t* ri = h->data + i * h->n_words;
+    const uint64_t* rj = h->data + j * h->n_words;
+    if (h->n_set[i] < h->scalar_cutoff || h->n_set[j] < h->scalar_cutoff) { /* :1253 */
+        /* the list kernel walks the shorter list; a row at/above the cutoff has no stored
+         * list, but it is then never the shorter one unless both are — not possible here
+         * because a dense row has >= cutoff > sparse-row bits. */
+        return orc_intersect_bitmaps_scalar_list(ri, rj, h->positions + h->pos_offset[i],
+                                                 h->positions + h->pos_offset[j], h->n_set[i],
+                                                 h->n_set[j]);
+    }
+    return h->leaf(ri, rj, h->n_words);
+}
+
+/* storm.c:1149-1173 */
+uint64_t orc_contig_pairw_intersect_cardinality(orc_contig_t* h) {
+    if (!h) return (uint64_t)-1;
+    if (h->positions && contig_any_sparse(h)) return orc_contig_pairw_intersect_cardinality_list(h);
+    return sweep_naive(h->n_rows, contig_pair, h);
+}
+
+/* storm.c:1175-1241 */
+uint64_t orc_contig_pairw_intersect_cardinality_blocked(orc_contig_t* h, uint32_t bsize) {
+    if (!h) return (uint64_t)-1;
+    if (h->positions && contig_any_sparse(h))
+        return orc_contig_pairw_intersect_cardinality_blocked_list(h, bsize);
+    if (bsize <= 2) return orc_contig_pairw_intersect_cardinality(h);
+    return sweep_blocked(h->n_rows, bsize, contig_pair, h);
+}
+
+/* storm.c:1243-1263 */
+uint64_t orc_contig_pairw_intersect_cardinality_list(orc_contig_t* h) {
+    if (!h) return (uint64_t)-1;
+    if (!h->positions) return (uint64_t)-2;
+    if (!h->n_set) return (uint64_t)-3;
+    return sweep_naive(h->n_rows, contig_pair_list, h);
+}
+
+/* storm.c:1265-1346 */
+uint64_t orc_contig_pairw_intersect_cardinality_blocked_list(orc_contig_t* h, uint32_t bsize) {
+    if (!h) return (uint64_t)-1;
+    if (!h->positions) return (uint64_t)-2;
+    if (!h->n_set) return (uint64_t)-3;
+    if (bsize <= 2) return orc_contig_pairw_intersect_cardinality_list(h);
+    return sweep_blocked(h->n_rows, bsize, contig_pair_list, h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_t restatement (storm.h:157-178; storm.c:372-973)
+ * row -> sorted run of 65536-bit blocks; a block is EITHER a sorted uint16 list (fewer than
+ * 4096 input values, storm.c:745-746) OR a 1024-word bitmap (:747-748).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t id;       /* block index = value / 65536              */
+    uint32_t n_list;   /* entries in `list` (list kind)            */
+    uint32_t n_words;  /* 1024 for bitmap kind, 0 for list kind    */
+    uint32_t n_bits;   /* distinct bits set                        */
+    uint16_t* list;
+    uint64_t* words;
+} orc_block;
+
+typedef struct {
+    orc_block* blocks;
+    uint32_t* ids; /* parallel copy of block ids (storm.h:170) */
+    uint32_t n_blocks, m_blocks;
+} orc_row;
+
+struct orc_storm_s {
+    orc_row* rows;
+    uint64_t n_rows, m_rows;
+};
+
+orc_storm_t* orc_storm_new(void) { return (orc_storm_t*)calloc(1, sizeof(orc_storm_t)); }
+
+static void row_release(orc_row* r) {
+    for (uint32_t b = 0; b < r->m_blocks; ++b) {
+        free(r->blocks[b].list);
+        orc_aligned_free(r->blocks[b].words);
+    }
+    free(r->blocks);
+    free(r->ids);
+    memset(r, 0, sizeof(*r));
+}
+
+void orc_storm_free(orc_storm_t* h) {
+    if (!h) return;
+    for (uint64_t i = 0; i < h->m_rows; ++i) row_release(&h->rows[i]);
+    free(h->rows);
+    free(h);
+}
+
+/* storm.c:692-758 */
+static int row_add(orc_row* r, const uint32_t* values, uint32_t n_values) {
+    if (!values) return -2;
+    if (n_values == 0) return 0;
+    uint32_t start = 0;
+    while (start < n_values) {
+        const uint32_t id = values[start] / ORC_BLOCK_BITS;
+        uint32_t stop = start;
+        while (stop < n_values && values[stop] / ORC_BLOCK_BITS == id) ++stop;
+
+        if (r->n_blocks == r->m_blocks) { /* :697-707 start at 2, :727-736 grow by 8 */
+            const uint32_t new_m = r->m_blocks == 0 ? 2 : r->m_blocks + 8;
+            r->blocks = (orc_block*)realloc(r->blocks, new_m * sizeof(orc_block));
+            r->ids = (uint32_t*)realloc(r->ids, new_m * sizeof(uint32_t));
+            memset(r->blocks + r->m_blocks, 0, (new_m - r->m_blocks) * sizeof(orc_block));
+            r->m_blocks = new_m;
+        }
+        orc_block* blk = &r->blocks[r->n_blocks];
+        blk->id = id;
+        r->ids[r->n_blocks] = id;
+        blk->n_list = 0;
+        blk->n_bits = 0;
+        const uint32_t count = stop - start;
+        const uint32_t base = id * ORC_BLOCK_BITS;
+        if (count < ORC_SCALAR_THRESHOLD) { /* list kind, storm.c:521-558 */
+            blk->list = (uint16_t*)realloc(blk->list, count * sizeof(uint16_t));
+            blk->n_words = 0;
+            for (uint32_t k = start; k < stop; ++k) {
+                if (k != start && values[k] == values[k - 1]) continue; /* keep lists unique */
+                blk->list[blk->n_list++] = (uint16_t)(values[k] - base);
+            }
+            blk->n_bits = blk->n_list;
+        } else { /* bitmap kind, storm.c:442-465 */
+            if (!blk->words) blk->words = (uint64_t*)orc_aligned_malloc(64, ORC_BLOCK_WORDS * 8);
+            memset(blk->words, 0, ORC_BLOCK_WORDS * 8);
+            blk->n_words = ORC_BLOCK_WORDS;
+            for (uint32_t k = start; k < stop; ++k) {
+                const uint32_t v = values[k] - base;
+                blk->n_bits += (uint32_t)(((blk->words[v >> 6] >> (v & 63u)) & 1u) == 0);
+                blk->words[v >> 6] |= 1ULL << (v & 63u);
+            }
+        }
+        ++r->n_blocks;
+        start = stop;
+    }
+    return 1;
+}
+
+/* storm.c:844-866: rows grow by 1024; an empty input still consumes a row (:864, :695);
+ * always returns 1 for a non-NULL handle. */
+int orc_storm_add(orc_storm_t* h, const uint32_t* values, uint32_t n_values) {
+    if (!h) return -1;
+    if (h->n_rows == h->m_rows) {
+        const uint64_t new_m = h->m_rows + 1024;
+        h->rows = (orc_row*)realloc(h->rows, new_m * sizeof(orc_row));
+        memset(h->rows + h->m_rows, 0, (new_m - h->m_rows) * sizeof(orc_row));
+        h->m_rows = new_m;
+    }
+    row_add(&h->rows[h->n_rows++], values, n_values);
+    return 1;
+}
+
+/* storm.c:868-875 (+ :816-824, :561-569): rows are recycled, buffers kept */
+int orc_storm_clear(orc_storm_t* h) {
+    if (!h) return -1;
+    for (uint64_t i = 0; i < h->n_rows; ++i) h->rows[i].n_blocks = 0;
+    h->n_rows = 0;
+    return 1;
+}
+
+uint64_t orc_storm_n_rows(const orc_storm_t* h) { return h ? h->n_rows : 0; }
+
+/* byte counts only — storm.c:372-394 (block: 8*words + 2*list + 16; row: sum + 4*blocks + 12)
+ * and :963-973 (container: sum + 8) */
+static uint32_t row_serialized_size(const orc_row* r) {
+    uint32_t bytes = 0;
+    for (uint32_t b = 0; b < r->n_blocks; ++b)
+        bytes += 8u * r->blocks[b].n_words + 2u * r->blocks[b].n_list + 16u;
+    return bytes + 4u * r->n_blocks + 12u;
+}
+
+uint64_t orc_storm_serialized_size(const orc_storm_t* h) {
+    if (!h) return 0;
+    uint64_t bytes = 0;
+    for (uint64_t i = 0; i < h->n_rows; ++i) bytes += row_serialized_size(&h->rows[i]);
+    return bytes + 8;
+}
+
+void orc_storm_block_census(const orc_storm_t* h, uint64_t out[2]) {
+    out[0] = out[1] = 0;
+    if (!h) return;
+    for (uint64_t i = 0; i < h->n_rows; ++i)
+        for (uint32_t b = 0; b < h->rows[i].n_blocks; ++b) out[h->rows[i].blocks[b].n_words != 0]++;
+}
+
+/* 4-way dispatch on the two blocks' kinds — storm.c:618-656. The two mixed cases probe the
+ * list's positions in the other block's bitmap and count the PROBED bit (the reference's
+ * `a & b != 0` at :636,:644 parses as a & (b != 0): defect D1, not reproduced). */
+static uint64_t block_pair(const orc_block* x, const orc_block* y, orc_compute_func leaf) {
+    if (x->id != y->id) return 0; /* :625-626 */
+    if (x->n_words == 0 && y->n_words == 0)
+        return orc_intersect_vector16_cardinality(x->list, y->list, x->n_list, y->n_list);
+    if (x->n_words != 0 && y->n_words == 0) {
+        uint64_t hits = 0;
+        for (uint32_t k = 0; k < y->n_list; ++k) hits += bit_test(x->words, y->list[k]);
+        return hits;
+    }
+    if (x->n_words == 0 && y->n_words != 0) {
+        uint64_t hits = 0;
+        for (uint32_t k = 0; k < x->n_list; ++k) hits += bit_test(y->words, x->list[k]);
+        return hits;
+    }
+    return leaf(x->words, y->words, x->n_words);
+}
+
+typedef struct {
+    const orc_storm_t* h;
+    orc_compute_func leaf;
+    uint32_t* scratch; /* 2 * 4096 uint32, storm.c:880,:900 */
+} storm_ctx;
+
+/* storm.c:790-814: merge the two rows' block-id lists, then sum the matching block pairs */
+static uint64_t storm_pair(const void* c, uint64_t i, uint64_t j) {
+    const storm_ctx* s = (const storm_ctx*)c;
+    const orc_row* a = &s->h->rows[i];
+    const orc_row* b = &s->h->rows[j];
+    if (a->n_blocks == 0 || b->n_blocks == 0) return 0;
+    const uint64_t n =
+        orc_intersect_vector32_unsafe(a->ids, b->ids, a->n_blocks, b->n_blocks, s->scratch);
+    uint64_t total = 0;
+    for (uint64_t k = 0; k < n; k += 2)
+        total += block_pair(&a->blocks[s->scratch[k]], &b->blocks[s->scratch[k + 1]], s->leaf);
+    return total;
+}
+
+/* storm.c:877-895 */
+uint64_t orc_storm_pairw_intersect_cardinality(orc_storm_t* h) {
+    if (!h) return (uint64_t)-1;
+    storm_ctx c = {h, orc_get_intersect_count_func(ORC_BLOCK_WORDS),
+                   (uint32_t*)malloc(sizeof(uint32_t) * 2 * ORC_SCALAR_THRESHOLD)};
+    const uint64_t total = sweep_naive(h->n_rows, storm_pair, &c);
+    free(c.scratch);
+    return total;
+}
+
+/* storm.c:897-961: bsize 0 -> ceil(256e3 / average serialized row bytes) (:903-911), then a
+ * floor of 5 (:914). (An empty container divides by zero in the reference; 0 here.) */
+uint64_t orc_storm_pairw_intersect_cardinality_blocked(orc_storm_t* h, uint32_t bsize) {
+    if (!h) return (uint64_t)-1;
+    if (h->n_rows == 0) return 0;
+    if (bsize == 0) {
+        uint64_t bytes = 0;
+        for (uint64_t i = 0; i < h->n_rows; ++i) bytes += row_serialized_size(&h->rows[i]);
+        const uint32_t average = (uint32_t)(bytes / h->n_rows);
+        bsize = (uint32_t)ceil((double)ORC_CACHE_BLOCK / average);
+    }
+    if (bsize < 5) bsize = 5;
+    storm_ctx c = {h, orc_get_intersect_count_func(ORC_BLOCK_WORDS),
+                   (uint32_t*)malloc(sizeof(uint32_t) * 2 * ORC_SCALAR_THRESHOLD)};
+    const uint64_t total = sweep_blocked(h->n_rows, bsize, storm_pair, &c);
+    free(c.scratch);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Independent truths
+ * ---------------------------------------------------------------------------------------- */
+uint64_t orc_truth_naive_dense(const uint64_t* vals, uint64_t n_rows, uint64_t n_words) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n_rows; ++i)
+        for (uint64_t j = i + 1; j < n_rows; ++j) {
+            const uint64_t* a = vals + i * n_words;
+            const uint64_t* b = vals + j * n_words;
+            for (uint64_t k = 0; k < n_words; ++k) {
+                uint64_t x = a[k] & b[k];
+                while (x) { /* Kernighan bit-clear loop: shares no code with any leaf */
+                    x &= x - 1;
+                    ++total;
+                }
+            }
+        }
+    return total;
+}
+
+uint64_t orc_truth_column_count(const uint64_t* vals, uint64_t n_rows, uint64_t n_words) {
+    uint64_t total = 0;
+    uint32_t* col = (uint32_t*)malloc(64 * sizeof(uint32_t));
+    for (uint64_t k = 0; k < n_words; ++k) {
+        memset(col, 0, 64 * sizeof(uint32_t));
+        for (uint64_t i = 0; i < n_rows; ++i) {
+            uint64_t x = vals[i * n_words + k];
+            while (x) {
+                col[__builtin_ctzll(x)]++;
+                x &= x - 1;
+            }
+        }
+        for (int b = 0; b < 64; ++b) total += (uint64_t)col[b] * (col[b] - (col[b] != 0)) / 2;
+    }
+    free(col);
+    return total;
+}
+
+void orc_tile_counts(const uint64_t* vals, uint64_t n_words, uint64_t i0, uint64_t i1,
+                     uint64_t j0, uint64_t j1, uint32_t* out) {
+    for (uint64_t i = i0; i < i1; ++i)
+        for (uint64_t j = j0; j < j1; ++j)
+            out[(i - i0) * (j1 - j0) + (j - j0)] = (uint32_t)orc_intersect_count_scalar(
+                vals + i * n_words, vals + j * n_words, n_words);
+}
+
+double orc_time_blocked(const uint64_t* vals, uint32_t n_rows, uint32_t n_words, int leaf_kind,
+                        uint32_t bsize, uint64_t* total_out) {
+    orc_compute_func f = orc_get_intersect_count_func_kind(leaf_kind);
+    if (!f) return -1.0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const uint64_t total = orc_wrapper_diag_blocked(n_rows, vals, n_words, f, bsize);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (total_out) *total_out = total;
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
