@@ -1,0 +1,236 @@
+/*
+ * storm.h — the StormBitmaps container API, served by the MI355X-native library
+ * libstorm_hip.so (stormbitmaps_amd/). Source-compatible with the reference header
+ * (mklarqvist/StormBitmaps storm.h): same type names, same public struct members in the same
+ * order, same function signatures and return conventions, so a C/C++ caller of the reference
+ * recompiles against this header and links -lstorm_hip instead of storm.c.
+ *
+ * What differs behind the API
+ *   - The all-pairs entry points (STORM_contig_pairw_*, STORM_pairw_*, STORM_wrapper_*) run on
+ *     the GPU: hand-written gfx950 kernels reached through the C-ABI shim in storm_hip.h.
+ *     There is no CPU fallback; without a usable device they return (uint64_t)-1 and leave
+ *     a message in storm_hip_last_error().
+ *   - `bsize` / `block_size` arguments are accepted and ignored as tuning hints: the device
+ *     tiling is chosen internally and the integer result does not depend on it.
+ *   - Results follow the intended semantics (the mathematically exact count). The reference
+ *     deviates from it in three sparse regimes (SURVEY.md §8 a-note, defects D1-D3).
+ *   - *_free() also releases the handle itself and every device buffer.
+ *   - Both container structs carry private members after the reference's public ones.
+ *
+ * Every declaration cites the reference lines it stands in for (storm.h / storm.c).
+ */
+#ifndef STORM_H_MI355X_DROPIN
+#define STORM_H_MI355X_DROPIN
+
+#include <assert.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "libalgebra/libalgebra.h" /* reference storm.h:33 */
+
+/* reference storm.h:35-47 — kept for callers that size blocks with them */
+#ifndef STORM_CACHE_BLOCK_SIZE
+#define STORM_CACHE_BLOCK_SIZE 256e3
+#endif
+#ifndef STORM_DEFAULT_BLOCK_SIZE
+#define STORM_DEFAULT_BLOCK_SIZE 65536
+#endif
+#ifndef STORM_DEFAULT_SCALAR_THRESHOLD
+#define STORM_DEFAULT_SCALAR_THRESHOLD 4096
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ list kernels (host) --
+ * Single-pair helpers on host memory (reference storm.h:56-61, storm.c:4-129). They are not
+ * on the all-pairs path; they exist so that one-pair callers keep working. */
+uint64_t STORM_intersect_vector16_cardinality(const uint16_t* STORM_RESTRICT v1,
+                                              const uint16_t* STORM_RESTRICT v2,
+                                              const uint32_t len1, const uint32_t len2);
+uint64_t STORM_intersect_vector32_unsafe(const uint32_t* STORM_RESTRICT v1,
+                                         const uint32_t* STORM_RESTRICT v2, const uint32_t len1,
+                                         const uint32_t len2, uint32_t* STORM_RESTRICT out);
+uint64_t STORM_intersect_bitmaps_scalar_list(const uint64_t* STORM_RESTRICT b1,
+                                             const uint64_t* STORM_RESTRICT b2,
+                                             const uint32_t* l1, const uint32_t* l2,
+                                             const uint32_t n1, const uint32_t n2);
+
+/* list-aware leaf signature (reference storm.h:66-67) */
+typedef uint64_t (*STORM_compute_lfunc)(const uint64_t*, const uint64_t*, const uint32_t*,
+                                        const uint32_t*, const size_t, const size_t);
+
+/* ------------------------------------------------------ raw-buffer all-pairs (device) ----
+ * sum over row pairs of popcount(row_i & row_j) for `n_vectors` rows of `n_ints` 64-bit words
+ * in a caller-owned HOST buffer (reference storm.h:95-148, storm.c:132-369). The buffer is
+ * copied to the device per call. `f` / `fl` must be NULL or leaves exported by this library.
+ * The *_list variants return the same exact count as the plain ones (the position lists are
+ * a CPU-side shortcut; the device kernel is density independent). */
+uint64_t STORM_wrapper_diag(const uint32_t n_vectors, const uint64_t* vals,
+                            const uint32_t n_ints, const STORM_compute_func f);
+uint64_t STORM_wrapper_diag_blocked(const uint32_t n_vectors, const uint64_t* vals,
+                                    const uint32_t n_ints, const STORM_compute_func f,
+                                    uint32_t block_size);
+/* every row of vals1 against every row of vals2 (storm.c:153-171, intent of storm.h:72-77) */
+uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_RESTRICT vals1,
+                              const uint32_t n_vectors2, const uint64_t* STORM_RESTRICT vals2,
+                              const uint32_t n_ints, const STORM_compute_func f);
+uint64_t STORM_wrapper_diag_list(const uint32_t n_vectors, const uint64_t* STORM_RESTRICT vals,
+                                 const uint32_t n_ints, const uint32_t* STORM_RESTRICT n_alts,
+                                 const uint32_t* STORM_RESTRICT alt_positions,
+                                 const uint32_t* STORM_RESTRICT alt_offsets,
+                                 const STORM_compute_func f, const STORM_compute_lfunc fl,
+                                 const uint32_t cutoff);
+uint64_t STORM_wrapper_diag_list_blocked(const uint32_t n_vectors,
+                                         const uint64_t* STORM_RESTRICT vals,
+                                         const uint32_t n_ints,
+                                         const uint32_t* STORM_RESTRICT n_alts,
+                                         const uint32_t* STORM_RESTRICT alt_positions,
+                                         const uint32_t* STORM_RESTRICT alt_offsets,
+                                         const STORM_compute_func f,
+                                         const STORM_compute_lfunc fl, const uint32_t cutoff,
+                                         uint32_t block_size);
+
+/* ------------------------------------------------------------------------ containers ---- */
+typedef struct STORM_bitmap_s STORM_bitmap_t;
+typedef struct STORM_bitmap_cont_s STORM_bitmap_cont_t;
+typedef struct STORM_s STORM_t;
+typedef struct STORM_contiguous_bitmap_s STORM_contiguous_bitmap_t;
+typedef struct STORM_contiguous_s STORM_contiguous_t;
+
+/* one 65536-bit block of one row: a sorted uint16 list OR a 1024-word bitmap
+ * (reference storm.h:158-166) */
+struct STORM_bitmap_s {
+    STORM_ALIGN(64) uint64_t* data;
+    STORM_ALIGN(64) uint16_t* scalar;
+    uint32_t n_bitmap : 30, own_data : 1, own_scalar : 1;
+    uint32_t n_bits_set;
+    uint32_t n_scalar : 31, n_scalar_set : 1, n_missing;
+    uint32_t m_scalar;
+    uint32_t id;
+};
+
+/* one row: its blocks in ascending id order (reference storm.h:168-173) */
+struct STORM_bitmap_cont_s {
+    STORM_bitmap_t* bitmaps;
+    uint32_t* block_ids;
+    uint32_t n_bitmaps, m_bitmaps;
+    uint32_t prev_inserted_value;
+};
+
+/* sparse container (reference storm.h:175-178) + private device state */
+struct STORM_s {
+    STORM_bitmap_cont_t* conts;
+    uint32_t n_conts, m_conts;
+    /* private */
+    void* hip_arena;        /* storm_hip_sparse_t*, rebuilt when dirty */
+    uint32_t hip_dirty;
+};
+
+/* one row of the dense container (reference storm.h:181-186) */
+struct STORM_contiguous_bitmap_s {
+    uint64_t* data;
+    uint32_t* scalar;
+    uint32_t n_scalar;
+};
+
+/* dense container (reference storm.h:188-200) + private device state */
+struct STORM_contiguous_s {
+    uint64_t* data;
+    uint32_t* scalar;
+    uint32_t* n_scalar;
+    STORM_contiguous_bitmap_t* bitmaps;
+    uint64_t n_data, m_data;
+    uint64_t tot_scalar, m_scalar;
+    uint64_t vector_length;
+    uint32_t n_bitmaps_vector;
+    STORM_compute_func intsec_func;
+    uint32_t alignment;
+    uint32_t scalar_cutoff;
+    /* private */
+    uint64_t* scalar_offset; /* start of each row's list in `scalar` (per row)     */
+    void* hip_matrix;        /* storm_hip_matrix_t*: device mirror of `data`        */
+    uint64_t hip_rows_synced;
+    uint64_t hip_rows_capacity;
+};
+
+/* per-block API (reference storm.h:203-212, storm.c:372-380, :398-656) */
+STORM_bitmap_t* STORM_bitmap_new();
+void STORM_bitmap_init(STORM_bitmap_t* all);
+void STORM_bitmap_free(STORM_bitmap_t* bitmap);
+int STORM_bitmap_add(STORM_bitmap_t* bitmap, const uint32_t* values, const uint32_t n_values);
+int STORM_bitmap_add_with_scalar(STORM_bitmap_t* bitmap, const uint32_t* values,
+                                 const uint32_t n_values);
+int STORM_bitmap_add_scalar_only(STORM_bitmap_t* bitmap, const uint32_t* values,
+                                 const uint32_t n_values);
+uint64_t STORM_bitmap_intersect_cardinality(STORM_bitmap_t* STORM_RESTRICT bitmap1,
+                                            STORM_bitmap_t* STORM_RESTRICT bitmap2);
+uint64_t STORM_bitmap_intersect_cardinality_func(STORM_bitmap_t* STORM_RESTRICT bitmap1,
+                                                 STORM_bitmap_t* STORM_RESTRICT bitmap2,
+                                                 const STORM_compute_func func);
+int STORM_bitmap_clear(STORM_bitmap_t* bitmap);
+uint32_t STORM_bitmap_serialized_size(STORM_bitmap_t* bitmap);
+
+/* per-row API (reference storm.h:215-222, storm.c:383-394, :659-824) */
+STORM_bitmap_cont_t* STORM_bitmap_cont_new();
+void STORM_bitmap_cont_init(STORM_bitmap_cont_t* bitmap);
+void STORM_bitmap_cont_free(STORM_bitmap_cont_t* bitmap);
+int STORM_bitmap_cont_add(STORM_bitmap_cont_t* bitmap, const uint32_t* values,
+                          const uint32_t n_values);
+int STORM_bitmap_cont_clear(STORM_bitmap_cont_t* bitmap);
+uint64_t STORM_bitmap_cont_intersect_cardinality(
+    const STORM_bitmap_cont_t* STORM_RESTRICT bitmap1,
+    const STORM_bitmap_cont_t* STORM_RESTRICT bitmap2);
+uint64_t STORM_bitmap_cont_intersect_cardinality_premade(
+    const STORM_bitmap_cont_t* STORM_RESTRICT bitmap1,
+    const STORM_bitmap_cont_t* STORM_RESTRICT bitmap2, const STORM_compute_func func,
+    uint32_t* out);
+uint32_t STORM_bitmap_cont_serialized_size(STORM_bitmap_cont_t* bitmap);
+
+/* sparse container (reference storm.h:225-232, storm.c:827-973).
+ * STORM_add: values sorted ascending; returns 1 (an empty input still appends an empty row).
+ * STORM_pairw_*: sum over row pairs i<j of |row_i ∩ row_j|, computed on the GPU;
+ * NULL handle or device failure -> (uint64_t)-1. */
+STORM_t* STORM_new();
+void STORM_free(STORM_t* bitmap);
+int STORM_add(STORM_t* bitmap, const uint32_t* values, const uint32_t n_values);
+int STORM_clear(STORM_t* bitmap);
+uint64_t STORM_pairw_intersect_cardinality(STORM_t* bitmap);
+uint64_t STORM_pairw_intersect_cardinality_blocked(STORM_t* bitmap, uint32_t bsize);
+uint64_t STORM_serialized_size(const STORM_t* bitmap);
+/* (reference storm.h:231 declares STORM_intersect_cardinality_square but never defines it,
+ *  storm.c:975; nothing to stand in for.) */
+
+/* dense container (reference storm.h:235-242, storm.c:1001-1346).
+ * STORM_contig_add: returns n_values; 0 for an empty input (no row appended); -1 / -2 for a
+ * NULL handle / NULL values.
+ * STORM_contig_pairw_*: GPU; NULL handle or device failure -> (uint64_t)-1; the *_list
+ * variants return (uint64_t)-2 / -3 before the first add, like the reference. */
+STORM_contiguous_t* STORM_contig_new(size_t vector_length);
+void STORM_contig_free(STORM_contiguous_t* bitmap);
+int STORM_contig_add(STORM_contiguous_t* bitmap, const uint32_t* values,
+                     const uint32_t n_values);
+int STORM_contig_clear(STORM_contiguous_t* bitmap);
+uint64_t STORM_contig_pairw_intersect_cardinality(STORM_contiguous_t* bitmap);
+uint64_t STORM_contig_pairw_intersect_cardinality_blocked(STORM_contiguous_t* bitmap,
+                                                          uint32_t bsize);
+uint64_t STORM_contig_pairw_intersect_cardinality_list(STORM_contiguous_t* bitmap);
+uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_t* bitmap,
+                                                               uint32_t bsize);
+
+/* ------------------------------------------------------------- extensions (not in ref) ---
+ * Device selection for the entry points above. By default device 0 computes everything.
+ * STORM_hip_set_devices(n, ids): the pair space is sharded over the listed GPUs of this node
+ * (one replica of the data per GPU, disjoint shards of the tile list) and the per-GPU partial
+ * sums are added on the host. Multi-PROCESS runs (one rank per GPU, RCCL all-reduce) use
+ * STORM_hip_set_shard(rank, world): each process then returns only its shard's partial. */
+int STORM_hip_set_devices(int n_devices, const int* device_ids);
+int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
+const char* STORM_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORM_H_MI355X_DROPIN */

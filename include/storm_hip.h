@@ -1,0 +1,149 @@
+/*
+ * storm_hip.h — C-ABI of the MI355X (gfx950) device shim behind the storm.h API.
+ *
+ * This is the drop-in boundary for the pairwise AND+popcount hot path: plain pointers and
+ * sizes, no C++ or torch types. Host code (C) calls these; they launch hand-written HIP
+ * kernels (stormbitmaps_amd/csrc/storm_hip.hip). Each entry point names the reference
+ * interface it replaces (file:line in mklarqvist/StormBitmaps).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative STORM_HIP_E* code; the message of the
+ *     last failure on the calling thread is available from storm_hip_last_error().
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     fails with STORM_HIP_ENODEV / STORM_HIP_EHIP.
+ *   - `stream` arguments are hipStream_t passed as void* (NULL = the default stream).
+ *   - a "dense matrix" is the device mirror of STORM_contiguous_t::data (storm.h:188-200):
+ *     row-major uint64 rows, bit v of a row in word v/64 at bit v%64 (storm.c:1114). On the
+ *     device the rows are padded with zeros to a multiple of 64 words and the row count to a
+ *     multiple of 128 so that no kernel needs a ragged-edge path.
+ */
+#ifndef STORM_HIP_H_
+#define STORM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STORM_HIP_OK 0
+#define STORM_HIP_EINVAL (-1) /* bad argument                                  */
+#define STORM_HIP_ENODEV (-2) /* no HIP device / not gfx950                    */
+#define STORM_HIP_EHIP (-3)   /* a HIP runtime call failed                     */
+#define STORM_HIP_ENOMEM (-4) /* host or device allocation failed              */
+
+typedef struct storm_hip_ctx_s storm_hip_ctx_t;       /* one device + stream + workspace */
+typedef struct storm_hip_matrix_s storm_hip_matrix_t; /* dense bitmap matrix in HBM      */
+typedef struct storm_hip_sparse_s storm_hip_sparse_t; /* flattened STORM_t arena in HBM  */
+
+/* ---- library / device ---- */
+const char* storm_hip_last_error(void);
+int storm_hip_device_count(void);
+/* arch string of `device` ("gfx950:sramecc+:xnack-") into buf */
+int storm_hip_device_arch(int device, char* buf, size_t buflen);
+
+/* ---- context: device, stream, reusable workspace ---- */
+int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out);
+int storm_hip_ctx_set_stream(storm_hip_ctx_t* ctx, void* stream);
+int storm_hip_ctx_synchronize(storm_hip_ctx_t* ctx);
+void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx);
+
+/* ---- dense matrix lifecycle (device mirror of STORM_contiguous_t, storm.c:1001-1147) ---- */
+int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
+                            storm_hip_matrix_t** out); /* zero-filled */
+/* copy n_rows host rows (row stride = src_stride_words) into rows [row0, row0+n_rows) */
+int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                            uint64_t n_rows, const uint64_t* host_rows,
+                            uint64_t src_stride_words);
+/* same from a device buffer (e.g. a torch tensor's data_ptr), device-to-device */
+int storm_hip_matrix_import(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                            uint64_t n_rows, const void* device_rows,
+                            uint64_t src_stride_words);
+/* copy rows back to the host (tests) */
+int storm_hip_matrix_download(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t row0,
+                              uint64_t n_rows, uint64_t* host_rows, uint64_t dst_stride_words);
+/* device-side construction from sorted position lists in CSR form (host pointers):
+ * replaces the bit-setting loop of STORM_contig_add, storm.c:1103-1115 */
+int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
+                                             uint64_t row0, uint64_t n_rows,
+                                             const uint64_t* offsets, const uint32_t* positions);
+/* synthetic fill on the device: identical bits to storm_synth_positions() (storm_synth.h) */
+int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
+                                    uint64_t n_bits, uint32_t draws, uint64_t seed);
+int storm_hip_matrix_clear(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m);
+void storm_hip_matrix_destroy(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m);
+uint64_t storm_hip_matrix_rows(const storm_hip_matrix_t* m);
+uint32_t storm_hip_matrix_words(const storm_hip_matrix_t* m);
+uint64_t storm_hip_matrix_stride_words(const storm_hip_matrix_t* m);
+void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m);
+
+/* ---- the hot path --------------------------------------------------------------------
+ * total = sum over row pairs i<j of popcount(row_i & row_j), restricted to this shard's share
+ * of the pair space (shard_rank of shard_count; 0 of 1 = everything). The shards partition
+ * the pairs, so the sum of the per-shard totals over all ranks is the full total.
+ * Replaces: STORM_contig_pairw_intersect_cardinality[_blocked] (storm.c:1149-1241),
+ *           STORM_wrapper_diag[_blocked] (storm.c:132-150, :222-279) and, through them, the
+ *           libalgebra leaf STORM_compute_func (call sites storm.c:1167,1205,1217,1227,1236).
+ * _launch: asynchronous on the ctx stream; d_total is a DEVICE pointer to one uint64.
+ * plain   : synchronous; *h_total on the host. */
+int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                 uint32_t shard_rank, uint32_t shard_count, uint64_t* d_total);
+int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                          uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);
+/* split form, so that one host thread can keep several GPUs busy: _begin launches into the
+ * ctx's own result word, _end waits for it and copies it to the host */
+int storm_hip_pairw_dense_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                uint32_t shard_rank, uint32_t shard_count);
+int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total);
+/* rectangle: sum over i in A, j in B of popcount(A_i & B_j) — STORM_wrapper_square,
+ * storm.c:153-171 (intended semantics, storm.h:72-77) */
+int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                           const storm_hip_matrix_t* b, uint64_t* h_total);
+/* per-pair counts of one tile (tests / materialised output):
+ * out[(i-i0)*(j1-j0)+(j-j0)] = popcount(row_i & row_j); out is a HOST buffer */
+int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t i0,
+                          uint64_t i1, uint64_t j0, uint64_t j1, uint32_t* h_out);
+/* sum_c C(n_c,2) on the device — verification identity only, never the product
+ * path: used by tests at sizes where a CPU pairwise oracle is infeasible */
+int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                              uint64_t* h_total);
+
+/* kernel selection / tuning knobs (benchmarks; defaults are what ships)
+ *   key "variant": 0 = direct global->VGPR B stream, 1 = LDS-staged via VGPR, 2 = LDS-staged
+ *                  via global_load_lds (default)
+ *   key "seg_rows": B rows per work item (default 256)
+ *   key "chunks_per_item": k-chunks (64 words each) per work item, 0 = auto */
+int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
+int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
+/* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,
+ * [2]=word-pairs executed (including zero padding), [3]=segments */
+int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);
+
+/* ---- sparse (STORM_t) arena: flattened rows -> blocks (storm.h:157-178) --------------
+ * Host-side flat description of all rows' 65536-bit blocks:
+ *   row_block_offset[n_rows+1]   CSR over blocks
+ *   block_id[n_blocks]           ascending within a row (storm.c:711-723)
+ *   block_kind[n_blocks]         0 = uint16 list, 1 = 1024-word bitmap (storm.c:745-749)
+ *   block_data_offset[n_blocks]  offset into list_pool (uint16 units) or bitmap_pool (words)
+ *   block_n[n_blocks]            list length (kind 0)
+ * Replaces STORM_pairw_intersect_cardinality[_blocked] (storm.c:877-961) and the per-pair
+ * dispatch STORM_bitmap_cont_intersect_cardinality_premade / STORM_bitmap_intersect_
+ * cardinality_func (storm.c:790-814, :618-656). */
+int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                            const uint64_t* row_block_offset, const uint32_t* block_id,
+                            const uint8_t* block_kind, const uint64_t* block_data_offset,
+                            const uint32_t* block_n, const uint16_t* list_pool,
+                            uint64_t list_pool_len, const uint64_t* bitmap_pool,
+                            uint64_t bitmap_pool_words, storm_hip_sparse_t** out);
+void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);
+int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
+                           uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);
+/* work census of the last sparse call: out[0]=list×list block pairs, [1]=list×bitmap,
+ * [2]=bitmap×bitmap, [3]=block columns */
+int storm_hip_sparse_last_census(storm_hip_ctx_t* ctx, uint64_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORM_HIP_H_ */

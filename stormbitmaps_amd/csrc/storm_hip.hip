@@ -1,0 +1,963 @@
+// storm_hip.hip — gfx950 (MI355X / CDNA4) kernels and the C-ABI shim for the dense pairwise
+// AND+popcount path (include/storm_hip.h).
+//
+// K1 "pairw_dense": sum_{i<j} popcount(X_i & X_j) over a row-major uint64 bitmap matrix.
+//   Replaces the blocked upper-triangle loop of STORM_contig_pairw_intersect_cardinality_blocked
+//   (storm.c:1175-1241), STORM_wrapper_diag_blocked (storm.c:222-279) and the libalgebra leaf
+//   they call per pair (STORM_compute_func; storm.c:1205,1217,1227,1236).
+//
+//   Work item  = (segment, k-slice). A segment pairs a 128-row A block with a run of up to
+//                seg_rows later B rows; a k-slice is `cps` chunks of 64 words.
+//   Workgroup  = 4 waves. Lane l owns word (chunk*64 + l) of every row it touches, so every
+//                global access is a fully coalesced 512-byte row slice and no cross-lane data
+//                movement is needed until the final reduction.
+//   A operand  = 32 rows per wave, kept in 64 VGPRs for the whole chunk (register-stationary).
+//   B operand  = streamed: 32-row stages of the B run go global -> LDS (global_load_lds,
+//                16 B/lane, double-buffered) once per workgroup and are read by all 4 waves
+//                with conflict-free ds_read_b64.
+//   Math       = per A row and B word: 2x v_and_b32 + 2x v_bcnt_u32_b32 (accumulating form),
+//                i.e. 128 VALU instructions per ds_read_b64 — the kernel is VALU-issue bound
+//                by construction; HBM/L2/LDS traffic is a few percent of their peaks.
+//   Reduction  = per-lane uint32 -> wave shuffle -> one 64-bit atomic per wave into one of
+//                4096 slots -> tiny second kernel folds the slots into the result word.
+#include "storm_hip_internal.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdlib>
+#include <cstring>
+
+namespace storm {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t popc_and(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo,
+                                             uint32_t b_hi, uint32_t acc) {
+    // v_and_b32 x2 + v_bcnt_u32_b32 x2. The bcnt is written as asm because it must be the
+    // ACCUMULATING form (D = popcount(S0) + S1): left to itself hipcc emits bcnt(x, 0) twice
+    // plus a v_add3_u32, i.e. 5 VALU instructions per word pair instead of 4.
+    uint32_t t;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(t) : "v"(a_lo & b_lo), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(a_hi & b_hi), "v"(t));
+    return acc;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kLanes);
+    return v;  // valid in lane 0
+}
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+// One LDS stage = kStageRows rows x 512 B = 16 KiB = 16 wave-instructions of 1 KiB.
+// Wave w issues instructions q*4+w (q = 0..3). Instruction n fills LDS bytes [n*1024, +1024):
+// 16-byte piece p = n*64 + lane is row p/32, 16-byte column p%32 of the stage.
+__device__ __forceinline__ void stage_b_glds(uint64_t* lds_stage, const uint64_t* __restrict__ X,
+                                             uint64_t stride, uint32_t kbase, uint32_t j0,
+                                             uint32_t j_last, uint32_t wave, uint32_t lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t n = (uint32_t)q * 4u + wave;
+        const uint32_t p = n * 64u + lane;
+        uint32_t j = j0 + (p >> 5);
+        j = j < j_last ? j : j_last;  // rows past the run re-read the last row; never consumed
+        const char* g = reinterpret_cast<const char*>(X + (uint64_t)j * stride + kbase) +
+                        (p & 31u) * 16u;
+        char* l = reinterpret_cast<char*>(lds_stage) + n * 1024u;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+    }
+}
+
+// Same stage through VGPRs (no LDS-DMA): global_load_dwordx4 + ds_write_b128.
+__device__ __forceinline__ void stage_b_regs(uint64_t* lds_stage, const uint64_t* __restrict__ X,
+                                             uint64_t stride, uint32_t kbase, uint32_t j0,
+                                             uint32_t j_last, uint32_t tid) {
+    uint4 tmp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t p = (uint32_t)q * 256u + tid;
+        uint32_t j = j0 + (p >> 5);
+        j = j < j_last ? j : j_last;
+        const char* g = reinterpret_cast<const char*>(X + (uint64_t)j * stride + kbase) +
+                        (p & 31u) * 16u;
+        tmp[q] = *reinterpret_cast<const uint4*>(g);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t p = (uint32_t)q * 256u + tid;
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(lds_stage) + p * 16u) = tmp[q];
+    }
+}
+
+// All kRowsPerWave A rows against one B word. DIAG: only rows r < rmax (wave-uniform).
+template <bool DIAG>
+__device__ __forceinline__ void row_step(const uint32_t (&a_lo)[kRowsPerWave],
+                                         const uint32_t (&a_hi)[kRowsPerWave], uint64_t b,
+                                         int rmax, uint32_t (&acc)[4]) {
+    const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
+#pragma unroll
+    for (int r = 0; r < kRowsPerWave; ++r) {
+        if (!DIAG || r < rmax) acc[r & 3] = popc_and(a_lo[r], a_hi[r], b_lo, b_hi, acc[r & 3]);
+    }
+}
+
+// A full 32-row stage: groups of 4 B words, the next group's ds_reads issued before the
+// current group's 512 VALU instructions so the LDS latency is never exposed.
+__device__ __forceinline__ void stage_compute(const uint32_t (&a_lo)[kRowsPerWave],
+                                              const uint32_t (&a_hi)[kRowsPerWave],
+                                              const uint64_t* __restrict__ col,
+                                              uint32_t (&acc)[4]) {
+    constexpr int G = 4;
+    uint64_t cur[G], nxt[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) cur[u] = col[u * kChunkWords];
+#pragma unroll
+    for (int g = 0; g < kStageRows / G; ++g) {
+        if (g + 1 < kStageRows / G) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) nxt[u] = col[((g + 1) * G + u) * kChunkWords];
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) row_step<false>(a_lo, a_hi, cur[u], 0, acc);
+#pragma unroll
+        for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+    }
+}
+
+// VARIANT 0: B rows straight from global memory into VGPRs (each wave loads its own copy)
+// VARIANT 1: B stages through VGPRs into LDS (single buffer, two barriers per stage)
+// VARIANT 2: B stages by global_load_lds, double-buffered, one barrier per stage
+template <int VARIANT>
+__global__ __launch_bounds__(kThreads, 4) void pairw_dense_kernel(
+    const uint64_t* __restrict__ X, uint64_t stride, const Seg* __restrict__ segs,
+    uint32_t n_segs, uint32_t n_chunks, uint32_t cps, unsigned long long* __restrict__ slots) {
+    __shared__ uint64_t lds[VARIANT == 0 ? 1 : (VARIANT == 1 ? 1 : 2)]
+                           [VARIANT == 0 ? 1 : kStageRows * kChunkWords];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t item = blockIdx.x;
+    const uint32_t ks = item / n_segs;  // k-slice major: concurrent workgroups share columns
+    const Seg seg = segs[item - ks * n_segs];
+    const uint32_t a_row = seg.a_row0 + wave * kRowsPerWave;
+    const uint32_t j_lo = seg.j_lo, j_hi = seg.j_hi, j_last = seg.j_hi - 1;
+    const bool diag = seg.j_lo == seg.a_row0;
+
+    uint32_t acc[4] = {0, 0, 0, 0};
+    const uint32_t c_end = min(n_chunks, (ks + 1) * cps);
+    for (uint32_t c = ks * cps; c < c_end; ++c) {
+        const uint32_t kbase = c * kChunkWords;
+        // ---- A block: 32 rows of this wave, one 64-bit word per lane, into VGPRs ----
+        uint32_t a_lo[kRowsPerWave], a_hi[kRowsPerWave];
+        {
+            const uint64_t* ap = X + (uint64_t)a_row * stride + kbase + lane;
+#pragma unroll
+            for (int r = 0; r < kRowsPerWave; ++r) {
+                uint64_t v = ap[(uint64_t)r * stride];
+                if (a_row + r >= seg.a_end) v = 0;  // wave-uniform: rows past the block edge
+                a_lo[r] = (uint32_t)v;
+                a_hi[r] = (uint32_t)(v >> 32);
+            }
+        }
+
+        if (VARIANT == 0) {
+            const uint64_t* bp = X + kbase + lane;
+            uint64_t cur[4], nxt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = bp[(uint64_t)min(j_lo + u, j_last) * stride];
+            for (uint32_t j = j_lo; j < j_hi; j += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    nxt[u] = bp[(uint64_t)min(j + 4 + u, j_last) * stride];
+                if (!diag && j + 4 <= j_hi) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) row_step<false>(a_lo, a_hi, cur[u], 0, acc);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < j_hi) {
+                            const int rmax = diag ? (int)(j + u) - (int)a_row : kRowsPerWave;
+                            row_step<true>(a_lo, a_hi, cur[u], rmax, acc);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+            }
+        } else {
+            const uint32_t n_stages = (j_hi - j_lo + kStageRows - 1) / kStageRows;
+            if (VARIANT == 2) stage_b_glds(lds[0], X, stride, kbase, j_lo, j_last, wave, lane);
+            for (uint32_t s = 0; s < n_stages; ++s) {
+                const uint32_t j0 = j_lo + s * kStageRows;
+                const uint64_t* buf;
+                if (VARIANT == 2) {
+                    // Drain this wave's LDS-DMA, then the barrier makes every wave's share of
+                    // stage s visible and proves every wave is done reading the buffer that
+                    // stage s+1 is about to overwrite. The wait is explicit: hipcc (ROCm 7.2)
+                    // emits only lgkmcnt(0) for __syncthreads() inside this loop, and an
+                    // LDS-DMA is tracked by vmcnt.
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (s + 1 < n_stages)
+                        stage_b_glds(lds[(s + 1) & 1], X, stride, kbase, j0 + kStageRows, j_last,
+                                     wave, lane);
+                    buf = lds[s & 1];
+                } else {
+                    __syncthreads();  // previous stage fully consumed
+                    stage_b_regs(lds[0], X, stride, kbase, j0, j_last, tid);
+                    __syncthreads();
+                    buf = lds[0];
+                }
+                const uint32_t rows = min((uint32_t)kStageRows, j_hi - j0);
+                if (!diag && rows == kStageRows) {
+                    stage_compute(a_lo, a_hi, buf + lane, acc);
+                } else {
+                    for (uint32_t jj = 0; jj < rows; ++jj) {
+                        const int rmax = diag ? (int)(j0 + jj) - (int)a_row : kRowsPerWave;
+                        row_step<true>(a_lo, a_hi, buf[jj * kChunkWords + lane], rmax, acc);
+                    }
+                }
+            }
+            // the next chunk's first stage overwrites lds[0]: wait for every wave to finish
+            if (c + 1 < c_end) __syncthreads();
+        }
+    }
+
+    const uint64_t mine = (uint64_t)acc[0] + acc[1] + acc[2] + acc[3];
+    const uint64_t wsum = wave_sum_u64(mine);
+    if (lane == 0 && wsum != 0)
+        atomicAdd(&slots[(item * kWaves + wave) & (kSlots - 1)], (unsigned long long)wsum);
+}
+
+// Folds the slot array into out[0] and re-zeroes the slots for the next launch.
+__global__ __launch_bounds__(1024) void fold_slots_kernel(unsigned long long* __restrict__ slots,
+                                                          unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long part[16];
+    unsigned long long v = 0;
+    for (int i = threadIdx.x; i < kSlots; i += 1024) {
+        v += slots[i];
+        slots[i] = 0;
+    }
+    v = wave_sum_u64(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t;
+    }
+}
+
+// Rectangle A x B^T (STORM_wrapper_square): same inner loop, segments pair A blocks of `xa`
+// with row runs of `xb`; never diagonal.
+__global__ __launch_bounds__(kThreads, 4) void square_dense_kernel(
+    const uint64_t* __restrict__ XA, uint64_t stride_a, const uint64_t* __restrict__ XB,
+    uint64_t stride_b, uint32_t n_rows_b, uint32_t seg_rows, uint32_t segs_per_ablock,
+    uint32_t n_segs, uint32_t n_chunks, unsigned long long* __restrict__ slots) {
+    __shared__ uint64_t lds[2][kStageRows * kChunkWords];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t item = blockIdx.x;
+    const uint32_t c = item / n_segs;
+    const uint32_t si = item - c * n_segs;
+    const uint32_t a_row = (si / segs_per_ablock) * kABlockRows + wave * kRowsPerWave;
+    const uint32_t j_lo = (si % segs_per_ablock) * seg_rows;
+    const uint32_t j_hi = min(n_rows_b, j_lo + seg_rows);
+    const uint32_t j_last = j_hi - 1;
+    const uint32_t kbase = c * kChunkWords;
+
+    uint32_t acc[4] = {0, 0, 0, 0};
+    uint32_t a_lo[kRowsPerWave], a_hi[kRowsPerWave];
+    {
+        const uint64_t* ap = XA + (uint64_t)a_row * stride_a + kbase + lane;
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r) {
+            const uint64_t v = ap[(uint64_t)r * stride_a];
+            a_lo[r] = (uint32_t)v;
+            a_hi[r] = (uint32_t)(v >> 32);
+        }
+    }
+    const uint32_t n_stages = (j_hi - j_lo + kStageRows - 1) / kStageRows;
+    stage_b_glds(lds[0], XB, stride_b, kbase, j_lo, j_last, wave, lane);
+    for (uint32_t s = 0; s < n_stages; ++s) {
+        const uint32_t j0 = j_lo + s * kStageRows;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < n_stages)
+            stage_b_glds(lds[(s + 1) & 1], XB, stride_b, kbase, j0 + kStageRows, j_last, wave,
+                         lane);
+        const uint64_t* buf = lds[s & 1];
+        const uint32_t rows = min((uint32_t)kStageRows, j_hi - j0);
+        if (rows == kStageRows) {
+            stage_compute(a_lo, a_hi, buf + lane, acc);
+        } else {
+            for (uint32_t jj = 0; jj < rows; ++jj)
+                row_step<false>(a_lo, a_hi, buf[jj * kChunkWords + lane], 0, acc);
+        }
+    }
+    const uint64_t wsum = wave_sum_u64((uint64_t)acc[0] + acc[1] + acc[2] + acc[3]);
+    if (lane == 0 && wsum != 0)
+        atomicAdd(&slots[(item * kWaves + wave) & (kSlots - 1)], (unsigned long long)wsum);
+}
+
+// Per-pair counts of one tile (tests / materialised output). One wave per pair.
+__global__ __launch_bounds__(kThreads) void tile_counts_kernel(
+    const uint64_t* __restrict__ X, uint64_t stride, uint32_t n_words, uint64_t i0, uint64_t j0,
+    uint32_t ni, uint32_t nj, uint32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t pair = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (pair >= (uint64_t)ni * nj) return;
+    const uint64_t* a = X + (i0 + pair / nj) * stride;
+    const uint64_t* b = X + (j0 + pair % nj) * stride;
+    uint32_t cnt = 0;
+    for (uint32_t k = lane; k < n_words; k += kLanes) cnt += (uint32_t)__popcll(a[k] & b[k]);
+    const uint64_t s = wave_sum_u64(cnt);
+    if (lane == 0) out[pair] = (uint32_t)s;
+}
+
+// sum_c C(n_c, 2): verification identity only. One wave per 64-bit word column,
+// lane = bit; 4 word columns per workgroup.
+__global__ __launch_bounds__(kThreads) void column_identity_kernel(
+    const uint64_t* __restrict__ X, uint64_t stride, uint64_t n_rows, uint32_t n_words,
+    unsigned long long* __restrict__ slots) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    uint64_t n = 0;
+    if (w < n_words) {
+        for (uint64_t i = 0; i < n_rows; ++i) n += (X[i * stride + w] >> lane) & 1ull;
+    }
+    const uint64_t s = wave_sum_u64(n * (n - (n != 0)) / 2);
+    if (lane == 0 && s != 0) atomicAdd(&slots[w & (kSlots - 1)], (unsigned long long)s);
+}
+
+// OR sorted position lists (CSR) into rows [row0, ...): one workgroup per row.
+__global__ __launch_bounds__(kThreads) void set_bits_kernel(uint64_t* __restrict__ X,
+                                                            uint64_t stride, uint64_t row0,
+                                                            const uint64_t* __restrict__ offsets,
+                                                            const uint32_t* __restrict__ pos) {
+    const uint64_t r = blockIdx.x;
+    unsigned long long* row = reinterpret_cast<unsigned long long*>(X + (row0 + r) * stride);
+    const uint64_t base = offsets[0];
+    for (uint64_t p = offsets[r] - base + threadIdx.x; p < offsets[r + 1] - base; p += kThreads) {
+        const uint32_t v = pos[p];
+        atomicOr(&row[v >> 6], 1ull << (v & 63u));
+    }
+}
+
+// Synthetic fill, bit-identical to storm_synth_fill_dense (storm_synth.h).
+__device__ __forceinline__ uint64_t synth_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kThreads) void synth_fill_kernel(uint64_t* __restrict__ X,
+                                                              uint64_t stride, uint64_t n_rows,
+                                                              uint64_t n_bits, uint32_t draws,
+                                                              uint64_t seed) {
+    const uint64_t total = n_rows * draws;
+    for (uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t row = t / draws;
+        const uint64_t z = synth_mix(seed + (t + 1) * 0x9E3779B97F4A7C15ull);
+        const uint64_t v = __umul64hi(z, n_bits);
+        atomicOr(reinterpret_cast<unsigned long long*>(X + row * stride + (v >> 6)),
+                 1ull << (v & 63u));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int ensure_segments(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t shard_rank,
+                           uint32_t shard_count) {
+    const uint32_t seg_len = (uint32_t)ctx->seg_rows;
+    if (ctx->d_segs && ctx->seg_rows_n == n_rows && ctx->seg_shard_rank == shard_rank &&
+        ctx->seg_shard_count == shard_count && ctx->seg_len == seg_len)
+        return STORM_HIP_OK;
+
+    // Full segments first (A-block major), the short diagonal segments last; the shard takes
+    // every shard_count-th entry of each list, so the shards partition the pair space.
+    std::vector<Seg> full, diag, mine;
+    for (uint64_t a0 = 0; a0 < n_rows; a0 += kABlockRows) {
+        const uint32_t a_end = (uint32_t)std::min<uint64_t>(a0 + kABlockRows, n_rows);
+        if (a_end - a0 > 1) diag.push_back({(uint32_t)a0, a_end, (uint32_t)a0, a_end});
+        for (uint64_t j = a0 + kABlockRows; j < n_rows; j += seg_len)
+            full.push_back({(uint32_t)a0, a_end, (uint32_t)j,
+                            (uint32_t)std::min<uint64_t>(j + seg_len, n_rows)});
+    }
+    for (size_t i = shard_rank; i < full.size(); i += shard_count) mine.push_back(full[i]);
+    // rotate the diagonal list so that rank r does not always start at the same A block
+    for (size_t i = shard_rank; i < diag.size(); i += shard_count) mine.push_back(diag[i]);
+
+    uint64_t row_sum = 0;
+    for (const Seg& s : mine) row_sum += s.j_hi - s.j_lo;
+    if (mine.size() > ctx->segs_capacity) {
+        if (ctx->d_segs) STORM_HIP_TRY(hipFree(ctx->d_segs));
+        ctx->d_segs = nullptr;
+        ctx->segs_capacity = 0;
+        const size_t cap = std::max<size_t>(mine.size(), 1024);
+        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_segs), cap * sizeof(Seg)));
+        ctx->segs_capacity = cap;
+    }
+    if (!mine.empty()) {
+        // pageable host memory: the copy is complete (staged) when the call returns
+        STORM_HIP_TRY(hipMemcpyAsync(ctx->d_segs, mine.data(), mine.size() * sizeof(Seg),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_segs = (uint32_t)mine.size();
+    ctx->seg_row_sum = row_sum;
+    ctx->seg_rows_n = n_rows;
+    ctx->seg_shard_rank = shard_rank;
+    ctx->seg_shard_count = shard_count;
+    ctx->seg_len = seg_len;
+    return STORM_HIP_OK;
+}
+
+static int check_ctx(const storm_hip_ctx_t* ctx) {
+    if (!ctx) {
+        set_error("NULL context");
+        return STORM_HIP_EINVAL;
+    }
+    return STORM_HIP_OK;
+}
+
+}  // namespace storm
+
+using namespace storm;
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+const char* storm_hip_last_error(void) { return g_error; }
+
+int storm_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int storm_hip_device_arch(int device, char* buf, size_t buflen) {
+    if (!buf || buflen == 0) return STORM_HIP_EINVAL;
+    hipDeviceProp_t prop;
+    STORM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
+    if (!out) {
+        set_error("storm_hip_ctx_create: NULL out");
+        return STORM_HIP_EINVAL;
+    }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) {
+        set_error("no HIP device visible (this library has no CPU fallback)");
+        return STORM_HIP_ENODEV;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (%d visible)", device, n);
+        return STORM_HIP_EINVAL;
+    }
+    hipDeviceProp_t prop;
+    STORM_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; this library carries gfx950 code objects only", device,
+                  prop.gcnArchName);
+        return STORM_HIP_ENODEV;
+    }
+    STORM_HIP_TRY(hipSetDevice(device));
+    storm_hip_ctx_t* ctx = new (std::nothrow) storm_hip_ctx_t();
+    if (!ctx) return STORM_HIP_ENOMEM;
+    ctx->device = device;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_slots), kSlots * sizeof(uint64_t)) !=
+            hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_scalar), 64) != hipSuccess) {
+        set_error("workspace allocation failed");
+        storm_hip_ctx_destroy(ctx);
+        return STORM_HIP_ENOMEM;
+    }
+    if (hipMemset(ctx->d_slots, 0, kSlots * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(ctx->d_scalar, 0, 64) != hipSuccess) {
+        set_error("workspace memset failed");
+        storm_hip_ctx_destroy(ctx);
+        return STORM_HIP_EHIP;
+    }
+    if (const char* v = getenv("STORM_HIP_VARIANT")) ctx->variant = atoi(v);
+    if (const char* v = getenv("STORM_HIP_SEG_ROWS")) ctx->seg_rows = atoi(v);
+    if (const char* v = getenv("STORM_HIP_CHUNKS_PER_ITEM")) ctx->chunks_per_item = atoi(v);
+    *out = ctx;
+    return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_set_stream(storm_hip_ctx_t* ctx, void* stream) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    return STORM_HIP_OK;
+}
+
+int storm_hip_ctx_synchronize(storm_hip_ctx_t* ctx) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+    if (ctx->d_segs) (void)hipFree(ctx->d_segs);
+    delete ctx;
+}
+
+int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
+    if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
+    if (!strcmp(key, "variant")) {
+        if (value < 0 || value > 2) {
+            set_error("variant must be 0, 1 or 2");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->variant = (int)value;
+    } else if (!strcmp(key, "seg_rows")) {
+        if (value < 1 || value > (1 << 20)) {
+            set_error("seg_rows out of range");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->seg_rows = (int)value;
+    } else if (!strcmp(key, "chunks_per_item")) {
+        if (value < 0 || value > 4096) {
+            set_error("chunks_per_item out of range");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->chunks_per_item = (int)value;
+    } else {
+        set_error("unknown option '%s'", key);
+        return STORM_HIP_EINVAL;
+    }
+    return STORM_HIP_OK;
+}
+
+int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
+    if (check_ctx(ctx) || !key) return -1;
+    if (!strcmp(key, "variant")) return ctx->variant;
+    if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
+    if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
+    if (!strcmp(key, "n_cus")) return ctx->n_cus;
+    return -1;
+}
+
+int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]) {
+    if (check_ctx(ctx) || !out) return STORM_HIP_EINVAL;
+    memcpy(out, ctx->last_info, sizeof(ctx->last_info));
+    return STORM_HIP_OK;
+}
+
+// ---- dense matrix ----
+int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
+                            storm_hip_matrix_t** out) {
+    if (check_ctx(ctx) || !out) return STORM_HIP_EINVAL;
+    *out = nullptr;
+    if (n_words == 0 || n_rows >= (1ull << 32) - kABlockRows) {
+        set_error("matrix shape out of range (rows=%llu words=%u)", (unsigned long long)n_rows,
+                  n_words);
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    storm_hip_matrix_t* m = new (std::nothrow) storm_hip_matrix_t();
+    if (!m) return STORM_HIP_ENOMEM;
+    m->n_rows = n_rows;
+    m->n_words = n_words;
+    m->n_rows_pad = std::max<uint64_t>(kABlockRows,
+                                       (n_rows + kABlockRows - 1) / kABlockRows * kABlockRows);
+    m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
+    const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
+    if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
+        set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);
+        delete m;
+        return STORM_HIP_ENOMEM;
+    }
+    if (hipMemsetAsync(m->d, 0, bytes, ctx->stream) != hipSuccess) {
+        set_error("hipMemsetAsync failed");
+        (void)hipFree(m->d);
+        delete m;
+        return STORM_HIP_EHIP;
+    }
+    *out = m;
+    return STORM_HIP_OK;
+}
+
+static int check_rows(const storm_hip_matrix_t* m, uint64_t row0, uint64_t n_rows) {
+    if (!m) {
+        set_error("NULL matrix");
+        return STORM_HIP_EINVAL;
+    }
+    if (row0 + n_rows > m->n_rows || row0 + n_rows < row0) {
+        set_error("rows [%llu, +%llu) outside the matrix (%llu rows)", (unsigned long long)row0,
+                  (unsigned long long)n_rows, (unsigned long long)m->n_rows);
+        return STORM_HIP_EINVAL;
+    }
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                            uint64_t n_rows, const uint64_t* host_rows,
+                            uint64_t src_stride_words) {
+    if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
+    if (n_rows == 0) return STORM_HIP_OK;
+    if (!host_rows || src_stride_words < m->n_words) {
+        set_error("upload: bad source");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemcpy2DAsync(m->d + row0 * m->stride_words, m->stride_words * 8, host_rows,
+                                   src_stride_words * 8, (size_t)m->n_words * 8, n_rows,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_import(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                            uint64_t n_rows, const void* device_rows,
+                            uint64_t src_stride_words) {
+    if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
+    if (n_rows == 0) return STORM_HIP_OK;
+    if (!device_rows || src_stride_words < m->n_words) {
+        set_error("import: bad source");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemcpy2DAsync(m->d + row0 * m->stride_words, m->stride_words * 8,
+                                   device_rows, src_stride_words * 8, (size_t)m->n_words * 8,
+                                   n_rows, hipMemcpyDeviceToDevice, ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_download(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t row0,
+                              uint64_t n_rows, uint64_t* host_rows, uint64_t dst_stride_words) {
+    if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
+    if (n_rows == 0) return STORM_HIP_OK;
+    if (!host_rows || dst_stride_words < m->n_words) {
+        set_error("download: bad destination");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemcpy2DAsync(host_rows, dst_stride_words * 8,
+                                   m->d + row0 * m->stride_words, m->stride_words * 8,
+                                   (size_t)m->n_words * 8, n_rows, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
+                                             uint64_t row0, uint64_t n_rows,
+                                             const uint64_t* offsets,
+                                             const uint32_t* positions) {
+    if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
+    if (n_rows == 0) return STORM_HIP_OK;
+    if (!offsets || (!positions && offsets[n_rows] != offsets[0])) {
+        set_error("set_rows_from_positions: NULL input");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t n_pos = offsets[n_rows] - offsets[0];
+    const uint64_t n_bits = (uint64_t)m->n_words * 64;
+    for (uint64_t p = 0; p < n_pos; ++p) {
+        if (positions[offsets[0] + p] >= n_bits) {
+            set_error("position %u outside the %llu-bit rows", positions[offsets[0] + p],
+                      (unsigned long long)n_bits);
+            return STORM_HIP_EINVAL;
+        }
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (n_pos == 0) return STORM_HIP_OK;
+    uint64_t* d_off = nullptr;
+    uint32_t* d_pos = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), (n_rows + 1) * sizeof(uint64_t)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_pos), n_pos * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipFree(d_off);
+        set_error("hipMalloc for %llu positions failed", (unsigned long long)n_pos);
+        return STORM_HIP_ENOMEM;
+    }
+    int rc = STORM_HIP_OK;
+    if (hipMemcpyAsync(d_off, offsets, (n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                       ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_pos, positions + offsets[0], n_pos * sizeof(uint32_t),
+                       hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        set_error("position upload failed");
+        rc = STORM_HIP_EHIP;
+    } else {
+        hipLaunchKernelGGL(set_bits_kernel, dim3((uint32_t)n_rows), dim3(kThreads), 0,
+                           ctx->stream, m->d, m->stride_words, row0, d_off, d_pos);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            set_error("set_bits_kernel failed");
+            rc = STORM_HIP_EHIP;
+        }
+    }
+    (void)hipFree(d_off);
+    (void)hipFree(d_pos);
+    return rc;
+}
+
+int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
+                                    uint64_t n_bits, uint32_t draws, uint64_t seed) {
+    if (check_ctx(ctx) || !m) return STORM_HIP_EINVAL;
+    if (n_bits == 0 || (n_bits + 63) / 64 != m->n_words) {
+        set_error("fill_synthetic: n_bits=%llu does not match %u words per row",
+                  (unsigned long long)n_bits, m->n_words);
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemsetAsync(m->d, 0, m->n_rows_pad * m->stride_words * 8, ctx->stream));
+    if (m->n_rows == 0 || draws == 0) return STORM_HIP_OK;
+    const uint64_t total = m->n_rows * draws;
+    const uint32_t grid =
+        (uint32_t)std::min<uint64_t>((total + kThreads - 1) / kThreads, 256u * 64u);
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(kThreads), 0, ctx->stream, m->d,
+                       m->stride_words, m->n_rows, n_bits, draws, seed);
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_clear(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
+    if (check_ctx(ctx) || !m) return STORM_HIP_EINVAL;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemsetAsync(m->d, 0, m->n_rows_pad * m->stride_words * 8, ctx->stream));
+    return STORM_HIP_OK;
+}
+
+void storm_hip_matrix_destroy(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
+    if (!m) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (m->d) (void)hipFree(m->d);
+    delete m;
+}
+
+uint64_t storm_hip_matrix_rows(const storm_hip_matrix_t* m) { return m ? m->n_rows : 0; }
+uint32_t storm_hip_matrix_words(const storm_hip_matrix_t* m) { return m ? m->n_words : 0; }
+uint64_t storm_hip_matrix_stride_words(const storm_hip_matrix_t* m) {
+    return m ? m->stride_words : 0;
+}
+void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m) { return m ? m->d : nullptr; }
+
+// ---- hot path ----
+}  // extern "C"
+
+namespace storm {
+
+int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
+                          const Seg* d_segs, uint32_t n_segs, uint64_t seg_row_sum,
+                          uint64_t* d_total) {
+    const uint32_t n_chunks = (uint32_t)(stride_words / kChunkWords);
+    uint32_t cps = (uint32_t)ctx->chunks_per_item;
+    if (cps == 0) {
+        // enough items to keep 256 CUs x 4 workgroups balanced; fewer, longer items once
+        // there are plenty (each item re-loads its A block per chunk either way)
+        const uint64_t items_at_1 = (uint64_t)n_segs * n_chunks;
+        cps = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, items_at_1 / 65536));
+    }
+    // a lane adds at most 32 rows x seg_rows x 64 bits per chunk into its uint32 accumulators
+    const uint64_t per_chunk = (uint64_t)kRowsPerWave * (uint64_t)ctx->seg_rows * 64u;
+    if (per_chunk >= (1ull << 32)) {
+        set_error("seg_rows=%d overflows the 32-bit lane accumulators", ctx->seg_rows);
+        return STORM_HIP_EINVAL;
+    }
+    while (cps > 1 && per_chunk * cps >= (1ull << 32)) --cps;
+    cps = std::max(1u, std::min(cps, n_chunks));
+    const uint32_t n_kslices = (n_chunks + cps - 1) / cps;
+    const uint64_t n_items = (uint64_t)n_segs * n_kslices;
+    if (n_items >= (1ull << 31)) {
+        set_error("work decomposition has %llu items (> 2^31): raise chunks_per_item",
+                  (unsigned long long)n_items);
+        return STORM_HIP_EINVAL;
+    }
+    ctx->last_info[0] = n_items;
+    ctx->last_info[1] = cps;
+    ctx->last_info[2] = (uint64_t)kABlockRows * seg_row_sum * stride_words;
+    ctx->last_info[3] = n_segs;
+
+    if (n_items > 0) {
+        const dim3 grid((uint32_t)n_items), block(kThreads);
+        switch (ctx->variant) {
+            case 0:
+                hipLaunchKernelGGL(pairw_dense_kernel<0>, grid, block, 0, ctx->stream, X,
+                                   stride_words, d_segs, n_segs, n_chunks, cps, ctx->d_slots);
+                break;
+            case 1:
+                hipLaunchKernelGGL(pairw_dense_kernel<1>, grid, block, 0, ctx->stream, X,
+                                   stride_words, d_segs, n_segs, n_chunks, cps, ctx->d_slots);
+                break;
+            default:
+                hipLaunchKernelGGL(pairw_dense_kernel<2>, grid, block, 0, ctx->stream, X,
+                                   stride_words, d_segs, n_segs, n_chunks, cps, ctx->d_slots);
+                break;
+        }
+        STORM_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
+                       reinterpret_cast<unsigned long long*>(d_total));
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+
+}  // namespace storm
+
+extern "C" {
+
+int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                 uint32_t shard_rank, uint32_t shard_count, uint64_t* d_total) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !d_total) {
+        set_error("pairw_dense: NULL matrix or result pointer");
+        return STORM_HIP_EINVAL;
+    }
+    if (shard_count == 0 || shard_rank >= shard_count) {
+        set_error("pairw_dense: shard %u of %u is not valid", shard_rank, shard_count);
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
+    return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
+                                 ctx->seg_row_sum, d_total);
+}
+
+int storm_hip_pairw_dense_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                uint32_t shard_rank, uint32_t shard_count) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    return storm_hip_pairw_dense_launch(ctx, m, shard_rank, shard_count,
+                                        reinterpret_cast<uint64_t*>(ctx->d_scalar));
+}
+
+int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!h_total) {
+        set_error("pairw_dense_end: NULL result pointer");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                          uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total) {
+    if (int rc = storm_hip_pairw_dense_begin(ctx, m, shard_rank, shard_count)) return rc;
+    return storm_hip_pairw_dense_end(ctx, h_total);
+}
+
+int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                           const storm_hip_matrix_t* b, uint64_t* h_total) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!a || !b || !h_total) {
+        set_error("square_dense: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    if (a->n_words != b->n_words) {
+        set_error("square_dense: row widths differ (%u vs %u words)", a->n_words, b->n_words);
+        return STORM_HIP_EINVAL;
+    }
+    *h_total = 0;
+    if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t seg_rows = (uint32_t)ctx->seg_rows;
+    const uint32_t a_blocks = (uint32_t)(a->n_rows_pad / kABlockRows);
+    const uint32_t spb = (uint32_t)((b->n_rows + seg_rows - 1) / seg_rows);
+    const uint32_t n_segs = a_blocks * spb;
+    const uint32_t n_chunks = (uint32_t)(a->stride_words / kChunkWords);
+    const uint64_t n_items = (uint64_t)n_segs * n_chunks;
+    if (n_items >= (1ull << 31)) {
+        set_error("square_dense: too many work items");
+        return STORM_HIP_EINVAL;
+    }
+    hipLaunchKernelGGL(square_dense_kernel, dim3((uint32_t)n_items), dim3(kThreads), 0,
+                       ctx->stream, a->d, a->stride_words, b->d, b->stride_words,
+                       (uint32_t)b->n_rows, seg_rows, spb, n_segs, n_chunks, ctx->d_slots);
+    STORM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
+                       ctx->d_scalar);
+    STORM_HIP_TRY(hipGetLastError());
+    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t i0,
+                          uint64_t i1, uint64_t j0, uint64_t j1, uint32_t* h_out) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !h_out || i1 < i0 || j1 < j0 || i1 > m->n_rows || j1 > m->n_rows) {
+        set_error("tile_counts: bad tile");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t ni = i1 - i0, nj = j1 - j0, n = ni * nj;
+    if (n == 0) return STORM_HIP_OK;
+    if (n >= (1ull << 31) || ni >= (1ull << 31) || nj >= (1ull << 31)) {
+        set_error("tile_counts: tile too large");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t* d_out = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(uint32_t)));
+    hipLaunchKernelGGL(tile_counts_kernel, dim3((uint32_t)((n + kWaves - 1) / kWaves)),
+                       dim3(kThreads), 0, ctx->stream, m->d, m->stride_words, m->n_words, i0, j0,
+                       (uint32_t)ni, (uint32_t)nj, d_out);
+    int rc = STORM_HIP_OK;
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(h_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) !=
+            hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        set_error("tile_counts kernel/copy failed");
+        rc = STORM_HIP_EHIP;
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                              uint64_t* h_total) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !h_total) {
+        set_error("column_identity: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(column_identity_kernel, dim3((m->n_words + kWaves - 1) / kWaves),
+                       dim3(kThreads), 0, ctx->stream, m->d, m->stride_words, m->n_rows,
+                       m->n_words, ctx->d_slots);
+    STORM_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
+                       ctx->d_scalar);
+    STORM_HIP_TRY(hipGetLastError());
+    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+}  // extern "C"

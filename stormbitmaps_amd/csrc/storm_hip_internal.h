@@ -1,0 +1,82 @@
+// storm_hip_internal.h — shared between the .hip translation units of libstorm_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "storm_hip.h"
+
+struct storm_hip_ctx_s;
+typedef struct storm_hip_ctx_s storm_hip_ctx_t;
+
+namespace storm {
+
+void set_error(const char* fmt, ...);
+
+#define STORM_HIP_TRY(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::storm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                               __FILE__, __LINE__);                                          \
+            return STORM_HIP_EHIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+// Geometry of the dense kernel (see DESIGN.md "K1").
+constexpr int kLanes = 64;                           // gfx950 wavefront
+constexpr int kWaves = 4;                            // waves per workgroup
+constexpr int kThreads = kLanes * kWaves;            // 256
+constexpr int kChunkWords = 64;                      // k-chunk: one 64-bit word per lane
+constexpr int kRowsPerWave = 32;                     // A rows held in VGPRs by one wave
+constexpr int kABlockRows = kWaves * kRowsPerWave;   // 128 A rows per workgroup
+constexpr int kStageRows = 32;                       // B rows per LDS stage
+constexpr int kSlots = 4096;                         // partial-sum slots (uint64 each)
+
+struct Seg {            // one (A block, B row range) segment of the upper triangle
+    uint32_t a_row0;    // first A row of the block (kABlockRows rows are loaded from here)
+    uint32_t a_end;     // A rows >= a_end are treated as all-zero (block-column / matrix edge)
+    uint32_t j_lo;      // B rows [j_lo, j_hi)
+    uint32_t j_hi;      // j_lo == a_row0 marks a diagonal segment: count only pairs i < j
+};
+
+// shared launcher of the dense kernel over an arbitrary segment table (dense + sparse paths)
+int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
+                          const Seg* d_segs, uint32_t n_segs, uint64_t seg_row_sum,
+                          uint64_t* d_total);
+
+}  // namespace storm
+
+struct storm_hip_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cus = 0;
+    // workspace
+    unsigned long long* d_slots = nullptr;   // kSlots partial sums
+    unsigned long long* d_scalar = nullptr;  // one uint64 result
+    storm::Seg* d_segs = nullptr;            // segment table of the last geometry
+    size_t segs_capacity = 0;
+    // cache key of d_segs
+    uint64_t seg_rows_n = 0;
+    uint32_t seg_shard_rank = 0, seg_shard_count = 0, seg_len = 0;
+    uint32_t n_segs = 0;
+    uint64_t seg_row_sum = 0;  // sum over segments of (j_hi - j_lo)
+    // options
+    int variant = 2;
+    int seg_rows = 256;
+    int chunks_per_item = 0;
+    // info of the last dense launch
+    uint64_t last_info[4] = {0, 0, 0, 0};
+    uint64_t sparse_census[4] = {0, 0, 0, 0};
+};
+
+struct storm_hip_matrix_s {
+    uint64_t* d = nullptr;
+    uint64_t n_rows = 0;        // logical rows
+    uint64_t n_rows_pad = 0;    // allocated rows (multiple of kABlockRows)
+    uint32_t n_words = 0;       // logical words per row
+    uint64_t stride_words = 0;  // allocated words per row (multiple of kChunkWords)
+};

@@ -1,0 +1,939 @@
+/*
+ * storm_host.c — host side (C) of the storm.h API served by libstorm_hip.so.
+ *
+ * Containers are built on the host exactly as a caller of the reference expects (same public
+ * struct members, same growth steps, same return codes; reference lines cited per function),
+ * and every ALL-PAIRS entry point hands the data to the MI355X through the C-ABI shim of
+ * storm_hip.h. Nothing in this file computes an all-pairs total on the CPU: if the device
+ * path fails the entry points return (uint64_t)-1 and STORM_hip_error() says why.
+ *
+ * The only CPU arithmetic here is in the ONE-PAIR helpers of the reference API
+ * (STORM_bitmap_intersect_cardinality & co., STORM_intersect_*): they answer a question
+ * about two host-resident blocks and are never called by the all-pairs functions.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "storm.h"
+#include "storm_hip.h"
+
+#define BLOCK_BITS ((uint32_t)STORM_DEFAULT_BLOCK_SIZE)
+#define BLOCK_WORDS (BLOCK_BITS / 64u)
+#define MAX_DEVICES 16
+#define ALL_PAIRS_FAILED ((uint64_t)-1)
+
+/* ------------------------------------------------------------------------------------------
+ * device runtime state (process-wide, like the reference: no locking, single caller thread)
+ * ---------------------------------------------------------------------------------------- */
+static int g_n_devices = 0; /* 0 = not configured yet */
+static int g_device_ids[MAX_DEVICES];
+static storm_hip_ctx_t* g_ctx[MAX_DEVICES];
+static uint32_t g_shard_rank = 0, g_shard_count = 1;
+static char g_host_error[256] = "";
+
+const char* STORM_hip_error(void) {
+    return g_host_error[0] ? g_host_error : storm_hip_last_error();
+}
+
+static void host_error(const char* msg) {
+    snprintf(g_host_error, sizeof(g_host_error), "%s", msg);
+    fprintf(stderr, "[storm_hip] %s\n", msg);
+}
+
+static void device_error(const char* where) {
+    g_host_error[0] = '\0';
+    fprintf(stderr, "[storm_hip] %s: %s\n", where, storm_hip_last_error());
+}
+
+int STORM_hip_set_devices(int n_devices, const int* device_ids) {
+    if (n_devices < 1 || n_devices > MAX_DEVICES || !device_ids) return -1;
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        if (g_ctx[d]) storm_hip_ctx_destroy(g_ctx[d]);
+        g_ctx[d] = NULL;
+    }
+    for (int d = 0; d < n_devices; ++d) g_device_ids[d] = device_ids[d];
+    g_n_devices = n_devices;
+    return 0;
+}
+
+int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count) {
+    if (shard_count == 0 || shard_rank >= shard_count) return -1;
+    g_shard_rank = shard_rank;
+    g_shard_count = shard_count;
+    return 0;
+}
+
+/* STORM_HIP_DEVICES = "all" | "0,2,3";  STORM_HIP_SHARD = "rank/count" */
+static void configure_from_env(void) {
+    if (g_n_devices != 0) return;
+    const char* devs = getenv("STORM_HIP_DEVICES");
+    if (devs && !strcmp(devs, "all")) {
+        int n = storm_hip_device_count();
+        if (n > MAX_DEVICES) n = MAX_DEVICES;
+        for (int d = 0; d < n; ++d) g_device_ids[d] = d;
+        g_n_devices = n > 0 ? n : 1;
+    } else if (devs && devs[0]) {
+        int n = 0;
+        const char* p = devs;
+        while (*p && n < MAX_DEVICES) {
+            g_device_ids[n++] = (int)strtol(p, (char**)&p, 10);
+            if (*p == ',') ++p;
+        }
+        g_n_devices = n > 0 ? n : 1;
+    } else {
+        g_device_ids[0] = 0;
+        g_n_devices = 1;
+    }
+    const char* shard = getenv("STORM_HIP_SHARD");
+    unsigned r = 0, c = 1;
+    if (shard && sscanf(shard, "%u/%u", &r, &c) == 2 && c > 0 && r < c) {
+        g_shard_rank = r;
+        g_shard_count = c;
+    }
+}
+
+static storm_hip_ctx_t* device_ctx(int slot) {
+    configure_from_env();
+    if (slot < 0 || slot >= g_n_devices) return NULL;
+    if (!g_ctx[slot]) {
+        if (storm_hip_ctx_create(g_device_ids[slot], NULL, &g_ctx[slot]) != STORM_HIP_OK) {
+            device_error("storm_hip_ctx_create");
+            g_ctx[slot] = NULL;
+        }
+    }
+    return g_ctx[slot];
+}
+
+/* a STORM_compute_func is only an identity token on the device path (libalgebra.h) */
+static int leaf_is_ours(STORM_compute_func f) {
+    return f == NULL || f == STORM_intersect_count_scalar;
+}
+static int lleaf_is_ours(STORM_compute_lfunc f) {
+    return f == NULL || f == (STORM_compute_lfunc)STORM_intersect_count_scalar_list;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * libalgebra surface
+ * ---------------------------------------------------------------------------------------- */
+uint64_t STORM_intersect_count_scalar(const uint64_t* STORM_RESTRICT b1,
+                                      const uint64_t* STORM_RESTRICT b2, const size_t n) {
+    uint64_t total = 0;
+    for (size_t k = 0; k < n; ++k) total += (uint64_t)__builtin_popcountll(b1[k] & b2[k]);
+    return total;
+}
+
+uint64_t STORM_intersect_count_scalar_list(const uint64_t* STORM_RESTRICT b1,
+                                           const uint64_t* STORM_RESTRICT b2,
+                                           const uint32_t* STORM_RESTRICT l1,
+                                           const uint32_t* STORM_RESTRICT l2, const size_t n1,
+                                           const size_t n2) {
+    return STORM_intersect_bitmaps_scalar_list(b1, b2, l1, l2, (uint32_t)n1, (uint32_t)n2);
+}
+
+STORM_compute_func STORM_get_intersect_count_func(const size_t n_bitmaps_vector) {
+    (void)n_bitmaps_vector;
+    return STORM_intersect_count_scalar;
+}
+
+uint32_t STORM_get_alignment(void) { return 64; }
+
+void* STORM_aligned_malloc(size_t alignment, size_t size) {
+    void* p = NULL;
+    if (alignment < sizeof(void*)) alignment = sizeof(void*);
+    if (size == 0) size = alignment;
+    return posix_memalign(&p, alignment, size) == 0 ? p : NULL;
+}
+
+void STORM_aligned_free(void* memblock) { free(memblock); }
+
+int STORM_get_cpuid(void) {
+    int bits = 0;
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("sse4.2")) bits |= STORM_CPUID_runtime_bit_SSE42;
+    if (__builtin_cpu_supports("avx2")) bits |= STORM_CPUID_runtime_bit_AVX2;
+    if (__builtin_cpu_supports("avx512bw")) bits |= STORM_CPUID_runtime_bit_AVX512BW;
+    if (storm_hip_device_count() > 0) bits |= STORM_CPUID_runtime_bit_GFX950;
+    return bits;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * one-pair list helpers (reference storm.c:4-129)
+ * ---------------------------------------------------------------------------------------- */
+uint64_t STORM_intersect_vector16_cardinality(const uint16_t* STORM_RESTRICT v1,
+                                              const uint16_t* STORM_RESTRICT v2,
+                                              const uint32_t len1, const uint32_t len2) {
+    uint64_t common = 0;
+    uint32_t i = 0, j = 0;
+    while (i < len1 && j < len2) {
+        if (v1[i] < v2[j]) ++i;
+        else if (v2[j] < v1[i]) ++j;
+        else { ++common; ++i; ++j; }
+    }
+    return common;
+}
+
+uint64_t STORM_intersect_vector32_unsafe(const uint32_t* STORM_RESTRICT v1,
+                                         const uint32_t* STORM_RESTRICT v2, const uint32_t len1,
+                                         const uint32_t len2, uint32_t* STORM_RESTRICT out) {
+    if (!out || !v1 || !v2 || !len1 || !len2) return 0; /* storm.c:81-84 */
+    uint64_t n = 0;
+    uint32_t i = 0, j = 0;
+    while (i < len1 && j < len2) {
+        if (v1[i] < v2[j]) ++i;
+        else if (v2[j] < v1[i]) ++j;
+        else { out[n++] = i++; out[n++] = j++; }
+    }
+    return n; /* 2 x matches: interleaved (index in v1, index in v2) */
+}
+
+static inline uint64_t probe(const uint64_t* words, uint32_t pos) {
+    return (words[pos >> 6] >> (pos & 63u)) & 1u;
+}
+
+uint64_t STORM_intersect_bitmaps_scalar_list(const uint64_t* STORM_RESTRICT b1,
+                                             const uint64_t* STORM_RESTRICT b2,
+                                             const uint32_t* l1, const uint32_t* l2,
+                                             const uint32_t n1, const uint32_t n2) {
+    uint64_t count = 0; /* the shorter list probes the other row (storm.c:116-126) */
+    if (n1 < n2) {
+        for (uint32_t k = 0; k < n1; ++k) count += probe(b2, l1[k]);
+    } else {
+        for (uint32_t k = 0; k < n2; ++k) count += probe(b1, l2[k]);
+    }
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * dense all-pairs on the device
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    storm_hip_matrix_t* m[MAX_DEVICES];
+} dense_state_t;
+
+static void dense_state_release(dense_state_t* st) {
+    if (!st) return;
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        if (st->m[d]) storm_hip_matrix_destroy(g_ctx[d], st->m[d]);
+        st->m[d] = NULL;
+    }
+}
+
+/* replicate `n_rows` host rows on every configured device (one replica per GPU) */
+static int dense_state_upload(dense_state_t* st, const uint64_t* rows, uint64_t n_rows,
+                              uint32_t n_words, uint64_t stride_words) {
+    configure_from_env();
+    for (int d = 0; d < g_n_devices; ++d) {
+        storm_hip_ctx_t* ctx = device_ctx(d);
+        if (!ctx) return -1;
+        if (storm_hip_matrix_create(ctx, n_rows, n_words, &st->m[d]) != STORM_HIP_OK ||
+            storm_hip_matrix_upload(ctx, st->m[d], 0, n_rows, rows, stride_words) !=
+                STORM_HIP_OK) {
+            device_error("dense upload");
+            return -1;
+        }
+    }
+    return 0;
+}
+
+/* all configured devices work concurrently on disjoint shards; the host adds the partials */
+static uint64_t dense_state_pairw(dense_state_t* st) {
+    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
+    for (int d = 0; d < g_n_devices; ++d) {
+        const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+        if (storm_hip_pairw_dense_begin(g_ctx[d], st->m[d], rank, world) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_dense_begin");
+            return ALL_PAIRS_FAILED;
+        }
+    }
+    uint64_t total = 0;
+    for (int d = 0; d < g_n_devices; ++d) {
+        uint64_t part = 0;
+        if (storm_hip_pairw_dense_end(g_ctx[d], &part) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_dense_end");
+            return ALL_PAIRS_FAILED;
+        }
+        total += part;
+    }
+    return total;
+}
+
+static uint64_t raw_pairw(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints) {
+    if (n_vectors < 2 || n_ints == 0) return 0;
+    if (!vals) {
+        host_error("all-pairs wrapper: NULL buffer");
+        return ALL_PAIRS_FAILED;
+    }
+    dense_state_t st;
+    memset(&st, 0, sizeof(st));
+    uint64_t total = ALL_PAIRS_FAILED;
+    if (dense_state_upload(&st, vals, n_vectors, n_ints, n_ints) == 0)
+        total = dense_state_pairw(&st);
+    dense_state_release(&st);
+    return total;
+}
+
+/* reference storm.c:132-150 */
+uint64_t STORM_wrapper_diag(const uint32_t n_vectors, const uint64_t* vals,
+                            const uint32_t n_ints, const STORM_compute_func f) {
+    if (!leaf_is_ours(f)) {
+        host_error("STORM_wrapper_diag: foreign STORM_compute_func cannot run on the device");
+        return ALL_PAIRS_FAILED;
+    }
+    return raw_pairw(n_vectors, vals, n_ints);
+}
+
+/* reference storm.c:222-279 — block_size is a CPU cache hint, ignored */
+uint64_t STORM_wrapper_diag_blocked(const uint32_t n_vectors, const uint64_t* vals,
+                                    const uint32_t n_ints, const STORM_compute_func f,
+                                    uint32_t block_size) {
+    (void)block_size;
+    return STORM_wrapper_diag(n_vectors, vals, n_ints, f);
+}
+
+/* reference storm.c:190-219 */
+uint64_t STORM_wrapper_diag_list(const uint32_t n_vectors, const uint64_t* STORM_RESTRICT vals,
+                                 const uint32_t n_ints, const uint32_t* STORM_RESTRICT n_alts,
+                                 const uint32_t* STORM_RESTRICT alt_positions,
+                                 const uint32_t* STORM_RESTRICT alt_offsets,
+                                 const STORM_compute_func f, const STORM_compute_lfunc fl,
+                                 const uint32_t cutoff) {
+    (void)n_alts; (void)alt_positions; (void)alt_offsets; (void)cutoff;
+    if (!leaf_is_ours(f) || !lleaf_is_ours(fl)) {
+        host_error("STORM_wrapper_diag_list: foreign leaf cannot run on the device");
+        return ALL_PAIRS_FAILED;
+    }
+    return raw_pairw(n_vectors, vals, n_ints);
+}
+
+/* reference storm.c:282-369 */
+uint64_t STORM_wrapper_diag_list_blocked(const uint32_t n_vectors,
+                                         const uint64_t* STORM_RESTRICT vals,
+                                         const uint32_t n_ints,
+                                         const uint32_t* STORM_RESTRICT n_alts,
+                                         const uint32_t* STORM_RESTRICT alt_positions,
+                                         const uint32_t* STORM_RESTRICT alt_offsets,
+                                         const STORM_compute_func f,
+                                         const STORM_compute_lfunc fl, const uint32_t cutoff,
+                                         uint32_t block_size) {
+    (void)block_size;
+    return STORM_wrapper_diag_list(n_vectors, vals, n_ints, n_alts, alt_positions, alt_offsets,
+                                   f, fl, cutoff);
+}
+
+/* reference storm.c:153-171 (rectangle; device 0 only) */
+uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_RESTRICT vals1,
+                              const uint32_t n_vectors2, const uint64_t* STORM_RESTRICT vals2,
+                              const uint32_t n_ints, const STORM_compute_func f) {
+    if (!leaf_is_ours(f)) {
+        host_error("STORM_wrapper_square: foreign STORM_compute_func cannot run on the device");
+        return ALL_PAIRS_FAILED;
+    }
+    if (n_vectors1 == 0 || n_vectors2 == 0 || n_ints == 0) return 0;
+    if (!vals1 || !vals2) {
+        host_error("STORM_wrapper_square: NULL buffer");
+        return ALL_PAIRS_FAILED;
+    }
+    storm_hip_ctx_t* ctx = device_ctx(0);
+    if (!ctx) return ALL_PAIRS_FAILED;
+    storm_hip_matrix_t *a = NULL, *b = NULL;
+    uint64_t total = ALL_PAIRS_FAILED;
+    if (storm_hip_matrix_create(ctx, n_vectors1, n_ints, &a) == STORM_HIP_OK &&
+        storm_hip_matrix_create(ctx, n_vectors2, n_ints, &b) == STORM_HIP_OK &&
+        storm_hip_matrix_upload(ctx, a, 0, n_vectors1, vals1, n_ints) == STORM_HIP_OK &&
+        storm_hip_matrix_upload(ctx, b, 0, n_vectors2, vals2, n_ints) == STORM_HIP_OK &&
+        storm_hip_square_dense(ctx, a, b, &total) == STORM_HIP_OK) {
+        /* total set */
+    } else {
+        device_error("STORM_wrapper_square");
+        total = ALL_PAIRS_FAILED;
+    }
+    storm_hip_matrix_destroy(ctx, a);
+    storm_hip_matrix_destroy(ctx, b);
+    return total;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_contiguous_t (reference storm.h:188-200, storm.c:1001-1346)
+ * ---------------------------------------------------------------------------------------- */
+STORM_contiguous_t* STORM_contig_new(size_t vector_length) {
+    STORM_contiguous_t* h = (STORM_contiguous_t*)calloc(1, sizeof(*h));
+    if (!h) return NULL; /* storm.c:1003 */
+    h->vector_length = vector_length;
+    h->n_bitmaps_vector = (uint32_t)((vector_length + 63) / 64);            /* storm.c:1013 */
+    h->alignment = STORM_get_alignment();
+    h->intsec_func = STORM_get_intersect_count_func(h->n_bitmaps_vector);
+    h->scalar_cutoff = (uint32_t)(vector_length / 200 > 200 ? 200 : vector_length / 200); /* :1016 */
+    return h;
+}
+
+static void contig_drop_device(STORM_contiguous_t* h) {
+    if (h->hip_matrix) {
+        dense_state_release((dense_state_t*)h->hip_matrix);
+        free(h->hip_matrix);
+        h->hip_matrix = NULL;
+    }
+    h->hip_rows_synced = 0;
+}
+
+void STORM_contig_free(STORM_contiguous_t* h) {
+    if (!h) return;
+    contig_drop_device(h);
+    STORM_aligned_free(h->data);
+    STORM_aligned_free(h->scalar);
+    STORM_aligned_free(h->n_scalar);
+    free(h->bitmaps);
+    free(h->scalar_offset);
+    free(h); /* the reference leaks the handle (storm.c:1020-1029); callers never free it */
+}
+
+/* rows grow by 512 (storm.c:1046, :1082); returns 0 on success */
+static int contig_reserve_rows(STORM_contiguous_t* h) {
+    if (h->data && h->n_data < h->m_data) return 0;
+    const uint64_t new_m = h->m_data + 512;
+    const size_t W = h->n_bitmaps_vector;
+    uint64_t* nd = (uint64_t*)STORM_aligned_malloc(h->alignment, new_m * W * sizeof(uint64_t));
+    uint32_t* nn = (uint32_t*)STORM_aligned_malloc(h->alignment, new_m * sizeof(uint32_t));
+    STORM_contiguous_bitmap_t* nb =
+        (STORM_contiguous_bitmap_t*)realloc(h->bitmaps, new_m * sizeof(*nb));
+    uint64_t* no = (uint64_t*)realloc(h->scalar_offset, new_m * sizeof(uint64_t));
+    if (nb) h->bitmaps = nb;
+    if (no) h->scalar_offset = no;
+    if (!nd || !nn || !nb || !no) {
+        STORM_aligned_free(nd);
+        STORM_aligned_free(nn);
+        return -1;
+    }
+    memset(nd, 0, new_m * W * sizeof(uint64_t));
+    if (h->data) memcpy(nd, h->data, h->n_data * W * sizeof(uint64_t));
+    if (h->n_scalar) memcpy(nn, h->n_scalar, h->n_data * sizeof(uint32_t));
+    STORM_aligned_free(h->data);
+    STORM_aligned_free(h->n_scalar);
+    h->data = nd;
+    h->n_scalar = nn;
+    h->m_data = new_m;
+    return 0;
+}
+
+/* the per-row views (storm.h:181-186) always follow the current buffers */
+static void contig_rebuild_views(STORM_contiguous_t* h) {
+    for (uint64_t i = 0; i < h->m_data; ++i) {
+        h->bitmaps[i].data = h->data + i * h->n_bitmaps_vector;
+        if (i < h->n_data) {
+            h->bitmaps[i].n_scalar = h->n_scalar[i];
+            h->bitmaps[i].scalar = h->scalar + h->scalar_offset[i];
+        } else {
+            h->bitmaps[i].n_scalar = 0;
+            h->bitmaps[i].scalar = NULL;
+        }
+    }
+}
+
+int STORM_contig_add(STORM_contiguous_t* h, const uint32_t* values, const uint32_t n_values) {
+    if (!h) return -1;
+    if (!values) return -2;
+    if (n_values == 0) return 0; /* no row appended, storm.c:1034 */
+
+    int views_stale = 0;
+    if (!h->scalar) { /* storm.c:1037-1041 */
+        h->m_scalar = 512 * 32;
+        h->tot_scalar = 0;
+        h->scalar = (uint32_t*)STORM_aligned_malloc(h->alignment, h->m_scalar * sizeof(uint32_t));
+        if (!h->scalar) return -3;
+        views_stale = 1;
+    }
+    if (!h->data || h->n_data >= h->m_data) {
+        if (contig_reserve_rows(h)) return -3;
+        views_stale = 1;
+    }
+    if (h->tot_scalar + n_values >= h->m_scalar) { /* storm.c:1060-1073 */
+        const uint64_t add = (uint64_t)5 * n_values < 65535 ? 65535 : (uint64_t)5 * n_values;
+        uint32_t* ns =
+            (uint32_t*)STORM_aligned_malloc(h->alignment, (h->m_scalar + add) * sizeof(uint32_t));
+        if (!ns) return -3;
+        memcpy(ns, h->scalar, h->tot_scalar * sizeof(uint32_t));
+        STORM_aligned_free(h->scalar);
+        h->scalar = ns;
+        h->m_scalar += add;
+        views_stale = 1;
+    }
+    if (views_stale) contig_rebuild_views(h);
+
+    uint64_t* row = h->data + h->n_data * h->n_bitmaps_vector;
+    uint32_t distinct = 0;
+    for (uint32_t k = 0; k < n_values; ++k) { /* storm.c:1103-1115 */
+        if (k != 0 && values[k] == values[k - 1]) continue;
+        assert(k == 0 || values[k] > values[k - 1]);
+        assert(values[k] < h->n_bitmaps_vector * 64ull);
+        row[values[k] >> 6] |= 1ULL << (values[k] & 63u);
+        ++distinct;
+    }
+    h->scalar_offset[h->n_data] = h->tot_scalar;
+    h->bitmaps[h->n_data].scalar = h->scalar + h->tot_scalar;
+    if (distinct < h->scalar_cutoff) { /* storm.c:1119-1129; list kept compact */
+        uint32_t* dst = h->scalar + h->tot_scalar;
+        uint32_t w = 0;
+        for (uint32_t k = 0; k < n_values; ++k) {
+            if (k != 0 && values[k] == values[k - 1]) continue;
+            dst[w++] = values[k];
+        }
+        h->tot_scalar += distinct;
+    }
+    h->n_scalar[h->n_data] = distinct; /* storm.c:1132-1134 */
+    h->bitmaps[h->n_data].n_scalar = distinct;
+    ++h->n_data;
+    return (int)n_values;
+}
+
+int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
+    if (!h) return -1;
+    if (!h->data) return 0;
+    memset(h->data, 0, (size_t)h->n_bitmaps_vector * h->m_data * sizeof(uint64_t));
+    h->n_data = 0;
+    h->tot_scalar = 0;
+    contig_drop_device(h);
+    return 1;
+}
+
+/* the device mirror is rebuilt whenever rows were added since the last all-pairs call */
+static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
+    if (h->n_data < 2) return 0;
+    if (!h->hip_matrix || h->hip_rows_synced != h->n_data) {
+        contig_drop_device(h);
+        dense_state_t* st = (dense_state_t*)calloc(1, sizeof(*st));
+        if (!st) return ALL_PAIRS_FAILED;
+        h->hip_matrix = st;
+        if (dense_state_upload(st, h->data, h->n_data, h->n_bitmaps_vector,
+                               h->n_bitmaps_vector) != 0) {
+            contig_drop_device(h);
+            return ALL_PAIRS_FAILED;
+        }
+        h->hip_rows_synced = h->n_data;
+        h->hip_rows_capacity = h->n_data;
+    }
+    return dense_state_pairw((dense_state_t*)h->hip_matrix);
+}
+
+uint64_t STORM_contig_pairw_intersect_cardinality(STORM_contiguous_t* h) { /* :1149-1173 */
+    if (!h) return (uint64_t)-1;
+    return contig_pairw_device(h);
+}
+
+uint64_t STORM_contig_pairw_intersect_cardinality_blocked(STORM_contiguous_t* h,
+                                                          uint32_t bsize) { /* :1175-1241 */
+    (void)bsize;
+    if (!h) return (uint64_t)-1;
+    return contig_pairw_device(h);
+}
+
+uint64_t STORM_contig_pairw_intersect_cardinality_list(STORM_contiguous_t* h) { /* :1243-1263 */
+    if (!h) return (uint64_t)-1;
+    if (!h->scalar) return (uint64_t)-2;
+    if (!h->n_scalar) return (uint64_t)-3;
+    return contig_pairw_device(h);
+}
+
+uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_t* h,
+                                                               uint32_t bsize) { /* :1265-1346 */
+    (void)bsize;
+    return STORM_contig_pairw_intersect_cardinality_list(h);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_bitmap_t — one 65536-bit block (reference storm.c:372-380, :398-656)
+ * ---------------------------------------------------------------------------------------- */
+void STORM_bitmap_init(STORM_bitmap_t* b) {
+    if (!b) return;
+    memset(b, 0, sizeof(*b));
+    b->own_data = 1;
+    b->own_scalar = 1;
+}
+
+STORM_bitmap_t* STORM_bitmap_new() {
+    STORM_bitmap_t* b = (STORM_bitmap_t*)STORM_aligned_malloc(64, sizeof(*b));
+    STORM_bitmap_init(b);
+    return b;
+}
+
+static void bitmap_release_buffers(STORM_bitmap_t* b) {
+    if (b->own_data) STORM_aligned_free(b->data);
+    if (b->own_scalar) STORM_aligned_free(b->scalar);
+    b->data = NULL;
+    b->scalar = NULL;
+}
+
+void STORM_bitmap_free(STORM_bitmap_t* b) {
+    if (!b) return;
+    bitmap_release_buffers(b);
+    STORM_aligned_free(b);
+}
+
+static int bitmap_ensure_words(STORM_bitmap_t* b) {
+    if (!b->data) {
+        b->data = (uint64_t*)STORM_aligned_malloc(STORM_get_alignment(), BLOCK_WORDS * 8);
+        if (!b->data) return -1;
+        memset(b->data, 0, BLOCK_WORDS * 8);
+    }
+    b->n_bitmap = BLOCK_WORDS;
+    return 0;
+}
+
+static int bitmap_ensure_list(STORM_bitmap_t* b, uint32_t extra) {
+    if (b->scalar && b->n_scalar + extra <= b->m_scalar) return 0;
+    const uint32_t new_m = b->scalar ? b->n_scalar + extra + 1024 : (extra > 256 ? extra + 256 : 256);
+    uint16_t* nl = (uint16_t*)STORM_aligned_malloc(STORM_get_alignment(), new_m * sizeof(uint16_t));
+    if (!nl) return -1;
+    if (b->scalar) memcpy(nl, b->scalar, b->n_scalar * sizeof(uint16_t));
+    if (b->own_scalar) STORM_aligned_free(b->scalar);
+    b->scalar = nl;
+    b->m_scalar = new_m;
+    b->own_scalar = 1;
+    return 0;
+}
+
+/* bitmap kind: reference storm.c:442-465 (-1 / -2 / -3 for NULL handle / NULL values / empty) */
+int STORM_bitmap_add(STORM_bitmap_t* b, const uint32_t* values, const uint32_t n_values) {
+    if (!b) return -1;
+    if (!values) return -2;
+    if (n_values == 0) return -3;
+    if (bitmap_ensure_words(b)) return -5;
+    const uint32_t base = b->id * BLOCK_BITS;
+    for (uint32_t k = 0; k < n_values; ++k) {
+        const uint32_t v = values[k] - base;
+        assert(values[k] >= base && v < BLOCK_BITS);
+        b->n_bits_set += (uint32_t)(probe(b->data, v) == 0);
+        b->data[v >> 6] |= 1ULL << (v & 63u);
+    }
+    return (int)n_values;
+}
+
+/* both representations: reference storm.c:468-518 (-1 / -3 / -4) */
+int STORM_bitmap_add_with_scalar(STORM_bitmap_t* b, const uint32_t* values,
+                                 const uint32_t n_values) {
+    if (!b) return -1;
+    if (!values) return -3;
+    if (n_values == 0) return -4;
+    if (bitmap_ensure_words(b) || bitmap_ensure_list(b, n_values)) return -5;
+    const uint32_t base = b->id * BLOCK_BITS;
+    b->n_scalar_set = 1;
+    for (uint32_t k = 0; k < n_values; ++k) {
+        const uint32_t v = values[k] - base;
+        assert(values[k] >= base && v < BLOCK_BITS);
+        if (probe(b->data, v) == 0) {
+            b->data[v >> 6] |= 1ULL << (v & 63u);
+            b->scalar[b->n_scalar] = (uint16_t)v;
+            b->n_scalar = b->n_scalar + 1;
+            ++b->n_bits_set;
+        }
+    }
+    return (int)n_values;
+}
+
+/* list kind: reference storm.c:521-558 (-1 / -3 / -4); equal neighbours stored once so the
+ * list stays duplicate-free, which the list intersections require */
+int STORM_bitmap_add_scalar_only(STORM_bitmap_t* b, const uint32_t* values,
+                                 const uint32_t n_values) {
+    if (!b) return -1;
+    if (!values) return -3;
+    if (n_values == 0) return -4;
+    if (bitmap_ensure_list(b, n_values)) return -5;
+    const uint32_t base = b->id * BLOCK_BITS;
+    b->n_scalar_set = 1;
+    for (uint32_t k = 0; k < n_values; ++k) {
+        const uint32_t v = values[k] - base;
+        assert(values[k] >= base && v < BLOCK_BITS);
+        if (b->n_scalar != 0 && b->scalar[b->n_scalar - 1] == (uint16_t)v) continue;
+        b->scalar[b->n_scalar] = (uint16_t)v;
+        b->n_scalar = b->n_scalar + 1;
+        ++b->n_bits_set;
+    }
+    return (int)n_values;
+}
+
+int STORM_bitmap_clear(STORM_bitmap_t* b) { /* storm.c:561-569: buffers are kept */
+    if (!b) return -1;
+    if (b->data) memset(b->data, 0, sizeof(uint64_t) * BLOCK_WORDS);
+    b->n_scalar = 0;
+    b->n_bits_set = 0;
+    b->n_bitmap = 0;
+    return 1;
+}
+
+uint32_t STORM_bitmap_serialized_size(STORM_bitmap_t* b) { /* storm.c:372-380 */
+    uint32_t bytes = (uint32_t)sizeof(uint64_t) * b->n_bitmap;
+    if (b->n_scalar_set) bytes += (uint32_t)sizeof(uint16_t) * b->n_scalar;
+    return bytes + 4 * (uint32_t)sizeof(uint32_t);
+}
+
+/* one block pair on the host: the 4-way kind dispatch of storm.c:618-656, counting the probed
+ * bit itself in the mixed cases (the reference's `a & b != 0` at :636,:644 is defect D1) */
+uint64_t STORM_bitmap_intersect_cardinality_func(STORM_bitmap_t* STORM_RESTRICT b1,
+                                                 STORM_bitmap_t* STORM_RESTRICT b2,
+                                                 const STORM_compute_func func) {
+    if (!b1 || !b2 || b1->id != b2->id) return 0;
+    const STORM_compute_func f = func ? func : STORM_intersect_count_scalar;
+    if (!b1->n_bitmap && !b2->n_bitmap)
+        return STORM_intersect_vector16_cardinality(b1->scalar, b2->scalar, b1->n_scalar,
+                                                    b2->n_scalar);
+    if (b1->n_bitmap && b2->n_bitmap) return f(b1->data, b2->data, b1->n_bitmap);
+    const STORM_bitmap_t* dense = b1->n_bitmap ? b1 : b2;
+    const STORM_bitmap_t* list = b1->n_bitmap ? b2 : b1;
+    uint64_t count = 0;
+    for (uint32_t k = 0; k < list->n_scalar; ++k) count += probe(dense->data, list->scalar[k]);
+    return count;
+}
+
+uint64_t STORM_bitmap_intersect_cardinality(STORM_bitmap_t* STORM_RESTRICT b1,
+                                            STORM_bitmap_t* STORM_RESTRICT b2) { /* :572-616 */
+    return STORM_bitmap_intersect_cardinality_func(b1, b2, NULL);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_bitmap_cont_t — one row (reference storm.c:383-394, :659-824)
+ * ---------------------------------------------------------------------------------------- */
+void STORM_bitmap_cont_init(STORM_bitmap_cont_t* r) {
+    if (r) memset(r, 0, sizeof(*r));
+}
+
+STORM_bitmap_cont_t* STORM_bitmap_cont_new() {
+    return (STORM_bitmap_cont_t*)calloc(1, sizeof(STORM_bitmap_cont_t));
+}
+
+static void cont_release(STORM_bitmap_cont_t* r) {
+    for (uint32_t b = 0; b < r->m_bitmaps; ++b) bitmap_release_buffers(&r->bitmaps[b]);
+    STORM_aligned_free(r->bitmaps);
+    free(r->block_ids);
+    memset(r, 0, sizeof(*r));
+}
+
+void STORM_bitmap_cont_free(STORM_bitmap_cont_t* r) {
+    if (!r) return;
+    cont_release(r);
+    free(r);
+}
+
+static int cont_reserve(STORM_bitmap_cont_t* r) {
+    if (r->n_bitmaps < r->m_bitmaps) return 0;
+    const uint32_t new_m = r->m_bitmaps == 0 ? 2 : r->m_bitmaps + 8; /* storm.c:698, :730 */
+    STORM_bitmap_t* nb = (STORM_bitmap_t*)STORM_aligned_malloc(64, new_m * sizeof(*nb));
+    uint32_t* ni = (uint32_t*)realloc(r->block_ids, new_m * sizeof(uint32_t));
+    if (ni) r->block_ids = ni;
+    if (!nb || !ni) {
+        STORM_aligned_free(nb);
+        return -1;
+    }
+    if (r->bitmaps) memcpy(nb, r->bitmaps, r->m_bitmaps * sizeof(*nb));
+    for (uint32_t b = r->m_bitmaps; b < new_m; ++b) STORM_bitmap_init(&nb[b]);
+    STORM_aligned_free(r->bitmaps);
+    r->bitmaps = nb;
+    r->m_bitmaps = new_m;
+    return 0;
+}
+
+/* split the sorted values by value/65536 and give each run to a block: fewer than 4096
+ * values -> list kind, else bitmap kind (reference storm.c:692-758) */
+int STORM_bitmap_cont_add(STORM_bitmap_cont_t* r, const uint32_t* values,
+                          const uint32_t n_values) {
+    if (!r) return -1;
+    if (!values) return -2;
+    if (n_values == 0) return 0;
+    uint32_t start = 0;
+    while (start < n_values) {
+        const uint32_t block = values[start] / BLOCK_BITS;
+        uint32_t stop = start + 1;
+        while (stop < n_values && values[stop] / BLOCK_BITS == block) ++stop;
+        if (cont_reserve(r)) return -3;
+        STORM_bitmap_t* b = &r->bitmaps[r->n_bitmaps];
+        b->id = block;
+        r->block_ids[r->n_bitmaps] = block;
+        if (stop - start < STORM_DEFAULT_SCALAR_THRESHOLD)
+            STORM_bitmap_add_scalar_only(b, values + start, stop - start);
+        else
+            STORM_bitmap_add(b, values + start, stop - start);
+        ++r->n_bitmaps;
+        r->prev_inserted_value = values[stop - 1];
+        start = stop;
+    }
+    return 1;
+}
+
+int STORM_bitmap_cont_clear(STORM_bitmap_cont_t* r) { /* storm.c:816-824 */
+    if (!r) return -1;
+    for (uint32_t b = 0; b < r->n_bitmaps; ++b) STORM_bitmap_clear(&r->bitmaps[b]);
+    r->n_bitmaps = 0;
+    r->prev_inserted_value = 0;
+    return 1;
+}
+
+uint32_t STORM_bitmap_cont_serialized_size(STORM_bitmap_cont_t* r) { /* storm.c:383-394 */
+    uint32_t bytes = 0;
+    if (r->bitmaps)
+        for (uint32_t b = 0; b < r->n_bitmaps; ++b)
+            bytes += STORM_bitmap_serialized_size(&r->bitmaps[b]);
+    return bytes + (uint32_t)sizeof(uint32_t) * r->n_bitmaps + 3 * (uint32_t)sizeof(uint32_t);
+}
+
+/* one row pair on the host (reference storm.c:790-814) */
+uint64_t STORM_bitmap_cont_intersect_cardinality_premade(
+    const STORM_bitmap_cont_t* STORM_RESTRICT r1, const STORM_bitmap_cont_t* STORM_RESTRICT r2,
+    const STORM_compute_func func, uint32_t* out) {
+    if (!r1 || !r2 || !out || r1->n_bitmaps == 0 || r2->n_bitmaps == 0) return 0;
+    const uint64_t n = STORM_intersect_vector32_unsafe(r1->block_ids, r2->block_ids,
+                                                       r1->n_bitmaps, r2->n_bitmaps, out);
+    uint64_t count = 0;
+    for (uint64_t k = 0; k < n; k += 2)
+        count += STORM_bitmap_intersect_cardinality_func(&r1->bitmaps[out[k]],
+                                                         &r2->bitmaps[out[k + 1]], func);
+    return count;
+}
+
+uint64_t STORM_bitmap_cont_intersect_cardinality(
+    const STORM_bitmap_cont_t* STORM_RESTRICT r1,
+    const STORM_bitmap_cont_t* STORM_RESTRICT r2) { /* storm.c:760-788 */
+    if (!r1 || !r2 || r1->n_bitmaps == 0 || r2->n_bitmaps == 0) return 0;
+    const uint32_t cap = 2 * (r1->n_bitmaps < r2->n_bitmaps ? r1->n_bitmaps : r2->n_bitmaps);
+    uint32_t* out = (uint32_t*)malloc((cap ? cap : 2) * sizeof(uint32_t));
+    if (!out) return 0;
+    const uint64_t count = STORM_bitmap_cont_intersect_cardinality_premade(r1, r2, NULL, out);
+    free(out);
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * STORM_t — sparse container (reference storm.c:827-973)
+ * ---------------------------------------------------------------------------------------- */
+STORM_t* STORM_new() { return (STORM_t*)calloc(1, sizeof(STORM_t)); }
+
+static void storm_drop_device(STORM_t* h) {
+    if (h->hip_arena) {
+        storm_hip_sparse_destroy(g_ctx[0], (storm_hip_sparse_t*)h->hip_arena);
+        h->hip_arena = NULL;
+    }
+    h->hip_dirty = 1;
+}
+
+void STORM_free(STORM_t* h) {
+    if (!h) return;
+    storm_drop_device(h);
+    for (uint32_t i = 0; i < h->m_conts; ++i) cont_release(&h->conts[i]);
+    free(h->conts);
+    free(h);
+}
+
+int STORM_add(STORM_t* h, const uint32_t* values, const uint32_t n_values) { /* :844-866 */
+    if (!h) return -1;
+    if (h->n_conts == h->m_conts) {
+        const uint32_t new_m = h->m_conts + 1024;
+        STORM_bitmap_cont_t* nc =
+            (STORM_bitmap_cont_t*)realloc(h->conts, (size_t)new_m * sizeof(*nc));
+        if (!nc) return -3;
+        for (uint32_t i = h->m_conts; i < new_m; ++i) STORM_bitmap_cont_init(&nc[i]);
+        h->conts = nc;
+        h->m_conts = new_m;
+    }
+    STORM_bitmap_cont_add(&h->conts[h->n_conts++], values, n_values);
+    h->hip_dirty = 1;
+    return 1;
+}
+
+int STORM_clear(STORM_t* h) { /* storm.c:868-875 */
+    if (!h) return -1;
+    for (uint32_t i = 0; i < h->n_conts; ++i) STORM_bitmap_cont_clear(&h->conts[i]);
+    h->n_conts = 0;
+    storm_drop_device(h);
+    return 1;
+}
+
+uint64_t STORM_serialized_size(const STORM_t* h) { /* storm.c:963-973 */
+    if (!h) return 0;
+    uint64_t bytes = 0;
+    for (uint32_t i = 0; i < h->n_conts; ++i)
+        bytes += STORM_bitmap_cont_serialized_size(&h->conts[i]);
+    return bytes + 2 * sizeof(uint32_t);
+}
+
+/* Flatten rows -> blocks into the arrays storm_hip_sparse_create() takes (storm_hip.h). */
+static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
+    uint64_t n_blocks = 0, n_list = 0, n_dense = 0;
+    for (uint32_t i = 0; i < h->n_conts; ++i)
+        for (uint32_t b = 0; b < h->conts[i].n_bitmaps; ++b) {
+            const STORM_bitmap_t* blk = &h->conts[i].bitmaps[b];
+            ++n_blocks;
+            if (blk->n_bitmap) ++n_dense; else n_list += blk->n_scalar;
+        }
+    uint64_t* row_off = (uint64_t*)malloc((h->n_conts + 1ull) * sizeof(uint64_t));
+    uint32_t* ids = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
+    uint8_t* kinds = (uint8_t*)malloc(n_blocks + 1);
+    uint64_t* offs = (uint64_t*)malloc((n_blocks + 1) * sizeof(uint64_t));
+    uint32_t* lens = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
+    uint16_t* lists = (uint16_t*)malloc((n_list + 1) * sizeof(uint16_t));
+    uint64_t* words = (uint64_t*)malloc((n_dense * BLOCK_WORDS + 1) * sizeof(uint64_t));
+    int rc = -1;
+    if (row_off && ids && kinds && offs && lens && lists && words) {
+        uint64_t nb = 0, nl = 0, nw = 0;
+        for (uint32_t i = 0; i < h->n_conts; ++i) {
+            row_off[i] = nb;
+            for (uint32_t b = 0; b < h->conts[i].n_bitmaps; ++b, ++nb) {
+                const STORM_bitmap_t* blk = &h->conts[i].bitmaps[b];
+                ids[nb] = blk->id;
+                if (blk->n_bitmap) {
+                    kinds[nb] = 1;
+                    offs[nb] = nw;
+                    lens[nb] = 0;
+                    memcpy(words + nw, blk->data, BLOCK_WORDS * sizeof(uint64_t));
+                    nw += BLOCK_WORDS;
+                } else {
+                    kinds[nb] = 0;
+                    offs[nb] = nl;
+                    lens[nb] = blk->n_scalar;
+                    memcpy(lists + nl, blk->scalar, blk->n_scalar * sizeof(uint16_t));
+                    nl += blk->n_scalar;
+                }
+            }
+        }
+        row_off[h->n_conts] = nb;
+        storm_hip_sparse_t* arena = NULL;
+        if (storm_hip_sparse_create(ctx, h->n_conts, n_blocks, row_off, ids, kinds, offs, lens,
+                                    lists, n_list, words, n_dense * BLOCK_WORDS,
+                                    &arena) == STORM_HIP_OK) {
+            h->hip_arena = arena;
+            h->hip_dirty = 0;
+            rc = 0;
+        } else {
+            device_error("storm_hip_sparse_create");
+        }
+    }
+    free(row_off); free(ids); free(kinds); free(offs); free(lens); free(lists); free(words);
+    return rc;
+}
+
+static uint64_t storm_pairw_device(STORM_t* h) {
+    if (h->n_conts < 2) return 0;
+    storm_hip_ctx_t* ctx = device_ctx(0);
+    if (!ctx) return ALL_PAIRS_FAILED;
+    if (!h->hip_arena || h->hip_dirty) {
+        if (h->hip_arena) {
+            storm_hip_sparse_destroy(ctx, (storm_hip_sparse_t*)h->hip_arena);
+            h->hip_arena = NULL;
+        }
+        if (storm_build_arena(h, ctx)) return ALL_PAIRS_FAILED;
+    }
+    uint64_t total = 0;
+    if (storm_hip_pairw_sparse(ctx, (storm_hip_sparse_t*)h->hip_arena, g_shard_rank,
+                               g_shard_count, &total) != STORM_HIP_OK) {
+        device_error("storm_hip_pairw_sparse");
+        return ALL_PAIRS_FAILED;
+    }
+    return total;
+}
+
+uint64_t STORM_pairw_intersect_cardinality(STORM_t* h) { /* storm.c:877-895 */
+    if (!h) return (uint64_t)-1;
+    return storm_pairw_device(h);
+}
+
+uint64_t STORM_pairw_intersect_cardinality_blocked(STORM_t* h, uint32_t bsize) { /* :897-961 */
+    (void)bsize;
+    if (!h) return (uint64_t)-1;
+    return storm_pairw_device(h);
+}
