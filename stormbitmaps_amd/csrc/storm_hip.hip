@@ -41,14 +41,39 @@ void set_error(const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
+// acc += popcount(a & b) for word pairs: 2x v_and_b32 + 2x v_bcnt_u32_b32 per 64-bit pair.
+// Hand-written because both of these matter on gfx950 (measured with tools/ubench_regs,
+// profiles/r01_b_ubench_regs.txt):
+//  * the bcnt must be the ACCUMULATING form (D = popcount(S0) + S1); left to itself hipcc
+//    emits bcnt(x, 0) twice plus a v_add3_u32 — 5 VALU instructions per word pair, not 4;
+//  * one `s_nop 0` between each and and its bcnt: a pure and,bcnt,and,bcnt stream issues at
+//    ~4.3 cycles per instruction per SIMD, the same stream with the scalar no-op at ~3.05
+//    (= 2 for the and + 4 for the half-rate bcnt, i.e. the VALU ceiling): +40 %.
+// Four A rows per asm statement so that hipcc's own conservative s_nop between two asm
+// statements appears once per 16 VALU instructions instead of after every pair.
+#define STORM_PAIR(A, B)                 \
+    "v_and_b32 %[t], %[" A "], %[" B "]\n\t" \
+    "s_nop 0\n\t"                        \
+    "v_bcnt_u32_b32 %[acc], %[t], %[acc]\n\t"
+
+__device__ __forceinline__ uint32_t popc_and4(uint32_t l0, uint32_t h0, uint32_t l1, uint32_t h1,
+                                              uint32_t l2, uint32_t h2, uint32_t l3, uint32_t h3,
+                                              uint32_t b_lo, uint32_t b_hi, uint32_t acc) {
+    uint32_t t;
+    asm(STORM_PAIR("l0", "bl") STORM_PAIR("h0", "bh") STORM_PAIR("l1", "bl") STORM_PAIR("h1", "bh")
+        STORM_PAIR("l2", "bl") STORM_PAIR("h2", "bh") STORM_PAIR("l3", "bl") STORM_PAIR("h3", "bh")
+        : [acc] "+v"(acc), [t] "=&v"(t)
+        : [l0] "v"(l0), [h0] "v"(h0), [l1] "v"(l1), [h1] "v"(h1), [l2] "v"(l2), [h2] "v"(h2),
+          [l3] "v"(l3), [h3] "v"(h3), [bl] "v"(b_lo), [bh] "v"(b_hi));
+    return acc;
+}
+
 __device__ __forceinline__ uint32_t popc_and(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo,
                                              uint32_t b_hi, uint32_t acc) {
-    // v_and_b32 x2 + v_bcnt_u32_b32 x2. The bcnt is written as asm because it must be the
-    // ACCUMULATING form (D = popcount(S0) + S1): left to itself hipcc emits bcnt(x, 0) twice
-    // plus a v_add3_u32, i.e. 5 VALU instructions per word pair instead of 4.
     uint32_t t;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(t) : "v"(a_lo & b_lo), "v"(acc));
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(a_hi & b_hi), "v"(t));
+    asm(STORM_PAIR("l0", "bl") STORM_PAIR("h0", "bh")
+        : [acc] "+v"(acc), [t] "=&v"(t)
+        : [l0] "v"(a_lo), [h0] "v"(a_hi), [bl] "v"(b_lo), [bh] "v"(b_hi));
     return acc;
 }
 
@@ -107,9 +132,16 @@ __device__ __forceinline__ void row_step(const uint32_t (&a_lo)[kRowsPerWave],
                                          const uint32_t (&a_hi)[kRowsPerWave], uint64_t b,
                                          int rmax, uint32_t (&acc)[4]) {
     const uint32_t b_lo = (uint32_t)b, b_hi = (uint32_t)(b >> 32);
+    if (!DIAG) {
 #pragma unroll
-    for (int r = 0; r < kRowsPerWave; ++r) {
-        if (!DIAG || r < rmax) acc[r & 3] = popc_and(a_lo[r], a_hi[r], b_lo, b_hi, acc[r & 3]);
+        for (int r = 0; r < kRowsPerWave; r += 4)
+            acc[(r >> 2) & 3] = popc_and4(a_lo[r], a_hi[r], a_lo[r + 1], a_hi[r + 1], a_lo[r + 2],
+                                          a_hi[r + 2], a_lo[r + 3], a_hi[r + 3], b_lo, b_hi,
+                                          acc[(r >> 2) & 3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRowsPerWave; ++r)
+            if (r < rmax) acc[r & 3] = popc_and(a_lo[r], a_hi[r], b_lo, b_hi, acc[r & 3]);
     }
 }
 

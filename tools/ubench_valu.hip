@@ -51,6 +51,91 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, unsigned seed
     if (s == 0xDEADBEEF) out[0] = s;
 }
 
+// ---- emulation of the dense kernel's inner loop (csrc/storm_hip.hip: popc_and / row_step /
+// stage_compute), without any global traffic: MODE 3 = B words from registers, MODE 4 = B
+// words from a 16 KiB LDS stage exactly like the product kernel reads them.
+__device__ __forceinline__ unsigned popc_and(unsigned a_lo, unsigned a_hi, unsigned b_lo,
+                                             unsigned b_hi, unsigned acc) {
+    unsigned t;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(t) : "v"(a_lo & b_lo), "v"(acc));
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(acc) : "v"(a_hi & b_hi), "v"(t));
+    return acc;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void kemu(unsigned* out, const unsigned long long* src,
+                                               int iters) {
+    __shared__ unsigned long long lds[32 * 64];
+    const unsigned lane = threadIdx.x & 63u;
+    unsigned a_lo[32], a_hi[32], acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        const unsigned long long v = src[r * 64 + lane];
+        a_lo[r] = (unsigned)v;
+        a_hi[r] = (unsigned)(v >> 32);
+    }
+    for (int i = threadIdx.x; i < 32 * 64; i += 256) lds[i] = src[i] * 0x9E3779B97F4A7C15ull;
+    __syncthreads();
+    unsigned long long b = src[lane];
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 3) {
+#pragma unroll
+            for (int jj = 0; jj < 32; ++jj) {
+                const unsigned b_lo = (unsigned)b + jj, b_hi = (unsigned)(b >> 32);
+#pragma unroll
+                for (int r = 0; r < 32; ++r)
+                    acc[r & 3] = popc_and(a_lo[r], a_hi[r], b_lo, b_hi, acc[r & 3]);
+            }
+            b += 0x100000001ull;
+        } else {
+            constexpr int G = 4;
+            const unsigned long long* col = lds + lane;
+            unsigned long long cur[G], nxt[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) cur[u] = col[u * 64];
+#pragma unroll
+            for (int g = 0; g < 32 / G; ++g) {
+                if (g + 1 < 32 / G) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) nxt[u] = col[((g + 1) * G + u) * 64];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const unsigned b_lo = (unsigned)cur[u], b_hi = (unsigned)(cur[u] >> 32);
+#pragma unroll
+                    for (int r = 0; r < 32; ++r)
+                        acc[r & 3] = popc_and(a_lo[r], a_hi[r], b_lo, b_hi, acc[r & 3]);
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) cur[u] = nxt[u];
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned s = acc[0] + acc[1] + acc[2] + acc[3];
+    if (s == 0xDEADBEEF) out[0] = s;
+}
+
+template <int MODE>
+static int run_emu(const char* name, int blocks, int iters, unsigned* d,
+                   const unsigned long long* src) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kemu<MODE>, dim3(blocks), dim3(256), 0, 0, d, src, iters / 10 + 1);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kemu<MODE>, dim3(blocks), dim3(256), 0, 0, d, src, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr = (double)blocks * 256 * (double)iters * 32 * 32 * 4;  // lane-instructions
+    printf("%-10s blocks=%d iters=%d  %.3f ms  %.3e lane-ops/s = %.3e word-pairs/s\n", name, blocks,
+           iters, ms, instr / (ms * 1e-3), instr / 4 / (ms * 1e-3));
+    return 0;
+}
+
 template <int MODE>
 static int run(const char* name, int blocks, int iters, unsigned* d) {
     hipEvent_t e0, e1;
@@ -83,5 +168,10 @@ int main(int argc, char** argv) {
     if (run<0>("bcnt", blocks, iters, d)) return 1;
     if (run<1>("and", blocks, iters, d)) return 1;
     if (run<2>("and+bcnt", blocks, iters, d)) return 1;
+    unsigned long long* src;
+    CHECK(hipMalloc(&src, 32 * 64 * 8));
+    CHECK(hipMemset(src, 0x5A, 32 * 64 * 8));
+    if (run_emu<3>("emu-regB", blocks, iters / 64 + 1, d, src)) return 1;
+    if (run_emu<4>("emu-ldsB", blocks, iters / 64 + 1, d, src)) return 1;
     return 0;
 }
