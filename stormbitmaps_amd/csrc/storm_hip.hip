@@ -561,14 +561,15 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
+    release_mfma_state(ctx);
     delete ctx;
 }
 
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
     if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
     if (!strcmp(key, "variant")) {
-        if (value < 0 || value > 2) {
-            set_error("variant must be 0, 1 or 2");
+        if (value < 0 || value > 3) {
+            set_error("variant must be 0, 1, 2 or 3");
             return STORM_HIP_EINVAL;
         }
         ctx->variant = (int)value;
@@ -578,6 +579,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->seg_rows = (int)value;
+    } else if (!strcmp(key, "k2_stages_per_item")) {
+        if (value < 1 || value > 65536) {
+            set_error("k2_stages_per_item out of range");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_stages_per_item = (int)value;
     } else if (!strcmp(key, "chunks_per_item")) {
         if (value < 0 || value > 4096) {
             set_error("chunks_per_item out of range");
@@ -596,6 +603,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "variant")) return ctx->variant;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
+    if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     return -1;
 }
@@ -801,6 +809,13 @@ void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m) { return m ? m->d
 
 namespace storm {
 
+int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total) {
+    hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
+                       reinterpret_cast<unsigned long long*>(d_total));
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+
 int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                           const Seg* d_segs, uint32_t n_segs, uint64_t seg_row_sum,
                           uint64_t* d_total) {
@@ -872,6 +887,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->variant == 3) return launch_pairw_mfma(ctx, m, shard_rank, shard_count, d_total);
     if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
     return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
                                  ctx->seg_row_sum, d_total);

@@ -11,6 +11,7 @@
 
 struct storm_hip_ctx_s;
 typedef struct storm_hip_ctx_s storm_hip_ctx_t;
+struct storm_hip_matrix_s;
 
 namespace storm {
 
@@ -71,7 +72,24 @@ struct storm_hip_ctx_s {
     // info of the last dense launch
     uint64_t last_info[4] = {0, 0, 0, 0};
     uint64_t sparse_census[4] = {0, 0, 0, 0};
+    // K2 (MFMA FP4) state: nibble-expanded shadow of the matrix + item table
+    uint8_t* d_x4 = nullptr;
+    size_t x4_capacity = 0;
+    void* d_items = nullptr;
+    size_t items_capacity = 0;
+    uint64_t items_key[4] = {0, 0, 0, 0};  // rows, stages, shard rank/count, stages per item
+    uint32_t n_items = 0;
+    int k2_stages_per_item = 32;
 };
+
+namespace storm {
+// K2: all-pairs total of a dense matrix through v_mfma_f32_32x32x64_f8f6f4 (storm_hip_mfma.hip)
+int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
+                      uint32_t shard_count, uint64_t* d_total);
+void release_mfma_state(storm_hip_ctx_t* ctx);
+// folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)
+int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
+}  // namespace storm
 
 struct storm_hip_matrix_s {
     uint64_t* d = nullptr;

@@ -1,0 +1,319 @@
+// storm_hip_mfma.hip — K2: the all-pairs AND+popcount total through the gfx950 matrix cores.
+//
+// Why: the popcount path (K1, storm_hip.hip) is bound by VALU issue — v_bcnt_u32_b32 is a
+// half-rate instruction, so a 64-bit word pair costs 2x2 + 2x4 = 12 SIMD cycles per 64 lanes
+// (measured ceiling 1.24e13 word pairs/s, profiles/r01_b_*). popcount(a & b) is the dot
+// product of the two bit vectors, and 0/1 are exact in FP4 (E2M1: 0b0010 = 1.0), so
+// v_mfma_f32_32x32x64_f8f6f4 with FP4 operands does 32x32 row pairs x 64 bits per 32 cycles
+// per SIMD: measured 6.4e13 word pairs/s peak (tools/mfma_fp4_probe), 5x the VALU ceiling.
+// The f32 accumulators hold exact integers below 2^24, guaranteed by k-slicing.
+//
+// Pipeline per all-pairs call
+//   1. expand_fp4_kernel: bit-packed rows -> nibble rows (4 bits per bit), once per call:
+//      an O(N*M) pass, ~2 % of the O(N^2*M) product at the headline shape.
+//   2. pairw_fp4_kernel: work item = (256x256 row-block tile with I <= J, k-slice).
+//      512 threads = 8 waves as 2 (M) x 4 (N); each wave owns 128x64 of the tile = 4x2
+//      MFMA blocks (128 accumulator registers). Per stage (128 bits of k = 64 B per row) the
+//      A and B row blocks go global -> LDS by global_load_lds (16 B/lane, double-buffered,
+//      one barrier per stage), XOR-swizzled through the SOURCE address so that the
+//      ds_read_b128 operand fetches are bank-conflict free; 2 k-steps x 8 MFMAs per stage.
+//      Off-diagonal tiles add every entry; diagonal tiles add (all - trace) / 2, which is the
+//      strict upper triangle because the tile is symmetric — no global correction term, so
+//      any subset of items (a multi-GPU shard) yields an exact partial.
+//   3. items are ordered k-slice-major and dealt to the 8 XCDs in groups of 32 neighbouring
+//      tiles (4 x 8 row blocks), so the 32 CUs of one XCD share 12 row-block slices in L2.
+#include "storm_hip_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace storm {
+
+constexpr int kTile = 256;           // rows per tile side
+constexpr int kStageBytes = 64;      // bytes of one row per stage = 128 nibbles = 128 bits of k
+constexpr int kMfmaThreads = 512;
+constexpr int kTileStageBytes = kTile * kStageBytes;  // 16 KiB per operand per stage
+
+struct MfmaItem {
+    uint16_t I, J;       // row-block indices, I <= J
+    uint32_t stage0;     // first stage of the k-slice
+    uint32_t n_stages;   // stages in this k-slice
+};
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+__device__ __forceinline__ uint32_t spread8_fp4(uint32_t b) {  // 8 bits -> 8 nibbles of 0b0010
+    uint32_t x = (b | (b << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x << 1;
+}
+
+// One thread per 32-bit half word: 16 output bytes, fully coalesced on both sides.
+// Rows >= n_rows_src (padding up to a multiple of 256) are written as zeros.
+__global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restrict__ X,
+                                                         uint64_t stride_words,
+                                                         uint64_t n_rows_src, uint64_t n_rows_dst,
+                                                         uint4* __restrict__ X4) {
+    const uint64_t halves_per_row = stride_words * 2;
+    const uint64_t total = n_rows_dst * halves_per_row;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total;
+         t += (uint64_t)gridDim.x * 256) {
+        const uint64_t row = t / halves_per_row;
+        uint32_t w = 0;
+        if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[t];
+        uint4 o;
+        o.x = spread8_fp4(w & 0xFFu);
+        o.y = spread8_fp4((w >> 8) & 0xFFu);
+        o.z = spread8_fp4((w >> 16) & 0xFFu);
+        o.w = spread8_fp4(w >> 24);
+        X4[t] = o;
+    }
+}
+
+// LDS image of one operand stage: 256 rows x 64 B, the 16-byte slot s of row r stored at
+// slot s ^ ((r >> 2) & 3). A wave's ds_read_b128 of 32 rows x one slot then touches all 16
+// slots of the 256-byte bank row once per 16-lane group (conflict free).
+__device__ __forceinline__ void stage_tile(uint8_t* lds_tile, const uint8_t* __restrict__ X4,
+                                           uint64_t row_bytes, uint32_t row0, uint64_t kbyte,
+                                           uint32_t wave, uint32_t lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t n = (uint32_t)q * 8u + wave;  // wave-instruction index, 1 KiB each
+        const uint32_t p = n * 64u + lane;           // 16-byte piece of the LDS image
+        const uint32_t r = p >> 2;
+        const uint32_t slot = (p & 3u) ^ ((r >> 2) & 3u);
+        const uint8_t* g = X4 + (uint64_t)(row0 + r) * row_bytes + kbyte + slot * 16u;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds_tile + n * 1024u), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
+    const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
+    unsigned long long* __restrict__ slots) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[2][2][kTileStageBytes];  // [buf][A|B]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 2, wn = wave & 3u;
+    const MfmaItem it = items[blockIdx.x];
+    const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
+
+    // per-lane byte offset of its 16-byte operand piece inside a 32-row block, per k-step
+    const uint32_t swz = (lane >> 2) & 3u;
+    const uint32_t off0 = (lane & 31u) * kStageBytes + (((0u + (lane >> 5)) ^ swz) * 16u);
+    const uint32_t off1 = (lane & 31u) * kStageBytes + (((2u + (lane >> 5)) ^ swz) * 16u);
+
+    v16f acc[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
+
+    const uint32_t S = it.n_stages;
+    {
+        const uint64_t kb = (uint64_t)it.stage0 * kStageBytes;
+        stage_tile(lds[0][0], X4, row_bytes, a_row0, kb, wave, lane);
+        stage_tile(lds[0][1], X4, row_bytes, b_row0, kb, wave, lane);
+    }
+    for (uint32_t s = 0; s < S; ++s) {
+        // this wave's LDS-DMA has landed; after the barrier every wave's has, and every wave
+        // is done reading the buffer the next stage overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < S) {
+            const uint64_t kb = (uint64_t)(it.stage0 + s + 1) * kStageBytes;
+            stage_tile(lds[(s + 1) & 1][0], X4, row_bytes, a_row0, kb, wave, lane);
+            stage_tile(lds[(s + 1) & 1][1], X4, row_bytes, b_row0, kb, wave, lane);
+        }
+        const uint8_t* la = lds[s & 1][0] + wm * (128u * kStageBytes);
+        const uint8_t* lb = lds[s & 1][1] + wn * (64u * kStageBytes);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t off = kk ? off1 : off0;
+            v8i a[4], b[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const v4i t = *reinterpret_cast<const v4i*>(la + m * (32u * kStageBytes) + off);
+                a[m] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const v4i t = *reinterpret_cast<const v4i*>(lb + n * (32u * kStageBytes) + off);
+                b[n] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        a[m], b[n], acc[m][n], 4 /*A: FP4*/, 4 /*B: FP4*/, 0, 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: exact integer sum of this wave's 128x64 block ----
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool diag_tile = it.I == it.J;
+    uint32_t all = 0, trace = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const bool diag_block = diag_tile && (wm * 4u + m == wn * 2u + n);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t v = (uint32_t)acc[m][n][r];
+                all += v;
+                const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (diag_block && row == (lane & 31u)) trace += v;
+            }
+        }
+    uint64_t mine = all;
+    if (diag_tile) {
+        // symmetric tile: strict upper triangle = (all - trace) / 2, exact on the WAVE sums only
+        // after adding the mirrored block — so reduce `all` and `trace` over the workgroup first
+        // (the reduction words live in the staging array: a second __shared__ object next to
+        //  an LDS-DMA target makes hipcc drain vmcnt(0) before every ds_read of the main loop)
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(&lds[0][0][0]);
+        __syncthreads();
+        if (tid < 2) red[tid] = 0;
+        __syncthreads();
+        uint64_t wa = all, wt = trace;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            wa += __shfl_down(wa, o, 64);
+            wt += __shfl_down(wt, o, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(&red[0], (unsigned long long)wa);
+            atomicAdd(&red[1], (unsigned long long)wt);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long upper = (red[0] - red[1]) / 2;
+            if (upper) atomicAdd(&slots[blockIdx.x & (kSlots - 1)], upper);
+        }
+        return;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0 && mine != 0)
+        atomicAdd(&slots[(blockIdx.x * 8u + wave) & (kSlots - 1)], (unsigned long long)mine);
+}
+
+void release_mfma_state(storm_hip_ctx_t* ctx) {
+    if (ctx->d_x4) (void)hipFree(ctx->d_x4);
+    if (ctx->d_items) (void)hipFree(ctx->d_items);
+    ctx->d_x4 = nullptr;
+    ctx->d_items = nullptr;
+    ctx->x4_capacity = ctx->items_capacity = 0;
+}
+
+static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_stages,
+                        uint32_t shard_rank, uint32_t shard_count) {
+    const uint32_t spi = (uint32_t)std::max(1, ctx->k2_stages_per_item);
+    const uint64_t key[4] = {n_rows, total_stages, ((uint64_t)shard_rank << 32) | shard_count, spi};
+    if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
+
+    const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
+    // tiles of the upper triangle in groups of 4 (I) x 8 (J) row blocks; this shard keeps
+    // every shard_count-th tile of the group-ordered list
+    std::vector<std::pair<uint16_t, uint16_t>> tiles;
+    for (uint32_t gi = 0; gi < nT; gi += 4)
+        for (uint32_t gj = gi / 8 * 8; gj < nT; gj += 8)
+            for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
+                for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
+                    tiles.emplace_back((uint16_t)i, (uint16_t)j);
+    std::vector<std::pair<uint16_t, uint16_t>> mine;
+    for (size_t t = shard_rank; t < tiles.size(); t += shard_count) mine.push_back(tiles[t]);
+
+    // k-slice major; within a slice, runs of 32 consecutive tiles go to one XCD. Block b runs
+    // on XCD b % 8 (observed round-robin dispatch; only speed depends on it), so each chunk of
+    // 256 tiles (8 runs of 32) is emitted interleaved: position-major, run-minor.
+    std::vector<MfmaItem> items;
+    const uint32_t n_slices = (total_stages + spi - 1) / spi;
+    const size_t n = mine.size();
+    for (uint32_t ks = 0; ks < n_slices; ++ks) {
+        const uint32_t s0 = ks * spi, ns = std::min(spi, total_stages - s0);
+        for (size_t c = 0; c < n; c += 256)
+            for (size_t pos = 0; pos < 32; ++pos)
+                for (size_t x = 0; x < 8; ++x) {
+                    const size_t L = c + x * 32 + pos;
+                    if (L < n) items.push_back({mine[L].first, mine[L].second, s0, ns});
+                }
+    }
+    if (items.size() != (size_t)n_slices * mine.size()) {
+        set_error("K2 item table construction lost tiles (%zu != %zu)", items.size(),
+                  (size_t)n_slices * mine.size());
+        return STORM_HIP_EINVAL;
+    }
+    if (items.size() > ctx->items_capacity) {
+        if (ctx->d_items) STORM_HIP_TRY(hipFree(ctx->d_items));
+        ctx->d_items = nullptr;
+        ctx->items_capacity = 0;
+        const size_t cap = std::max<size_t>(items.size(), 4096);
+        STORM_HIP_TRY(hipMalloc(&ctx->d_items, cap * sizeof(MfmaItem)));
+        ctx->items_capacity = cap;
+    }
+    if (!items.empty()) {
+        STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, items.data(), items.size() * sizeof(MfmaItem),
+                                     hipMemcpyHostToDevice, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_items = (uint32_t)items.size();
+    memcpy(ctx->items_key, key, sizeof(key));
+    return STORM_HIP_OK;
+}
+
+int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
+                      uint32_t shard_count, uint64_t* d_total) {
+    const uint64_t n_rows4 = (m->n_rows + kTile - 1) / kTile * kTile;
+    const uint64_t row_bytes = m->stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
+    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows4, kTile) * row_bytes;
+    if (n_rows4 / kTile >= 65535) {
+        set_error("K2: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    if (x4_bytes > ctx->x4_capacity) {
+        if (ctx->d_x4) STORM_HIP_TRY(hipFree(ctx->d_x4));
+        ctx->d_x4 = nullptr;
+        ctx->x4_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_x4), x4_bytes) != hipSuccess) {
+            set_error("K2: hipMalloc of %zu bytes for the FP4 shadow matrix failed", x4_bytes);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->x4_capacity = x4_bytes;
+    }
+    const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
+    if (int rc = ensure_items(ctx, m->n_rows, total_stages, shard_rank, shard_count)) return rc;
+    // accumulators are f32: a k-slice must stay below 2^24 bits
+    if ((uint64_t)ctx->k2_stages_per_item * 128u >= (1u << 24)) {
+        set_error("K2: k-slice too long for exact f32 accumulation");
+        return STORM_HIP_EINVAL;
+    }
+    if (ctx->n_items > 0) {
+        const uint64_t work = n_rows4 * m->stride_words * 2;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+                           m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
+                           reinterpret_cast<uint4*>(ctx->d_x4));
+        STORM_HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(pairw_fp4_kernel, dim3(ctx->n_items), dim3(kMfmaThreads), 0,
+                           ctx->stream, ctx->d_x4, row_bytes,
+                           static_cast<const MfmaItem*>(ctx->d_items), ctx->d_slots);
+        STORM_HIP_TRY(hipGetLastError());
+    }
+    ctx->last_info[0] = ctx->n_items;
+    ctx->last_info[1] = ctx->k2_stages_per_item;
+    ctx->last_info[2] = 0;
+    ctx->last_info[3] = 0;
+    return launch_fold_slots(ctx, d_total);
+}
+
+}  // namespace storm

@@ -81,7 +81,7 @@ def test_dense_golden_vectors(hip_ctx, case):
     mat = synth.dense_matrix_c(case["M"], case["N"], case["draws"], seed=42)
     m = hip_ctx.matrix_from_host(mat)
     try:
-        for variant in (2, 0, 1):
+        for variant in (2, 0, 1, 3):  # 3 = K2, the FP4 matrix-core path
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == case["total"], f"variant {variant}"
     finally:
@@ -173,14 +173,43 @@ def test_device_side_construction_from_positions(hip_ctx, orc):
     m.close()
 
 
-def test_shards_partition_the_pair_space(hip_ctx):
+@pytest.mark.parametrize("variant", [2, 3])
+def test_shards_partition_the_pair_space(hip_ctx, variant):
     mat = synth.dense_matrix_c(8192, 1100, 3000, seed=9)
     m = hip_ctx.matrix_from_host(mat)
     total = m.pairw()
-    for world in (2, 3, 8):
-        parts = [m.pairw(r, world) for r in range(world)]
-        assert sum(parts) == total and max(parts) < total
+    hip_ctx.set_option("variant", variant)
+    try:
+        assert m.pairw() == total
+        for world in (2, 3, 8):
+            parts = [m.pairw(r, world) for r in range(world)]
+            assert sum(parts) == total and max(parts) < total
+    finally:
+        hip_ctx.set_option("variant", 2)
     m.close()
+
+
+def test_matrix_core_path_k_slicing_and_edges(hip_ctx, orc):
+    """K2 (variant 3): every k-slice length, ragged row counts around the 256-row tile edge,
+    all-ones rows (largest f32 accumulator values), and a diagonal-only problem."""
+    try:
+        hip_ctx.set_option("variant", 3)
+        for n in (2, 255, 256, 257, 513):
+            mat = synth.dense_matrix_c(9000, n, 4000, seed=n)
+            m = hip_ctx.matrix_from_host(mat)
+            want = orc.wrapper_diag_blocked(mat, 31)
+            for spi in (1, 3, 32, 1000):
+                hip_ctx.set_option("k2_stages_per_item", spi)
+                assert m.pairw() == want, (n, spi)
+            m.close()
+        hip_ctx.set_option("k2_stages_per_item", 32)
+        mat = np.full((300, 130), np.uint64(0xFFFFFFFFFFFFFFFF))
+        m = hip_ctx.matrix_from_host(mat)
+        assert m.pairw() == 300 * 299 // 2 * 130 * 64
+        m.close()
+    finally:
+        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("k2_stages_per_item", 32)
 
 
 def test_tiling_options_do_not_change_the_result(hip_ctx):
@@ -220,9 +249,10 @@ def test_headline_shape_properties(hip_ctx):
     total = m.pairw()
     assert total == m.column_identity()                      # sum_c C(n_c, 2)
     assert sum(m.pairw(r, 8) for r in range(8)) == total      # 8-way shard partition
-    hip_ctx.set_option("variant", 0)
     try:
-        assert m.pairw() == total                             # independent B-operand path
+        for variant in (0, 3):                                # independent operand paths
+            hip_ctx.set_option("variant", variant)
+            assert m.pairw() == total, variant
     finally:
         hip_ctx.set_option("variant", 2)
     head = hip_ctx.matrix(2000, M // 64)
@@ -243,6 +273,11 @@ def test_wide_shape_properties(hip_ctx):
     m.fill_synthetic(M, d, seed=42)
     total = m.pairw()
     assert total == m.column_identity()
+    hip_ctx.set_option("variant", 3)
+    try:
+        assert m.pairw() == total
+    finally:
+        hip_ctx.set_option("variant", 2)
     head = hip_ctx.matrix(300, M // 64)
     head.import_device(m.device_ptr, 300, m.stride_words)
     gold = {c["name"]: c["total"] for c in _load("synth_totals.json")["dense"]}
