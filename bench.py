@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (tuning)")
     args = ap.parse_args()
 
     import torch
@@ -88,6 +89,9 @@ def main():
     ctx = sb.HipContext(local_rank, stream.cuda_stream)
     if args.variant >= 0:
         ctx.set_option("variant", args.variant)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     mat = ctx.matrix(N, W)
     mat.fill_synthetic(M, draws, seed=args.seed)  # resident in HBM before any timing
     total_t = torch.zeros(1, dtype=torch.int64, device=dev)

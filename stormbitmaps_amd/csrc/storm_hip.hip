@@ -585,6 +585,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_stages_per_item = (int)value;
+    } else if (!strcmp(key, "k2_debug")) {
+        ctx->k2_debug = (int)value;
     } else if (!strcmp(key, "chunks_per_item")) {
         if (value < 0 || value > 4096) {
             set_error("chunks_per_item out of range");

@@ -80,6 +80,7 @@ struct storm_hip_ctx_s {
     uint64_t items_key[4] = {0, 0, 0, 0};  // rows, stages, shard rank/count, stages per item
     uint32_t n_items = 0;
     int k2_stages_per_item = 32;
+    int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };
 
 namespace storm {

@@ -33,6 +33,7 @@ constexpr int kTile = 256;           // rows per tile side
 constexpr int kStageBytes = 64;      // bytes of one row per stage = 128 nibbles = 128 bits of k
 constexpr int kMfmaThreads = 512;
 constexpr int kTileStageBytes = kTile * kStageBytes;  // 16 KiB per operand per stage
+constexpr int kRing = 4;             // LDS stages (4 x 32 KiB = 128 KiB of the CU's 160 KiB)
 
 struct MfmaItem {
     uint16_t I, J;       // row-block indices, I <= J
@@ -93,10 +94,11 @@ __device__ __forceinline__ void stage_tile(uint8_t* lds_tile, const uint8_t* __r
     }
 }
 
+template <uint32_t probe>
 __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[2][2][kTileStageBytes];  // [buf][A|B]
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[kRing][2][kTileStageBytes];  // [stage][A|B]
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -116,45 +118,77 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
 
+    // Ring of kRing LDS stages with the operand fetch software-pipelined ACROSS the barrier:
+    //   iteration s:  wait(stage s+1 landed) ; barrier ; issue DMA of stage s+3 ;
+    //                 read frags(s, k-step 1) ; 8 MFMAs on frags(s, k-step 0)   [read last iteration]
+    //                 read frags(s+1, k-step 0) ; 8 MFMAs on frags(s, k-step 1)
+    // so every ds_read_b128 is issued >= 8 MFMAs (256 cycles) before its use, and the wave
+    // reaches the next wait/barrier with 8 MFMAs still executing — the barrier and LDS latency
+    // hide behind them instead of idling the matrix cores (the first version, with a plain
+    // double buffer and reads after the barrier, ran them 51 % busy: profiles/r01_c_k2_*).
+    // Ring safety: the DMA of stage s+3 overwrites the buffer of stage s-1, whose last read
+    // (k-step 1) every wave completed before it arrived at this iteration's barrier. A stage is
+    // first read one iteration AFTER the wait+barrier that retires it. Each wave issues 4
+    // LDS-DMA instructions per stage, hence the counted vmcnt(4 x stages allowed in flight);
+    // raw s_barrier, because __syncthreads() would drain vmcnt(0).
     const uint32_t S = it.n_stages;
-    {
-        const uint64_t kb = (uint64_t)it.stage0 * kStageBytes;
-        stage_tile(lds[0][0], X4, row_bytes, a_row0, kb, wave, lane);
-        stage_tile(lds[0][1], X4, row_bytes, b_row0, kb, wave, lane);
-    }
+    // `probe` (timing experiments only, results are then wrong): bit 2 = issue no LDS-DMA,
+    // bit 3 = issue no MFMA
+    auto issue = [&](uint32_t s) {
+        if constexpr ((probe & 4u) != 0) return;
+        const uint64_t kb = (uint64_t)(it.stage0 + s) * kStageBytes;
+        stage_tile(lds[s % kRing][0], X4, row_bytes, a_row0, kb, wave, lane);
+        stage_tile(lds[s % kRing][1], X4, row_bytes, b_row0, kb, wave, lane);
+    };
+    auto fetch = [&](uint32_t s, uint32_t off, v8i (&a)[4], v8i (&b)[2]) {
+        const uint8_t* la = lds[s % kRing][0] + wm * (128u * kStageBytes) + off;
+        const uint8_t* lb = lds[s % kRing][1] + wn * (64u * kStageBytes) + off;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const v4i t = *reinterpret_cast<const v4i*>(la + m * (32u * kStageBytes));
+            a[m] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const v4i t = *reinterpret_cast<const v4i*>(lb + n * (32u * kStageBytes));
+            b[n] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
+        }
+    };
+    auto multiply = [&](const v8i (&a)[4], const v8i (&b)[2]) {
+        if constexpr ((probe & 8u) != 0) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[m]));
+#pragma unroll
+            for (int n = 0; n < 2; ++n) asm volatile("" ::"v"(b[n]));
+            return;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    a[m], b[n], acc[m][n], 4 /*A: FP4*/, 4 /*B: FP4*/, 0, 0, 0, 0);
+    };
+
+    for (uint32_t s = 0; s < kRing - 1; ++s)
+        if (s < S) issue(s);
+    // stage 0 must have landed before its first read: stages 1 and 2 may stay in flight
+    if (S >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (S == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    v8i a0[4], b0[2], a1[4], b1[2];
+    fetch(0, off0, a0, b0);
     for (uint32_t s = 0; s < S; ++s) {
-        // this wave's LDS-DMA has landed; after the barrier every wave's has, and every wave
-        // is done reading the buffer the next stage overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < S) {
-            const uint64_t kb = (uint64_t)(it.stage0 + s + 1) * kStageBytes;
-            stage_tile(lds[(s + 1) & 1][0], X4, row_bytes, a_row0, kb, wave, lane);
-            stage_tile(lds[(s + 1) & 1][1], X4, row_bytes, b_row0, kb, wave, lane);
-        }
-        const uint8_t* la = lds[s & 1][0] + wm * (128u * kStageBytes);
-        const uint8_t* lb = lds[s & 1][1] + wn * (64u * kStageBytes);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t off = kk ? off1 : off0;
-            v8i a[4], b[2];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const v4i t = *reinterpret_cast<const v4i*>(la + m * (32u * kStageBytes) + off);
-                a[m] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const v4i t = *reinterpret_cast<const v4i*>(lb + n * (32u * kStageBytes) + off);
-                b[n] = v8i{t.x, t.y, t.z, t.w, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                        a[m], b[n], acc[m][n], 4 /*A: FP4*/, 4 /*B: FP4*/, 0, 0, 0, 0);
-        }
+        // retire stage s+1 (stage s+2, if any, may stay in flight)
+        if (s + 2 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + kRing - 1 < S) issue(s + kRing - 1);
+        fetch(s, off1, a1, b1);
+        multiply(a0, b0);
+        if (s + 1 < S) fetch(s + 1, off0, a0, b0);
+        multiply(a1, b1);
     }
 
     // ---- epilogue: exact integer sum of this wave's 128x64 block ----
@@ -218,7 +252,8 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
 static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_stages,
                         uint32_t shard_rank, uint32_t shard_count) {
     const uint32_t spi = (uint32_t)std::max(1, ctx->k2_stages_per_item);
-    const uint64_t key[4] = {n_rows, total_stages, ((uint64_t)shard_rank << 32) | shard_count, spi};
+    const uint64_t key[4] = {n_rows, total_stages, ((uint64_t)shard_rank << 32) | shard_count,
+                             spi | ((uint64_t)ctx->k2_debug << 32)};
     if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
 
     const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
@@ -245,7 +280,15 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
             for (size_t pos = 0; pos < 32; ++pos)
                 for (size_t x = 0; x < 8; ++x) {
                     const size_t L = c + x * 32 + pos;
-                    if (L < n) items.push_back({mine[L].first, mine[L].second, s0, ns});
+                    if (L >= n) continue;
+                    if ((ctx->k2_debug & 3) == 1)  // timing probe only: every item reads tile (0,0)
+                        items.push_back({0, 0, s0, ns});
+                    else if ((ctx->k2_debug & 3) == 2)  // timing probe: no XCD grouping, plain order
+                        items.push_back({mine[(c + pos * 8 + x) < n ? (c + pos * 8 + x) : L].first,
+                                         mine[(c + pos * 8 + x) < n ? (c + pos * 8 + x) : L].second,
+                                         s0, ns});
+                    else
+                        items.push_back({mine[L].first, mine[L].second, s0, ns});
                 }
     }
     if (items.size() != (size_t)n_slices * mine.size()) {
@@ -304,9 +347,22 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4));
         STORM_HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(pairw_fp4_kernel, dim3(ctx->n_items), dim3(kMfmaThreads), 0,
-                           ctx->stream, ctx->d_x4, row_bytes,
-                           static_cast<const MfmaItem*>(ctx->d_items), ctx->d_slots);
+        const dim3 kgrid(ctx->n_items), block(kMfmaThreads);
+        const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
+        switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
+            case 4:
+                hipLaunchKernelGGL(pairw_fp4_kernel<4>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                   row_bytes, items, ctx->d_slots);
+                break;
+            case 8:
+                hipLaunchKernelGGL(pairw_fp4_kernel<8>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                   row_bytes, items, ctx->d_slots);
+                break;
+            default:
+                hipLaunchKernelGGL(pairw_fp4_kernel<0>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                   row_bytes, items, ctx->d_slots);
+                break;
+        }
         STORM_HIP_TRY(hipGetLastError());
     }
     ctx->last_info[0] = ctx->n_items;
