@@ -568,8 +568,8 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
     if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
     if (!strcmp(key, "variant")) {
-        if (value < 0 || value > 3) {
-            set_error("variant must be 0, 1, 2 or 3");
+        if (value < 0 || value > 4) {
+            set_error("variant must be 0..4");
             return STORM_HIP_EINVAL;
         }
         ctx->variant = (int)value;
@@ -889,7 +889,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    if (ctx->variant == 3) return launch_pairw_mfma(ctx, m, shard_rank, shard_count, d_total);
+    if (ctx->variant >= 3) return launch_pairw_mfma(ctx, m, shard_rank, shard_count, d_total);
     if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
     return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
                                  ctx->seg_row_sum, d_total);

@@ -79,6 +79,10 @@ struct storm_hip_ctx_s {
     size_t items_capacity = 0;
     uint64_t items_key[4] = {0, 0, 0, 0};  // rows, stages, shard rank/count, stages per item
     uint32_t n_items = 0;
+    void* d_strip_items = nullptr;
+    size_t strip_capacity = 0;
+    uint64_t strip_key[4] = {0, 0, 0, 0};
+    uint32_t n_strip_items = 0;
     int k2_stages_per_item = 32;
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };

@@ -186,9 +186,13 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
         __builtin_amdgcn_s_barrier();
         if (s + kRing - 1 < S) issue(s + kRing - 1);
         fetch(s, off1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (see strip kernel)
         multiply(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < S) fetch(s + 1, off0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         multiply(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: exact integer sum of this wave's 128x64 block ----
@@ -241,19 +245,198 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
         atomicAdd(&slots[(blockIdx.x * 8u + wave) & (kSlots - 1)], (unsigned long long)mine);
 }
 
+// ------------------------------------------------------------------------------------------
+// K2s "strip" kernel: the off-diagonal part of the triangle, A-stationary.
+//
+// Ablating the tile kernel above (k2_debug probes, profiles/r01_d_*) showed that its limit is
+// operand delivery, not the matrix cores: an LDS-DMA instruction occupies its wave for ~100
+// cycles, the two waves of a SIMD run in lockstep, and 32 KiB of DMA + 96 KiB of ds_read per
+// stage left the MFMA pipe 55 % busy. Only the grand total is wanted, so the accumulators never
+// have to be flushed per B block — which allows K1's dataflow on the matrix cores:
+//   work item = (A row block I of 256 rows, k-slice of 256 bits, run of later 64-row B blocks).
+//   A operand : this wave's 64 rows x 256 bits live in 32 VGPRs for the whole item
+//               (8 fragment loads straight from global memory, once per item).
+//   B operand : one stage = 64 B rows x the k-slice = 64 rows x 128 B, FULL 128-byte lines,
+//               2 LDS-DMA instructions per wave; ring of 4 stages (3 in flight) = 32 KiB.
+//   per stage : 4 k-steps x (2 ds_read_b128 + 4 MFMA) per wave into 4 accumulator blocks that
+//               are never flushed (f32 exact: <= 256 bits x 4096 stages < 2^24).
+//   occupancy : 4 waves (one per SIMD, 64 A rows each), <= 168 VGPRs -> THREE workgroups per
+//               CU, i.e. 3 waves per SIMD from three independent barrier domains: while one
+//               wave issues DMA or sits at its barrier, the others feed the matrix pipe.
+// Per MFMA this moves half the DMA bytes of the tile kernel. Items of one k-slice are dealt to
+// one XCD, whose L2 then holds that slice of all rows (N x 128 B = 1.3 MB at N = 10000), so HBM
+// sees each byte about once.
+// ------------------------------------------------------------------------------------------
+constexpr int kStripRowBytes = 128;                      // 256 bits of k as nibbles
+constexpr int kStripBRows = 64;                          // B rows per stage
+constexpr int kStripStageBytes = kStripBRows * kStripRowBytes;  // 8 KiB
+constexpr int kStripThreads = 256;
+constexpr int kStripRing = 4;
+
+struct StripItem {
+    uint16_t I;       // A block (256 rows)
+    uint16_t pad;
+    uint32_t j0, j1;  // B stages: 64-row blocks [j0, j1)
+    uint32_t ks;      // k-slice index (128 bytes of the nibble rows each)
+};
+
+__global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
+    const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
+    unsigned long long* __restrict__ slots) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[kStripRing][kStripStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave;  // 4 waves stacked along A; every wave multiplies all 64 B rows
+    const StripItem it = items[blockIdx.x];
+    const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
+    const uint32_t T = it.j1 - it.j0;
+
+    // B stage = 8 LDS-DMA instructions of 8 rows x 128 B; wave w issues instructions w and
+    // w + 4. Piece p = n*64 + lane is row p/8, 16-byte slot (p%8) ^ ((row/2)%8) of the stage;
+    // stepping n by 4 adds 32 rows and leaves the swizzle unchanged, so one per-lane offset
+    // serves both and the rest is a scalar base (host guarantees 64 * row_bytes < 2^32).
+    const uint32_t r0 = (wave * 64u + lane) >> 3;
+    const uint32_t goff0 = r0 * (uint32_t)row_bytes + (((lane & 7u) ^ ((r0 >> 1) & 7u)) * 16u);
+    auto issue = [&](uint32_t t) {
+        const uint8_t* base =
+            X4 + (uint64_t)((it.j0 + t) * (uint32_t)kStripBRows) * row_bytes + kbyte;
+        uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + goff0), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
+                                         (lptr_t)(dst + 4096u), 16, 0, 0);
+    };
+
+    // A fragments first (older in the VMEM queue than the DMAs, so waiting for them does not
+    // drain the ring), then the first stages of B
+    v4i a[4][2];
+    {
+        const uint8_t* ap = X4 + (uint64_t)((uint32_t)it.I * kTile + wm * 64u + (lane & 31u)) *
+                                     row_bytes + kbyte + (lane >> 5) * 16u;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                a[kk][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 32u * row_bytes +
+                                                         kk * 32);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kStripRing - 1; ++t)
+        if (t < T) issue(t);
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
+
+    // per-lane LDS byte offset of its 16-byte B piece inside a stage, per k-step
+    const uint32_t swz = (lane >> 1) & 7u;
+    const uint32_t lds_base =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    uint32_t boff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        boff[kk] = lds_base + (lane & 31u) * kStripRowBytes +
+                   ((((uint32_t)kk * 2u + (lane >> 5)) ^ swz) * 16u);
+    // The B-fragment reads are inline asm with hand-counted lgkmcnt: the two ds_read_b128 of
+    // k-step k+1 are issued BEFORE the 4 MFMAs of k-step k and retired by lgkmcnt(2) ("all but
+    // the 2 youngest") one step later; sched_barrier(0) keeps hipcc from moving MFMAs across
+    // the asm (cdna guide §5.4 rule 18). hipcc's own waits for ds_reads it can see are
+    // lgkmcnt(0) right behind the read.
+    auto fetch = [&](uint32_t t, int kk, v4i (&b)[2]) {
+        const uint32_t addr = boff[kk] + (t % kStripRing) * kStripStageBytes;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
+                     : "=&v"(b[0]), "=&v"(b[1])
+                     : "v"(addr));
+    };
+    auto multiply = [&](int kk, const v4i (&b)[2]) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                    v8i{a[kk][m].x, a[kk][m].y, a[kk][m].z, a[kk][m].w, 0, 0, 0, 0},
+                    v8i{b[n].x, b[n].y, b[n].z, b[n].w, 0, 0, 0, 0}, acc[m][n], 4, 4, 0, 0, 0, 0);
+    };
+#define STORM_LGKM(n)                                       \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+#define STORM_STEP(q, cur, nxt_fetch, wait) \
+    nxt_fetch;                               \
+    wait;                                    \
+    multiply(q, cur);                        \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // Make hipcc retire the A-fragment loads HERE (they are older than the DMAs, so its counted
+    // wait leaves the ring in flight). Without this use it cannot prove inside the loop that the
+    // loads are done and drains vmcnt(0) in front of the first MFMA of every stage.
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(a[kk][m]));
+
+    if (T > 0) {
+        // stage 0 landed (stages 1, 2 may stay in flight: 2 DMA instructions per wave each)
+        if (T >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (T == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+        __builtin_amdgcn_s_barrier();
+        v4i b0[2], b1[2];
+        fetch(0, 0, b0);
+        for (uint32_t t = 0; t < T; ++t) {
+            // retire stage t+1; the barrier also proves every wave finished reading stage t-1,
+            // whose buffer the DMA of stage t+3 overwrites
+            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            STORM_STEP(0, b0, fetch(t, 1, b1), STORM_LGKM(2));
+            STORM_STEP(1, b1, fetch(t, 2, b0), STORM_LGKM(2));
+            STORM_STEP(2, b0, fetch(t, 3, b1), STORM_LGKM(2));
+            // (after the last stage this re-reads k-step 0 of the same stage: never consumed;
+            //  keeping the loop body branch-free lets hipcc accumulate in place — with a
+            //  two-armed tail it ping-ponged between two accumulator sets and spilled)
+            STORM_STEP(3, b1, fetch(t + 1 < T ? t + 1 : t, 0, b0), STORM_LGKM(2));
+        }
+        STORM_LGKM(0);
+    }
+#undef STORM_STEP
+#undef STORM_LGKM
+
+    uint32_t all = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) all += (uint32_t)acc[m][n][r];
+    uint64_t mine = all;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0 && mine != 0)
+        atomicAdd(&slots[(blockIdx.x * 4u + wave) & (kSlots - 1)], (unsigned long long)mine);
+}
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
+    if (ctx->d_strip_items) (void)hipFree(ctx->d_strip_items);
+    ctx->d_strip_items = nullptr;
+    ctx->strip_capacity = 0;
     ctx->d_x4 = nullptr;
     ctx->d_items = nullptr;
     ctx->x4_capacity = ctx->items_capacity = 0;
 }
 
 static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_stages,
-                        uint32_t shard_rank, uint32_t shard_count) {
+                        uint32_t shard_rank, uint32_t shard_count, bool diag_only) {
     const uint32_t spi = (uint32_t)std::max(1, ctx->k2_stages_per_item);
     const uint64_t key[4] = {n_rows, total_stages, ((uint64_t)shard_rank << 32) | shard_count,
-                             spi | ((uint64_t)ctx->k2_debug << 32)};
+                             spi | ((uint64_t)ctx->k2_debug << 32) | ((uint64_t)diag_only << 63)};
     if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
 
     const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
@@ -264,7 +447,7 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
         for (uint32_t gj = gi / 8 * 8; gj < nT; gj += 8)
             for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
                 for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
-                    tiles.emplace_back((uint16_t)i, (uint16_t)j);
+                    if (!diag_only || i == j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
     std::vector<std::pair<uint16_t, uint16_t>> mine;
     for (size_t t = shard_rank; t < tiles.size(); t += shard_count) mine.push_back(tiles[t]);
 
@@ -314,6 +497,49 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
     return STORM_HIP_OK;
 }
 
+// Strip items for this shard: k-slice ks belongs to rank ks % shard_count; the shard's slices
+// are dealt to the 8 XCDs (block b runs on XCD b % 8 — observed, speed only), and inside an
+// XCD's list the items of one slice are consecutive, longest run first.
+static int ensure_strip_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_kslices,
+                              uint32_t shard_rank, uint32_t shard_count) {
+    const uint64_t key[4] = {n_rows, n_kslices, ((uint64_t)shard_rank << 32) | shard_count, 0};
+    if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
+    const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
+    constexpr uint32_t kMaxRun = 4096;  // stages per item: keeps the f32 accumulators exact
+    const uint32_t nB = (uint32_t)((n_rows + kStripBRows - 1) / kStripBRows);  // 64-row B blocks
+    std::vector<std::vector<StripItem>> per_xcd(8);
+    uint32_t local = 0;
+    for (uint32_t ks = shard_rank; ks < n_kslices; ks += shard_count, ++local) {
+        std::vector<StripItem>& dst = per_xcd[local % 8];
+        for (uint32_t i = 0; i + 1 < nT; ++i)
+            for (uint32_t j0 = (i + 1) * (kTile / kStripBRows); j0 < nB; j0 += kMaxRun)
+                dst.push_back({(uint16_t)i, 0, j0, std::min(nB, j0 + kMaxRun), ks});
+    }
+    std::vector<StripItem> items;
+    size_t longest = 0;
+    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+    for (size_t pos = 0; pos < longest; ++pos)
+        for (int x = 0; x < 8; ++x)
+            if (pos < per_xcd[x].size()) items.push_back(per_xcd[x][pos]);
+    if (items.size() > ctx->strip_capacity) {
+        if (ctx->d_strip_items) STORM_HIP_TRY(hipFree(ctx->d_strip_items));
+        ctx->d_strip_items = nullptr;
+        ctx->strip_capacity = 0;
+        const size_t cap = std::max<size_t>(items.size(), 4096);
+        STORM_HIP_TRY(hipMalloc(&ctx->d_strip_items, cap * sizeof(StripItem)));
+        ctx->strip_capacity = cap;
+    }
+    if (!items.empty()) {
+        STORM_HIP_TRY(hipMemcpyAsync(ctx->d_strip_items, items.data(),
+                                     items.size() * sizeof(StripItem), hipMemcpyHostToDevice,
+                                     ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->n_strip_items = (uint32_t)items.size();
+    memcpy(ctx->strip_key, key, sizeof(key));
+    return STORM_HIP_OK;
+}
+
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total) {
     const uint64_t n_rows4 = (m->n_rows + kTile - 1) / kTile * kTile;
@@ -334,20 +560,33 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         ctx->x4_capacity = x4_bytes;
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
-    if (int rc = ensure_items(ctx, m->n_rows, total_stages, shard_rank, shard_count)) return rc;
+    const bool strips = ctx->variant == 4;  // 4: diagonal tiles here + A-stationary strips
+    if (int rc = ensure_items(ctx, m->n_rows, total_stages, shard_rank, shard_count, strips))
+        return rc;
+    const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
+    if (strips)
+        if (int rc = ensure_strip_items(ctx, m->n_rows, n_kslices, shard_rank, shard_count))
+            return rc;
     // accumulators are f32: a k-slice must stay below 2^24 bits
     if ((uint64_t)ctx->k2_stages_per_item * 128u >= (1u << 24)) {
         set_error("K2: k-slice too long for exact f32 accumulation");
         return STORM_HIP_EINVAL;
     }
-    if (ctx->n_items > 0) {
+    if (ctx->n_items > 0 || (strips && ctx->n_strip_items > 0)) {
         const uint64_t work = n_rows4 * m->stride_words * 2;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4));
         STORM_HIP_TRY(hipGetLastError());
-        const dim3 kgrid(ctx->n_items), block(kMfmaThreads);
+        if (strips && ctx->n_strip_items > 0) {
+            hipLaunchKernelGGL(strip_fp4_kernel, dim3(ctx->n_strip_items), dim3(kStripThreads), 0,
+                               ctx->stream, ctx->d_x4, row_bytes,
+                               static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+            STORM_HIP_TRY(hipGetLastError());
+        }
+        const dim3 kgrid(std::max(ctx->n_items, 1u)), block(kMfmaThreads);
+        if (ctx->n_items == 0) goto fold;
         const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
         switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
             case 4:
@@ -365,7 +604,8 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         }
         STORM_HIP_TRY(hipGetLastError());
     }
-    ctx->last_info[0] = ctx->n_items;
+fold:
+    ctx->last_info[0] = ctx->n_items + (strips ? ctx->n_strip_items : 0);
     ctx->last_info[1] = ctx->k2_stages_per_item;
     ctx->last_info[2] = 0;
     ctx->last_info[3] = 0;

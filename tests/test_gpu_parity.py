@@ -81,7 +81,7 @@ def test_dense_golden_vectors(hip_ctx, case):
     mat = synth.dense_matrix_c(case["M"], case["N"], case["draws"], seed=42)
     m = hip_ctx.matrix_from_host(mat)
     try:
-        for variant in (2, 0, 1, 3):  # 3 = K2, the FP4 matrix-core path
+        for variant in (2, 0, 1, 3, 4):  # 3/4 = K2, the FP4 matrix-core paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == case["total"], f"variant {variant}"
     finally:
@@ -173,7 +173,7 @@ def test_device_side_construction_from_positions(hip_ctx, orc):
     m.close()
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 4])
 def test_shards_partition_the_pair_space(hip_ctx, variant):
     mat = synth.dense_matrix_c(8192, 1100, 3000, seed=9)
     m = hip_ctx.matrix_from_host(mat)
@@ -193,6 +193,12 @@ def test_matrix_core_path_k_slicing_and_edges(hip_ctx, orc):
     """K2 (variant 3): every k-slice length, ragged row counts around the 256-row tile edge,
     all-ones rows (largest f32 accumulator values), and a diagonal-only problem."""
     try:
+        for variant, n in ((4, 257), (4, 700), (4, 1025)):
+            hip_ctx.set_option("variant", variant)
+            mat = synth.dense_matrix_c(9000, n, 4000, seed=n)
+            m = hip_ctx.matrix_from_host(mat)
+            assert m.pairw() == orc.wrapper_diag_blocked(mat, 31), (variant, n)
+            m.close()
         hip_ctx.set_option("variant", 3)
         for n in (2, 255, 256, 257, 513):
             mat = synth.dense_matrix_c(9000, n, 4000, seed=n)
@@ -250,7 +256,7 @@ def test_headline_shape_properties(hip_ctx):
     assert total == m.column_identity()                      # sum_c C(n_c, 2)
     assert sum(m.pairw(r, 8) for r in range(8)) == total      # 8-way shard partition
     try:
-        for variant in (0, 3):                                # independent operand paths
+        for variant in (0, 3, 4):                             # independent operand paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
@@ -273,9 +279,10 @@ def test_wide_shape_properties(hip_ctx):
     m.fill_synthetic(M, d, seed=42)
     total = m.pairw()
     assert total == m.column_identity()
-    hip_ctx.set_option("variant", 3)
     try:
-        assert m.pairw() == total
+        for variant in (3, 4):
+            hip_ctx.set_option("variant", variant)
+            assert m.pairw() == total, variant
     finally:
         hip_ctx.set_option("variant", 2)
     head = hip_ctx.matrix(300, M // 64)
