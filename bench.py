@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WORDPAIRS = 256 * 4 * 32 * 2.4e9 / 4  # 4 VALU lane-ops per 64-bit word pair
+FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
+FP4_MEASURED_WORDPAIRS = 6.4e13  # tools/mfma_fp4_probe: back-to-back v_mfma_f32_32x32x64_f8f6f4
 
 
 def cpu_baseline(head_rows_fn, n_words, budget_s=12.0):
@@ -138,16 +140,38 @@ def main():
     ok = (total == identity)
 
     if rank == 0:
-        shard_wordpairs = info["word_pairs_executed"]           # this rank's launch
+        used = ctx.get_option("variant_used")
         alg_bytes_launch = pairs * W * 16 / world                # 16 B / word pair
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
+        alg_flop_launch = pairs * W * 64 * 2 / world             # 64 bit-MACs per word pair
+        hbm_gbs = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"variant{used}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        if used >= 3:
+            # K2/K2s: the bits are multiplied as FP4 on the matrix cores -> MFMA-bound
+            achieved = alg_flop_launch / (kernel_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP4_PEAK_TFLOPS, "traffic": traffic,
+                    "kernel": "storm::strip_fp4_kernel (+ expand_fp4, diagonal pairw_fp4, fold: all inside kernel_ms)",
+                    "kernel_ms": kernel_ms, "algorithmic_flop_per_launch": alg_flop_launch,
+                    "measured_fp4_mfma_peak_frac": (pairs * W / world / (kernel_ms * 1e-3)) / FP4_MEASURED_WORDPAIRS,
+                    "hbm_algorithmic_gb_s": hbm_gbs, "hbm_algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
+                    "note": "1 word pair = 64 bit-MACs = 128 FLOP on v_mfma_f32_32x32x64_f8f6f4 (FP4). The "
+                            "reference's no-reuse byte accounting (16 B per word pair, benchmark.cpp:131) is "
+                            "kept as hbm_algorithmic_*; on-chip reuse puts it far above the HBM peak."}
+        else:
+            roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "kernel": f"storm::pairw_dense_kernel<{used}>", "kernel_ms": kernel_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes_launch,
+                    "valu_popcount_frac": (info["word_pairs_executed"] / (kernel_ms * 1e-3)) / VALU_PEAK_WORDPAIRS,
+                    "note": "algorithmic bytes use the reference's no-reuse accounting (16 B per word pair, "
+                            "benchmark.cpp:131); on-chip reuse lets it exceed the HBM peak — the binding "
+                            "resource is VALU popcount issue (valu_popcount_frac)"}
         out = {
             "metric": "64-bit bitmap words/s, XX^T upper-tri pairwise AND+popcount (10000x65536)",
             "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps,
@@ -158,18 +182,10 @@ def main():
                                    "(BASELINE configs[1], README `benchmark 65536 10000`)",
                        "entry_point": "storm_hip_pairw_dense_launch == STORM_contig_pairw_intersect_cardinality_blocked",
                        "parallelism": f"pair-space shard x{world}, X replicated, uint64 all-reduce",
-                       "kernel_variant": ctx.get_option("variant"),
-                       "work_items": info["items"], "segments": info["segments"]},
+                       "kernel_variant": used, "work_items": info["items"]},
             "gb_per_s_algorithmic": value * 8 / 1e9,
             "total": total, "verified_against_column_identity": ok,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "storm::pairw_dense_kernel<2>", "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch,
-                         "valu_popcount_frac": (shard_wordpairs / (kernel_ms * 1e-3)) / VALU_PEAK_WORDPAIRS,
-                         "note": "algorithmic bytes use the reference's no-reuse accounting (16 B per "
-                                 "word pair, benchmark.cpp:131); on-chip reuse lets it exceed the HBM "
-                                 "peak — the binding resource is VALU popcount issue (valu_popcount_frac)"},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lambda n: mat.download(0, min(n, N)), W)

@@ -110,10 +110,14 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                               uint64_t* h_total);
 
 /* kernel selection / tuning knobs (benchmarks; defaults are what ships)
- *   key "variant": 0 = direct global->VGPR B stream, 1 = LDS-staged via VGPR, 2 = LDS-staged
- *                  via global_load_lds (default)
- *   key "seg_rows": B rows per work item (default 256)
- *   key "chunks_per_item": k-chunks (64 words each) per work item, 0 = auto */
+ *   key "variant": -1 = auto (default): 4 for >= 1024 rows, else 2
+ *                  0/1/2 = K1 popcount kernel, B operand direct / via VGPR->LDS / via LDS-DMA
+ *                  3 = K2 FP4 matrix-core tiles, 4 = K2s FP4 matrix-core strips (+3 on the diagonal)
+ *   key "seg_rows": K1 B rows per work item (default 256)
+ *   key "chunks_per_item": K1 k-chunks (64 words each) per work item, 0 = auto
+ *   key "k2_stages_per_item": K2 tile kernel k-slice length in 128-bit stages (default 32)
+ *   key "k2_debug": timing probes only (results are then wrong), see storm_hip_mfma.hip
+ *   read-only "variant_used": what the last dense launch ran; "n_cus" */
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
 /* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,

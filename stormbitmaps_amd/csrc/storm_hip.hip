@@ -568,8 +568,8 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
     if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
     if (!strcmp(key, "variant")) {
-        if (value < 0 || value > 4) {
-            set_error("variant must be 0..4");
+        if (value < -1 || value > 4) {
+            set_error("variant must be -1 (auto) or 0..4");
             return STORM_HIP_EINVAL;
         }
         ctx->variant = (int)value;
@@ -603,6 +603,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (check_ctx(ctx) || !key) return -1;
     if (!strcmp(key, "variant")) return ctx->variant;
+    if (!strcmp(key, "variant_used")) return ctx->variant_used;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
@@ -851,7 +852,7 @@ int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stri
 
     if (n_items > 0) {
         const dim3 grid((uint32_t)n_items), block(kThreads);
-        switch (ctx->variant) {
+        switch (ctx->variant < 0 ? 2 : ctx->variant) {
             case 0:
                 hipLaunchKernelGGL(pairw_dense_kernel<0>, grid, block, 0, ctx->stream, X,
                                    stride_words, d_segs, n_segs, n_chunks, cps, ctx->d_slots);
@@ -889,7 +890,19 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    if (ctx->variant >= 3) return launch_pairw_mfma(ctx, m, shard_rank, shard_count, d_total);
+    // variant -1 = auto: the matrix-core path pays once there are enough 256-row blocks to fill
+    // the chip with strips (and its 64-row B stages need 64 * row_bytes < 2^32); below that the
+    // popcount kernel wins on latency.
+    int variant = ctx->variant;
+    if (variant < 0) variant = (m->n_rows >= 1024 && m->stride_words * 32ull * 64ull < (1ull << 32)) ? 4 : 2;
+    ctx->variant_used = variant;
+    if (variant >= 3) {
+        const int saved = ctx->variant;
+        ctx->variant = variant;
+        const int rc = launch_pairw_mfma(ctx, m, shard_rank, shard_count, d_total);
+        ctx->variant = saved;
+        return rc;
+    }
     if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
     return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
                                  ctx->seg_row_sum, d_total);

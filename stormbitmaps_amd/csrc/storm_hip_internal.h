@@ -66,7 +66,8 @@ struct storm_hip_ctx_s {
     uint32_t n_segs = 0;
     uint64_t seg_row_sum = 0;  // sum over segments of (j_hi - j_lo)
     // options
-    int variant = 2;
+    int variant = -1;       // -1 auto, 0/1/2 popcount kernel (B path), 3 MFMA tiles, 4 MFMA strips
+    int variant_used = 2;   // what the last dense launch ran
     int seg_rows = 256;
     int chunks_per_item = 0;
     // info of the last dense launch

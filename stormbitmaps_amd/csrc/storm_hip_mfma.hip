@@ -300,8 +300,12 @@ __global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
     const uint32_t r0 = (wave * 64u + lane) >> 3;
     const uint32_t goff0 = r0 * (uint32_t)row_bytes + (((lane & 7u) ^ ((r0 >> 1) & 7u)) * 16u);
     auto issue = [&](uint32_t t) {
+        // B blocks are walked from the LAST one down: all items of one k-slice then start on
+        // the same block at the same time and stay aligned (the shorter ones just stop
+        // earlier), so one of them misses in L2 and the others hit. Walking up from j0, item I
+        // trails item I+1 by four stages and the slice was re-fetched ~7x (profiles/r01_e_*).
         const uint8_t* base =
-            X4 + (uint64_t)((it.j0 + t) * (uint32_t)kStripBRows) * row_bytes + kbyte;
+            X4 + (uint64_t)((it.j1 - 1u - t) * (uint32_t)kStripBRows) * row_bytes + kbyte;
         uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
         __builtin_amdgcn_global_load_lds((gptr_t)(base + goff0), (lptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
@@ -563,6 +567,11 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
     const bool strips = ctx->variant == 4;  // 4: diagonal tiles here + A-stationary strips
     if (int rc = ensure_items(ctx, m->n_rows, total_stages, shard_rank, shard_count, strips))
         return rc;
+    if (strips && row_bytes * (uint64_t)kStripBRows >= (1ull << 32)) {
+        set_error("K2 strips: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 3",
+                  (unsigned long long)row_bytes);
+        return STORM_HIP_EINVAL;
+    }
     const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
     if (strips)
         if (int rc = ensure_strip_items(ctx, m->n_rows, n_kslices, shard_rank, shard_count))

@@ -85,7 +85,7 @@ def test_dense_golden_vectors(hip_ctx, case):
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == case["total"], f"variant {variant}"
     finally:
-        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("variant", -1)
         m.close()
     assert sb.wrapper_diag(mat) == case["total"]
     assert sb.wrapper_diag_blocked(mat, 31) == case["total"]
@@ -185,7 +185,7 @@ def test_shards_partition_the_pair_space(hip_ctx, variant):
             parts = [m.pairw(r, world) for r in range(world)]
             assert sum(parts) == total and max(parts) < total
     finally:
-        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("variant", -1)
     m.close()
 
 
@@ -214,14 +214,28 @@ def test_matrix_core_path_k_slicing_and_edges(hip_ctx, orc):
         assert m.pairw() == 300 * 299 // 2 * 130 * 64
         m.close()
     finally:
-        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("variant", -1)
         hip_ctx.set_option("k2_stages_per_item", 32)
+
+
+def test_auto_variant_selection(hip_ctx):
+    hip_ctx.set_option("variant", -1)
+    small = hip_ctx.matrix_from_host(synth.dense_matrix_c(4096, 300, 900, seed=3))
+    small.pairw()
+    assert hip_ctx.get_option("variant_used") == 2       # popcount kernel
+    big = hip_ctx.matrix_from_host(synth.dense_matrix_c(4096, 1500, 900, seed=3))
+    got = big.pairw()
+    assert hip_ctx.get_option("variant_used") == 4       # matrix-core strips
+    assert got == big.column_identity()
+    small.close()
+    big.close()
 
 
 def test_tiling_options_do_not_change_the_result(hip_ctx):
     mat = synth.dense_matrix_c(16384, 700, 5000, seed=10)
     m = hip_ctx.matrix_from_host(mat)
     base = m.pairw()
+    hip_ctx.set_option("variant", 2)
     try:
         for seg_rows in (32, 100, 256, 1024):
             for cps in (0, 1, 3, 4):
@@ -231,6 +245,7 @@ def test_tiling_options_do_not_change_the_result(hip_ctx):
     finally:
         hip_ctx.set_option("seg_rows", 256)
         hip_ctx.set_option("chunks_per_item", 0)
+        hip_ctx.set_option("variant", -1)
         m.close()
 
 
@@ -260,7 +275,7 @@ def test_headline_shape_properties(hip_ctx):
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
-        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("variant", -1)
     head = hip_ctx.matrix(2000, M // 64)
     head.import_device(m.device_ptr, 2000, m.stride_words)
     gold = {c["name"]: c["total"] for c in _load("synth_totals.json")["dense"]}
@@ -284,7 +299,7 @@ def test_wide_shape_properties(hip_ctx):
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
-        hip_ctx.set_option("variant", 2)
+        hip_ctx.set_option("variant", -1)
     head = hip_ctx.matrix(300, M // 64)
     head.import_device(m.device_ptr, 300, m.stride_words)
     gold = {c["name"]: c["total"] for c in _load("synth_totals.json")["dense"]}
