@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (tuning)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal)")
+    ap.add_argument("--all-on-device0", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -84,11 +87,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: the hot path has no CPU fallback")
+    if args.all_on_device0:
+        if args.backend == "nccl":
+            raise SystemExit("--all-on-device0 needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     under_launcher = "RANK" in os.environ and "MASTER_ADDR" in os.environ
     if world > 1 or under_launcher:
-        sdist.init_process_group("nccl")  # RCCL over xGMI
+        sdist.init_process_group(args.backend)  # "nccl" = RCCL over xGMI
 
     N, M = args.rows, args.bits
     draws = args.draws or M // 2
@@ -106,10 +113,19 @@ def main():
 
     collective = dist.is_initialized()
 
+    def reduce_total():
+        if not collective:
+            return
+        if args.backend == "gloo":  # CPU transport (rehearsal only)
+            host = total_t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            total_t.copy_(host)
+        else:
+            dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
+
     def step():
         mat.pairw_launch(total_t.data_ptr(), rank, world)
-        if collective:
-            dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
+        reduce_total()
 
     def fence():
         if collective:
@@ -127,12 +143,11 @@ def main():
         a.record(stream)
         mat.pairw_launch(total_t.data_ptr(), rank, world)
         b.record(stream)
-        if collective:
-            dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
+        reduce_total()
     fence()
     elapsed = time.perf_counter() - t0
     if collective:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total = int(total_t.item())
