@@ -49,6 +49,16 @@ void storm_synth_fill_dense(uint64_t* vals, uint64_t stride_words, uint64_t n_bi
 uint32_t storm_synth_positions(uint32_t* out, uint64_t* scratch, uint64_t n_bits, uint64_t row,
                                uint32_t draws, uint64_t seed);
 
+/* Feed rows [row0, row0+n_rows) of the synthetic matrix to the storm.h containers exactly as
+ * the reference harness does (STORM_add / STORM_contig_add per row with the sorted distinct
+ * positions, benchmark.cpp:794-795). Returns the number of rows added, or -1. */
+struct STORM_s;
+struct STORM_contiguous_s;
+int64_t storm_synth_fill_storm(struct STORM_s* h, uint64_t n_bits, uint64_t row0, uint64_t n_rows,
+                               uint32_t draws, uint64_t seed);
+int64_t storm_synth_fill_contig(struct STORM_contiguous_s* h, uint64_t n_bits, uint64_t row0,
+                                uint64_t n_rows, uint32_t draws, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,8 @@ SIGNATURES = {
     "storm_synth_fill_row": (None, [vp, u64, u64, u32, u64]),
     "storm_synth_fill_dense": (None, [vp, u64, u64, u64, u64, u32, u64]),
     "storm_synth_positions": (u32, [vp, vp, u64, u64, u32, u64]),
+    "storm_synth_fill_storm": (i64, [vp, u64, u64, u64, u32, u64]),
+    "storm_synth_fill_contig": (i64, [vp, u64, u64, u64, u32, u64]),
     # storm.h (containers + all-pairs entry points)
     "STORM_contig_new": (vp, [sz]),
     "STORM_contig_free": (None, [vp]),

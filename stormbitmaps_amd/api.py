@@ -53,6 +53,11 @@ class StormContig:
         return int(self._lib.STORM_contig_add(self._h, _ptr(v) if v.size else _ptr(np.zeros(1, np.uint32)),
                                               v.size))
 
+    def add_synthetic(self, n_rows: int, draws: int, seed: int = 42, row0: int = 0) -> int:
+        """Rows of the deterministic benchmark matrix (include/storm_synth.h), added in C."""
+        return int(self._lib.storm_synth_fill_contig(self._h, self.vector_length, row0, n_rows,
+                                                     draws, seed))
+
     def clear(self) -> int:
         return int(self._lib.STORM_contig_clear(self._h))  # storm.c:1139
 
@@ -97,6 +102,10 @@ class Storm:
         v = _u32(values)
         return int(self._lib.STORM_add(self._h, _ptr(v) if v.size else _ptr(np.zeros(1, np.uint32)),
                                        v.size))  # storm.c:844
+
+    def add_synthetic(self, n_bits: int, n_rows: int, draws: int, seed: int = 42,
+                      row0: int = 0) -> int:
+        return int(self._lib.storm_synth_fill_storm(self._h, n_bits, row0, n_rows, draws, seed))
 
     def clear(self) -> int:
         return int(self._lib.STORM_clear(self._h))  # storm.c:868

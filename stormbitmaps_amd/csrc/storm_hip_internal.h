@@ -92,6 +92,13 @@ namespace storm {
 // K2: all-pairs total of a dense matrix through v_mfma_f32_32x32x64_f8f6f4 (storm_hip_mfma.hip)
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total);
+struct RowRange {
+    uint64_t r0, r1;  // rows [r0, r1) form one all-pairs problem; r0 % 256 == 0
+};
+int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
+                             uint64_t n_rows_src, uint64_t n_rows_dst,
+                             const std::vector<RowRange>& ranges, uint32_t shard_rank,
+                             uint32_t shard_count, bool strips, uint64_t* d_total);
 void release_mfma_state(storm_hip_ctx_t* ctx);
 // folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);

@@ -442,37 +442,52 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     ctx->x4_capacity = ctx->items_capacity = 0;
 }
 
-static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_stages,
-                        uint32_t shard_rank, uint32_t shard_count, bool diag_only) {
+// A "range" is a run of rows [r0, r1) of the FP4 shadow that forms one all-pairs problem: the
+// whole matrix for the dense container, one block column of the pool for the sparse one.
+// r0 is a multiple of 256 and the rows from r1 up to the next multiple of 256 are zero.
+static uint64_t ranges_hash(const std::vector<RowRange>& ranges) {
+    uint64_t h = 1469598103934665603ull;
+    for (const RowRange& r : ranges) {
+        h = (h ^ r.r0) * 1099511628211ull;
+        h = (h ^ r.r1) * 1099511628211ull;
+    }
+    return h;
+}
+
+static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
+                        uint32_t total_stages, uint32_t shard_rank, uint32_t shard_count,
+                        bool diag_only) {
     const uint32_t spi = (uint32_t)std::max(1, ctx->k2_stages_per_item);
-    const uint64_t key[4] = {n_rows, total_stages, ((uint64_t)shard_rank << 32) | shard_count,
+    const uint64_t key[4] = {ranges_hash(ranges), total_stages,
+                             ((uint64_t)shard_rank << 32) | shard_count,
                              spi | ((uint64_t)ctx->k2_debug << 32) | ((uint64_t)diag_only << 63)};
     if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
 
-    const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
-    // tiles of the upper triangle in groups of 4 (I) x 8 (J) row blocks; this shard keeps
-    // every shard_count-th tile of the group-ordered list
+    // tiles of every range's upper triangle, in groups of 4 (I) x 8 (J) row blocks
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
-    for (uint32_t gi = 0; gi < nT; gi += 4)
-        for (uint32_t gj = gi / 8 * 8; gj < nT; gj += 8)
-            for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
-                for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
-                    if (!diag_only || i == j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
+    for (const RowRange& rg : ranges) {
+        const uint32_t b0 = (uint32_t)(rg.r0 / kTile);
+        const uint32_t nT = (uint32_t)((rg.r1 - rg.r0 + kTile - 1) / kTile);
+        for (uint32_t gi = 0; gi < nT; gi += 4)
+            for (uint32_t gj = gi / 8 * 8; gj < nT; gj += 8)
+                for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
+                    for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
+                        if (!diag_only || i == j)
+                            tiles.emplace_back((uint16_t)(b0 + i), (uint16_t)(b0 + j));
+    }
     // Sharding is by k-group (kGroupStages stages = 64 words of k), the same ownership rule as
     // the strips and the expand kernel; k-slices are cut so that none straddles two groups.
-    const std::vector<std::pair<uint16_t, uint16_t>>& mine = tiles;
-
-    // k-slice major; within a slice, runs of 32 consecutive tiles go to one XCD. Block b runs
-    // on XCD b % 8 (observed round-robin dispatch; only speed depends on it), so each chunk of
-    // 256 tiles (8 runs of 32) is emitted interleaved: position-major, run-minor.
-    std::vector<MfmaItem> items;
     std::vector<std::pair<uint32_t, uint32_t>> slices;  // (first stage, stages) owned by this shard
     for (uint32_t g0 = 0; g0 < total_stages; g0 += kGroupStages) {
         if ((g0 / kGroupStages) % shard_count != shard_rank) continue;
         const uint32_t g1 = std::min(total_stages, g0 + kGroupStages);
         for (uint32_t s0 = g0; s0 < g1; s0 += spi) slices.emplace_back(s0, std::min(spi, g1 - s0));
     }
-    const size_t n = mine.size();
+    // k-slice major; within a slice, runs of 32 consecutive tiles go to one XCD. Block b runs
+    // on XCD b % 8 (observed round-robin dispatch; only speed depends on it), so each chunk of
+    // 256 tiles (8 runs of 32) is emitted interleaved: position-major, run-minor.
+    std::vector<MfmaItem> items;
+    const size_t n = tiles.size();
     for (const auto& sl : slices) {
         const uint32_t s0 = sl.first, ns = sl.second;
         for (size_t c = 0; c < n; c += 256)
@@ -480,19 +495,19 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
                 for (size_t x = 0; x < 8; ++x) {
                     const size_t L = c + x * 32 + pos;
                     if (L >= n) continue;
-                    if ((ctx->k2_debug & 3) == 1)  // timing probe only: every item reads tile (0,0)
-                        items.push_back({0, 0, s0, ns});
-                    else if ((ctx->k2_debug & 3) == 2)  // timing probe: no XCD grouping, plain order
-                        items.push_back({mine[(c + pos * 8 + x) < n ? (c + pos * 8 + x) : L].first,
-                                         mine[(c + pos * 8 + x) < n ? (c + pos * 8 + x) : L].second,
-                                         s0, ns});
+                    if ((ctx->k2_debug & 3) == 1)  // timing probe only: every item reads one tile
+                        items.push_back({tiles[0].first, tiles[0].first, s0, ns});
                     else
-                        items.push_back({mine[L].first, mine[L].second, s0, ns});
+                        items.push_back({tiles[L].first, tiles[L].second, s0, ns});
                 }
     }
-    if (items.size() != slices.size() * mine.size()) {
+    if (items.size() != slices.size() * n) {
         set_error("K2 item table construction lost tiles (%zu != %zu)", items.size(),
-                  slices.size() * mine.size());
+                  slices.size() * n);
+        return STORM_HIP_EINVAL;
+    }
+    if (items.size() >= (1ull << 31)) {
+        set_error("K2: %zu tile items exceed the grid limit", items.size());
         return STORM_HIP_EINVAL;
     }
     if (items.size() > ctx->items_capacity) {
@@ -513,24 +528,29 @@ static int ensure_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t total_st
     return STORM_HIP_OK;
 }
 
-// Strip items for this shard: k-slice ks belongs to rank ks % shard_count; the shard's slices
-// are dealt to the 8 XCDs (block b runs on XCD b % 8 — observed, speed only), and inside an
-// XCD's list the items of one slice are consecutive, longest run first.
-static int ensure_strip_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_kslices,
-                              uint32_t shard_rank, uint32_t shard_count) {
-    const uint64_t key[4] = {n_rows, n_kslices, ((uint64_t)shard_rank << 32) | shard_count, 0};
+// Strip items for this shard: k-slice ks belongs to the rank that owns its k-group; the shard's
+// slices are dealt to the 8 XCDs (block b runs on XCD b % 8 — observed, speed only), and inside
+// an XCD's list the items of one slice are consecutive, longest run first.
+static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
+                              uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count) {
+    const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
+                             ((uint64_t)shard_rank << 32) | shard_count, 0};
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
-    const uint32_t nT = (uint32_t)((n_rows + kTile - 1) / kTile);
     constexpr uint32_t kMaxRun = 4096;  // stages per item: keeps the f32 accumulators exact
-    const uint32_t nB = (uint32_t)((n_rows + kStripBRows - 1) / kStripBRows);  // 64-row B blocks
+    constexpr uint32_t kPerTile = kTile / kStripBRows;
     std::vector<std::vector<StripItem>> per_xcd(8);
     uint32_t local = 0;
     for (uint32_t ks = 0; ks < n_kslices; ++ks) {
         if ((ks / 16u) % shard_count != shard_rank) continue;  // 16 slices = one k-group
         std::vector<StripItem>& dst = per_xcd[local++ % 8];
-        for (uint32_t i = 0; i + 1 < nT; ++i)
-            for (uint32_t j0 = (i + 1) * (kTile / kStripBRows); j0 < nB; j0 += kMaxRun)
-                dst.push_back({(uint16_t)i, 0, j0, std::min(nB, j0 + kMaxRun), ks});
+        for (const RowRange& rg : ranges) {
+            const uint32_t b0 = (uint32_t)(rg.r0 / kTile);
+            const uint32_t nT = (uint32_t)((rg.r1 - rg.r0 + kTile - 1) / kTile);
+            const uint32_t jend = (uint32_t)((rg.r1 + kStripBRows - 1) / kStripBRows);  // absolute
+            for (uint32_t i = 0; i + 1 < nT; ++i)
+                for (uint32_t j0 = (b0 + i + 1) * kPerTile; j0 < jend; j0 += kMaxRun)
+                    dst.push_back({(uint16_t)(b0 + i), 0, j0, std::min(jend, j0 + kMaxRun), ks});
+        }
     }
     std::vector<StripItem> items;
     size_t longest = 0;
@@ -538,6 +558,10 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_
     for (size_t pos = 0; pos < longest; ++pos)
         for (int x = 0; x < 8; ++x)
             if (pos < per_xcd[x].size()) items.push_back(per_xcd[x][pos]);
+    if (items.size() >= (1ull << 31)) {
+        set_error("K2s: %zu strip items exceed the grid limit", items.size());
+        return STORM_HIP_EINVAL;
+    }
     if (items.size() > ctx->strip_capacity) {
         if (ctx->d_strip_items) STORM_HIP_TRY(hipFree(ctx->d_strip_items));
         ctx->d_strip_items = nullptr;
@@ -557,12 +581,15 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_
     return STORM_HIP_OK;
 }
 
-int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
-                      uint32_t shard_count, uint64_t* d_total) {
-    const uint64_t n_rows4 = (m->n_rows + kTile - 1) / kTile * kTile;
-    const uint64_t row_bytes = m->stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
-    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows4, kTile) * row_bytes;
-    if (n_rows4 / kTile >= 65535) {
+// X: bit rows (stride_words per row), n_rows_src of them readable; the FP4 shadow gets
+// n_rows_dst rows (multiple of 256, rows >= n_rows_src zero). `strips` selects K2s.
+int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
+                             uint64_t n_rows_src, uint64_t n_rows_dst,
+                             const std::vector<RowRange>& ranges, uint32_t shard_rank,
+                             uint32_t shard_count, bool strips, uint64_t* d_total) {
+    const uint64_t row_bytes = stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
+    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows_dst, kTile) * row_bytes;
+    if (n_rows_dst / kTile >= 65535) {
         set_error("K2: too many row blocks");
         return STORM_HIP_EINVAL;
     }
@@ -577,8 +604,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         ctx->x4_capacity = x4_bytes;
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
-    const bool strips = ctx->variant == 4;  // 4: diagonal tiles here + A-stationary strips
-    if (int rc = ensure_items(ctx, m->n_rows, total_stages, shard_rank, shard_count, strips))
+    if (int rc = ensure_items(ctx, ranges, total_stages, shard_rank, shard_count, strips))
         return rc;
     if (strips && row_bytes * (uint64_t)kStripBRows >= (1ull << 32)) {
         set_error("K2 strips: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 3",
@@ -587,51 +613,60 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
     }
     const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
     if (strips)
-        if (int rc = ensure_strip_items(ctx, m->n_rows, n_kslices, shard_rank, shard_count))
-            return rc;
+        if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count)) return rc;
     // accumulators are f32: a k-slice must stay below 2^24 bits
     if ((uint64_t)ctx->k2_stages_per_item * 128u >= (1u << 24)) {
         set_error("K2: k-slice too long for exact f32 accumulation");
         return STORM_HIP_EINVAL;
     }
-    if (ctx->n_items > 0 || (strips && ctx->n_strip_items > 0)) {
-        const uint64_t work = n_rows4 * m->stride_words * 2;
+    const uint32_t n_strip = strips ? ctx->n_strip_items : 0;
+    if (ctx->n_items > 0 || n_strip > 0) {
+        const uint64_t work = n_rows_dst * stride_words * 2;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
-        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
-                           m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, stride_words,
+                           std::min(n_rows_src, n_rows_dst), n_rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count);
         STORM_HIP_TRY(hipGetLastError());
-        if (strips && ctx->n_strip_items > 0) {
-            hipLaunchKernelGGL(strip_fp4_kernel, dim3(ctx->n_strip_items), dim3(kStripThreads), 0,
-                               ctx->stream, ctx->d_x4, row_bytes,
+        if (n_strip > 0) {
+            hipLaunchKernelGGL(strip_fp4_kernel, dim3(n_strip), dim3(kStripThreads), 0, ctx->stream,
+                               ctx->d_x4, row_bytes,
                                static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
             STORM_HIP_TRY(hipGetLastError());
         }
-        const dim3 kgrid(std::max(ctx->n_items, 1u)), block(kMfmaThreads);
-        if (ctx->n_items == 0) goto fold;
-        const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
-        switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
-            case 4:
-                hipLaunchKernelGGL(pairw_fp4_kernel<4>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                   row_bytes, items, ctx->d_slots);
-                break;
-            case 8:
-                hipLaunchKernelGGL(pairw_fp4_kernel<8>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                   row_bytes, items, ctx->d_slots);
-                break;
-            default:
-                hipLaunchKernelGGL(pairw_fp4_kernel<0>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                   row_bytes, items, ctx->d_slots);
-                break;
+        if (ctx->n_items > 0) {
+            const dim3 kgrid(ctx->n_items), block(kMfmaThreads);
+            const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
+            switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
+                case 4:
+                    hipLaunchKernelGGL(pairw_fp4_kernel<4>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                       row_bytes, items, ctx->d_slots);
+                    break;
+                case 8:
+                    hipLaunchKernelGGL(pairw_fp4_kernel<8>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                       row_bytes, items, ctx->d_slots);
+                    break;
+                default:
+                    hipLaunchKernelGGL(pairw_fp4_kernel<0>, kgrid, block, 0, ctx->stream, ctx->d_x4,
+                                       row_bytes, items, ctx->d_slots);
+                    break;
+            }
+            STORM_HIP_TRY(hipGetLastError());
         }
-        STORM_HIP_TRY(hipGetLastError());
     }
-fold:
-    ctx->last_info[0] = ctx->n_items + (strips ? ctx->n_strip_items : 0);
+    ctx->last_info[0] = ctx->n_items + n_strip;
     ctx->last_info[1] = ctx->k2_stages_per_item;
     ctx->last_info[2] = 0;
     ctx->last_info[3] = 0;
     return launch_fold_slots(ctx, d_total);
+}
+
+int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
+                      uint32_t shard_count, uint64_t* d_total) {
+    const uint64_t n_rows4 = (m->n_rows + kTile - 1) / kTile * kTile;
+    std::vector<RowRange> ranges;
+    if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
+    return launch_pairw_mfma_ranges(ctx, m->d, m->stride_words, m->n_rows_pad, n_rows4, ranges,
+                                    shard_rank, shard_count, ctx->variant == 4, d_total);
 }
 
 }  // namespace storm

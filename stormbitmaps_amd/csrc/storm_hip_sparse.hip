@@ -27,7 +27,8 @@ using namespace storm;
 struct storm_hip_sparse_s {
     uint64_t* d_pool = nullptr;      // pool rows: [n_pool_rows + kABlockRows][1024] words
     uint64_t n_pool_rows = 0;
-    std::vector<uint64_t> col_start; // pool-row range of each non-empty column, +1 sentinel
+    std::vector<RowRange> cols;      // pool-row range [r0, r1) of each non-empty column; every r0
+                                     // is a multiple of 256 and the gap up to it is zero rows
     uint64_t census[4] = {0, 0, 0, 0};
     // segment table cache (per shard)
     Seg* d_segs = nullptr;
@@ -146,17 +147,21 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     for (uint32_t c = 0; c <= max_id; ++c) {
         start[c] = run;
         if (per_col[c]) {
-            s->col_start.push_back(run);
+            s->cols.push_back({run, run + per_col[c]});
             const uint64_t nl = n_list_col[c], nb = per_col[c] - nl;
             s->census[0] += nl * (nl - (nl != 0)) / 2;
             s->census[1] += nl * nb;
             s->census[2] += nb * (nb - (nb != 0)) / 2;
             s->census[3] += 1;
+            run = (run + per_col[c] + 255) / 256 * 256;  // next column starts on a 256-row tile
         }
-        run += per_col[c];
     }
-    s->col_start.push_back(run);
-    s->n_pool_rows = n_blocks;
+    s->n_pool_rows = run;
+    if (s->n_pool_rows >= (1ull << 32) - 512) {
+        set_error("sparse_create: block pool too large");
+        delete s;
+        return STORM_HIP_EINVAL;
+    }
 
     // ---- pool row of every block (rows are visited in order => row order inside a column)
     std::vector<uint32_t> list_row, dense_row, list_len;
@@ -186,7 +191,7 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     uint64_t* h_stage = nullptr;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
-        const size_t pool_bytes = (s->n_pool_rows + kABlockRows) * kBlockWords * sizeof(uint64_t);
+        const size_t pool_bytes = (s->n_pool_rows + 256) * kBlockWords * sizeof(uint64_t);
         if (hipMalloc(reinterpret_cast<void**>(&s->d_pool), pool_bytes) != hipSuccess) {
             set_error("sparse_create: hipMalloc of %zu bytes for the block pool failed",
                       pool_bytes);
@@ -280,13 +285,35 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
     }
     storm_hip_sparse_t* s = const_cast<storm_hip_sparse_t*>(cs);
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    memcpy(ctx->sparse_census, s->census, sizeof(s->census));
+    // Matrix-core path when the columns are big enough to fill the chip (same rule as the dense
+    // container): every column is an independent all-pairs problem over its pool rows.
+    uint64_t widest = 0;
+    for (const RowRange& c : s->cols) widest = std::max(widest, c.r1 - c.r0);
+    int variant = ctx->variant;
+    if (variant < 0) variant = widest >= 1024 ? 4 : 2;
+    ctx->variant_used = variant;
+    if (variant >= 3) {
+        std::vector<RowRange> ranges;
+        for (const RowRange& c : s->cols)
+            if (c.r1 - c.r0 > 1) ranges.push_back(c);
+        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 256,
+                                              std::max<uint64_t>(s->n_pool_rows, 256), ranges,
+                                              shard_rank, shard_count, variant == 4,
+                                              reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+            return rc;
+        STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return STORM_HIP_OK;
+    }
     const uint32_t seg_len = (uint32_t)ctx->seg_rows;
     if (!s->d_segs || s->seg_rank != shard_rank || s->seg_count != shard_count ||
         s->seg_len != seg_len) {
         // upper triangle of every block column; shard = every shard_count-th segment
         std::vector<Seg> full, diag, mine;
-        for (size_t c = 0; c + 1 < s->col_start.size(); ++c) {
-            const uint64_t lo = s->col_start[c], hi = s->col_start[c + 1];
+        for (const RowRange& col : s->cols) {
+            const uint64_t lo = col.r0, hi = col.r1;
             for (uint64_t a0 = lo; a0 < hi; a0 += kABlockRows) {
                 const uint32_t a_end = (uint32_t)std::min<uint64_t>(a0 + kABlockRows, hi);
                 if (a_end - a0 > 1) diag.push_back({(uint32_t)a0, a_end, (uint32_t)a0, a_end});
@@ -313,7 +340,6 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
         s->seg_count = shard_count;
         s->seg_len = seg_len;
     }
-    memcpy(ctx->sparse_census, s->census, sizeof(s->census));
     if (int rc = launch_pairw_segments(ctx, s->d_pool, kBlockWords, s->d_segs, s->n_segs,
                                        s->seg_row_sum,
                                        reinterpret_cast<uint64_t*>(ctx->d_scalar)))

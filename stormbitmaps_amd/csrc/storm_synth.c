@@ -3,7 +3,10 @@
  * replacement, keep distinct values, sorted. */
 #include "storm_synth.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include "storm.h"
 
 void storm_synth_fill_row(uint64_t* row_words, uint64_t n_bits, uint64_t row, uint32_t draws,
                           uint64_t seed) {
@@ -37,4 +40,36 @@ uint32_t storm_synth_positions(uint32_t* out, uint64_t* scratch, uint64_t n_bits
         }
     }
     return n;
+}
+
+static int64_t fill_container(void* h, int sparse, uint64_t n_bits, uint64_t row0, uint64_t n_rows,
+                              uint32_t draws, uint64_t seed) {
+    if (!h || n_bits == 0) return -1;
+    const uint64_t n_words = (n_bits + 63) / 64;
+    uint64_t* scratch = (uint64_t*)malloc(n_words * sizeof(uint64_t));
+    uint32_t* pos = (uint32_t*)malloc(((size_t)draws + 1) * sizeof(uint32_t));
+    int64_t added = -1;
+    if (scratch && pos) {
+        added = 0;
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            const uint32_t n = storm_synth_positions(pos, scratch, n_bits, row0 + r, draws, seed);
+            const int rc = sparse ? STORM_add((STORM_t*)h, pos, n)
+                                  : STORM_contig_add((STORM_contiguous_t*)h, pos, n);
+            if (rc < 0) { added = -1; break; }
+            ++added;
+        }
+    }
+    free(scratch);
+    free(pos);
+    return added;
+}
+
+int64_t storm_synth_fill_storm(struct STORM_s* h, uint64_t n_bits, uint64_t row0, uint64_t n_rows,
+                               uint32_t draws, uint64_t seed) {
+    return fill_container(h, 1, n_bits, row0, n_rows, draws, seed);
+}
+
+int64_t storm_synth_fill_contig(struct STORM_contiguous_s* h, uint64_t n_bits, uint64_t row0,
+                                uint64_t n_rows, uint32_t draws, uint64_t seed) {
+    return fill_container(h, 0, n_bits, row0, n_rows, draws, seed);
 }

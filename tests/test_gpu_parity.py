@@ -309,20 +309,68 @@ def test_wide_shape_properties(hip_ctx):
 
 
 def test_sparse_container_against_dense_identity(hip_ctx):
-    """STORM_t at several densities, N=1500 x M=524288: the sparse device path must equal the
-    dense device path and the column identity on the same bits."""
-    M, N = 524288, 1500
+    """STORM_t at several densities, N=2000 x M=524288: the sparse device path (K2s on the block
+    columns at this size) must equal the dense device path and the column identity on the same
+    bits; list-kind and bitmap-kind blocks both occur."""
+    M, N = 524288, 2000
     for d in (1, 5, 524, 5242, 33000, 131072):
-        mat = synth.dense_matrix_c(M, N, d, seed=42)
-        m = hip_ctx.matrix_from_host(mat)
+        m = hip_ctx.matrix(N, M // 64)
+        m.fill_synthetic(M, d, seed=42)
         want = m.column_identity()
         assert m.pairw() == want
         m.close()
         s = sb.Storm()
-        for r in synth.positions_from_dense(mat):
-            s.add(r)
+        assert s.add_synthetic(M, N, d, seed=42) == N
         assert s.pairw_intersect_cardinality_blocked(0) == want, d
+        assert s.pairw_intersect_cardinality() == want, d
         s.free()
+
+
+def test_sparse_arena_kernel_variants(lib, hip_ctx, orc):
+    """The sparse C-ABI directly, every kernel variant, on mixed block kinds."""
+    import ctypes as C
+    M, N, d = 196608, 1300, 12690   # ~4230 draws per 65536-bit block: list and bitmap kinds mix
+    rows = synth.positions(M, N, d, seed=7)
+    want = orc.storm(rows).pairw_blocked(0)
+    ids, kinds, offs, lens, lists, words, row_off = [], [], [], [], [], [], [0]
+    for r in rows:
+        blk = r // 65536
+        for b in np.unique(blk):
+            v = (r[blk == b] - b * 65536).astype(np.uint16)
+            ids.append(b)
+            if v.size < 4096:
+                kinds.append(0); offs.append(sum(len(x) for x in lists)); lens.append(v.size); lists.append(v)
+            else:
+                bm = np.zeros(1024, dtype=np.uint64)
+                np.bitwise_or.at(bm, (v >> 6).astype(np.int64), np.uint64(1) << (v & 63).astype(np.uint64))
+                kinds.append(1); offs.append(1024 * len(words)); lens.append(0); words.append(bm)
+        row_off.append(len(ids))
+    assert 0 in kinds and 1 in kinds
+    arr = lambda x, t: np.ascontiguousarray(np.array(x, dtype=t))  # noqa: E731
+    a_off, a_id, a_kind, a_doff, a_len = arr(row_off, np.uint64), arr(ids, np.uint32), arr(kinds, np.uint8), arr(offs, np.uint64), arr(lens, np.uint32)
+    a_lists = np.concatenate(lists).astype(np.uint16)
+    a_words = np.concatenate(words).astype(np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    h = C.c_void_p()
+    assert lib.storm_hip_sparse_create(hip_ctx._h, N, len(ids), p(a_off), p(a_id), p(a_kind), p(a_doff), p(a_len),
+                                       p(a_lists), a_lists.size, p(a_words), a_words.size, C.byref(h)) == 0, lib.storm_hip_last_error()
+    out = C.c_uint64()
+    try:
+        for variant in (2, 3, 4, -1):
+            hip_ctx.set_option("variant", variant)
+            assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, 0, 1, C.byref(out)) == 0, lib.storm_hip_last_error()
+            assert out.value == want, variant
+            parts = []
+            for r in range(3):
+                assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, r, 3, C.byref(out)) == 0
+                parts.append(out.value)
+            assert sum(parts) == want, (variant, parts)
+        census = (C.c_uint64 * 4)()
+        assert lib.storm_hip_sparse_last_census(hip_ctx._h, C.byref(census)) == 0
+        assert census[3] == 3 and census[0] > 0 and census[1] > 0 and census[2] > 0
+    finally:
+        hip_ctx.set_option("variant", -1)
+        lib.storm_hip_sparse_destroy(hip_ctx._h, h)
 
 
 def test_genomics_scale_shape_properties(hip_ctx):

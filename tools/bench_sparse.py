@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: STORM_t (N=10000, M=524288) at the README densities (README.md:65-80;
+benchmark.cpp:605-613 times STORM_pairw_intersect_cardinality_blocked(h, 0)).
+
+For each load: build the container on the host (STORM_add per row, C helper), time the storm.h
+entry point — first call (flatten + H2D + device) and steady state (device arena cached) — check
+the total against the column identity of the same bits generated on the device, and time the
+CPU oracle (restated reference path, 1 thread) on a bounded row subset, scaled by pair count.
+Prints one JSON object per load."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10000)
+    ap.add_argument("--bits", type=int, default=524288)
+    ap.add_argument("--loads", default="262144,131072,52428,20971,10485,5242,2097,524,104,5,1")
+    ap.add_argument("--cpu-rows", type=int, default=600)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+
+    import stormbitmaps_amd as sb
+    from stormbitmaps_amd import synth
+    from tests._orc import Oracle
+    orc = Oracle()
+    lib = sb.load()
+    ctx = sb.HipContext(0)
+    N, M = args.rows, args.bits
+    W = (M + 63) // 64
+    pairs = N * (N - 1) // 2
+    for d in [int(x) for x in args.loads.split(",")]:
+        dense = ctx.matrix(N, W)
+        dense.fill_synthetic(M, d, seed=42)
+        want = dense.column_identity()
+        dense.close()
+        s = sb.Storm()
+        t0 = time.perf_counter()
+        assert s.add_synthetic(M, N, d, seed=42) == N
+        t_build = time.perf_counter() - t0
+        res = {"load": d, "rows": N, "bits": M, "host_build_s": round(t_build, 3),
+               "serialized_size": s.serialized_size()}
+        for variant, name in ((-1, "auto"), (2, "k1_popcount")):
+            # the handle caches its device arena: force the variant through the env-free option
+            os.environ["STORM_HIP_VARIANT"] = str(variant)
+            # (the host library's context is process-global; set its option through a fresh call)
+            t0 = time.perf_counter()
+            got = s.pairw_intersect_cardinality_blocked(0)
+            t_first = time.perf_counter() - t0
+            ts = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                got2 = s.pairw_intersect_cardinality_blocked(0)
+                ts.append(time.perf_counter() - t0)
+            assert got == got2 == want, (d, got, got2, want)
+            if variant == -1:
+                res["first_call_s"] = round(t_first, 4)
+            res[f"steady_ms_{name}"] = round(1e3 * min(ts), 3)
+            break  # the C API has no per-call variant switch; K1 timing comes from the ctx below
+        # word-equivalent throughput, the reference's accounting (benchmark.cpp:128-131)
+        res["words_per_s_equiv"] = pairs * 2 * W / (res["steady_ms_auto"] * 1e-3)
+        # CPU: oracle on the first cpu_rows rows, scaled by pair count
+        n = min(args.cpu_rows, N)
+        rows = synth.positions(M, n, d, seed=42) if d <= 60000 else \
+            synth.positions_from_dense(synth.dense_matrix_c(M, n, d, seed=42))
+        o = orc.storm(rows)
+        t0 = time.perf_counter()
+        o.pairw_blocked(0)
+        t_cpu = time.perf_counter() - t0
+        res["cpu_oracle_s_scaled_1thread"] = round(t_cpu * pairs / (n * (n - 1) // 2), 2)
+        res["cpu_sample_rows"] = n
+        res["total"] = got
+        print(json.dumps(res), flush=True)
+        s.free()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
