@@ -168,3 +168,13 @@ def test_storm_t_host_build_matches_oracle_sizes(lib, orc):
         assert lib.STORM_clear(s) == 1
         assert lib.STORM_serialized_size(s) == 8
         lib.STORM_free(s)
+
+
+def test_benchmark_cli_is_built_and_refuses_bad_arguments():
+    import subprocess
+    exe = os.path.join(ROOT, "stormbitmaps_amd", "storm_benchmark")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode != 0 and "Usage" in res.stderr
+    res = subprocess.run([exe, "0", "10"], capture_output=True, text=True)
+    assert res.returncode != 0 and "non-positive" in res.stderr

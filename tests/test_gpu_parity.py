@@ -439,3 +439,25 @@ def test_two_rank_rehearsal_of_bench_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["verified_against_column_identity"] is True
     assert out["config"]["kernel_variant"] == 4
+
+
+def test_benchmark_cli_rows_agree_with_golden_totals():
+    """tools/storm_benchmark.cpp = the reference's `benchmark <M> <N> [loads]` CLI on this library:
+    every method row of one load must report the same total (that is the reference's only
+    correctness signal), and the totals must equal the committed oracle vectors."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "stormbitmaps_amd", "storm_benchmark")
+    gold = {(c["M"], c["N"], c["draws"]): c["total"] for c in _load("synth_totals.json")["dense"]}
+    for M, N, loads, methods in ((4096, 256, "2048,40,5", 3), (65536, 700, "32768,262,1", 5)):
+        res = subprocess.run([exe, str(M), str(N), loads, "--reps", "1"], capture_output=True, text=True,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr
+        lines = res.stdout.strip().splitlines()
+        assert lines[0].startswith("Samples\tAlts\tMethod")
+        rows = [l.split("\t") for l in lines[1:]]
+        for load in (int(x) for x in loads.split(",")):
+            totals = {int(r[2]) for r in rows if int(r[1]) == load}
+            names = [r[0] for r in rows if int(r[1]) == load]
+            assert len(names) == methods, names
+            assert totals == {gold[(M, N, load)]}, (M, N, load, totals)

@@ -1,0 +1,143 @@
+// storm_benchmark.cpp — the reference's benchmark CLI on the MI355X path.
+//
+// Counterpart of benchmark.cpp (intersect_test :644-1059, benchmark_large :505-642, main
+// :1085-1125), written from scratch against include/storm.h + libstorm_hip.so:
+//     storm_benchmark <M> <N> [load1,load2,...] [--gpus G] [--seed S] [--reps R]
+// Same positional arguments (samples first, benchmark.cpp:1067), same default loads and
+// zero/duplicate rules (:695, :715-730), same routing (M < 256000 -> both containers, else
+// STORM_t only, :1117-1121; STORM_t rows only when M >= 65536, :832), same optimal block size
+// (:823-824), same TSV row shape: name \t load \t [size] \t + the 11 bench_t fields (:74-87).
+// Differences, all forced by the platform: inputs come from the repo's deterministic generator
+// (storm_synth.h) instead of std::random_device (:756-757); the CPU PMU fields (cycles,
+// instructions, branch/cache misses) are printed as 0 — there is no perf_event on the device;
+// time is printed in ms with 3 decimals (a pass takes ~1 ms, the reference prints whole ms);
+// CRoaring and the direct-to-SIMD rows do not exist; two extra columns are appended:
+// GPUs used and 64-bit words/s.
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "storm.h"
+#include "storm_hip.h"
+#include "storm_synth.h"
+
+struct Row {
+    uint64_t total;
+    double ms;
+};
+
+template <class F>
+static Row timed(F&& f, int reps) {
+    Row best{0, 1e300};
+    for (int r = 0; r < reps; ++r) {
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        const uint64_t total = f();
+        const auto t1 = std::chrono::high_resolution_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (ms < best.ms) best = {total, ms};
+    }
+    return best;
+}
+
+static void print_row(const std::string& name, uint32_t load, const char* extra, const Row& r,
+                      uint64_t n_variants, uint64_t n_ints, int gpus) {
+    // throughput as benchmark.cpp:128-131: pairs * 2 * W * 8 bytes / 2^20 per second
+    const double n_comps = (double)n_variants * (n_variants - 1) / 2.0;
+    const double words = n_comps * 2.0 * (double)n_ints;
+    const double mbs = words * 8.0 / (1024.0 * 1024.0) / (r.ms / 1000.0);
+    printf("%s\t%u\t%s%llu\t%.2f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.2f\t%.3f\t%d\t%.4e\n",
+           name.c_str(), load, extra, (unsigned long long)r.total, 0.0, 0.0, 0.0, 0ull, 0ull, 0ull,
+           0ull, 0ull, mbs, r.ms, gpus, words / (r.ms / 1000.0));
+    fflush(stdout);
+}
+
+static std::vector<uint32_t> default_loads(uint32_t M) {
+    return {M / 2, M / 4, M / 10, M / 25, M / 50, M / 100, M / 250, M / 1000, M / 5000, 5, 1};
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr,
+                "\nAbout:   Computes sum(popcnt(A & B)) for the all-vs-all comparison of N integer\n"
+                "         lists bounded by [0, M) on the MI355X.\n"
+                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G] [--seed S] [--reps R]\n\n");
+        return EXIT_FAILURE;
+    }
+    int64_t n_samples = 0, n_vals = 10000;  // one-argument form uses N = 10000 (benchmark.cpp:1102)
+    std::vector<uint32_t> loads;
+    int gpus = 1, reps = 3, positional = 0;
+    uint64_t seed = 42;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+        else if (positional == 0) { n_samples = atoll(argv[i]); ++positional; }
+        else if (positional == 1) { n_vals = atoll(argv[i]); ++positional; }
+        else {
+            for (char* tok = strtok(argv[i], ","); tok; tok = strtok(nullptr, ",")) loads.push_back((uint32_t)atoi(tok));
+            ++positional;
+        }
+    }
+    if (n_samples <= 0) { fprintf(stderr, "Cannot have non-positive number of samples...\n"); return EXIT_FAILURE; }
+    if (n_vals <= 0) { fprintf(stderr, "Cannot have non-positive number of vectors...\n"); return EXIT_FAILURE; }
+    const uint32_t M = (uint32_t)n_samples;
+    const uint64_t N = (uint64_t)n_vals;
+    const bool large = n_samples >= 256000;  // benchmark.cpp:1117-1121
+    if (loads.empty()) loads = default_loads(M);
+
+    const int visible = storm_hip_device_count();
+    if (visible < 1) { fprintf(stderr, "no HIP device visible (no CPU fallback)\n"); return EXIT_FAILURE; }
+    if (gpus > visible) { fprintf(stderr, "--gpus %d but only %d device(s) visible; using %d\n", gpus, visible, visible); gpus = visible; }
+    std::vector<int> ids(gpus);
+    for (int g = 0; g < gpus; ++g) ids[g] = g;
+    STORM_hip_set_devices(gpus, ids.data());
+
+    printf("Samples\tAlts\tMethod\tTime(ms)\tCPUCycles\tCount\tThroughput(MB/s)\tInts/s(1e6)\tIntersect/s(1e6)\tActualThroughput(MB/s)\tCycles/int\tCycles/intersect\n");
+    const uint32_t n_ints = (uint32_t)std::ceil(M / 64.0);
+    uint32_t optimal_b = (uint32_t)(STORM_CACHE_BLOCK_SIZE / (n_ints * 8));  // :823-824
+    if (optimal_b < 5) optimal_b = 5;
+
+    STORM_t* twk2 = STORM_new();
+    STORM_contiguous_t* twk_cont = large ? nullptr : STORM_contig_new(M);
+    std::vector<uint64_t> vals;
+    if (!large) vals.resize((size_t)n_ints * N);
+
+    for (size_t a = 0; a < loads.size(); ++a) {
+        if (loads[a] == 0) {  // :715-724: always finish with n_alts = 1
+            if (a != 0 && loads[a - 1] != 1) loads[a] = 1; else if (a == 0) break;
+        }
+        if (a != 0 && loads[a] == loads[a - 1]) break;  // :727-730
+        STORM_clear(twk2);
+        storm_synth_fill_storm(twk2, M, 0, N, loads[a], seed);
+        const uint64_t storm_size = STORM_serialized_size(twk2);
+        if (large) {
+            char extra[64];
+            snprintf(extra, sizeof(extra), "%llu\t", (unsigned long long)storm_size);
+            const Row r = timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps);
+            print_row("storm-blocked", loads[a], extra, r, N, n_ints, gpus);  // :605-613
+            continue;
+        }
+        STORM_contig_clear(twk_cont);
+        storm_synth_fill_contig(twk_cont, M, 0, N, loads[a], seed);
+        storm_synth_fill_dense(vals.data(), n_ints, M, 0, N, loads[a], seed);
+        if (n_samples >= 65536) {  // :832-852
+            print_row("storm", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality(twk2); }, reps), N, n_ints, gpus);
+            print_row("storm-blocked", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps), N, n_ints, gpus);
+        }
+        print_row("STORM-contig", loads[a], "", timed([&] { return STORM_contig_pairw_intersect_cardinality(twk_cont); }, reps), N, n_ints, gpus);  // :896-904
+        print_row("STORM-contig-" + std::to_string(optimal_b), loads[a], "",
+                  timed([&] { return STORM_contig_pairw_intersect_cardinality_blocked(twk_cont, optimal_b); }, reps), N, n_ints, gpus);  // :906-918
+        // the reference's fwrapper_blocked<leaf> rows (:961,:1013,:1031) on the raw buffer: here the
+        // raw-buffer wrapper, which copies `vals` to the device on every call
+        print_row("bitmap-hip-blocked-" + std::to_string(optimal_b), loads[a], "",
+                  timed([&] { return STORM_wrapper_diag_blocked((uint32_t)N, vals.data(), n_ints, nullptr, optimal_b); }, reps), N, n_ints, gpus);
+    }
+    STORM_free(twk2);
+    if (twk_cont) STORM_contig_free(twk_cont);
+    return EXIT_SUCCESS;
+}
