@@ -585,6 +585,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_stages_per_item = (int)value;
+    } else if (!strcmp(key, "k2_max_run")) {
+        if (value < 1 || value > 4096) {
+            set_error("k2_max_run out of range");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_max_run = (int)value;
     } else if (!strcmp(key, "k2_debug")) {
         ctx->k2_debug = (int)value;
     } else if (!strcmp(key, "chunks_per_item")) {
@@ -607,6 +613,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
+    if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     return -1;
 }

@@ -85,6 +85,7 @@ struct storm_hip_ctx_s {
     uint64_t strip_key[4] = {0, 0, 0, 0};
     uint32_t n_strip_items = 0;
     int k2_stages_per_item = 32;
+    int k2_max_run = 4096;  // K2s: B stages per strip item
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };
 

@@ -281,12 +281,12 @@ constexpr int kStripRing = 4;
 
 struct StripItem {
     uint16_t I;       // A block (256 rows)
-    uint16_t pad;
-    uint32_t j0, j1;  // B stages: 64-row blocks [j0, j1)
+    uint16_t diag;    // 1: the item starts with the 4 stages of its own tile (strict upper part)
+    uint32_t j0, j1;  // then the later B stages: 64-row blocks [j0, j1), walked downwards
     uint32_t ks;      // k-slice index (128 bytes of the nibble rows each)
 };
 
-__global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
+__global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kStripRing][kStripStageBytes];
@@ -297,7 +297,11 @@ __global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
     const uint32_t wm = wave;  // 4 waves stacked along A; every wave multiplies all 64 B rows
     const StripItem it = items[blockIdx.x];
     const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
-    const uint32_t T = it.j1 - it.j0;
+    // Stage order: first (if it.diag) the 4 blocks of the A tile itself — wave wm contributes
+    // nothing for blocks before its own rows, the strict upper triangle of its own 64x64 block,
+    // and everything after — then the later blocks from the LAST one down.
+    const uint32_t D = it.diag ? (uint32_t)(kTile / kStripBRows) : 0u;
+    const uint32_t T = D + (it.j1 - it.j0);
 
     // B stage = 8 LDS-DMA instructions of 8 rows x 128 B; wave w issues instructions w and
     // w + 4. Piece p = n*64 + lane is row p/8, 16-byte slot (p%8) ^ ((row/2)%8) of the stage;
@@ -310,8 +314,9 @@ __global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
         // the same block at the same time and stay aligned (the shorter ones just stop
         // earlier), so one of them misses in L2 and the others hit. Walking up from j0, item I
         // trails item I+1 by four stages and the slice was re-fetched ~7x (profiles/r01_e_*).
-        const uint8_t* base =
-            X4 + (uint64_t)((it.j1 - 1u - t) * (uint32_t)kStripBRows) * row_bytes + kbyte;
+        const uint32_t blk = t < D ? (uint32_t)it.I * (uint32_t)(kTile / kStripBRows) + t
+                                   : it.j1 - 1u - (t - D);
+        const uint8_t* base = X4 + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
         uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
         __builtin_amdgcn_global_load_lds((gptr_t)(base + goff0), (lptr_t)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
@@ -387,21 +392,74 @@ __global__ __launch_bounds__(kStripThreads, 3) void strip_fp4_kernel(
 #pragma unroll
         for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(a[kk][m]));
 
-    if (T > 0) {
-        // stage 0 landed (stages 1, 2 may stay in flight: 2 DMA instructions per wave each)
-        if (T >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (T == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // Ring protocol. Stages 0..2 are issued by the prologue; every wave issues 2 LDS-DMA
+    // instructions per stage. retire(t, newest): wait until this wave's share of stage t has
+    // landed — the younger stages issued so far (up to `newest`) may stay in flight, hence
+    // vmcnt(2 x their number) — then the barrier makes every wave's share visible and proves that every wave is
+    // done with the stages it read before arriving here.
+    auto retire = [&](uint32_t t, uint32_t newest_issued) {
+        const uint32_t younger = min(T - 1u, newest_issued) - t;  // issued stages newer than t
+        if (younger >= 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
         __builtin_amdgcn_s_barrier();
-        v4i b0[2], b1[2];
-        fetch(0, 0, b0);
-        for (uint32_t t = 0; t < T; ++t) {
-            // retire stage t+1; the barrier also proves every wave finished reading stage t-1,
-            // whose buffer the DMA of stage t+3 overwrites
-            if (t + 2 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+    };
+
+    v4i b0[2], b1[2];
+    uint32_t t = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    // ---- the A tile's own 4 blocks (strict upper triangle), not software-pipelined: wave wm
+    //      skips the blocks before its own rows (only pairs with i > j there), masks its own
+    //      64x64 block, and takes the later ones whole. Kept apart from the main loop so that
+    //      the main loop stays free of selects (hipcc turned an `if (x) frag = 0` inside it into
+    //      v_cndmask on every k-step, which costs MFMA issue slots).
+#pragma unroll 1
+    for (; t < D; ++t) {
+        retire(t, t + 2);  // also: everyone finished stage t-1 -> its buffer may take stage t+3
+        if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= wm) {
+            fetch(t, 0, b0);
+            fetch(t, 1, b1);
+            STORM_LGKM(2);
+            multiply(0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(t, 2, b0);
+            STORM_LGKM(2);
+            multiply(1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(t, 3, b1);
+            STORM_LGKM(2);
+            multiply(2, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(0);
+            multiply(3, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == wm) {
+                // so far the accumulators hold exactly this wave's own 64x64 block: clear the
+                // pairs with i >= j in place. C/D map: col = lane & 31,
+                // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+                acc[1][0] = v16f{};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool keep = row < (lane & 31u);
+                    acc[0][0][r] = keep ? acc[0][0][r] : 0.0f;
+                    acc[1][1][r] = keep ? acc[1][1][r] : 0.0f;
+                }
+            }
+        }
+    }
+    // ---- later blocks, software-pipelined: stage t is retired one iteration early so that the
+    //      fragments of its first k-step are fetched while stage t-1 is still being multiplied;
+    //      iteration t therefore retires stage t+1, and refills the ring with stage t+3 (whose
+    //      buffer held stage t-1: every wave finished it before this iteration's barrier).
+    if (t < T) {
+        retire(t, t + 2);
+        fetch(t, 0, b0);
+        for (; t < T; ++t) {
+            if (t + 1 < T) retire(t + 1, t + 2);  // stage t+3 is issued below, after the barrier
+            else __builtin_amdgcn_s_barrier();
             if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
             __builtin_amdgcn_sched_barrier(0);
             STORM_STEP(0, b0, fetch(t, 1, b1), STORM_LGKM(2));
@@ -534,9 +592,11 @@ static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& range
 static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count) {
     const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
-                             ((uint64_t)shard_rank << 32) | shard_count, 0};
+                             ((uint64_t)shard_rank << 32) | shard_count, (uint64_t)ctx->k2_max_run};
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
-    constexpr uint32_t kMaxRun = 4096;  // stages per item: keeps the f32 accumulators exact
+    // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
+    // load per run for a shorter tail at the end of the launch
+    const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
     constexpr uint32_t kPerTile = kTile / kStripBRows;
     std::vector<std::vector<StripItem>> per_xcd(8);
     uint32_t local = 0;
@@ -547,9 +607,16 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
             const uint32_t b0 = (uint32_t)(rg.r0 / kTile);
             const uint32_t nT = (uint32_t)((rg.r1 - rg.r0 + kTile - 1) / kTile);
             const uint32_t jend = (uint32_t)((rg.r1 + kStripBRows - 1) / kStripBRows);  // absolute
-            for (uint32_t i = 0; i + 1 < nT; ++i)
-                for (uint32_t j0 = (b0 + i + 1) * kPerTile; j0 < jend; j0 += kMaxRun)
-                    dst.push_back({(uint16_t)(b0 + i), 0, j0, std::min(jend, j0 + kMaxRun), ks});
+            for (uint32_t i = 0; i < nT; ++i) {
+                const uint32_t first = (b0 + i + 1) * kPerTile;
+                if (first >= jend) {  // last tile of the range: only its own triangle
+                    dst.push_back({(uint16_t)(b0 + i), 1, first, first, ks});
+                    continue;
+                }
+                for (uint32_t j0 = first; j0 < jend; j0 += kMaxRun)
+                    dst.push_back({(uint16_t)(b0 + i), (uint16_t)(j0 == first), j0,
+                                   std::min(jend, j0 + kMaxRun), ks});
+            }
         }
     }
     std::vector<StripItem> items;
@@ -604,8 +671,12 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
         ctx->x4_capacity = x4_bytes;
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
-    if (int rc = ensure_items(ctx, ranges, total_stages, shard_rank, shard_count, strips))
+    if (strips) {
+        ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
+        memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    } else if (int rc = ensure_items(ctx, ranges, total_stages, shard_rank, shard_count, false)) {
         return rc;
+    }
     if (strips && row_bytes * (uint64_t)kStripBRows >= (1ull << 32)) {
         set_error("K2 strips: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 3",
                   (unsigned long long)row_bytes);
