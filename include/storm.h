@@ -127,6 +127,7 @@ struct STORM_s {
     /* private */
     void* hip_arena;        /* storm_hip_sparse_t*, rebuilt when dirty */
     uint32_t hip_dirty;
+    uint32_t hip_generation; /* device configuration the arena was built for */
 };
 
 /* one row of the dense container (reference storm.h:181-186) */

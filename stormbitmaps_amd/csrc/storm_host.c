@@ -27,6 +27,7 @@
  * device runtime state (process-wide, like the reference: no locking, single caller thread)
  * ---------------------------------------------------------------------------------------- */
 static int g_n_devices = 0; /* 0 = not configured yet */
+static uint32_t g_config_generation = 1; /* bumped by STORM_hip_set_devices */
 static int g_device_ids[MAX_DEVICES];
 static storm_hip_ctx_t* g_ctx[MAX_DEVICES];
 static uint32_t g_shard_rank = 0, g_shard_count = 1;
@@ -54,6 +55,7 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     }
     for (int d = 0; d < n_devices; ++d) g_device_ids[d] = device_ids[d];
     g_n_devices = n_devices;
+    ++g_config_generation; /* device mirrors cached in handles are rebuilt on their next use */
     return 0;
 }
 
@@ -209,6 +211,7 @@ uint64_t STORM_intersect_bitmaps_scalar_list(const uint64_t* STORM_RESTRICT b1,
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     storm_hip_matrix_t* m[MAX_DEVICES];
+    uint32_t config_generation; /* device configuration these replicas were made for */
 } dense_state_t;
 
 static void dense_state_release(dense_state_t* st) {
@@ -223,6 +226,7 @@ static void dense_state_release(dense_state_t* st) {
 static int dense_state_upload(dense_state_t* st, const uint64_t* rows, uint64_t n_rows,
                               uint32_t n_words, uint64_t stride_words) {
     configure_from_env();
+    st->config_generation = g_config_generation;
     for (int d = 0; d < g_n_devices; ++d) {
         storm_hip_ctx_t* ctx = device_ctx(d);
         if (!ctx) return -1;
@@ -498,7 +502,8 @@ int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
 /* the device mirror is rebuilt whenever rows were added since the last all-pairs call */
 static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
     if (h->n_data < 2) return 0;
-    if (!h->hip_matrix || h->hip_rows_synced != h->n_data) {
+    if (!h->hip_matrix || h->hip_rows_synced != h->n_data ||
+        ((dense_state_t*)h->hip_matrix)->config_generation != g_config_generation) {
         contig_drop_device(h);
         dense_state_t* st = (dense_state_t*)calloc(1, sizeof(*st));
         if (!st) return ALL_PAIRS_FAILED;
@@ -898,6 +903,7 @@ static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
                                     &arena) == STORM_HIP_OK) {
             h->hip_arena = arena;
             h->hip_dirty = 0;
+            h->hip_generation = g_config_generation;
             rc = 0;
         } else {
             device_error("storm_hip_sparse_create");
@@ -911,7 +917,8 @@ static uint64_t storm_pairw_device(STORM_t* h) {
     if (h->n_conts < 2) return 0;
     storm_hip_ctx_t* ctx = device_ctx(0);
     if (!ctx) return ALL_PAIRS_FAILED;
-    if (!h->hip_arena || h->hip_dirty) {
+    if (!h->hip_arena || h->hip_dirty || h->hip_dirty != 0 ||
+        h->hip_generation != g_config_generation) {
         if (h->hip_arena) {
             storm_hip_sparse_destroy(ctx, (storm_hip_sparse_t*)h->hip_arena);
             h->hip_arena = NULL;

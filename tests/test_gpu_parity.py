@@ -461,3 +461,46 @@ def test_benchmark_cli_rows_agree_with_golden_totals():
             names = [r[0] for r in rows if int(r[1]) == load]
             assert len(names) == methods, names
             assert totals == {gold[(M, N, load)]}, (M, N, load, totals)
+
+
+def test_repeated_launches_are_stable(hip_ctx):
+    """Race screen for the hand-synchronised LDS rings: 30 back-to-back launches of every MFMA
+    variant on the headline shape must all give the identity's total (a wrong vmcnt count showed
+    up here as a 5e-7 relative error in 1 launch out of a few)."""
+    M, N, d = 65536, 10000, 32768
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=43)
+    want = m.column_identity()
+    try:
+        for variant in (4, 3, 2):
+            hip_ctx.set_option("variant", variant)
+            got = {m.pairw() for _ in range(30 if variant != 2 else 5)}
+            assert got == {want}, (variant, got, want)
+    finally:
+        hip_ctx.set_option("variant", -1)
+        m.close()
+
+
+def test_in_process_multi_device_sharding_through_the_c_api(lib):
+    """STORM_hip_set_devices(): the storm.h entry points shard one call over several contexts and
+    add the partials on the host. With one GPU in the box the device list is [0, 0, 0]: three
+    contexts, three replicas, three disjoint shards."""
+    import ctypes as C
+    M, N, d = 65536, 2600, 9000
+    c = sb.StormContig(M)
+    assert c.add_synthetic(N, d, seed=5) == N
+    one = c.pairw_intersect_cardinality_blocked(31)
+    ids = (C.c_int * 3)(0, 0, 0)
+    try:
+        assert lib.STORM_hip_set_devices(3, ids) == 0
+        c2 = sb.StormContig(M)
+        assert c2.add_synthetic(N, d, seed=5) == N
+        assert c2.pairw_intersect_cardinality_blocked(31) == one
+        assert c2.pairw_intersect_cardinality() == one
+        mat = synth.dense_matrix_c(M, 300, d, seed=5)
+        assert sb.wrapper_diag(mat) == sb.HipContext(0).matrix_from_host(mat).pairw()
+        c2.free()
+    finally:
+        one_dev = (C.c_int * 1)(0)
+        assert lib.STORM_hip_set_devices(1, one_dev) == 0
+    c.free()
