@@ -591,6 +591,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_max_run = (int)value;
+    } else if (!strcmp(key, "k2_ring")) {
+        if ((value < 3 || value > 5) && (value < 11 || value > 17)) {
+            set_error("k2_ring must be 3, 4 or 5 (10 + bits = timing probes)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_ring = (int)value;
     } else if (!strcmp(key, "k2_debug")) {
         ctx->k2_debug = (int)value;
     } else if (!strcmp(key, "chunks_per_item")) {

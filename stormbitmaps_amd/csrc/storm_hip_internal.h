@@ -86,6 +86,7 @@ struct storm_hip_ctx_s {
     uint32_t n_strip_items = 0;
     int k2_stages_per_item = 32;
     int k2_max_run = 4096;  // K2s: B stages per strip item
+    int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };
 

@@ -276,16 +276,22 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
 constexpr int kStripRowBytes = 128;                      // 256 bits of k as nibbles
 constexpr int kStripBRows = 64;                          // B rows per stage
 constexpr int kStripStageBytes = kStripBRows * kStripRowBytes;  // 8 KiB
-constexpr int kStripThreads = 256;
-constexpr int kStripRing = 4;
+constexpr int kStripWaves = 4;                           // waves per workgroup = A tile / 64 rows
+constexpr int kStripATile = 64 * kStripWaves;            // A rows per workgroup (256; 8 waves / 512 rows measured slower)
+constexpr int kStripThreads = 64 * kStripWaves;
+constexpr int kStripPieces = 8 / kStripWaves;            // LDS-DMA instructions per wave and stage
+static_assert(kStripWaves == 4 || kStripWaves == 8, "a B stage is 8 DMA pieces");
+constexpr int kStripRingDefault = 4;
 
 struct StripItem {
-    uint16_t I;       // A block (256 rows)
-    uint16_t diag;    // 1: the item starts with the 4 stages of its own tile (strict upper part)
+    uint32_t a_row0;  // first row of the A tile (kStripATile rows, multiple of 64)
+    uint32_t diag;    // 1: the item starts with the stages of its own tile (strict upper part)
     uint32_t j0, j1;  // then the later B stages: 64-row blocks [j0, j1), walked downwards
     uint32_t ks;      // k-slice index (128 bytes of the nibble rows each)
 };
 
+// kProbe: timing probes with WRONG results: bit 0 no barriers, bit 1 no LDS-DMA, bit 2 no ds_read
+template <int kStripRing, int kProbe = 0>
 __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {
@@ -294,13 +300,13 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave;  // 4 waves stacked along A; every wave multiplies all 64 B rows
+    const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
     const StripItem it = items[blockIdx.x];
     const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
     // Stage order: first (if it.diag) the 4 blocks of the A tile itself — wave wm contributes
     // nothing for blocks before its own rows, the strict upper triangle of its own 64x64 block,
     // and everything after — then the later blocks from the LAST one down.
-    const uint32_t D = it.diag ? (uint32_t)(kTile / kStripBRows) : 0u;
+    const uint32_t D = it.diag ? (uint32_t)(kStripATile / kStripBRows) : 0u;
     const uint32_t T = D + (it.j1 - it.j0);
 
     // B stage = 8 LDS-DMA instructions of 8 rows x 128 B; wave w issues instructions w and
@@ -310,24 +316,26 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     const uint32_t r0 = (wave * 64u + lane) >> 3;
     const uint32_t goff0 = r0 * (uint32_t)row_bytes + (((lane & 7u) ^ ((r0 >> 1) & 7u)) * 16u);
     auto issue = [&](uint32_t t) {
+        if constexpr ((kProbe & 2) != 0) return;
         // B blocks are walked from the LAST one down: all items of one k-slice then start on
         // the same block at the same time and stay aligned (the shorter ones just stop
         // earlier), so one of them misses in L2 and the others hit. Walking up from j0, item I
         // trails item I+1 by four stages and the slice was re-fetched ~7x (profiles/r01_e_*).
-        const uint32_t blk = t < D ? (uint32_t)it.I * (uint32_t)(kTile / kStripBRows) + t
+        const uint32_t blk = t < D ? it.a_row0 / (uint32_t)kStripBRows + t
                                    : it.j1 - 1u - (t - D);
         const uint8_t* base = X4 + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
         uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
         __builtin_amdgcn_global_load_lds((gptr_t)(base + goff0), (lptr_t)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
-                                         (lptr_t)(dst + 4096u), 16, 0, 0);
+        if constexpr (kStripPieces == 2)
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
+                                             (lptr_t)(dst + 4096u), 16, 0, 0);
     };
 
     // A fragments first (older in the VMEM queue than the DMAs, so waiting for them does not
     // drain the ring), then the first stages of B
     v4i a[4][2];
     {
-        const uint8_t* ap = X4 + (uint64_t)((uint32_t)it.I * kTile + wm * 64u + (lane & 31u)) *
+        const uint8_t* ap = X4 + (uint64_t)(it.a_row0 + wm * 64u + (lane & 31u)) *
                                      row_bytes + kbyte + (lane >> 5) * 16u;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -361,6 +369,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     // the asm (cdna guide §5.4 rule 18). hipcc's own waits for ds_reads it can see are
     // lgkmcnt(0) right behind the read.
     auto fetch = [&](uint32_t t, int kk, v4i (&b)[2]) {
+        if constexpr ((kProbe & 4) != 0) {
+            asm volatile("" : "+v"(b[0]), "+v"(b[1]));  // keep the fragments opaque, read nothing
+            return;
+        }
         const uint32_t addr = boff[kk] + (t % kStripRing) * kStripStageBytes;
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
                      : "=&v"(b[0]), "=&v"(b[1])
@@ -399,13 +411,22 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     // done with the stages it read before arriving here.
     auto retire = [&](uint32_t t, uint32_t newest_issued) {
         const uint32_t younger = min(T - 1u, newest_issued) - t;  // issued stages newer than t
-        if (younger >= 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (younger == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (kStripPieces == 2) {
+            if (younger >= 3u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (younger == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (younger == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (younger == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (younger == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if constexpr ((kProbe & 1) == 0) __builtin_amdgcn_s_barrier();
     };
+    static_assert(kStripRing >= 3 && kStripRing <= 5, "vmcnt cases above cover rings of 3..5");
 
-    v4i b0[2], b1[2];
+    v4i b0[2] = {}, b1[2] = {};
     uint32_t t = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
     // ---- the A tile's own 4 blocks (strict upper triangle), not software-pipelined: wave wm
@@ -415,7 +436,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     //      v_cndmask on every k-step, which costs MFMA issue slots).
 #pragma unroll 1
     for (; t < D; ++t) {
-        retire(t, t + 2);  // also: everyone finished stage t-1 -> its buffer may take stage t+3
+        // (stages up to t + kStripRing - 2 are in the ring; everyone finished stage t-1, so its
+        //  buffer may take stage t + kStripRing - 1)
+        retire(t, t + kStripRing - 2);
         if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
         __builtin_amdgcn_sched_barrier(0);
         if (t >= wm) {
@@ -455,10 +478,10 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     //      iteration t therefore retires stage t+1, and refills the ring with stage t+3 (whose
     //      buffer held stage t-1: every wave finished it before this iteration's barrier).
     if (t < T) {
-        retire(t, t + 2);
+        retire(t, t + kStripRing - 2);
         fetch(t, 0, b0);
         for (; t < T; ++t) {
-            if (t + 1 < T) retire(t + 1, t + 2);  // stage t+3 is issued below, after the barrier
+            if (t + 1 < T) retire(t + 1, t + kStripRing - 2);  // the refill comes after the barrier
             else __builtin_amdgcn_s_barrier();
             if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -486,7 +509,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if (lane == 0 && mine != 0)
-        atomicAdd(&slots[(blockIdx.x * 4u + wave) & (kSlots - 1)], (unsigned long long)mine);
+        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+                  (unsigned long long)mine);
 }
 
 void release_mfma_state(storm_hip_ctx_t* ctx) {
@@ -597,24 +621,26 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
     // load per run for a shorter tail at the end of the launch
     const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
-    constexpr uint32_t kPerTile = kTile / kStripBRows;
+    constexpr uint32_t kPerTile = kStripATile / kStripBRows;
     std::vector<std::vector<StripItem>> per_xcd(8);
     uint32_t local = 0;
     for (uint32_t ks = 0; ks < n_kslices; ++ks) {
         if ((ks / 16u) % shard_count != shard_rank) continue;  // 16 slices = one k-group
         std::vector<StripItem>& dst = per_xcd[local++ % 8];
         for (const RowRange& rg : ranges) {
-            const uint32_t b0 = (uint32_t)(rg.r0 / kTile);
-            const uint32_t nT = (uint32_t)((rg.r1 - rg.r0 + kTile - 1) / kTile);
+            // A tiles of kStripATile rows from the start of the range (the rows between r1 and
+            // the end of its last A tile are zero: the caller pads ranges accordingly)
+            const uint32_t nA = (uint32_t)((rg.r1 - rg.r0 + kStripATile - 1) / kStripATile);
             const uint32_t jend = (uint32_t)((rg.r1 + kStripBRows - 1) / kStripBRows);  // absolute
-            for (uint32_t i = 0; i < nT; ++i) {
-                const uint32_t first = (b0 + i + 1) * kPerTile;
+            for (uint32_t i = 0; i < nA; ++i) {
+                const uint32_t a_row0 = (uint32_t)rg.r0 + i * (uint32_t)kStripATile;
+                const uint32_t first = a_row0 / (uint32_t)kStripBRows + kPerTile;
                 if (first >= jend) {  // last tile of the range: only its own triangle
-                    dst.push_back({(uint16_t)(b0 + i), 1, first, first, ks});
+                    dst.push_back({a_row0, 1, first, first, ks});
                     continue;
                 }
                 for (uint32_t j0 = first; j0 < jend; j0 += kMaxRun)
-                    dst.push_back({(uint16_t)(b0 + i), (uint16_t)(j0 == first), j0,
+                    dst.push_back({a_row0, (uint32_t)(j0 == first), j0,
                                    std::min(jend, j0 + kMaxRun), ks});
             }
         }
@@ -699,9 +725,30 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count);
         STORM_HIP_TRY(hipGetLastError());
         if (n_strip > 0) {
-            hipLaunchKernelGGL(strip_fp4_kernel, dim3(n_strip), dim3(kStripThreads), 0, ctx->stream,
-                               ctx->d_x4, row_bytes,
-                               static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+            const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
+            const dim3 sgrid(n_strip), sblock(kStripThreads);
+            switch (ctx->k2_ring) {  // LDS ring depth of the strip kernel (tuning probe)
+                case 3:
+                    hipLaunchKernelGGL(strip_fp4_kernel<3>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
+                                       row_bytes, sit, ctx->d_slots);
+                    break;
+                case 5:
+                    hipLaunchKernelGGL(strip_fp4_kernel<5>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
+                                       row_bytes, sit, ctx->d_slots);
+                    break;
+#define STORM_PROBE_CASE(n)                                                                   \
+    case 10 + n:                                                                              \
+        hipLaunchKernelGGL((strip_fp4_kernel<4, n>), sgrid, sblock, 0, ctx->stream, ctx->d_x4, \
+                           row_bytes, sit, ctx->d_slots);                                      \
+        break;
+                STORM_PROBE_CASE(1) STORM_PROBE_CASE(2) STORM_PROBE_CASE(4) STORM_PROBE_CASE(6)
+                STORM_PROBE_CASE(7)
+#undef STORM_PROBE_CASE
+                default:
+                    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock, 0,
+                                       ctx->stream, ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    break;
+            }
             STORM_HIP_TRY(hipGetLastError());
         }
         if (ctx->n_items > 0) {
@@ -733,7 +780,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
 
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total) {
-    const uint64_t n_rows4 = (m->n_rows + kTile - 1) / kTile * kTile;
+    const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     std::vector<RowRange> ranges;
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     return launch_pairw_mfma_ranges(ctx, m->d, m->stride_words, m->n_rows_pad, n_rows4, ranges,

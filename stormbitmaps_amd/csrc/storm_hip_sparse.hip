@@ -28,7 +28,7 @@ struct storm_hip_sparse_s {
     uint64_t* d_pool = nullptr;      // pool rows: [n_pool_rows + kABlockRows][1024] words
     uint64_t n_pool_rows = 0;
     std::vector<RowRange> cols;      // pool-row range [r0, r1) of each non-empty column; every r0
-                                     // is a multiple of 256 and the gap up to it is zero rows
+                                     // is a multiple of 512 and the gap up to it is zero rows
     uint64_t census[4] = {0, 0, 0, 0};
     // segment table cache (per shard)
     Seg* d_segs = nullptr;
@@ -153,7 +153,7 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
             s->census[1] += nl * nb;
             s->census[2] += nb * (nb - (nb != 0)) / 2;
             s->census[3] += 1;
-            run = (run + per_col[c] + 255) / 256 * 256;  // next column starts on a 256-row tile
+            run = (run + per_col[c] + 511) / 512 * 512;  // next column starts on a 512-row A tile
         }
     }
     s->n_pool_rows = run;
@@ -191,7 +191,7 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     uint64_t* h_stage = nullptr;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
-        const size_t pool_bytes = (s->n_pool_rows + 256) * kBlockWords * sizeof(uint64_t);
+        const size_t pool_bytes = (s->n_pool_rows + 512) * kBlockWords * sizeof(uint64_t);
         if (hipMalloc(reinterpret_cast<void**>(&s->d_pool), pool_bytes) != hipSuccess) {
             set_error("sparse_create: hipMalloc of %zu bytes for the block pool failed",
                       pool_bytes);
@@ -297,8 +297,8 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
         std::vector<RowRange> ranges;
         for (const RowRange& c : s->cols)
             if (c.r1 - c.r0 > 1) ranges.push_back(c);
-        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 256,
-                                              std::max<uint64_t>(s->n_pool_rows, 256), ranges,
+        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 512,
+                                              std::max<uint64_t>(s->n_pool_rows, 512), ranges,
                                               shard_rank, shard_count, variant == 4,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;
