@@ -296,6 +296,13 @@ class HipMatrix:
               "storm_hip_tile_counts")
         return out
 
+    def pairw_matrix(self) -> np.ndarray:
+        """[n_rows, n_rows] uint32, entry (i, j) = popcount(row_i & row_j) for i < j, else 0."""
+        out = np.zeros((self.n_rows, self.n_rows), dtype=np.uint32)
+        check(self._lib.storm_hip_pairw_matrix(self.ctx._h, self._h, _ptr(out)),
+              "storm_hip_pairw_matrix")
+        return out
+
     def column_identity(self) -> int:
         out = C.c_uint64()
         check(self._lib.storm_hip_column_identity(self.ctx._h, self._h, C.byref(out)),

@@ -1015,6 +1015,42 @@ int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uin
     return rc;
 }
 
+int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                  uint32_t* d_out, uint64_t ld) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !d_out || ld < m->n_rows) {
+        set_error("pairw_matrix: NULL argument or leading dimension < rows");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_pairw_matrix(ctx, m, d_out, ld);
+}
+
+int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_out) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !h_out) {
+        set_error("pairw_matrix: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t n = m->n_rows;
+    if (n == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t* d_out = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * n * sizeof(uint32_t)));
+    int rc = STORM_HIP_OK;
+    if (hipMemsetAsync(d_out, 0, n * n * sizeof(uint32_t), ctx->stream) != hipSuccess) {
+        rc = STORM_HIP_EHIP;
+    } else if ((rc = launch_pairw_matrix(ctx, m, d_out, n)) == STORM_HIP_OK) {
+        if (hipMemcpyAsync(h_out, d_out, n * n * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = STORM_HIP_EHIP;
+    }
+    if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
+    (void)hipFree(d_out);
+    return rc;
+}
+
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                               uint64_t* h_total) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;

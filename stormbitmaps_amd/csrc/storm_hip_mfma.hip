@@ -100,10 +100,13 @@ __device__ __forceinline__ void stage_tile(uint8_t* lds_tile, const uint8_t* __r
     }
 }
 
-template <uint32_t probe>
+// kWrite: instead of summing, store every pair count i < j of the tile to out[i * ld + j]
+// (materialised XX^T upper triangle); the item then spans the whole k range.
+template <uint32_t probe, bool kWrite = false>
 __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
-    unsigned long long* __restrict__ slots) {
+    unsigned long long* __restrict__ slots, uint32_t* __restrict__ out = nullptr, uint64_t ld = 0,
+    uint32_t n_rows = 0) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kRing][2][kTileStageBytes];  // [stage][A|B]
 
     const uint32_t tid = threadIdx.x;
@@ -201,8 +204,24 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: exact integer sum of this wave's 128x64 block ----
+    // ---- epilogue ----
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (kWrite) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const uint32_t j = b_row0 + wn * 64u + n * 32u + (lane & 31u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t i = a_row0 + wm * 128u + m * 32u + (r & 3) + 8 * (r >> 2) +
+                                       4 * (lane >> 5);
+                    if (i < j && j < n_rows) out[(uint64_t)i * ld + j] = (uint32_t)acc[m][n][r];
+                }
+            }
+        return;
+    }
+    // exact integer sum of this wave's 128x64 block
     const bool diag_tile = it.I == it.J;
     uint32_t all = 0, trace = 0;
 #pragma unroll
@@ -776,6 +795,62 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     ctx->last_info[2] = 0;
     ctx->last_info[3] = 0;
     return launch_fold_slots(ctx, d_total);
+}
+
+// Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
+// (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
+// exact for rows of fewer than 2^24 bits.
+int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_out,
+                        uint64_t ld) {
+    if ((uint64_t)m->n_words * 64u >= (1ull << 24)) {
+        set_error("pairw_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
+                  (unsigned long long)m->n_words * 64u);
+        return STORM_HIP_EINVAL;
+    }
+    if (m->n_rows < 2) return STORM_HIP_OK;
+    const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
+    const uint64_t row_bytes = m->stride_words * 32;
+    const size_t x4_bytes = (size_t)n_rows4 * row_bytes;
+    if (n_rows4 / kTile >= 65535) {
+        set_error("pairw_matrix: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    if (x4_bytes > ctx->x4_capacity) {
+        if (ctx->d_x4) STORM_HIP_TRY(hipFree(ctx->d_x4));
+        ctx->d_x4 = nullptr;
+        ctx->x4_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_x4), x4_bytes) != hipSuccess) {
+            set_error("pairw_matrix: hipMalloc of %zu bytes for the FP4 shadow failed", x4_bytes);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->x4_capacity = x4_bytes;
+    }
+    const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
+    const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
+    std::vector<MfmaItem> items;
+    for (uint32_t i = 0; i < nT; ++i)  // long rows of tiles first
+        for (uint32_t j = i; j < nT; ++j) items.push_back({(uint16_t)i, (uint16_t)j, 0, total_stages});
+    MfmaItem* d_items = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+    int rc = STORM_HIP_OK;
+    if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
+                       ctx->stream) != hipSuccess) {
+        rc = STORM_HIP_EHIP;
+    } else {
+        const uint64_t work = n_rows4 * m->stride_words * 2;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+                           m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
+                           reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u);
+        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
+                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, row_bytes, d_items,
+                           ctx->d_slots, d_out, ld, (uint32_t)m->n_rows);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = STORM_HIP_EHIP;
+    }
+    if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
+    (void)hipFree(d_items);
+    return rc;
 }
 
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,

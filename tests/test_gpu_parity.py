@@ -504,3 +504,16 @@ def test_in_process_multi_device_sharding_through_the_c_api(lib):
         one_dev = (C.c_int * 1)(0)
         assert lib.STORM_hip_set_devices(1, one_dev) == 0
     c.free()
+
+
+def test_materialised_upper_triangle(hip_ctx, orc):
+    """the per-pair matrix the reference only sums. Every entry i < j must equal the
+    oracle's pair count, entries i >= j stay 0, and the matrix sums to the all-pairs total."""
+    for M, N, d in ((9000, 700, 4000), (4096, 257, 2048), (70000, 300, 30000)):
+        mat = synth.dense_matrix_c(M, N, d, seed=21)
+        m = hip_ctx.matrix_from_host(mat)
+        got = m.pairw_matrix()
+        want = np.triu(orc.tile_counts(mat, 0, N, 0, N), k=1)
+        assert np.array_equal(got, want), (M, N, d)
+        assert int(got.sum(dtype=np.uint64)) == m.pairw()
+        m.close()
