@@ -104,15 +104,29 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
  * out[(i-i0)*(j1-j0)+(j-j0)] = popcount(row_i & row_j); out is a HOST buffer */
 int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t i0,
                           uint64_t i1, uint64_t j0, uint64_t j1, uint32_t* h_out);
+/* Sibling pair counts of the upstream leaf library (union / symmetric-difference cardinality,
+ * reference README.md:24-26). They are not separate kernels: with the per-row
+ * set-bit counts n_i,  |a|b| = n_a + n_b - |a&b|  and  |a^b| = n_a + n_b - 2|a&b|, so both ride
+ * on the intersect path. */
+#define STORM_HIP_OP_AND 0
+#define STORM_HIP_OP_OR 1
+#define STORM_HIP_OP_XOR 2
+/* h_counts[i] = popcount(row_i), n_rows entries (host pointer) */
+int storm_hip_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_counts);
+/* *h_total = sum_{i<j} popcount(row_i OP row_j) */
+int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                             uint64_t* h_total);
+
 /* Materialised strict upper triangle of XX^T on the matrix cores (the product the reference
  * deliberately does not write out, README.md:41):
- *   out[i * ld + j] = popcount(row_i & row_j) for i < j; other entries are left untouched.
+ *   out[i * ld + j] = popcount(row_i OP row_j) for i < j; other entries are left untouched.
  * _device: `d_out` is a DEVICE pointer to n_rows x ld uint32 (ld >= n_rows); synchronous.
  * plain  : `h_out` is a HOST n_rows x n_rows uint32 buffer; entries i >= j come back as 0.
  * Rows must be shorter than 2^24 bits (exact f32 accumulation). */
-int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                   uint32_t* d_out, uint64_t ld);
-int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_out);
+int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                           uint32_t* h_out);
 /* sum_c C(n_c,2) on the device — verification identity only, never the product
  * path: used by tests at sizes where a CPU pairwise oracle is infeasible */
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,

@@ -750,6 +750,35 @@ void orc_tile_counts(const uint64_t* vals, uint64_t n_words, uint64_t i0, uint64
                 vals + i * n_words, vals + j * n_words, n_words);
 }
 
+/* Sibling pair counts (union / symmetric difference), computed directly — no
+ * inclusion-exclusion — so they check the device's identity-based route independently.
+ * op: 0 = AND, 1 = OR, 2 = XOR. */
+static inline uint64_t op_word(uint64_t a, uint64_t b, int op) {
+    return op == 0 ? (a & b) : op == 1 ? (a | b) : (a ^ b);
+}
+
+void orc_tile_counts_op(const uint64_t* vals, uint64_t n_words, uint64_t i0, uint64_t i1,
+                        uint64_t j0, uint64_t j1, int op, uint32_t* out) {
+    for (uint64_t i = i0; i < i1; ++i)
+        for (uint64_t j = j0; j < j1; ++j) {
+            uint64_t n = 0;
+            for (uint64_t k = 0; k < n_words; ++k)
+                n += (uint64_t)__builtin_popcountll(
+                    op_word(vals[i * n_words + k], vals[j * n_words + k], op));
+            out[(i - i0) * (j1 - j0) + (j - j0)] = (uint32_t)n;
+        }
+}
+
+uint64_t orc_truth_naive_dense_op(const uint64_t* vals, uint64_t n_rows, uint64_t n_words, int op) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n_rows; ++i)
+        for (uint64_t j = i + 1; j < n_rows; ++j)
+            for (uint64_t k = 0; k < n_words; ++k)
+                total += (uint64_t)__builtin_popcountll(
+                    op_word(vals[i * n_words + k], vals[j * n_words + k], op));
+    return total;
+}
+
 double orc_time_blocked(const uint64_t* vals, uint32_t n_rows, uint32_t n_words, int leaf_kind,
                         uint32_t bsize, uint64_t* total_out) {
     orc_compute_func f = orc_get_intersect_count_func_kind(leaf_kind);

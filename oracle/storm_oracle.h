@@ -119,6 +119,10 @@ void orc_tile_counts(const uint64_t* vals, uint64_t n_words, uint64_t i0, uint64
 
 /* ---- timing helper for bench.py's cpu_baseline leg (1 thread) ----
  * Runs orc_wrapper_diag_blocked over the first n_rows rows; returns seconds, writes total. */
+/* union / symmetric-difference siblings of the pair count (op: 0 AND, 1 OR, 2 XOR) */
+void orc_tile_counts_op(const uint64_t* vals, uint64_t n_words, uint64_t i0, uint64_t i1,
+                        uint64_t j0, uint64_t j1, int op, uint32_t* out);
+uint64_t orc_truth_naive_dense_op(const uint64_t* vals, uint64_t n_rows, uint64_t n_words, int op);
 double orc_time_blocked(const uint64_t* vals, uint32_t n_rows, uint32_t n_words, int leaf_kind,
                         uint32_t bsize, uint64_t* total_out);
 

@@ -46,8 +46,10 @@ SIGNATURES = {
     "storm_hip_square_dense": (C.c_int, [vp, vp, vp, P(u64)]),
     "storm_hip_tile_counts": (C.c_int, [vp, vp, u64, u64, u64, u64, vp]),
     "storm_hip_column_identity": (C.c_int, [vp, vp, P(u64)]),
-    "storm_hip_pairw_matrix_device": (C.c_int, [vp, vp, vp, u64]),
-    "storm_hip_pairw_matrix": (C.c_int, [vp, vp, vp]),
+    "storm_hip_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
+    "storm_hip_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp]),
+    "storm_hip_row_counts": (C.c_int, [vp, vp, vp]),
+    "storm_hip_pairw_dense_op": (C.c_int, [vp, vp, C.c_int, P(u64)]),
     "storm_hip_ctx_set_option": (C.c_int, [vp, cp, i64]),
     "storm_hip_ctx_get_option": (i64, [vp, cp]),
     "storm_hip_last_launch_info": (C.c_int, [vp, P(u64 * 4)]),

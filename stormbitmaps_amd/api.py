@@ -296,12 +296,33 @@ class HipMatrix:
               "storm_hip_tile_counts")
         return out
 
-    def pairw_matrix(self) -> np.ndarray:
-        """[n_rows, n_rows] uint32, entry (i, j) = popcount(row_i & row_j) for i < j, else 0."""
+    OPS = {"and": 0, "or": 1, "xor": 2}
+
+    def pairw_matrix(self, op: str = "and") -> np.ndarray:
+        """[n_rows, n_rows] uint32, entry (i, j) = popcount(row_i OP row_j) for i < j, else 0."""
         out = np.zeros((self.n_rows, self.n_rows), dtype=np.uint32)
-        check(self._lib.storm_hip_pairw_matrix(self.ctx._h, self._h, _ptr(out)),
+        check(self._lib.storm_hip_pairw_matrix(self.ctx._h, self._h, self.OPS[op], _ptr(out)),
               "storm_hip_pairw_matrix")
         return out
+
+    def pairw_matrix_device(self, d_out: int, ld: int, op: str = "and") -> None:
+        """Same, into a device buffer (address `d_out`, n_rows x ld uint32); synchronous."""
+        check(self._lib.storm_hip_pairw_matrix_device(self.ctx._h, self._h, self.OPS[op],
+                                                      C.c_void_p(d_out), ld),
+              "storm_hip_pairw_matrix_device")
+
+    def row_counts(self) -> np.ndarray:
+        out = np.zeros(self.n_rows, dtype=np.uint32)
+        check(self._lib.storm_hip_row_counts(self.ctx._h, self._h, _ptr(out)),
+              "storm_hip_row_counts")
+        return out
+
+    def pairw_op(self, op: str) -> int:
+        """sum_{i<j} popcount(row_i OP row_j), OP in and / or / xor."""
+        total = C.c_uint64(0)
+        check(self._lib.storm_hip_pairw_dense_op(self.ctx._h, self._h, self.OPS[op],
+                                                 C.byref(total)), "storm_hip_pairw_dense_op")
+        return int(total.value)
 
     def column_identity(self) -> int:
         out = C.c_uint64()

@@ -376,6 +376,21 @@ __global__ __launch_bounds__(kThreads) void column_identity_kernel(
     if (lane == 0 && s != 0) atomicAdd(&slots[w & (kSlots - 1)], (unsigned long long)s);
 }
 
+// Per-row set-bit counts n_i (one wave per row). The sibling pair counts follow from the
+// intersect count by inclusion-exclusion: |a|b| = n_a + n_b - |a&b|, |a^b| = n_a + n_b - 2|a&b|.
+__global__ __launch_bounds__(kThreads) void row_counts_kernel(const uint64_t* __restrict__ X,
+                                                              uint64_t stride, uint64_t n_rows,
+                                                              uint32_t n_words,
+                                                              uint32_t* __restrict__ counts) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t r = (uint64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    uint64_t n = 0;
+    for (uint32_t k = lane; k < n_words; k += 64u) n += (uint64_t)__popcll(X[r * stride + k]);
+    n = wave_sum_u64(n);
+    if (lane == 0) counts[r] = (uint32_t)n;
+}
+
 // OR sorted position lists (CSR) into rows [row0, ...): one workgroup per row.
 __global__ __launch_bounds__(kThreads) void set_bits_kernel(uint64_t* __restrict__ X,
                                                             uint64_t stride, uint64_t row0,
@@ -1015,21 +1030,77 @@ int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uin
     return rc;
 }
 
-int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+}  // extern "C"
+
+namespace storm {
+int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_counts) {
+    if (m->n_rows == 0) return STORM_HIP_OK;
+    hipLaunchKernelGGL(row_counts_kernel, dim3((uint32_t)((m->n_rows + kWaves - 1) / kWaves)),
+                       dim3(kThreads), 0, ctx->stream, m->d, m->stride_words, m->n_rows,
+                       m->n_words, d_counts);
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+}  // namespace storm
+
+extern "C" {
+
+int storm_hip_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_counts) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !h_counts) {
+        set_error("row_counts: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    if (m->n_rows == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t* d_counts = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_counts), m->n_rows * sizeof(uint32_t)));
+    int rc = launch_row_counts(ctx, m, d_counts);
+    if (rc == STORM_HIP_OK &&
+        (hipMemcpyAsync(h_counts, d_counts, m->n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                        ctx->stream) != hipSuccess ||
+         hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        set_error("row_counts: HIP failure");
+        rc = STORM_HIP_EHIP;
+    }
+    (void)hipFree(d_counts);
+    return rc;
+}
+
+int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                             uint64_t* h_total) {
+    if (op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR) {
+        set_error("pairw_dense_op: unknown op %d", op);
+        return STORM_HIP_EINVAL;
+    }
+    if (int rc = storm_hip_pairw_dense(ctx, m, 0, 1, h_total)) return rc;
+    if (op == STORM_HIP_OP_AND || m->n_rows < 2) return STORM_HIP_OK;
+    std::vector<uint32_t> counts(m->n_rows);
+    if (int rc = storm_hip_row_counts(ctx, m, counts.data())) return rc;
+    uint64_t set_bits = 0;
+    for (uint32_t c : counts) set_bits += c;
+    // every row meets N-1 partners: sum_{i<j} (n_i + n_j) = (N-1) * sum_i n_i
+    const uint64_t both = (m->n_rows - 1) * set_bits;
+    *h_total = both - (op == STORM_HIP_OP_XOR ? 2 * *h_total : *h_total);
+    return STORM_HIP_OK;
+}
+
+int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                   uint32_t* d_out, uint64_t ld) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
-    if (!m || !d_out || ld < m->n_rows) {
-        set_error("pairw_matrix: NULL argument or leading dimension < rows");
+    if (!m || !d_out || ld < m->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR) {
+        set_error("pairw_matrix: NULL argument, unknown op or leading dimension < rows");
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    return launch_pairw_matrix(ctx, m, d_out, ld);
+    return launch_pairw_matrix(ctx, m, op, d_out, ld);
 }
 
-int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_out) {
+int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                           uint32_t* h_out) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
-    if (!m || !h_out) {
-        set_error("pairw_matrix: NULL argument");
+    if (!m || !h_out || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR) {
+        set_error("pairw_matrix: NULL argument or unknown op");
         return STORM_HIP_EINVAL;
     }
     const uint64_t n = m->n_rows;
@@ -1040,7 +1111,7 @@ int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, ui
     int rc = STORM_HIP_OK;
     if (hipMemsetAsync(d_out, 0, n * n * sizeof(uint32_t), ctx->stream) != hipSuccess) {
         rc = STORM_HIP_EHIP;
-    } else if ((rc = launch_pairw_matrix(ctx, m, d_out, n)) == STORM_HIP_OK) {
+    } else if ((rc = launch_pairw_matrix(ctx, m, op, d_out, n)) == STORM_HIP_OK) {
         if (hipMemcpyAsync(h_out, d_out, n * n * sizeof(uint32_t), hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess)

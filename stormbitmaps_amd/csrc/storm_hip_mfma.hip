@@ -106,7 +106,7 @@ template <uint32_t probe, bool kWrite = false>
 __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     unsigned long long* __restrict__ slots, uint32_t* __restrict__ out = nullptr, uint64_t ld = 0,
-    uint32_t n_rows = 0) {
+    uint32_t n_rows = 0, const uint32_t* __restrict__ row_counts = nullptr, uint32_t and_weight = 0) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kRing][2][kTileStageBytes];  // [stage][A|B]
 
     const uint32_t tid = threadIdx.x;
@@ -212,11 +212,17 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const uint32_t j = b_row0 + wn * 64u + n * 32u + (lane & 31u);
+                // union / symmetric difference: n_i + n_j - and_weight * |i & j|
+                const uint32_t nj = (row_counts && j < n_rows) ? row_counts[j] : 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t i = a_row0 + wm * 128u + m * 32u + (r & 3) + 8 * (r >> 2) +
                                        4 * (lane >> 5);
-                    if (i < j && j < n_rows) out[(uint64_t)i * ld + j] = (uint32_t)acc[m][n][r];
+                    if (i < j && j < n_rows) {
+                        const uint32_t c = (uint32_t)acc[m][n][r];
+                        out[(uint64_t)i * ld + j] =
+                            row_counts ? row_counts[i] + nj - and_weight * c : c;
+                    }
                 }
             }
         return;
@@ -800,7 +806,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
-int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_out,
+int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld) {
     if ((uint64_t)m->n_words * 64u >= (1ull << 24)) {
         set_error("pairw_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
@@ -832,8 +838,16 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint3
         for (uint32_t j = i; j < nT; ++j) items.push_back({(uint16_t)i, (uint16_t)j, 0, total_stages});
     MfmaItem* d_items = nullptr;
     STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+    uint32_t* d_counts = nullptr;
     int rc = STORM_HIP_OK;
-    if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
+    if (op != STORM_HIP_OP_AND) {
+        if (hipMalloc(reinterpret_cast<void**>(&d_counts), m->n_rows * sizeof(uint32_t)) != hipSuccess)
+            rc = STORM_HIP_ENOMEM;
+        else
+            rc = launch_row_counts(ctx, m, d_counts);
+    }
+    if (rc != STORM_HIP_OK) {
+    } else if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
                        ctx->stream) != hipSuccess) {
         rc = STORM_HIP_EHIP;
     } else {
@@ -844,12 +858,14 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint3
                            reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u);
         hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
                            dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, row_bytes, d_items,
-                           ctx->d_slots, d_out, ld, (uint32_t)m->n_rows);
+                           ctx->d_slots, d_out, ld, (uint32_t)m->n_rows, d_counts,
+                           op == STORM_HIP_OP_XOR ? 2u : 1u);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = STORM_HIP_EHIP;
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
     (void)hipFree(d_items);
+    (void)hipFree(d_counts);
     return rc;
 }
 

@@ -56,6 +56,8 @@ class Oracle:
             "orc_truth_naive_dense": (u64, [vp, u64, u64]),
             "orc_truth_column_count": (u64, [vp, u64, u64]),
             "orc_tile_counts": (None, [vp, u64, u64, u64, u64, u64, vp]),
+            "orc_tile_counts_op": (None, [vp, u64, u64, u64, u64, u64, C.c_int, vp]),
+            "orc_truth_naive_dense_op": (u64, [vp, u64, u64, C.c_int]),
             "orc_wrapper_diag": (u64, [u32, vp, u32, vp]),
             "orc_wrapper_diag_blocked": (u64, [u32, vp, u32, vp, u32]),
             "orc_wrapper_square": (u64, [u32, vp, u32, vp, u32, vp]),
@@ -97,6 +99,16 @@ class Oracle:
         out = np.zeros((i1 - i0, j1 - j0), dtype=np.uint32)
         self.lib.orc_tile_counts(_p(m), m.shape[1], i0, i1, j0, j1, _p(out))
         return out
+
+    def tile_counts_op(self, mat, i0, i1, j0, j1, op) -> np.ndarray:
+        m = np.ascontiguousarray(mat, dtype=np.uint64)
+        out = np.zeros((i1 - i0, j1 - j0), dtype=np.uint32)
+        self.lib.orc_tile_counts_op(_p(m), m.shape[1], i0, i1, j0, j1, op, _p(out))
+        return out
+
+    def truth_naive_op(self, mat: np.ndarray, op: int) -> int:
+        m = np.ascontiguousarray(mat, dtype=np.uint64)
+        return int(self.lib.orc_truth_naive_dense_op(_p(m), m.shape[0], m.shape[1], op))
 
     # ---- raw wrappers
     def wrapper_diag(self, mat, kind=-1) -> int:

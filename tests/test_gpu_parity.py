@@ -517,3 +517,18 @@ def test_materialised_upper_triangle(hip_ctx, orc):
         assert np.array_equal(got, want), (M, N, d)
         assert int(got.sum(dtype=np.uint64)) == m.pairw()
         m.close()
+
+
+def test_union_and_symmetric_difference(hip_ctx, orc):
+    """OR / XOR pair counts (by inclusion-exclusion on the device) against the
+    oracle's direct popcount(a|b) / popcount(a^b), as totals and as materialised matrices."""
+    for M, N, d in ((9000, 300, 4000), (4096, 513, 100), (65536, 130, 32768)):
+        mat = synth.dense_matrix_c(M, N, d, seed=33)
+        m = hip_ctx.matrix_from_host(mat)
+        assert np.array_equal(m.row_counts(),
+                              np.bitwise_count(mat).sum(axis=1, dtype=np.uint64).astype(np.uint32))
+        for name, op in (("and", 0), ("or", 1), ("xor", 2)):
+            assert m.pairw_op(name) == orc.truth_naive_op(mat, op), (M, N, d, name)
+            want = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, op), k=1)
+            assert np.array_equal(m.pairw_matrix(name), want), (M, N, d, name)
+        m.close()
