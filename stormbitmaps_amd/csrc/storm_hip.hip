@@ -976,6 +976,20 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     *h_total = 0;
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    // same choice as the all-pairs path: matrix cores once the rectangle is big enough to fill
+    // the chip with strip items, the popcount kernel below that (or when forced by `variant`)
+    const bool big = (uint64_t)a->n_rows * b->n_rows >= (1ull << 19) &&
+                     a->stride_words * 32ull * 64ull < (1ull << 32);
+    if (a->stride_words == b->stride_words && (ctx->variant >= 3 || (ctx->variant < 0 && big))) {
+        if (int rc = launch_square_mfma(ctx, a, b, reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+            return rc;
+        ctx->variant_used = 4;
+        STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t),
+                                     hipMemcpyDeviceToHost, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return STORM_HIP_OK;
+    }
+    ctx->variant_used = 2;
     const uint32_t seg_rows = (uint32_t)ctx->seg_rows;
     const uint32_t a_blocks = (uint32_t)(a->n_rows_pad / kABlockRows);
     const uint32_t spb = (uint32_t)((b->n_rows + seg_rows - 1) / seg_rows);

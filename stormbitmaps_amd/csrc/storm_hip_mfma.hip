@@ -803,6 +803,76 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     return launch_fold_slots(ctx, d_total);
 }
 
+// Rectangular sum_{i in A, j in B} popcount(a_i & b_j) (STORM_wrapper_square, storm.c:153-171,
+// with the reference's missing offset2 reset fixed) on the strip kernel: the FP4 shadow holds
+// [A ; B], each padded to a multiple of 256 rows, and every A tile walks all of B's 64-row
+// blocks with no diagonal phase.
+int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
+                       const storm_hip_matrix_s* b, uint64_t* d_total) {
+    const uint64_t stride_words = a->stride_words;
+    const uint64_t row_bytes = stride_words * 32;
+    const uint64_t rows_a = (a->n_rows + kStripATile - 1) / kStripATile * kStripATile;
+    const uint64_t rows_b = (b->n_rows + kStripATile - 1) / kStripATile * kStripATile;
+    const size_t x4_bytes = (size_t)(rows_a + rows_b) * row_bytes;
+    if (row_bytes * (uint64_t)kStripBRows >= (1ull << 32) || (rows_a + rows_b) >= (1ull << 31)) {
+        set_error("square (matrix cores): operand too large for the strip kernel's 32-bit offsets");
+        return STORM_HIP_EINVAL;
+    }
+    if (x4_bytes > ctx->x4_capacity) {
+        if (ctx->d_x4) STORM_HIP_TRY(hipFree(ctx->d_x4));
+        ctx->d_x4 = nullptr;
+        ctx->x4_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_x4), x4_bytes) != hipSuccess) {
+            set_error("square: hipMalloc of %zu bytes for the FP4 shadow failed", x4_bytes);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->x4_capacity = x4_bytes;
+    }
+    const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
+    const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
+    const uint32_t jb0 = (uint32_t)(rows_a / kStripBRows);
+    const uint32_t jb1 = jb0 + (uint32_t)((b->n_rows + kStripBRows - 1) / kStripBRows);
+    std::vector<StripItem> items;
+    for (uint32_t ks = 0; ks < n_kslices; ++ks)
+        for (uint32_t a_row0 = 0; a_row0 < a->n_rows; a_row0 += (uint32_t)kStripATile)
+            for (uint32_t j0 = jb0; j0 < jb1; j0 += kMaxRun)
+                items.push_back({a_row0, 0u, j0, std::min(jb1, j0 + kMaxRun), ks});
+    if (items.size() >= (1ull << 31)) {
+        set_error("square: %zu strip items exceed the grid limit", items.size());
+        return STORM_HIP_EINVAL;
+    }
+    if (items.size() > ctx->strip_capacity) {
+        if (ctx->d_strip_items) STORM_HIP_TRY(hipFree(ctx->d_strip_items));
+        ctx->d_strip_items = nullptr;
+        ctx->strip_capacity = 0;
+        const size_t cap = std::max<size_t>(items.size(), 4096);
+        STORM_HIP_TRY(hipMalloc(&ctx->d_strip_items, cap * sizeof(StripItem)));
+        ctx->strip_capacity = cap;
+    }
+    memset(ctx->strip_key, 0xff, sizeof(ctx->strip_key));  // the cached all-pairs table is gone
+    ctx->n_strip_items = 0;
+    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_strip_items, items.data(), items.size() * sizeof(StripItem),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` leaves scope
+    for (int side = 0; side < 2; ++side) {
+        const storm_hip_matrix_s* m = side ? b : a;
+        const uint64_t rows_dst = side ? rows_b : rows_a;
+        const uint64_t work = rows_dst * stride_words * 2;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+                           stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
+                           reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * row_bytes : 0)),
+                           0u, 1u);
+        STORM_HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
+                       dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, row_bytes,
+                       static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+    STORM_HIP_TRY(hipGetLastError());
+    ctx->last_info[0] = (uint32_t)items.size();
+    return launch_fold_slots(ctx, d_total);
+}
+
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.

@@ -532,3 +532,22 @@ def test_union_and_symmetric_difference(hip_ctx, orc):
             want = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, op), k=1)
             assert np.array_equal(m.pairw_matrix(name), want), (M, N, d, name)
         m.close()
+
+
+def test_square_on_matrix_cores(hip_ctx, orc):
+    """rectangular sum over A x B on the strip kernel ([A ; B] shadow, no diagonal
+    phase) against the oracle's wrapper_square and the popcount kernel; ragged row counts."""
+    mat = synth.dense_matrix_c(9000, 2003, 4000, seed=14)
+    for na in (1100, 257, 1):
+        a, b = mat[:na], mat[na:]
+        ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
+        want = orc.wrapper_square(a, b)
+        try:
+            for variant in (4, 2, -1):
+                hip_ctx.set_option("variant", variant)
+                assert ma.square(mb) == want, (na, variant)
+                assert mb.square(ma) == want, (na, variant)
+        finally:
+            hip_ctx.set_option("variant", -1)
+        assert ma.pairw() + mb.pairw() + want == orc.wrapper_diag(mat)
+        ma.close(); mb.close()
