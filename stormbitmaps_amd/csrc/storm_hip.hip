@@ -583,8 +583,8 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
     if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
     if (!strcmp(key, "variant")) {
-        if (value < -1 || value > 4) {
-            set_error("variant must be -1 (auto) or 0..4");
+        if (value < -1 || value > 5) {
+            set_error("variant must be -1 (auto) or 0..5");
             return STORM_HIP_EINVAL;
         }
         ctx->variant = (int)value;

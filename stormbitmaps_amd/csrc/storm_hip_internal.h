@@ -100,7 +100,7 @@ struct RowRange {
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
-                             uint32_t shard_count, bool strips, uint64_t* d_total);
+                             uint32_t shard_count, int strip_mode, uint64_t* d_total);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld);
 int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,

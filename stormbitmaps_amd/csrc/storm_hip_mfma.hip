@@ -316,8 +316,11 @@ struct StripItem {
 };
 
 // kProbe: timing probes with WRONG results: bit 0 no barriers, bit 1 no LDS-DMA, bit 2 no ds_read
-template <int kStripRing, int kProbe = 0>
-__global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
+// kMB: 32-row MFMA blocks of A per wave. 2 = 64 rows per wave, 256-row A tile, 4 workgroups per
+// CU; 4 = 128 rows per wave, 512-row A tile, 2 workgroups per CU ("wide": every B byte that
+// crosses the LDS feeds twice the MFMAs).
+template <int kStripRing, int kProbe = 0, int kMB = 2>
+__global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kStripRing][kStripStageBytes];
@@ -326,12 +329,16 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
+    constexpr uint32_t kWaveRows = 32u * kMB;                 // A rows of one wave
+    constexpr uint32_t kATile = kWaveRows * kStripWaves;      // A rows of the workgroup
+    constexpr uint32_t kBPW = kMB / 2;                        // 64-row B blocks per wave's rows
+    static_assert(kMB == 2 || kMB == 4, "A rows per wave: 64 or 128");
     const StripItem it = items[blockIdx.x];
     const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
     // Stage order: first (if it.diag) the 4 blocks of the A tile itself — wave wm contributes
     // nothing for blocks before its own rows, the strict upper triangle of its own 64x64 block,
     // and everything after — then the later blocks from the LAST one down.
-    const uint32_t D = it.diag ? (uint32_t)(kStripATile / kStripBRows) : 0u;
+    const uint32_t D = it.diag ? kATile / (uint32_t)kStripBRows : 0u;
     const uint32_t T = D + (it.j1 - it.j0);
 
     // B stage = 8 LDS-DMA instructions of 8 rows x 128 B; wave w issues instructions w and
@@ -358,14 +365,14 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
 
     // A fragments first (older in the VMEM queue than the DMAs, so waiting for them does not
     // drain the ring), then the first stages of B
-    v4i a[4][2];
+    v4i a[4][kMB];
     {
-        const uint8_t* ap = X4 + (uint64_t)(it.a_row0 + wm * 64u + (lane & 31u)) *
+        const uint8_t* ap = X4 + (uint64_t)(it.a_row0 + wm * kWaveRows + (lane & 31u)) *
                                      row_bytes + kbyte + (lane >> 5) * 16u;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < kMB; ++m)
                 a[kk][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 32u * row_bytes +
                                                          kk * 32);
     }
@@ -373,9 +380,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     for (uint32_t t = 0; t < kStripRing - 1; ++t)
         if (t < T) issue(t);
 
-    v16f acc[2][2];
+    v16f acc[kMB][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < kMB; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
 
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
     };
     auto multiply = [&](int kk, const v4i (&b)[2]) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < kMB; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) asm volatile("" ::"v"(a[kk][m]));
+        for (int m = 0; m < kMB; ++m) asm volatile("" ::"v"(a[kk][m]));
 
     // Ring protocol. Stages 0..2 are issued by the prologue; every wave issues 2 LDS-DMA
     // instructions per stage. retire(t, newest): wait until this wave's share of stage t has
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
         retire(t, t + kStripRing - 2);
         if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (t >= wm) {
+        if (t >= kBPW * wm) {
             fetch(t, 0, b0);
             fetch(t, 1, b1);
             STORM_LGKM(2);
@@ -483,17 +490,24 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
             STORM_LGKM(0);
             multiply(3, b1);
             __builtin_amdgcn_sched_barrier(0);
-            if (t == wm) {
-                // so far the accumulators hold exactly this wave's own 64x64 block: clear the
-                // pairs with i >= j in place. C/D map: col = lane & 31,
-                // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-                acc[1][0] = v16f{};
+            // Block t = kBPW * wm + q holds the q-th 64 rows of this wave (MFMA blocks 2q and
+            // 2q+1). Up to here blocks 2q.. of the accumulators have seen nothing but this
+            // stage (the earlier ones were cleared below), so the pairs with i >= j can be
+            // cleared in place: the blocks of later rows entirely, (2q+1, 0) entirely, and the
+            // two 32x32 blocks on the diagonal down to their strict upper triangle.
+            // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+            for (int q = 0; q < (int)kBPW; ++q) {
+                if (t != kBPW * wm + q) continue;
+#pragma unroll
+                for (int m = 2 * q + 2; m < kMB; ++m) acc[m][0] = acc[m][1] = v16f{};
+                acc[2 * q + 1][0] = v16f{};
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const bool keep = row < (lane & 31u);
-                    acc[0][0][r] = keep ? acc[0][0][r] : 0.0f;
-                    acc[1][1][r] = keep ? acc[1][1][r] : 0.0f;
+                    acc[2 * q][0][r] = keep ? acc[2 * q][0][r] : 0.0f;
+                    acc[2 * q + 1][1][r] = keep ? acc[2 * q + 1][1][r] : 0.0f;
                 }
             }
         }
@@ -523,14 +537,16 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip_fp4_kernel(
 #undef STORM_STEP
 #undef STORM_LGKM
 
-    uint32_t all = 0;
+    uint64_t mine = 0;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < kMB; ++m) {  // one 32x64 strip at a time stays below 2^32
+        uint32_t part = 0;
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) all += (uint32_t)acc[m][n][r];
-    uint64_t mine = all;
+            for (int r = 0; r < 16; ++r) part += (uint32_t)acc[m][n][r];
+        mine += part;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if (lane == 0 && mine != 0)
@@ -639,26 +655,28 @@ static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& range
 // slices are dealt to the 8 XCDs (block b runs on XCD b % 8 — observed, speed only), and inside
 // an XCD's list the items of one slice are consecutive, longest run first.
 static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
-                              uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count) {
+                              uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
+                              uint32_t a_tile) {
     const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
-                             ((uint64_t)shard_rank << 32) | shard_count, (uint64_t)ctx->k2_max_run};
+                             ((uint64_t)shard_rank << 32) | shard_count,
+                             ((uint64_t)a_tile << 32) | (uint32_t)ctx->k2_max_run};
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
     // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
     // load per run for a shorter tail at the end of the launch
     const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
-    constexpr uint32_t kPerTile = kStripATile / kStripBRows;
+    const uint32_t kPerTile = a_tile / kStripBRows;
     std::vector<std::vector<StripItem>> per_xcd(8);
     uint32_t local = 0;
     for (uint32_t ks = 0; ks < n_kslices; ++ks) {
         if ((ks / 16u) % shard_count != shard_rank) continue;  // 16 slices = one k-group
         std::vector<StripItem>& dst = per_xcd[local++ % 8];
         for (const RowRange& rg : ranges) {
-            // A tiles of kStripATile rows from the start of the range (the rows between r1 and
+            // A tiles of a_tile rows from the start of the range (the rows between r1 and
             // the end of its last A tile are zero: the caller pads ranges accordingly)
-            const uint32_t nA = (uint32_t)((rg.r1 - rg.r0 + kStripATile - 1) / kStripATile);
+            const uint32_t nA = (uint32_t)((rg.r1 - rg.r0 + a_tile - 1) / a_tile);
             const uint32_t jend = (uint32_t)((rg.r1 + kStripBRows - 1) / kStripBRows);  // absolute
             for (uint32_t i = 0; i < nA; ++i) {
-                const uint32_t a_row0 = (uint32_t)rg.r0 + i * (uint32_t)kStripATile;
+                const uint32_t a_row0 = (uint32_t)rg.r0 + i * a_tile;
                 const uint32_t first = a_row0 / (uint32_t)kStripBRows + kPerTile;
                 if (first >= jend) {  // last tile of the range: only its own triangle
                     dst.push_back({a_row0, 1, first, first, ks});
@@ -704,7 +722,11 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
-                             uint32_t shard_count, bool strips, uint64_t* d_total) {
+                             uint32_t shard_count, int strip_mode, uint64_t* d_total) {
+    // strip_mode: 0 = tile kernel, 1 = strips with 256-row A tiles, 2 = wide strips (512 rows;
+    // n_rows_dst and every range start must then be multiples of 512)
+    const bool strips = strip_mode != 0;
+    const uint32_t a_tile = strip_mode == 2 ? 512u : (uint32_t)kStripATile;
     const uint64_t row_bytes = stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
     const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows_dst, kTile) * row_bytes;
     if (n_rows_dst / kTile >= 65535) {
@@ -735,7 +757,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     }
     const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
     if (strips)
-        if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count)) return rc;
+        if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, a_tile))
+            return rc;
     // accumulators are f32: a k-slice must stay below 2^24 bits
     if ((uint64_t)ctx->k2_stages_per_item * 128u >= (1u << 24)) {
         set_error("K2: k-slice too long for exact f32 accumulation");
@@ -752,7 +775,19 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
         if (n_strip > 0) {
             const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
             const dim3 sgrid(n_strip), sblock(kStripThreads);
-            switch (ctx->k2_ring) {  // LDS ring depth of the strip kernel (tuning probe)
+            switch (strip_mode == 2 ? 100 + ctx->k2_ring : ctx->k2_ring) {  // ring depth: tuning probe
+                case 103:
+                    hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    break;
+                case 104:
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 4>), sgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    break;
+                case 105:
+                    hipLaunchKernelGGL((strip_fp4_kernel<5, 0, 4>), sgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    break;
                 case 3:
                     hipLaunchKernelGGL(strip_fp4_kernel<3>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
                                        row_bytes, sit, ctx->d_slots);
@@ -941,11 +976,13 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
 
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total) {
-    const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
+    const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
+    const uint64_t tile = strip_mode == 2 ? 512 : kStripATile;
+    const uint64_t n_rows4 = (m->n_rows + tile - 1) / tile * tile;
     std::vector<RowRange> ranges;
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     return launch_pairw_mfma_ranges(ctx, m->d, m->stride_words, m->n_rows_pad, n_rows4, ranges,
-                                    shard_rank, shard_count, ctx->variant == 4, d_total);
+                                    shard_rank, shard_count, strip_mode, d_total);
 }
 
 }  // namespace storm

@@ -299,7 +299,7 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
             if (c.r1 - c.r0 > 1) ranges.push_back(c);
         if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 512,
                                               std::max<uint64_t>(s->n_pool_rows, 512), ranges,
-                                              shard_rank, shard_count, variant == 4,
+                                              shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;
         STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t),

@@ -81,7 +81,7 @@ def test_dense_golden_vectors(hip_ctx, case):
     mat = synth.dense_matrix_c(case["M"], case["N"], case["draws"], seed=42)
     m = hip_ctx.matrix_from_host(mat)
     try:
-        for variant in (2, 0, 1, 3, 4):  # 3/4 = K2, the FP4 matrix-core paths
+        for variant in (2, 0, 1, 3, 4, 5):  # 3/4 = K2, the FP4 matrix-core paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == case["total"], f"variant {variant}"
     finally:
@@ -271,7 +271,7 @@ def test_headline_shape_properties(hip_ctx):
     assert total == m.column_identity()                      # sum_c C(n_c, 2)
     assert sum(m.pairw(r, 8) for r in range(8)) == total      # 8-way shard partition
     try:
-        for variant in (0, 3, 4):                             # independent operand paths
+        for variant in (0, 3, 4, 5):                             # independent operand paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
@@ -295,7 +295,7 @@ def test_wide_shape_properties(hip_ctx):
     total = m.pairw()
     assert total == m.column_identity()
     try:
-        for variant in (3, 4):
+        for variant in (3, 4, 5):
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
@@ -356,7 +356,7 @@ def test_sparse_arena_kernel_variants(lib, hip_ctx, orc):
                                        p(a_lists), a_lists.size, p(a_words), a_words.size, C.byref(h)) == 0, lib.storm_hip_last_error()
     out = C.c_uint64()
     try:
-        for variant in (2, 3, 4, -1):
+        for variant in (2, 3, 4, 5, -1):
             hip_ctx.set_option("variant", variant)
             assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, 0, 1, C.byref(out)) == 0, lib.storm_hip_last_error()
             assert out.value == want, variant
@@ -472,7 +472,7 @@ def test_repeated_launches_are_stable(hip_ctx):
     m.fill_synthetic(M, d, seed=43)
     want = m.column_identity()
     try:
-        for variant in (4, 3, 2):
+        for variant in (5, 4, 3, 2):
             hip_ctx.set_option("variant", variant)
             got = {m.pairw() for _ in range(30 if variant != 2 else 5)}
             assert got == {want}, (variant, got, want)
