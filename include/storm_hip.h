@@ -143,6 +143,19 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *   read-only "variant_used": what the last dense launch ran; "n_cus" */
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
+/* Tuning aid: with option "k2_ring" = 18 the strip kernel records, per work item, its start and
+ * end on the 100 MHz device counter and the HW_ID / XCC_ID registers of the workgroup's first
+ * wave. out[i*8 ..] = {start, end, hw_id, xcc_id, a_row0, diag, stages, k-slice}; results of the
+ * launch are unaffected. `out` may be NULL to query the item count. */
+int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t capacity_items,
+                                uint64_t* n_items);
+
+/* Duration of the dominant kernel alone (the popcount, tile or strip kernel — not the FP4
+ * expansion or the final fold), for roofline accounting: with option "time_kernels" = 1 every
+ * pairwise launch brackets that kernel with HIP events on the launch stream. This call waits for
+ * the stream, returns the summed duration and the number of launches since the last call, and
+ * starts a new series. */
+int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launches);
 /* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,
  * [2]=word-pairs executed (including zero padding), [3]=segments */
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);

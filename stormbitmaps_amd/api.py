@@ -189,6 +189,14 @@ class HipContext:
     def get_option(self, key: str) -> int:
         return int(self._lib.storm_hip_ctx_get_option(self._h, key.encode()))
 
+    def kernel_time(self):
+        """(summed ms, launches) of the dominant kernel since the last call; needs the
+        "time_kernels" option (storm_hip.h)."""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self._lib.storm_hip_kernel_time(self._h, C.byref(ms), C.byref(n)),
+              "storm_hip_kernel_time")
+        return float(ms.value), int(n.value)
+
     def last_launch_info(self) -> dict:
         out = (C.c_uint64 * 4)()
         check(self._lib.storm_hip_last_launch_info(self._h, C.byref(out)),

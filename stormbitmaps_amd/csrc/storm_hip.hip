@@ -283,6 +283,7 @@ __global__ __launch_bounds__(1024) void fold_slots_kernel(unsigned long long* __
         v += slots[i];
         slots[i] = 0;
     }
+    if (threadIdx.x < kSlotsExtra) slots[kSlots + threadIdx.x] = 0;  // queue heads of the strip kernel
     v = wave_sum_u64(v);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -537,14 +538,14 @@ int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
     ctx->device = device;
     ctx->stream = reinterpret_cast<hipStream_t>(stream);
     ctx->n_cus = prop.multiProcessorCount;
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_slots), kSlots * sizeof(uint64_t)) !=
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->d_slots), (kSlots + kSlotsExtra) * sizeof(uint64_t)) !=
             hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_scalar), 64) != hipSuccess) {
         set_error("workspace allocation failed");
         storm_hip_ctx_destroy(ctx);
         return STORM_HIP_ENOMEM;
     }
-    if (hipMemset(ctx->d_slots, 0, kSlots * sizeof(uint64_t)) != hipSuccess ||
+    if (hipMemset(ctx->d_slots, 0, (kSlots + kSlotsExtra) * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(ctx->d_scalar, 0, 64) != hipSuccess) {
         set_error("workspace memset failed");
         storm_hip_ctx_destroy(ctx);
@@ -577,6 +578,7 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
+    for (hipEvent_t ev : ctx->kernel_events) (void)hipEventDestroy(ev);
     delete ctx;
 }
 
@@ -607,13 +609,30 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_max_run = (int)value;
     } else if (!strcmp(key, "k2_ring")) {
-        if ((value < 3 || value > 5) && (value < 11 || value > 17)) {
+        if ((value < 3 || value > 5) && (value < 11 || value > 18)) {
             set_error("k2_ring must be 3, 4 or 5 (10 + bits = timing probes)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "k2_persistent")) {
+        ctx->k2_persistent = value != 0;
+    } else if (!strcmp(key, "k2_tail_slices")) {
+        if (value < 0 || value > 255) {
+            set_error("k2_tail_slices must be 0..255");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_tail_slices = (int)value;
+    } else if (!strcmp(key, "k2_tail_run")) {
+        if (value < 1 || value > 4096) {
+            set_error("k2_tail_run must be 1..4096");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_tail_run = (int)value;
     } else if (!strcmp(key, "k2_debug")) {
         ctx->k2_debug = (int)value;
+    } else if (!strcmp(key, "time_kernels")) {
+        ctx->time_kernels = value != 0;
+        ctx->kernel_events_used = 0;
     } else if (!strcmp(key, "chunks_per_item")) {
         if (value < 0 || value > 4096) {
             set_error("chunks_per_item out of range");
@@ -637,6 +656,46 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     return -1;
+}
+
+int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launches) {
+    if (check_ctx(ctx) || !sum_ms || !launches) return STORM_HIP_EINVAL;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *sum_ms = 0.0;
+    *launches = 0;
+    for (size_t i = 0; i + 1 < ctx->kernel_events_used; i += 2) {
+        float ms = 0.f;
+        STORM_HIP_TRY(hipEventElapsedTime(&ms, ctx->kernel_events[i], ctx->kernel_events[i + 1]));
+        *sum_ms += ms;
+        ++*launches;
+    }
+    ctx->kernel_events_used = 0;
+    return STORM_HIP_OK;
+}
+
+int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t capacity_items,
+                                uint64_t* n_items) {
+    if (check_ctx(ctx) || !n_items) return STORM_HIP_EINVAL;
+    *n_items = ctx->trace_items;
+    if (!out || ctx->trace_items == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const uint64_t n = std::min<uint64_t>(capacity_items, ctx->trace_items);
+    // per item: 4 trace words, then the item record {a_row0, diag, j0, j1} widened to 64 bit
+    std::vector<uint64_t> raw(n * 4);
+    std::vector<uint32_t> items(n * 5);
+    STORM_HIP_TRY(hipMemcpy(raw.data(), ctx->d_trace, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    STORM_HIP_TRY(hipMemcpy(items.data(), ctx->d_strip_items, n * 5 * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 4; ++k) out[i * 8 + k] = raw[i * 4 + k];
+        out[i * 8 + 4] = items[i * 5 + 0];
+        out[i * 8 + 5] = items[i * 5 + 1];
+        out[i * 8 + 6] = (uint64_t)items[i * 5 + 3] - items[i * 5 + 2];
+        out[i * 8 + 7] = items[i * 5 + 4];
+    }
+    return STORM_HIP_OK;
 }
 
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]) {
@@ -840,6 +899,16 @@ void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m) { return m ? m->d
 
 namespace storm {
 
+void kernel_time_mark(storm_hip_ctx_t* ctx) {
+    if (!ctx->time_kernels) return;
+    if (ctx->kernel_events_used == ctx->kernel_events.size()) {
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        ctx->kernel_events.push_back(ev);
+    }
+    (void)hipEventRecord(ctx->kernel_events[ctx->kernel_events_used++], ctx->stream);
+}
+
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total) {
     hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
                        reinterpret_cast<unsigned long long*>(d_total));
@@ -880,6 +949,7 @@ int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stri
 
     if (n_items > 0) {
         const dim3 grid((uint32_t)n_items), block(kThreads);
+        kernel_time_mark(ctx);
         switch (ctx->variant < 0 ? 2 : ctx->variant) {
             case 0:
                 hipLaunchKernelGGL(pairw_dense_kernel<0>, grid, block, 0, ctx->stream, X,
@@ -894,6 +964,7 @@ int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stri
                                    stride_words, d_segs, n_segs, n_chunks, cps, ctx->d_slots);
                 break;
         }
+        kernel_time_mark(ctx);
         STORM_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,

@@ -35,7 +35,8 @@ constexpr int kChunkWords = 64;                      // k-chunk: one 64-bit word
 constexpr int kRowsPerWave = 32;                     // A rows held in VGPRs by one wave
 constexpr int kABlockRows = kWaves * kRowsPerWave;   // 128 A rows per workgroup
 constexpr int kStageRows = 32;                       // B rows per LDS stage
-constexpr int kSlots = 4096;                         // partial-sum slots (uint64 each)
+constexpr int kSlots = 4096;  // partial-sum slots (uint64 each)
+constexpr int kSlotsExtra = 8;  // words behind the slots: work-queue heads, zeroed by the fold
 
 struct Seg {            // one (A block, B row range) segment of the upper triangle
     uint32_t a_row0;    // first A row of the block (kABlockRows rows are loaded from here)
@@ -85,8 +86,21 @@ struct storm_hip_ctx_s {
     uint64_t strip_key[4] = {0, 0, 0, 0};
     uint32_t n_strip_items = 0;
     int k2_stages_per_item = 32;
-    int k2_max_run = 4096;  // K2s: B stages per strip item
+    int k2_max_run = 128;   // K2s: B stages per strip item
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
+    int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)
+    uint32_t strip_queue_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t strip_queue_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k2_tail_slices = 3; // K2s: last slices of every XCD's list are cut into short runs ...
+    int k2_tail_run = 32;   //      ... of at most this many stages, merged longest-first
+    // "time_kernels" option: HIP event pairs around the dominant kernel of every pairwise launch
+    // (the popcount kernel, the tile kernel or the strip kernel), read by storm_hip_kernel_time
+    int time_kernels = 0;
+    std::vector<hipEvent_t> kernel_events;  // begin/end alternating
+    size_t kernel_events_used = 0;
+    unsigned long long* d_trace = nullptr;  // k2_ring = 18: per-item schedule trace of the strip kernel
+    size_t trace_capacity = 0;
+    uint32_t trace_items = 0;
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };
 
@@ -109,6 +123,8 @@ int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 void release_mfma_state(storm_hip_ctx_t* ctx);
 // folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
+// record the next event of the "time_kernels" series on the launch stream (no-op when off)
+void kernel_time_mark(storm_hip_ctx_t* ctx);
 }  // namespace storm
 
 struct storm_hip_matrix_s {

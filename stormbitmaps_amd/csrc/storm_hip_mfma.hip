@@ -319,21 +319,60 @@ struct StripItem {
 // kMB: 32-row MFMA blocks of A per wave. 2 = 64 rows per wave, 256-row A tile, 4 workgroups per
 // CU; 4 = 128 rows per wave, 512-row A tile, 2 workgroups per CU ("wide": every B byte that
 // crosses the LDS feeds twice the MFMAs).
-template <int kStripRing, int kProbe = 0, int kMB = 2>
+// kPersist: the grid is one workgroup per resident slot (CUs x workgroups per CU) and every
+// workgroup pulls items until its XCD's queue — then the other XCDs' — is empty. The hardware
+// dispatcher hands workgroup b to XCD b % 8 strictly in order, so with one item per workgroup
+// a full XCD blocks the refill of all the others: the schedule trace (tools/strip_trace.py)
+// showed ~700 of the 1024 slots occupied in steady state. Queues in memory do not block.
+struct StripQueues {
+    uint32_t base[8];   // first item of XCD x's list in the item table
+    uint32_t count[8];  // its length
+};
+constexpr uint32_t kNoItem = 0xffffffffu;
+
+template <int kStripRing, int kProbe = 0, int kMB = 2, bool kPersist = false>
 __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
-    unsigned long long* __restrict__ slots) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[kStripRing][kStripStageBytes];
+    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ trace = nullptr,
+    StripQueues queues = {}, unsigned int* __restrict__ heads = nullptr) {
+    // the ring, plus one word through which thread 0 hands the next item to the other waves
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripRing * kStripStageBytes + 64];
+    auto lds = reinterpret_cast<uint8_t(*)[kStripStageBytes]>(lds_raw);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
+    uint32_t item_idx = blockIdx.x;
+    const uint32_t my_queue = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // XCC_ID
+    for (;;) {
+    if constexpr (kPersist) {
+        const uint32_t word = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[kStripRing][0];
+        if (tid == 0) {
+            uint32_t got = kNoItem;
+            for (uint32_t r = 0; r < 8u && got == kNoItem; ++r) {  // own queue first, then steal
+                const uint32_t q = (my_queue + r) & 7u;
+                if (queues.count[q] == 0) continue;
+                const uint32_t i = atomicAdd(&heads[q], 1u);
+                if (i < queues.count[q]) got = queues.base[q] + i;
+            }
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(word), "v"(got) : "memory");
+        }
+        // also: every wave is done with the previous item's ring before the next DMA lands
+        __builtin_amdgcn_s_barrier();
+        uint32_t got_v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got_v) : "v"(word) : "memory");
+        item_idx = __builtin_amdgcn_readfirstlane(got_v);
+        if (item_idx == kNoItem) break;
+    }
+    // kProbe bit 3: schedule trace — per item {start, end (100 MHz counter), HW_ID, XCC_ID}
+    unsigned long long t_start = 0;
+    if constexpr ((kProbe & 8) != 0) t_start = __builtin_amdgcn_s_memrealtime();
     constexpr uint32_t kWaveRows = 32u * kMB;                 // A rows of one wave
     constexpr uint32_t kATile = kWaveRows * kStripWaves;      // A rows of the workgroup
     constexpr uint32_t kBPW = kMB / 2;                        // 64-row B blocks per wave's rows
     static_assert(kMB == 2 || kMB == 4, "A rows per wave: 64 or 128");
-    const StripItem it = items[blockIdx.x];
+    const StripItem it = items[item_idx];
     const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
     // Stage order: first (if it.diag) the 4 blocks of the A tile itself — wave wm contributes
     // nothing for blocks before its own rows, the strict upper triangle of its own 64x64 block,
@@ -550,14 +589,27 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if (lane == 0 && mine != 0)
-        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+        atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
                   (unsigned long long)mine);
+    if constexpr ((kProbe & 8) != 0) {
+        if (tid == 0 && trace) {
+            trace[item_idx * 4ull + 0] = t_start;
+            trace[item_idx * 4ull + 1] = __builtin_amdgcn_s_memrealtime();
+            trace[item_idx * 4ull + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+            trace[item_idx * 4ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+        }
+    }
+    if constexpr (!kPersist) break;
+    }  // items
 }
 
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
     if (ctx->d_strip_items) (void)hipFree(ctx->d_strip_items);
+    if (ctx->d_trace) (void)hipFree(ctx->d_trace);
+    ctx->d_trace = nullptr;
+    ctx->trace_capacity = 0;
     ctx->d_strip_items = nullptr;
     ctx->strip_capacity = 0;
     ctx->d_x4 = nullptr;
@@ -659,17 +711,27 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
                               uint32_t a_tile) {
     const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
                              ((uint64_t)shard_rank << 32) | shard_count,
-                             ((uint64_t)a_tile << 32) | (uint32_t)ctx->k2_max_run};
+                             ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
+                                 ((uint64_t)(ctx->k2_persistent != 0) << 47) |
+                                 ((uint64_t)(ctx->k2_tail_slices & 0xff) << 32) |
+                                 ((uint64_t)(ctx->k2_tail_run & 0xffff) << 16) |
+                                 (uint64_t)(ctx->k2_max_run & 0xffff)};
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
     // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
     // load per run for a shorter tail at the end of the launch
     const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
+    const uint32_t kTailRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_tail_run));
     const uint32_t kPerTile = a_tile / kStripBRows;
-    std::vector<std::vector<StripItem>> per_xcd(8);
+    // The slices of this shard, dealt to the XCDs in turn.
+    std::vector<std::vector<uint32_t>> slices_of(8);
     uint32_t local = 0;
-    for (uint32_t ks = 0; ks < n_kslices; ++ks) {
-        if ((ks / 16u) % shard_count != shard_rank) continue;  // 16 slices = one k-group
-        std::vector<StripItem>& dst = per_xcd[local++ % 8];
+    for (uint32_t ks = 0; ks < n_kslices; ++ks)
+        if ((ks / 16u) % shard_count == shard_rank) slices_of[local++ % 8].push_back(ks);  // 16 slices = one k-group
+    // One slice = every A tile against the B blocks behind it; `max_run` caps the stages per item.
+    auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
+        // k2_debug & 16 (timing probe, wrong results): every XCD re-reads one k-slice, i.e. the
+        // launch as it would run if nothing ever missed in L2
+        const uint32_t ks_data = (ctx->k2_debug & 16) ? ks % 8u : ks;
         for (const RowRange& rg : ranges) {
             // A tiles of a_tile rows from the start of the range (the rows between r1 and
             // the end of its last A tile are zero: the caller pads ranges accordingly)
@@ -679,21 +741,48 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
                 const uint32_t a_row0 = (uint32_t)rg.r0 + i * a_tile;
                 const uint32_t first = a_row0 / (uint32_t)kStripBRows + kPerTile;
                 if (first >= jend) {  // last tile of the range: only its own triangle
-                    dst.push_back({a_row0, 1, first, first, ks});
+                    dst.push_back({a_row0, 1, first, first, ks_data});
                     continue;
                 }
-                for (uint32_t j0 = first; j0 < jend; j0 += kMaxRun)
+                for (uint32_t j0 = first; j0 < jend; j0 += max_run)
                     dst.push_back({a_row0, (uint32_t)(j0 == first), j0,
-                                   std::min(jend, j0 + kMaxRun), ks});
+                                   std::min(jend, j0 + max_run), ks_data});
             }
         }
+    };
+    // An XCD runs its list in order on ~128 workgroup slots. Long items keep the per-item cost
+    // (A fragments, ring fill, diagonal phase) low, but whatever is still running when the list
+    // runs dry sets the tail: with whole-length items the last slices leave most slots idle for
+    // up to one 157-stage item (10 % of the launch at the headline shape, by list-scheduling
+    // simulation and by measurement). So the LAST k2_tail_slices slices of every XCD are cut into
+    // short runs and merged longest-first, which lets the list end on many small items.
+    const uint32_t kTail = (uint32_t)std::max(0, ctx->k2_tail_slices);
+    std::vector<std::vector<StripItem>> per_xcd(8);
+    for (int x = 0; x < 8; ++x) {
+        const std::vector<uint32_t>& sl = slices_of[x];
+        const size_t n_main = sl.size() > kTail ? sl.size() - kTail : 0;
+        for (size_t k = 0; k < n_main; ++k) emit_slice(sl[k], kMaxRun, per_xcd[x]);
+        std::vector<StripItem> tail;
+        for (size_t k = n_main; k < sl.size(); ++k) emit_slice(sl[k], std::min(kMaxRun, kTailRun), tail);
+        std::stable_sort(tail.begin(), tail.end(), [&](const StripItem& p, const StripItem& q) {
+            return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
+        });
+        per_xcd[x].insert(per_xcd[x].end(), tail.begin(), tail.end());
     }
     std::vector<StripItem> items;
-    size_t longest = 0;
-    for (auto& v : per_xcd) longest = std::max(longest, v.size());
-    for (size_t pos = 0; pos < longest; ++pos)
-        for (int x = 0; x < 8; ++x)
-            if (pos < per_xcd[x].size()) items.push_back(per_xcd[x][pos]);
+    if (ctx->k2_persistent) {  // one contiguous queue per XCD
+        for (int x = 0; x < 8; ++x) {
+            ctx->strip_queue_base[x] = (uint32_t)items.size();
+            ctx->strip_queue_count[x] = (uint32_t)per_xcd[x].size();
+            items.insert(items.end(), per_xcd[x].begin(), per_xcd[x].end());
+        }
+    } else {  // dispatcher order: block b runs on XCD b % 8
+        size_t longest = 0;
+        for (auto& v : per_xcd) longest = std::max(longest, v.size());
+        for (size_t pos = 0; pos < longest; ++pos)
+            for (int x = 0; x < 8; ++x)
+                if (pos < per_xcd[x].size()) items.push_back(per_xcd[x][pos]);
+    }
     if (items.size() >= (1ull << 31)) {
         set_error("K2s: %zu strip items exceed the grid limit", items.size());
         return STORM_HIP_EINVAL;
@@ -773,9 +862,38 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count);
         STORM_HIP_TRY(hipGetLastError());
         if (n_strip > 0) {
+            kernel_time_mark(ctx);
             const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
             const dim3 sgrid(n_strip), sblock(kStripThreads);
-            switch (strip_mode == 2 ? 100 + ctx->k2_ring : ctx->k2_ring) {  // ring depth: tuning probe
+            StripQueues queues;
+            memcpy(queues.base, ctx->strip_queue_base, sizeof(queues.base));
+            memcpy(queues.count, ctx->strip_queue_count, sizeof(queues.count));
+            unsigned int* heads = reinterpret_cast<unsigned int*>(ctx->d_slots + kSlots);
+            // persistent form: one workgroup per resident slot
+            const dim3 pgrid(std::min<uint32_t>(n_strip, (uint32_t)ctx->n_cus * (strip_mode == 2 ? 2u : 4u)));
+            const int sel = strip_mode == 2 ? 100 + ctx->k2_ring
+                                            : (ctx->k2_persistent && ctx->k2_ring == 4) ? 204
+                                            : (ctx->k2_persistent && ctx->k2_ring == 18) ? 218
+                                                                                         : ctx->k2_ring;
+            switch (sel) {  // ring depth: tuning probe
+                case 204:
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, nullptr, queues, heads);
+                    break;
+                case 218: {
+                    const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
+                    if (need > ctx->trace_capacity) {
+                        if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
+                        ctx->d_trace = nullptr;
+                        ctx->trace_capacity = 0;
+                        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace), need));
+                        ctx->trace_capacity = need;
+                    }
+                    ctx->trace_items = n_strip;
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 8, 2, true>), pgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, ctx->d_trace, queues, heads);
+                    break;
+                }
                 case 103:
                     hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, row_bytes, sit, ctx->d_slots);
@@ -804,14 +922,30 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                 STORM_PROBE_CASE(1) STORM_PROBE_CASE(2) STORM_PROBE_CASE(4) STORM_PROBE_CASE(6)
                 STORM_PROBE_CASE(7)
 #undef STORM_PROBE_CASE
+                case 18: {  // schedule trace (results stay correct)
+                    const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
+                    if (need > ctx->trace_capacity) {
+                        if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
+                        ctx->d_trace = nullptr;
+                        ctx->trace_capacity = 0;
+                        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace), need));
+                        ctx->trace_capacity = need;
+                    }
+                    ctx->trace_items = n_strip;
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 8>), sgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, ctx->d_trace);
+                    break;
+                }
                 default:
                     hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock, 0,
                                        ctx->stream, ctx->d_x4, row_bytes, sit, ctx->d_slots);
                     break;
             }
+            kernel_time_mark(ctx);
             STORM_HIP_TRY(hipGetLastError());
         }
         if (ctx->n_items > 0) {
+            kernel_time_mark(ctx);
             const dim3 kgrid(ctx->n_items), block(kMfmaThreads);
             const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
             switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
@@ -828,6 +962,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                                        row_bytes, items, ctx->d_slots);
                     break;
             }
+            kernel_time_mark(ctx);
             STORM_HIP_TRY(hipGetLastError());
         }
     }
