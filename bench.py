@@ -43,9 +43,15 @@ def cpu_baseline(head_rows_fn, n_words, budget_s=12.0):
     # rows whose pair count fits the time budget
     n = int(min(10000, max(600, (2 * budget_s * rate / (2 * n_words)) ** 0.5)))
     sample = head_rows_fn(n)
+    n = int(sample.shape[0])  # the matrix may have fewer rows than the budget allows
     secs, total = orc.time_blocked(sample, kind, bsize)
     words = (n * (n - 1) // 2) * 2 * n_words
-    return {"value": words / secs, "unit": "words/s", "cores": 1, "kind": "port",
+    # SURVEY §8d also asks for the plain scalar leaf (popcnt per word): a smaller row sample
+    ns = min(n, 2500)
+    s_secs, _ = orc.time_blocked(sample[:ns], 0, bsize)
+    scalar = {"value": (ns * (ns - 1) // 2) * 2 * n_words / max(s_secs, 1e-9), "leaf": orc.leaf_name(0),
+              "seconds": round(s_secs, 3), "sample": f"first {ns} rows"}
+    return {"value": words / secs, "unit": "words/s", "cores": 1, "kind": "port", "scalar_leaf": scalar,
             "leaf": orc.leaf_name(kind), "seconds": round(secs, 3),
             "sample": f"first {n} rows of the benchmark matrix ({n * (n - 1) // 2} pairs), "
                       f"orc_wrapper_diag_blocked bsize={bsize}",
