@@ -221,6 +221,12 @@ uint64_t STORM_contig_pairw_intersect_cardinality_list(STORM_contiguous_t* bitma
 uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_t* bitmap,
                                                                uint32_t bsize);
 
+/* Extension: the per-pair matrix the reference only sums (README.md:41). op: 0 = intersect,
+ * 1 = union, 2 = symmetric difference. `out` is n_data x n_data uint32, row-major; entry (i, j)
+ * = popcount(row_i OP row_j) for i < j, 0 elsewhere. Returns 0; -1 NULL handle, -2 NULL out,
+ * -3 device failure (see STORM_hip_error). */
+int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out);
+
 /* ------------------------------------------------------------- extensions (not in ref) ---
  * Device selection for the entry points above. By default device 0 computes everything.
  * STORM_hip_set_devices(n, ids): the pair space is sharded over the listed GPUs of this node

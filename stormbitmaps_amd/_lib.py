@@ -94,6 +94,7 @@ SIGNATURES = {
     "STORM_get_intersect_count_func": (vp, [sz]),
     "STORM_get_alignment": (u32, []),
     "STORM_get_cpuid": (C.c_int, []),
+    "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp]),
     "STORM_hip_set_devices": (C.c_int, [C.c_int, vp]),
     "STORM_hip_set_shard": (C.c_int, [u32, u32]),
     "STORM_hip_error": (cp, []),

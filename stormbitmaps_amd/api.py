@@ -70,6 +70,17 @@ class StormContig:
             self._lib.STORM_contig_pairw_intersect_cardinality_blocked(self._h, bsize),
             "STORM_contig_pairw_intersect_cardinality_blocked")  # storm.c:1175
 
+    def pairw_matrix(self, n_rows: int, op: str = "and") -> np.ndarray:
+        """STORM_contig_pairw_matrix (extension): [n_rows, n_rows] uint32 per-pair counts, i < j.
+        `n_rows` = rows added so far (the handle's n_data)."""
+        out = np.zeros((n_rows, n_rows), dtype=np.uint32)
+        rc = int(self._lib.STORM_contig_pairw_matrix(self._h, {"and": 0, "or": 1, "xor": 2}[op],
+                                                     _ptr(out)))
+        if rc != 0:
+            raise RuntimeError(f"STORM_contig_pairw_matrix -> {rc}: "
+                               f"{self._lib.STORM_hip_error().decode()}")
+        return out
+
     def pairw_intersect_cardinality_list(self) -> int:
         return int(self._lib.STORM_contig_pairw_intersect_cardinality_list(self._h))  # :1243
 

@@ -499,24 +499,46 @@ int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
     return 1;
 }
 
-/* the device mirror is rebuilt whenever rows were added since the last all-pairs call */
-static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
-    if (h->n_data < 2) return 0;
+/* make sure the device mirror of `h` is current; NULL on failure */
+static dense_state_t* contig_mirror(STORM_contiguous_t* h) {
     if (!h->hip_matrix || h->hip_rows_synced != h->n_data ||
         ((dense_state_t*)h->hip_matrix)->config_generation != g_config_generation) {
         contig_drop_device(h);
         dense_state_t* st = (dense_state_t*)calloc(1, sizeof(*st));
-        if (!st) return ALL_PAIRS_FAILED;
+        if (!st) return NULL;
         h->hip_matrix = st;
         if (dense_state_upload(st, h->data, h->n_data, h->n_bitmaps_vector,
                                h->n_bitmaps_vector) != 0) {
             contig_drop_device(h);
-            return ALL_PAIRS_FAILED;
+            return NULL;
         }
         h->hip_rows_synced = h->n_data;
         h->hip_rows_capacity = h->n_data;
     }
-    return dense_state_pairw((dense_state_t*)h->hip_matrix);
+    return (dense_state_t*)h->hip_matrix;
+}
+
+/* the device mirror is rebuilt whenever rows were added since the last all-pairs call */
+static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
+    if (h->n_data < 2) return 0;
+    dense_state_t* st = contig_mirror(h);
+    return st ? dense_state_pairw(st) : ALL_PAIRS_FAILED;
+}
+
+/* Extension (storm.h): the per-pair matrix the reference only sums (README.md:41). `op`:
+ * 0 intersect, 1 union, 2 symmetric difference. out = n_data x n_data uint32, row-major;
+ * entries i >= j are 0. Returns 0, -1 for a NULL handle, -2 for NULL out, -3 on device failure. */
+int STORM_contig_pairw_matrix(STORM_contiguous_t* h, int op, uint32_t* out) {
+    if (!h) return -1;
+    if (!out) return -2;
+    if (h->n_data == 0) return 0;
+    dense_state_t* st = contig_mirror(h);
+    if (!st) return -3;
+    if (storm_hip_pairw_matrix(g_ctx[0], st->m[0], op, out) != STORM_HIP_OK) {
+        device_error("storm_hip_pairw_matrix");
+        return -3;
+    }
+    return 0;
 }
 
 uint64_t STORM_contig_pairw_intersect_cardinality(STORM_contiguous_t* h) { /* :1149-1173 */

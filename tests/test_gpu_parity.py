@@ -551,3 +551,100 @@ def test_square_on_matrix_cores(hip_ctx, orc):
             hip_ctx.set_option("variant", -1)
         assert ma.pairw() + mb.pairw() + want == orc.wrapper_diag(mat)
         ma.close(); mb.close()
+
+
+def test_strip_item_shaping_options(hip_ctx, orc):
+    """The strip kernel's work-list knobs (run cap, short-item tail, persistent per-XCD queues)
+    reshape the schedule only: every combination must give the oracle's total, on a ragged
+    shape small enough for the CPU and on shards."""
+    M, N, d = 20000, 1500, 9000
+    mat = synth.dense_matrix_c(M, N, d, seed=77)
+    want = orc.wrapper_diag(mat)
+    m = hip_ctx.matrix_from_host(mat)
+    defaults = {k: hip_ctx.get_option(k) for k in ("k2_max_run",)}
+    try:
+        hip_ctx.set_option("variant", 4)
+        for persistent in (0, 1):
+            for max_run, tail_slices, tail_run in ((4096, 0, 32), (128, 3, 32), (5, 2, 3), (1, 255, 1)):
+                hip_ctx.set_option("k2_persistent", persistent)
+                hip_ctx.set_option("k2_max_run", max_run)
+                hip_ctx.set_option("k2_tail_slices", tail_slices)
+                hip_ctx.set_option("k2_tail_run", tail_run)
+                assert m.pairw() == want, (persistent, max_run, tail_slices, tail_run)
+                assert sum(m.pairw(r, 3) for r in range(3)) == want
+    finally:
+        hip_ctx.set_option("variant", -1)
+        hip_ctx.set_option("k2_persistent", 0)
+        hip_ctx.set_option("k2_max_run", defaults["k2_max_run"])
+        hip_ctx.set_option("k2_tail_slices", 3)
+        hip_ctx.set_option("k2_tail_run", 32)
+    m.close()
+
+
+def test_persistent_queues_at_headline_shape(hip_ctx):
+    """Persistent per-XCD queues at N=10000 x M=65536: repeated launches (the queue heads are
+    re-zeroed by the fold kernel) must all reproduce the column identity."""
+    M, N, d = 65536, 10000, 32768
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=44)
+    want = m.column_identity()
+    try:
+        hip_ctx.set_option("k2_persistent", 1)
+        assert {m.pairw() for _ in range(10)} == {want}
+        assert sum(m.pairw(r, 8) for r in range(8)) == want
+    finally:
+        hip_ctx.set_option("k2_persistent", 0)
+    m.close()
+
+
+def test_kernel_time_and_trace_probes(hip_ctx):
+    """Measurement aids: the in-library timing of the dominant kernel (bench.py's roofline) and the
+    per-item schedule trace leave results untouched and report sane numbers."""
+    import ctypes as C
+    M, N, d = 65536, 3000, 32768
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=45)
+    want = m.column_identity()
+    try:
+        hip_ctx.set_option("time_kernels", 1)
+        for _ in range(4):
+            assert m.pairw() == want
+        ms, n = hip_ctx.kernel_time()
+        assert n == 4 and 0.0 < ms < 100.0
+        assert hip_ctx.kernel_time() == (0.0, 0)          # the series restarts
+        hip_ctx.set_option("time_kernels", 0)
+        hip_ctx.set_option("k2_ring", 18)
+        assert m.pairw() == want
+        cnt = C.c_uint64(0)
+        lib = sb.load()
+        assert lib.storm_hip_debug_strip_trace(hip_ctx._h, None, 0, C.byref(cnt)) == 0
+        assert cnt.value == hip_ctx.last_launch_info()["items"] > 0
+        out = np.zeros((cnt.value, 8), dtype=np.uint64)
+        assert lib.storm_hip_debug_strip_trace(hip_ctx._h, out.ctypes.data_as(C.c_void_p), cnt.value,
+                                               C.byref(cnt)) == 0
+        assert (out[:, 1] > out[:, 0]).all() and (out[:, 3] & 0xf).max() < 8
+    finally:
+        hip_ctx.set_option("time_kernels", 0)
+        hip_ctx.set_option("k2_ring", 4)
+    m.close()
+
+
+def test_storm_h_matrix_extension(orc):
+    """STORM_contig_pairw_matrix on the reference's own container: rows added through
+    STORM_contig_add, matrix from the cached device mirror, grown between calls."""
+    M, N, d = 5000, 400, 1200
+    rows = synth.positions(M, N, d, seed=9)
+    mat = synth.dense_matrix(M, N, d, seed=9)
+    h = sb.StormContig(M)
+    try:
+        for r in rows[:250]:
+            h.add(r)
+        assert np.array_equal(h.pairw_matrix(250), np.triu(orc.tile_counts(mat[:250], 0, 250, 0, 250), k=1))
+        for r in rows[250:]:
+            h.add(r)
+        for name, op in (("and", 0), ("or", 1), ("xor", 2)):
+            assert np.array_equal(h.pairw_matrix(N, name),
+                                  np.triu(orc.tile_counts_op(mat, 0, N, 0, N, op), k=1)), name
+        assert int(h.pairw_matrix(N).sum(dtype=np.uint64)) == h.pairw_intersect_cardinality()
+    finally:
+        h.free()
