@@ -49,11 +49,12 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 using gptr_t = const __attribute__((address_space(1))) void*;
 using lptr_t = __attribute__((address_space(3))) void*;
 
-__device__ __forceinline__ uint32_t spread8_fp4(uint32_t b) {  // 8 bits -> 8 nibbles of 0b0010
+// 8 bits -> 8 nibbles holding `nib` (0b0010 = 1.0 in E2M1; other codes only for the power probe)
+__device__ __forceinline__ uint32_t spread8_fp4(uint32_t b, uint32_t nib = 2u) {
     uint32_t x = (b | (b << 12)) & 0x000F000Fu;
     x = (x | (x << 6)) & 0x03030303u;
     x = (x | (x << 3)) & 0x11111111u;
-    return x << 1;
+    return x * nib;
 }
 
 // One thread per 32-bit half word: 16 output bytes, fully coalesced on both sides.
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
                                                          uint64_t stride_words,
                                                          uint64_t n_rows_src, uint64_t n_rows_dst,
                                                          uint4* __restrict__ X4,
-                                                         uint32_t shard_rank, uint32_t shard_count) {
+                                                         uint32_t shard_rank, uint32_t shard_count,
+                                                         uint32_t nib = 2u) {
     const uint64_t halves_per_row = stride_words * 2;
     const uint64_t total = n_rows_dst * halves_per_row;
     for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -75,10 +77,10 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
         uint32_t w = 0;
         if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[t];
         uint4 o;
-        o.x = spread8_fp4(w & 0xFFu);
-        o.y = spread8_fp4((w >> 8) & 0xFFu);
-        o.z = spread8_fp4((w >> 16) & 0xFFu);
-        o.w = spread8_fp4(w >> 24);
+        o.x = spread8_fp4(w & 0xFFu, nib);
+        o.y = spread8_fp4((w >> 8) & 0xFFu, nib);
+        o.z = spread8_fp4((w >> 16) & 0xFFu, nib);
+        o.w = spread8_fp4(w >> 24, nib);
         X4[t] = o;
     }
 }
@@ -859,7 +861,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, stride_words,
                            std::min(n_rows_src, n_rows_dst), n_rows_dst,
-                           reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count);
+                           reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count,
+                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 7u : 2u);
         STORM_HIP_TRY(hipGetLastError());
         if (n_strip > 0) {
             kernel_time_mark(ctx);
