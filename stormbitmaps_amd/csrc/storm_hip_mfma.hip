@@ -621,7 +621,8 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
 
 // A "range" is a run of rows [r0, r1) of the FP4 shadow that forms one all-pairs problem: the
 // whole matrix for the dense container, one block column of the pool for the sparse one.
-// r0 is a multiple of 256 and the rows from r1 up to the next multiple of 256 are zero.
+// r0 is a multiple of the A tile (256 rows; 512 for the wide strips) and the rows from r1 up to the
+// next multiple of it are zero.
 static uint64_t ranges_hash(const std::vector<RowRange>& ranges) {
     uint64_t h = 1469598103934665603ull;
     for (const RowRange& r : ranges) {
@@ -809,7 +810,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
 }
 
 // X: bit rows (stride_words per row), n_rows_src of them readable; the FP4 shadow gets
-// n_rows_dst rows (multiple of 256, rows >= n_rows_src zero). `strips` selects K2s.
+// n_rows_dst rows (a multiple of the A tile, rows >= n_rows_src zero). `strip_mode` selects the kernel.
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
