@@ -989,11 +989,11 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    // variant -1 = auto: the matrix-core path pays once there are enough 256-row blocks to fill
-    // the chip with strips (and its 64-row B stages need 64 * row_bytes < 2^32); below that the
-    // popcount kernel wins on latency.
+    // variant -1 = auto: the matrix-core strips at every size they can address (their 64-row B
+    // stages need 64 * row_bytes < 2^32). Measured (tools/bench_crossover.py): they beat the
+    // popcount kernel from N = 64 up (10-37 us vs its 42-84 us latency floor at N <= 256).
     int variant = ctx->variant;
-    if (variant < 0) variant = (m->n_rows >= 1024 && m->stride_words * 32ull * 64ull < (1ull << 32)) ? 4 : 2;
+    if (variant < 0) variant = (m->stride_words * 32ull * 64ull < (1ull << 32)) ? 4 : 2;
     ctx->variant_used = variant;
     if (variant >= 3) {
         const int saved = ctx->variant;
@@ -1047,10 +1047,9 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     *h_total = 0;
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    // same choice as the all-pairs path: matrix cores once the rectangle is big enough to fill
-    // the chip with strip items, the popcount kernel below that (or when forced by `variant`)
-    const bool big = (uint64_t)a->n_rows * b->n_rows >= (1ull << 19) &&
-                     a->stride_words * 32ull * 64ull < (1ull << 32);
+    // same choice as the all-pairs path: matrix cores whenever the strips can address the rows,
+    // the popcount kernel otherwise (or when forced by `variant`)
+    const bool big = a->stride_words * 32ull * 64ull < (1ull << 32);
     if (a->stride_words == b->stride_words && (ctx->variant >= 3 || (ctx->variant < 0 && big))) {
         if (int rc = launch_square_mfma(ctx, a, b, reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;

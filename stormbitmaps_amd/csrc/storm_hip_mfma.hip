@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     unsigned long long* __restrict__ slots, unsigned long long* __restrict__ trace = nullptr,
     StripQueues queues = {}, unsigned int* __restrict__ heads = nullptr) {
     // the ring, plus one word through which thread 0 hands the next item to the other waves
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripRing * kStripStageBytes + 64];
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripRing * kStripStageBytes + (kPersist ? 64 : 0)];
     auto lds = reinterpret_cast<uint8_t(*)[kStripStageBytes]>(lds_raw);
 
     const uint32_t tid = threadIdx.x;

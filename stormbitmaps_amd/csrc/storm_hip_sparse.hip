@@ -291,7 +291,7 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
     uint64_t widest = 0;
     for (const RowRange& c : s->cols) widest = std::max(widest, c.r1 - c.r0);
     int variant = ctx->variant;
-    if (variant < 0) variant = widest >= 1024 ? 4 : 2;
+    if (variant < 0) variant = widest >= 64 ? 4 : 2;
     ctx->variant_used = variant;
     if (variant >= 3) {
         std::vector<RowRange> ranges;

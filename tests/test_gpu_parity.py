@@ -221,8 +221,8 @@ def test_matrix_core_path_k_slicing_and_edges(hip_ctx, orc):
 def test_auto_variant_selection(hip_ctx):
     hip_ctx.set_option("variant", -1)
     small = hip_ctx.matrix_from_host(synth.dense_matrix_c(4096, 300, 900, seed=3))
-    small.pairw()
-    assert hip_ctx.get_option("variant_used") == 2       # popcount kernel
+    assert small.pairw() == small.column_identity()
+    assert hip_ctx.get_option("variant_used") == 4       # strips win from N = 64 up (bench_crossover)
     big = hip_ctx.matrix_from_host(synth.dense_matrix_c(4096, 1500, 900, seed=3))
     got = big.pairw()
     assert hip_ctx.get_option("variant_used") == 4       # matrix-core strips
