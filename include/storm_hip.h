@@ -144,8 +144,9 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
 /* Tuning aid: with option "k2_ring" = 18 the strip kernel records, per work item, its start and
- * end on the 100 MHz device counter and the HW_ID / XCC_ID registers of the workgroup's first
- * wave. out[i*8 ..] = {start, end, hw_id, xcc_id, a_row0, diag, stages, k-slice}; results of the
+ * end on the 100 MHz device counter, three phase marks (operands in / diagonal phase done / main
+ * loop done, 16 bits each, relative to the start) and the XCC_ID register of the workgroup's first
+ * wave. out[i*8 ..] = {start, end, phases, xcc_id, a_row0, diag, stages, k-slice}; results of the
  * launch are unaffected. `out` may be NULL to query the item count. */
 int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t capacity_items,
                                 uint64_t* n_items);

@@ -609,11 +609,17 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_max_run = (int)value;
     } else if (!strcmp(key, "k2_ring")) {
-        if ((value < 3 || value > 5) && (value < 11 || value > 18)) {
+        if ((value < 3 || value > 5) && (value < 11 || value > 18) && value != 26) {
             set_error("k2_ring must be 3, 4 or 5 (10 + bits = timing probes)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "k2_lds_pad")) {
+        if (value < 0 || value > 120 * 1024) {
+            set_error("k2_lds_pad must be 0..122880");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_lds_pad = (int)value;
     } else if (!strcmp(key, "k2_persistent")) {
         ctx->k2_persistent = value != 0;
     } else if (!strcmp(key, "k2_tail_slices")) {

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
         if (item_idx == kNoItem) break;
     }
     // kProbe bit 3: schedule trace — per item {start, end (100 MHz counter), HW_ID, XCC_ID}
-    unsigned long long t_start = 0;
+    unsigned long long t_start = 0, t_ready = 0, t_diag = 0, t_main = 0;
     if constexpr ((kProbe & 8) != 0) t_start = __builtin_amdgcn_s_memrealtime();
     constexpr uint32_t kWaveRows = 32u * kMB;                 // A rows of one wave
     constexpr uint32_t kATile = kWaveRows * kStripWaves;      // A rows of the workgroup
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
                      : "v"(addr));
     };
     auto multiply = [&](int kk, const v4i (&b)[2]) {
+        if constexpr ((kProbe & 16) != 0) __builtin_amdgcn_s_setprio(2);  // probe: MFMA bursts first
 #pragma unroll
         for (int m = 0; m < kMB; ++m)
 #pragma unroll
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
                 acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                     v8i{a[kk][m].x, a[kk][m].y, a[kk][m].z, a[kk][m].w, 0, 0, 0, 0},
                     v8i{b[n].x, b[n].y, b[n].z, b[n].w, 0, 0, 0, 0}, acc[m][n], 4, 4, 0, 0, 0, 0);
+        if constexpr ((kProbe & 16) != 0) __builtin_amdgcn_s_setprio(0);
     };
 #define STORM_LGKM(n)                                       \
     asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
@@ -502,6 +504,10 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     v4i b0[2] = {}, b1[2] = {};
     uint32_t t = 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    if constexpr ((kProbe & 8) != 0) {  // trace only: when are the A fragments in?
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        t_ready = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- the A tile's own 4 blocks (strict upper triangle), not software-pipelined: wave wm
     //      skips the blocks before its own rows (only pairs with i > j there), masks its own
     //      64x64 block, and takes the later ones whole. Kept apart from the main loop so that
@@ -557,6 +563,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     //      fragments of its first k-step are fetched while stage t-1 is still being multiplied;
     //      iteration t therefore retires stage t+1, and refills the ring with stage t+3 (whose
     //      buffer held stage t-1: every wave finished it before this iteration's barrier).
+    if constexpr ((kProbe & 8) != 0) t_diag = __builtin_amdgcn_s_memrealtime();
     if (t < T) {
         retire(t, t + kStripRing - 2);
         fetch(t, 0, b0);
@@ -577,6 +584,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     }
 #undef STORM_STEP
 #undef STORM_LGKM
+    if constexpr ((kProbe & 8) != 0) t_main = __builtin_amdgcn_s_memrealtime();
 
     uint64_t mine = 0;
 #pragma unroll
@@ -597,7 +605,11 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
         if (tid == 0 && trace) {
             trace[item_idx * 4ull + 0] = t_start;
             trace[item_idx * 4ull + 1] = __builtin_amdgcn_s_memrealtime();
-            trace[item_idx * 4ull + 2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+            // phase marks relative to the start, 16 bits each in 10 ns units:
+            // A fragments + first stages in | diagonal phase done | main loop done
+            trace[item_idx * 4ull + 2] = ((t_ready - t_start) & 0xffffull) |
+                                         (((t_diag - t_start) & 0xffffull) << 16) |
+                                         (((t_main - t_start) & 0xffffull) << 32);
             trace[item_idx * 4ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
         }
     }
@@ -881,7 +893,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                                                                                          : ctx->k2_ring;
             switch (sel) {  // ring depth: tuning probe
                 case 204:
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock, 0, ctx->stream,
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock,
+                                       (size_t)ctx->k2_lds_pad, ctx->stream,
                                        ctx->d_x4, row_bytes, sit, ctx->d_slots, nullptr, queues, heads);
                     break;
                 case 218: {
@@ -926,6 +939,10 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                 STORM_PROBE_CASE(1) STORM_PROBE_CASE(2) STORM_PROBE_CASE(4) STORM_PROBE_CASE(6)
                 STORM_PROBE_CASE(7)
 #undef STORM_PROBE_CASE
+                case 26:  // probe: s_setprio around the MFMA bursts (results stay correct)
+                    hipLaunchKernelGGL((strip_fp4_kernel<4, 16>), sgrid, sblock, 0, ctx->stream,
+                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    break;
                 case 18: {  // schedule trace (results stay correct)
                     const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
                     if (need > ctx->trace_capacity) {
@@ -941,8 +958,10 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     break;
                 }
                 default:
-                    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock, 0,
-                                       ctx->stream, ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                    // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
+                    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
+                                       (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, row_bytes, sit,
+                                       ctx->d_slots);
                     break;
             }
             kernel_time_mark(ctx);

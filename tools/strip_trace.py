@@ -55,7 +55,17 @@ def main():
     for a, b in zip(grid[:-1], grid[1:]):
         mid = 0.5 * (a + b)
         print(f"t={mid:7.1f} us running {(np.sum((start <= mid) & (end > mid))):5d}")
+    ph = out[:, 2]
+    ready = (ph & 0xffff).astype(np.float64) / 100.0
+    diag_done = ((ph >> 16) & 0xffff).astype(np.float64) / 100.0
+    main_done = ((ph >> 32) & 0xffff).astype(np.float64) / 100.0
     dur = end - start
+    has_diag = out[:, 5] == 1
+    print(f"phases (us, mean): operands in {ready.mean():.2f} | diagonal phase {(diag_done - ready)[has_diag].mean():.2f} "
+          f"(items with one) | main loop {(main_done - diag_done).mean():.2f} | epilogue {(dur - main_done).mean():.2f}")
+    ms = (out[:, 6]).astype(np.float64)
+    sel = ms >= 8
+    print(f"main loop us/stage (items >= 8 stages): {((main_done - diag_done)[sel] / ms[sel]).mean():.3f}")
     per_stage = dur / np.maximum(stages, 1)
     for lo, hi in ((1, 8), (8, 32), (32, 64), (64, 128), (128, 400)):
         sel = (stages >= lo) & (stages < hi)
