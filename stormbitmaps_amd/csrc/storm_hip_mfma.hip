@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
                                                          uint64_t n_rows_src, uint64_t n_rows_dst,
                                                          uint4* __restrict__ X4,
                                                          uint32_t shard_rank, uint32_t shard_count,
-                                                         uint32_t nib = 2u) {
+                                                         uint32_t nib = 2u, uint64_t out_pitch_u4 = 0) {
+    // out_pitch_u4: row pitch of the shadow in 16-byte units (0 = dense, stride_words * 2)
+    if (out_pitch_u4 == 0) out_pitch_u4 = stride_words * 2;
     const uint64_t halves_per_row = stride_words * 2;
     const uint64_t total = n_rows_dst * halves_per_row;
     for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
         o.y = spread8_fp4((w >> 8) & 0xFFu, nib);
         o.z = spread8_fp4((w >> 16) & 0xFFu, nib);
         o.w = spread8_fp4(w >> 24, nib);
-        X4[t] = o;
+        X4[row * out_pitch_u4 + (t - row * halves_per_row)] = o;
     }
 }
 
@@ -776,7 +778,18 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     for (int x = 0; x < 8; ++x) {
         const std::vector<uint32_t>& sl = slices_of[x];
         const size_t n_main = sl.size() > kTail ? sl.size() - kTail : 0;
-        for (size_t k = 0; k < n_main; ++k) emit_slice(sl[k], kMaxRun, per_xcd[x]);
+        // Within a slice, longest first: the XCD's dispatcher deals consecutive workgroups to its
+        // shader engines in turn, so a list that alternates long and short items (the two runs of
+        // one A tile) sends all the long ones to the same engines and leaves the others idle
+        // (schedule trace: 60 % of the slots occupied; max_run = 64, 72 or 100 lost 10-25 %).
+        for (size_t k = 0; k < n_main; ++k) {
+            std::vector<StripItem> one;
+            emit_slice(sl[k], kMaxRun, one);
+            std::stable_sort(one.begin(), one.end(), [&](const StripItem& p, const StripItem& q) {
+                return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
+            });
+            per_xcd[x].insert(per_xcd[x].end(), one.begin(), one.end());
+        }
         std::vector<StripItem> tail;
         for (size_t k = n_main; k < sl.size(); ++k) emit_slice(sl[k], std::min(kMaxRun, kTailRun), tail);
         std::stable_sort(tail.begin(), tail.end(), [&](const StripItem& p, const StripItem& q) {
@@ -821,6 +834,18 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     return STORM_HIP_OK;
 }
 
+// Row pitch of the FP4 shadow. Rows whose byte length is a multiple of a large power of two put
+// every B block of a k-slice 2^21+ bytes apart, i.e. onto few L2 / memory channels; a few extra
+// 128-byte lines per row break the pattern (strip kernel 0.866 -> 0.835 ms at the headline
+// shape, its L2 misses 3.4 -> 0.86 GB per launch; 3 lines also suit the expansion's writes
+// better than 1). k2_pitch_pad: -1 = that rule, otherwise the pad in bytes.
+// The tile kernel (64-byte row pieces, A and B tiles) measured the other way round — 1.96 ms
+// dense, 2.25 ms padded for the materialised matrix — so the rule is for the strips only.
+static uint64_t shadow_pitch(const storm_hip_ctx_t* ctx, uint64_t row_bytes, bool strips) {
+    if (ctx->k2_pitch_pad >= 0) return row_bytes + (uint64_t)ctx->k2_pitch_pad;
+    return row_bytes + (strips && row_bytes % 1024 == 0 ? 384u : 0u);
+}
+
 // X: bit rows (stride_words per row), n_rows_src of them readable; the FP4 shadow gets
 // n_rows_dst rows (a multiple of the A tile, rows >= n_rows_src zero). `strip_mode` selects the kernel.
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
@@ -832,7 +857,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     const bool strips = strip_mode != 0;
     const uint32_t a_tile = strip_mode == 2 ? 512u : (uint32_t)kStripATile;
     const uint64_t row_bytes = stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
-    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows_dst, kTile) * row_bytes;
+    const uint64_t pitch = shadow_pitch(ctx, row_bytes, strip_mode != 0);
+    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows_dst, kTile) * pitch;
     if (n_rows_dst / kTile >= 65535) {
         set_error("K2: too many row blocks");
         return STORM_HIP_EINVAL;
@@ -854,7 +880,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     } else if (int rc = ensure_items(ctx, ranges, total_stages, shard_rank, shard_count, false)) {
         return rc;
     }
-    if (strips && row_bytes * (uint64_t)kStripBRows >= (1ull << 32)) {
+    if (strips && pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
         set_error("K2 strips: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 3",
                   (unsigned long long)row_bytes);
         return STORM_HIP_EINVAL;
@@ -875,7 +901,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, stride_words,
                            std::min(n_rows_src, n_rows_dst), n_rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count,
-                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 7u : 2u);
+                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 7u : 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
         if (n_strip > 0) {
             kernel_time_mark(ctx);
@@ -895,7 +921,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                 case 204:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock,
                                        (size_t)ctx->k2_lds_pad, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, nullptr, queues, heads);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots, nullptr, queues, heads);
                     break;
                 case 218: {
                     const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
@@ -908,40 +934,48 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     }
                     ctx->trace_items = n_strip;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8, 2, true>), pgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, ctx->d_trace, queues, heads);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace, queues, heads);
                     break;
                 }
                 case 103:
                     hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
                 case 104:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
                 case 105:
                     hipLaunchKernelGGL((strip_fp4_kernel<5, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
+#define STORM_WIDE_PROBE_CASE(n)                                                                  \
+    case 110 + n:                                                                                 \
+        hipLaunchKernelGGL((strip_fp4_kernel<4, n, 4>), sgrid, sblock, 0, ctx->stream, ctx->d_x4, \
+                           pitch, sit, ctx->d_slots);                                         \
+        break;
+                STORM_WIDE_PROBE_CASE(1) STORM_WIDE_PROBE_CASE(2) STORM_WIDE_PROBE_CASE(4)
+                STORM_WIDE_PROBE_CASE(6) STORM_WIDE_PROBE_CASE(7)
+#undef STORM_WIDE_PROBE_CASE
                 case 3:
                     hipLaunchKernelGGL(strip_fp4_kernel<3>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
-                                       row_bytes, sit, ctx->d_slots);
+                                       pitch, sit, ctx->d_slots);
                     break;
                 case 5:
                     hipLaunchKernelGGL(strip_fp4_kernel<5>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
-                                       row_bytes, sit, ctx->d_slots);
+                                       pitch, sit, ctx->d_slots);
                     break;
 #define STORM_PROBE_CASE(n)                                                                   \
     case 10 + n:                                                                              \
         hipLaunchKernelGGL((strip_fp4_kernel<4, n>), sgrid, sblock, 0, ctx->stream, ctx->d_x4, \
-                           row_bytes, sit, ctx->d_slots);                                      \
+                           pitch, sit, ctx->d_slots);                                      \
         break;
                 STORM_PROBE_CASE(1) STORM_PROBE_CASE(2) STORM_PROBE_CASE(4) STORM_PROBE_CASE(6)
                 STORM_PROBE_CASE(7)
 #undef STORM_PROBE_CASE
                 case 26:  // probe: s_setprio around the MFMA bursts (results stay correct)
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 16>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
                 case 18: {  // schedule trace (results stay correct)
                     const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
@@ -954,13 +988,13 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     }
                     ctx->trace_items = n_strip;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, row_bytes, sit, ctx->d_slots, ctx->d_trace);
+                                       ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace);
                     break;
                 }
                 default:
                     // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
                     hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
-                                       (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, row_bytes, sit,
+                                       (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
                                        ctx->d_slots);
                     break;
             }
@@ -974,15 +1008,15 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
                 case 4:
                     hipLaunchKernelGGL(pairw_fp4_kernel<4>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                       row_bytes, items, ctx->d_slots);
+                                       pitch, items, ctx->d_slots);
                     break;
                 case 8:
                     hipLaunchKernelGGL(pairw_fp4_kernel<8>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                       row_bytes, items, ctx->d_slots);
+                                       pitch, items, ctx->d_slots);
                     break;
                 default:
                     hipLaunchKernelGGL(pairw_fp4_kernel<0>, kgrid, block, 0, ctx->stream, ctx->d_x4,
-                                       row_bytes, items, ctx->d_slots);
+                                       pitch, items, ctx->d_slots);
                     break;
             }
             kernel_time_mark(ctx);
@@ -1004,10 +1038,11 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                        const storm_hip_matrix_s* b, uint64_t* d_total) {
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
+    const uint64_t pitch = shadow_pitch(ctx, row_bytes, true);
     const uint64_t rows_a = (a->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t rows_b = (b->n_rows + kStripATile - 1) / kStripATile * kStripATile;
-    const size_t x4_bytes = (size_t)(rows_a + rows_b) * row_bytes;
-    if (row_bytes * (uint64_t)kStripBRows >= (1ull << 32) || (rows_a + rows_b) >= (1ull << 31)) {
+    const size_t x4_bytes = (size_t)(rows_a + rows_b) * pitch;
+    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || (rows_a + rows_b) >= (1ull << 31)) {
         set_error("square (matrix cores): operand too large for the strip kernel's 32-bit offsets");
         return STORM_HIP_EINVAL;
     }
@@ -1054,12 +1089,12 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
-                           reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * row_bytes : 0)),
-                           0u, 1u);
+                           reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)),
+                           0u, 1u, 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
-                       dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, row_bytes,
+                       dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
                        static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
     STORM_HIP_TRY(hipGetLastError());
     ctx->last_info[0] = (uint32_t)items.size();
@@ -1079,7 +1114,8 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     if (m->n_rows < 2) return STORM_HIP_OK;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
-    const size_t x4_bytes = (size_t)n_rows4 * row_bytes;
+    const uint64_t pitch = shadow_pitch(ctx, row_bytes, false);
+    const size_t x4_bytes = (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
         set_error("pairw_matrix: too many row blocks");
         return STORM_HIP_EINVAL;
@@ -1118,9 +1154,9 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
-                           reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u);
+                           reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
         hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
-                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, row_bytes, d_items,
+                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
                            ctx->d_slots, d_out, ld, (uint32_t)m->n_rows, d_counts,
                            op == STORM_HIP_OP_XOR ? 2u : 1u);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)

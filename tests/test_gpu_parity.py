@@ -563,6 +563,13 @@ def test_strip_item_shaping_options(hip_ctx, orc):
     m = hip_ctx.matrix_from_host(mat)
     defaults = {k: hip_ctx.get_option(k) for k in ("k2_max_run",)}
     try:
+        for pad in (0, 128, 1152, -1):                     # row pitch of the FP4 shadow
+            hip_ctx.set_option("k2_pitch_pad", pad)
+            for variant in (3, 4, 5):
+                hip_ctx.set_option("variant", variant)
+                assert m.pairw() == want, (pad, variant)
+            assert np.array_equal(m.pairw_matrix()[:40, :300],
+                                  np.triu(orc.tile_counts(mat, 0, 40, 0, 300), k=1)), pad
         hip_ctx.set_option("variant", 4)
         for persistent in (0, 1):
             for max_run, tail_slices, tail_run in ((4096, 0, 32), (128, 3, 32), (5, 2, 3), (1, 255, 1)):
@@ -578,6 +585,7 @@ def test_strip_item_shaping_options(hip_ctx, orc):
         hip_ctx.set_option("k2_max_run", defaults["k2_max_run"])
         hip_ctx.set_option("k2_tail_slices", 3)
         hip_ctx.set_option("k2_tail_run", 32)
+        hip_ctx.set_option("k2_pitch_pad", -1)
     m.close()
 
 

@@ -18,18 +18,23 @@ def main():
     ap.add_argument("--bits", type=int, default=65536)
     ap.add_argument("--draws", type=int, default=32768)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--ops", default="and,or,xor")
     args = ap.parse_args()
 
     import torch
     import stormbitmaps_amd as sb
     ctx = sb.HipContext(0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     N, M = args.rows, args.bits
     W = (M + 63) // 64
     m = ctx.matrix(N, W)
     m.fill_synthetic(M, args.draws, seed=42)
     out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
     torch.cuda.synchronize()
-    for op in ("and", "or", "xor"):
+    for op in args.ops.split(","):
         want = m.pairw_op(op)
         m.pairw_matrix_device(out.data_ptr(), N, op)
         ts = []

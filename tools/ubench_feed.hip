@@ -86,23 +86,24 @@ __global__ __launch_bounds__(256, WPS) void feed(const uint8_t* __restrict__ src
     if (s == 12345.f) out[0] = s;
 }
 
-template <int MODE, int WPS>
+// RES: workgroups per CU actually launched (RES < WPS: the WPS-wave code at lower residency)
+template <int MODE, int WPS, int RES = WPS>
 static int run(const uint8_t* src, uint64_t row_bytes, float* out, int cus, const char* name) {
     const int iters = 4000;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((feed<MODE, WPS>), dim3(cus * WPS), dim3(256), 0, 0, src, row_bytes, out, 200);
+    hipLaunchKernelGGL((feed<MODE, WPS>), dim3(cus * RES), dim3(256), 0, 0, src, row_bytes, out, 200);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((feed<MODE, WPS>), dim3(cus * WPS), dim3(256), 0, 0, src, row_bytes, out, iters);
+    hipLaunchKernelGGL((feed<MODE, WPS>), dim3(cus * RES), dim3(256), 0, 0, src, row_bytes, out, iters);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
     // per SIMD: WPS waves x iters iterations x 16 MFMAs
     const double us_per_wave_iter = ms * 1e3 / iters;
-    const double mfma_ns = ms * 1e6 / ((double)iters * WPS * 16);
-    printf("%-44s waves/SIMD %d: %.3f us per wave-iteration, %.2f ns per MFMA per SIMD\n", name, WPS,
-           us_per_wave_iter, mfma_ns);
+    const double mfma_ns = ms * 1e6 / ((double)iters * RES * 16);
+    printf("%-44s code for %d, resident %d waves/SIMD: %.3f us per wave-iteration, %.2f ns per MFMA per SIMD\n",
+           name, WPS, RES, us_per_wave_iter, mfma_ns);
     return 0;
 }
 
@@ -124,5 +125,10 @@ int main() {
     ROW(4, "16 MFMA + 8 ds_read_b128")
     ROW(5, "16 MFMA + 2 global_load_lds + 8 ds_read")
     ROW(6, "16 MFMA + 2 gld + 2 ds_write + 8 ds_read")
+    // the 4-wave code at lower residency: is the LDS-DMA cost a matter of code or of concurrency?
+    if (run<1, 4, 2>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds")) return 1;
+    if (run<1, 4, 1>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds")) return 1;
+    if (run<5, 4, 2>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds + 8 ds_read")) return 1;
+    if (run<1, 2, 1>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds")) return 1;
     return 0;
 }
