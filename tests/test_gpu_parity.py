@@ -656,3 +656,17 @@ def test_storm_h_matrix_extension(orc):
         assert int(h.pairw_matrix(N).sum(dtype=np.uint64)) == h.pairw_intersect_cardinality()
     finally:
         h.free()
+
+
+def test_readme_usage_program_in_c():
+    """examples/readme_usage.c: the reference README's usage pattern (README.md:89-124) compiled
+    as plain C against include/storm.h and linked with libstorm_hip.so. The program compares both
+    containers with its own host loop; rows contain duplicate draws (set semantics)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "stormbitmaps_amd", "readme_usage")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for args in (["1500", "1000", "128"], ["700", "70000", "5000"], ["2", "64", "3"]):
+        r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (args, r.stdout, r.stderr)
+        assert "contig=" in r.stdout and "storm=" in r.stdout
