@@ -670,3 +670,17 @@ def test_readme_usage_program_in_c():
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (args, r.stdout, r.stderr)
         assert "contig=" in r.stdout and "storm=" in r.stdout
+
+
+def test_randomised_parity_soak():
+    """tools/soak_parity.py for a bounded time: random shapes, densities, shards and tuning
+    options through dense / matrix / square / sparse entries, each bit-exact against the oracle
+    (profiles/r01_h_soak_parity.json records a 4-minute run: 2598 cases)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "--seconds", "25",
+                        "--seed", "7", "--max-cases", "300"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    summary = json.loads(r.stdout.strip().splitlines()[-1])
+    assert summary["all_ok"] and summary["cases"] >= 20

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU: random shapes / densities / options through every all-pairs
+entry of the device library, each compared bit-for-bit with the CPU oracle (small shapes) or with
+the column identity and the popcount kernel (large shapes). Prints one line per case and a final
+summary; exit code 1 on the first mismatch.   soak_parity.py [--seconds 240] [--seed 1]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cases", type=int, default=100000)
+    args = ap.parse_args()
+    import stormbitmaps_amd as sb
+    from stormbitmaps_amd import synth
+    from tests._orc import Oracle
+    orc = Oracle()
+    ctx = sb.HipContext(0)
+    rng = np.random.default_rng(args.seed)
+    t_end = time.time() + args.seconds
+    n_cases = 0
+    kinds = {}
+    while time.time() < t_end and n_cases < args.max_cases:
+        kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "sparse"])
+        seed = int(rng.integers(1, 1 << 30))
+        opts = {"variant": int(rng.choice([-1, -1, 4, 5, 3, 2])),
+                "k2_max_run": int(rng.choice([128, 128, 1, 7, 64, 4096])),
+                "k2_tail_slices": int(rng.choice([3, 0, 1, 8])),
+                "k2_tail_run": int(rng.choice([32, 1, 5, 64])),
+                "k2_persistent": int(rng.choice([0, 0, 1])),
+                "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640]))}
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            if kind in ("dense_small", "matrix", "square"):
+                N = int(rng.integers(2, 1400))
+                M = int(rng.choice([64, 100, 4096, 9000, 65536, int(rng.integers(65, 150000))]))
+                d = int(max(1, M * rng.choice([0.5, 0.1, 0.01, 0.9]) * rng.random()))
+                mat = synth.dense_matrix_c(M, N, d, seed=seed)
+                if kind == "dense_small":
+                    m = ctx.matrix_from_host(mat)
+                    want = orc.wrapper_diag(mat)
+                    world = int(rng.choice([1, 1, 2, 3, 8]))
+                    got = sum(m.pairw(r, world) for r in range(world))
+                    ok = got == want
+                    m.close()
+                elif kind == "matrix":
+                    N = min(N, 600)
+                    mat = mat[:N]
+                    m = ctx.matrix_from_host(mat)
+                    op = int(rng.integers(0, 3))
+                    got_m = m.pairw_matrix(["and", "or", "xor"][op])
+                    ok = np.array_equal(got_m, np.triu(orc.tile_counts_op(mat, 0, N, 0, N, op), k=1))
+                    ok = ok and m.pairw_op(["and", "or", "xor"][op]) == int(got_m.sum(dtype=np.uint64))
+                    m.close()
+                else:
+                    na = int(rng.integers(1, N))
+                    a, b = mat[:na], mat[na:]
+                    ma, mb = ctx.matrix_from_host(a), ctx.matrix_from_host(b)
+                    ok = ma.square(mb) == orc.wrapper_square(a, b)
+                    ma.close(); mb.close()
+            elif kind == "dense_big":
+                N = int(rng.integers(1500, 9000))
+                M = int(rng.choice([4096, 20000, 65536, 131072]))
+                d = int(max(1, M * rng.choice([0.5, 0.05]) * rng.random()))
+                m = ctx.matrix(N, (M + 63) // 64)
+                m.fill_synthetic(M, d, seed=seed)
+                want = m.column_identity()
+                got = m.pairw()
+                ctx.set_option("variant", 2)
+                ok = got == want and (N > 4000 or m.pairw() == want)
+                m.close()
+            else:  # sparse container through storm.h (host library has its own context: defaults)
+                N = int(rng.integers(2, 700))
+                M = int(rng.choice([65536, 200000, 524288]))
+                d = int(rng.choice([1, 5, 60, 3000, 5000, 40000]))
+                rows = synth.positions(M, N, d, seed=seed)
+                s = sb.Storm()
+                for r in rows:
+                    s.add(r)
+                want = orc.storm(rows).pairw()
+                ok = s.pairw_intersect_cardinality() == want == s.pairw_intersect_cardinality_blocked(0)
+                s.free()
+        finally:
+            for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
+                         "k2_persistent": 0, "k2_pitch_pad": -1}.items():
+                ctx.set_option(k, v)
+        n_cases += 1
+        kinds[kind] = kinds.get(kind, 0) + 1
+        if not ok:
+            print(json.dumps({"FAILED": kind, "seed": seed, "opts": opts, "N": N, "M": M, "d": d}), flush=True)
+            sys.exit(1)
+        if n_cases % 25 == 0:
+            print(f"{n_cases} cases ok {kinds}", flush=True)
+    print(json.dumps({"cases": n_cases, "by_kind": kinds, "all_ok": True, "seed": args.seed}))
+
+
+if __name__ == "__main__":
+    main()
