@@ -127,6 +127,15 @@ int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t
                                   uint32_t* d_out, uint64_t ld);
 int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                            uint32_t* h_out);
+/* Materialised rectangle A x B (the two-matrix product XY^T):
+ *   out[i * ld + j] = popcount(a_i OP b_j) for every row i of `a` and j of `b` (same row width).
+ * _device: `d_out` is a DEVICE pointer, a->n_rows x ld uint32 with ld >= b->n_rows; synchronous.
+ * plain  : `h_out` is a HOST a->n_rows x b->n_rows uint32 buffer. */
+int storm_hip_square_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                                   const storm_hip_matrix_t* b, int op, uint32_t* d_out, uint64_t ld);
+int storm_hip_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                            const storm_hip_matrix_t* b, int op, uint32_t* h_out);
+
 /* sum_c C(n_c,2) on the device — verification identity only, never the product
  * path: used by tests at sizes where a CPU pairwise oracle is infeasible */
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,

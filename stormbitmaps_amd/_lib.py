@@ -49,6 +49,8 @@ SIGNATURES = {
     "storm_hip_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
     "storm_hip_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp]),
     "storm_hip_row_counts": (C.c_int, [vp, vp, vp]),
+    "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
+    "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),
     "storm_hip_debug_strip_trace": (C.c_int, [vp, vp, u64, P(u64)]),
     "storm_hip_pairw_dense_op": (C.c_int, [vp, vp, C.c_int, P(u64)]),

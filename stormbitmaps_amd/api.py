@@ -330,6 +330,13 @@ class HipMatrix:
                                                       C.c_void_p(d_out), ld),
               "storm_hip_pairw_matrix_device")
 
+    def square_matrix(self, other: "HipMatrix", op: str = "and") -> np.ndarray:
+        """[self.n_rows, other.n_rows] uint32: popcount(row_i(self) OP row_j(other)) for all i, j."""
+        out = np.zeros((self.n_rows, other.n_rows), dtype=np.uint32)
+        check(self._lib.storm_hip_square_matrix(self.ctx._h, self._h, other._h, self.OPS[op], _ptr(out)),
+              "storm_hip_square_matrix")
+        return out
+
     def row_counts(self) -> np.ndarray:
         out = np.zeros(self.n_rows, dtype=np.uint32)
         check(self._lib.storm_hip_row_counts(self.ctx._h, self._h, _ptr(out)),

@@ -1181,6 +1181,42 @@ int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, 
     return STORM_HIP_OK;
 }
 
+int storm_hip_square_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                                   const storm_hip_matrix_t* b, int op, uint32_t* d_out, uint64_t ld) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!a || !b || !d_out || ld < b->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR ||
+        a->n_words != b->n_words) {
+        set_error("square_matrix: NULL argument, unknown op, row widths differ or ld < rows of B");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_square_matrix(ctx, a, b, op, d_out, ld);
+}
+
+int storm_hip_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                            const storm_hip_matrix_t* b, int op, uint32_t* h_out) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!a || !b || !h_out) {
+        set_error("square_matrix: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t n = a->n_rows * b->n_rows;
+    if (n == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    uint32_t* d_out = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * sizeof(uint32_t)));
+    int rc = storm_hip_square_matrix_device(ctx, a, b, op, d_out, b->n_rows);
+    if (rc == STORM_HIP_OK &&
+        (hipMemcpyAsync(h_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) !=
+             hipSuccess ||
+         hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        set_error("square_matrix: HIP failure");
+        rc = STORM_HIP_EHIP;
+    }
+    (void)hipFree(d_out);
+    return rc;
+}
+
 int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                   uint32_t* d_out, uint64_t ld) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;

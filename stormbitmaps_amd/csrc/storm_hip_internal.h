@@ -121,6 +121,8 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
                         uint64_t ld);
 int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                        const storm_hip_matrix_s* b, uint64_t* d_total);
+int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
+                         const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld);
 int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_counts);
 void release_mfma_state(storm_hip_ctx_t* ctx);
 // folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)

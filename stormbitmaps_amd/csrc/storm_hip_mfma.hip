@@ -110,7 +110,11 @@ template <uint32_t probe, bool kWrite = false>
 __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     unsigned long long* __restrict__ slots, uint32_t* __restrict__ out = nullptr, uint64_t ld = 0,
-    uint32_t n_rows = 0, const uint32_t* __restrict__ row_counts = nullptr, uint32_t and_weight = 0) {
+    uint32_t n_rows = 0, const uint32_t* __restrict__ row_counts = nullptr, uint32_t and_weight = 0,
+    uint32_t j_base = 0, uint32_t j_count = 0) {
+    // kWrite window: rows i < n_rows of the shadow against shadow rows j_base + [0, j_count);
+    // j_count == 0 selects the triangle of one matrix (i < j < n_rows), otherwise the rectangle
+    // A x B of a shadow holding [A ; B] (B from shadow row j_base), written at column j - j_base.
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kRing][2][kTileStageBytes];  // [stage][A|B]
 
     const uint32_t tid = threadIdx.x;
@@ -216,15 +220,18 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const uint32_t j = b_row0 + wn * 64u + n * 32u + (lane & 31u);
+                const bool rect = j_count != 0;
+                const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_rows;
                 // union / symmetric difference: n_i + n_j - and_weight * |i & j|
-                const uint32_t nj = (row_counts && j < n_rows) ? row_counts[j] : 0u;
+                // (row_counts is indexed by shadow row)
+                const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t i = a_row0 + wm * 128u + m * 32u + (r & 3) + 8 * (r >> 2) +
                                        4 * (lane >> 5);
-                    if (i < j && j < n_rows) {
+                    if (j_ok && (rect ? i < n_rows : i < j)) {
                         const uint32_t c = (uint32_t)acc[m][n][r];
-                        out[(uint64_t)i * ld + j] =
+                        out[(uint64_t)i * ld + (j - j_base)] =
                             row_counts ? row_counts[i] + nj - and_weight * c : c;
                     }
                 }
@@ -1163,6 +1170,83 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
             rc = STORM_HIP_EHIP;
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
+    (void)hipFree(d_items);
+    (void)hipFree(d_counts);
+    return rc;
+}
+
+// Materialised rectangle: out[i * ld + j] = popcount(a_i OP b_j) for every row i of A and j of B
+// (device pointer, uint32, ld >= b->n_rows): the tile kernel over a shadow holding [A ; B].
+int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
+                         const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld) {
+    if ((uint64_t)a->n_words * 64u >= (1ull << 24)) {
+        set_error("square_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
+                  (unsigned long long)a->n_words * 64u);
+        return STORM_HIP_EINVAL;
+    }
+    if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
+    const uint64_t stride_words = a->stride_words;
+    const uint64_t row_bytes = stride_words * 32;
+    const uint64_t pitch = shadow_pitch(ctx, row_bytes, false);
+    const uint64_t rows_a = (a->n_rows + kTile - 1) / kTile * kTile;
+    const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;
+    if ((rows_a + rows_b) / kTile >= 65535) {
+        set_error("square_matrix: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    const size_t x4_bytes = (size_t)(rows_a + rows_b) * pitch;
+    if (x4_bytes > ctx->x4_capacity) {
+        if (ctx->d_x4) STORM_HIP_TRY(hipFree(ctx->d_x4));
+        ctx->d_x4 = nullptr;
+        ctx->x4_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_x4), x4_bytes) != hipSuccess) {
+            set_error("square_matrix: hipMalloc of %zu bytes for the FP4 shadow failed", x4_bytes);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->x4_capacity = x4_bytes;
+    }
+    const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
+    const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
+    std::vector<MfmaItem> items;
+    for (uint32_t i = 0; i < ta; ++i)
+        for (uint32_t j = 0; j < tb; ++j)
+            items.push_back({(uint16_t)i, (uint16_t)(ta + j), 0, total_stages});
+    MfmaItem* d_items = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+    uint32_t* d_counts = nullptr;  // per shadow row
+    int rc = STORM_HIP_OK;
+    if (op != STORM_HIP_OP_AND) {
+        if (hipMalloc(reinterpret_cast<void**>(&d_counts), (rows_a + rows_b) * sizeof(uint32_t)) !=
+            hipSuccess) {
+            rc = STORM_HIP_ENOMEM;
+        } else {
+            rc = launch_row_counts(ctx, a, d_counts);
+            if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
+        }
+    }
+    if (rc != STORM_HIP_OK) {
+    } else if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem),
+                              hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        rc = STORM_HIP_EHIP;
+    } else {
+        for (int side = 0; side < 2; ++side) {
+            const storm_hip_matrix_s* m = side ? b : a;
+            const uint64_t rows_dst = side ? rows_b : rows_a;
+            const uint64_t work = rows_dst * stride_words * 2;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+            hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+                               stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
+                               reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)), 0u,
+                               1u, 2u, pitch / 16);
+        }
+        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
+                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
+                           ctx->d_slots, d_out, ld, (uint32_t)a->n_rows, d_counts,
+                           op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = STORM_HIP_EHIP;
+    }
+    if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
     (void)hipFree(d_items);
     (void)hipFree(d_counts);
     return rc;

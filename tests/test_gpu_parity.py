@@ -684,3 +684,18 @@ def test_randomised_parity_soak():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     summary = json.loads(r.stdout.strip().splitlines()[-1])
     assert summary["all_ok"] and summary["cases"] >= 20
+
+
+def test_materialised_rectangle(hip_ctx, orc):
+    """SURVEY §8f-2 as an operator: every pair (row of A, row of B), AND / OR / XOR counts, ragged
+    shapes; sums agree with the rectangle total."""
+    mat = synth.dense_matrix_c(9000, 900, 3000, seed=15)
+    for na in (300, 257, 1, 899):
+        a, b = mat[:na], mat[na:]
+        ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
+        for name, op in (("and", 0), ("or", 1), ("xor", 2)):
+            want = orc.tile_counts_op(mat, 0, na, na, 900, op)
+            assert np.array_equal(ma.square_matrix(mb, name), want), (na, name)
+        assert int(ma.square_matrix(mb).sum(dtype=np.uint64)) == ma.square(mb)
+        assert np.array_equal(mb.square_matrix(ma), ma.square_matrix(mb).T)
+        ma.close(); mb.close()
