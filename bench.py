@@ -213,7 +213,10 @@ def main():
             "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            # integer bit counts; on the matrix-core path the 0/1 bits are FP4 operands with exact
+            # f32 accumulation (< 2^24 per accumulator), totals in uint64 — bit-exact either way
+            "dtype": "u64" if used < 3 else "u64 (bits as exact FP4 0/1 MFMA operands, f32 accumulate < 2^24)",
+            "data": "synthetic",
             "config": {"workload": f"STORM_contiguous_t N={N} M={M} dense draws={draws} seed={args.seed} "
                                    "(BASELINE configs[1], README `benchmark 65536 10000`)",
                        "entry_point": "storm_hip_pairw_dense_launch == STORM_contig_pairw_intersect_cardinality_blocked",
