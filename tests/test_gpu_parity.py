@@ -699,3 +699,22 @@ def test_materialised_rectangle(hip_ctx, orc):
         assert int(ma.square_matrix(mb).sum(dtype=np.uint64)) == ma.square(mb)
         assert np.array_equal(mb.square_matrix(ma), ma.square_matrix(mb).T)
         ma.close(); mb.close()
+
+
+def test_rows_beyond_the_strips_reach_fall_back_to_the_popcount_kernel(hip_ctx, orc):
+    """Rows longer than 2^27 bits do not fit the strip kernel's 32-bit DMA offsets: auto must pick
+    the popcount kernel and still be exact; forcing the strips must fail loudly, not wrongly."""
+    M, N = 140_000_000, 3
+    rng = np.random.default_rng(5)
+    mat = rng.integers(0, 1 << 63, size=(N, (M + 63) // 64), dtype=np.uint64)
+    mat[:, -1] &= np.uint64((1 << (M % 64)) - 1) if M % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    m = hip_ctx.matrix_from_host(mat)
+    assert m.pairw() == orc.wrapper_diag(mat)
+    assert hip_ctx.get_option("variant_used") == 2
+    try:
+        hip_ctx.set_option("variant", 4)
+        with pytest.raises(RuntimeError):
+            m.pairw()
+    finally:
+        hip_ctx.set_option("variant", -1)
+    m.close()
