@@ -614,6 +614,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "k2_matrix_split")) {
+        ctx->k2_matrix_split = value != 0;
     } else if (!strcmp(key, "k2_pitch_pad")) {
         if (value < -1 || value > 65536 || (value > 0 && value % 128 != 0)) {
             set_error("k2_pitch_pad must be -1 (auto) or a multiple of 128 in 0..65536");

@@ -91,6 +91,7 @@ struct storm_hip_ctx_s {
     int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)
     uint32_t strip_queue_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t strip_queue_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k2_matrix_split = 1; // matrix output: cut the last round's tiles along k to fill the CUs
     int k2_pitch_pad = -1;  // K2/K2s: extra bytes per row of the FP4 shadow (multiple of 128; -1 = auto)
     int k2_lds_pad = 0;     // K2s: bytes of unused dynamic LDS per workgroup (caps workgroups per CU)
     int k2_tail_slices = 3; // K2s: last slices of every XCD's list are cut into short runs ...

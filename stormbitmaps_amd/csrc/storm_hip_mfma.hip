@@ -111,7 +111,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     unsigned long long* __restrict__ slots, uint32_t* __restrict__ out = nullptr, uint64_t ld = 0,
     uint32_t n_rows = 0, const uint32_t* __restrict__ row_counts = nullptr, uint32_t and_weight = 0,
-    uint32_t j_base = 0, uint32_t j_count = 0) {
+    uint32_t j_base = 0, uint32_t j_count = 0, uint32_t split_from = 0xffffffffu) {
+    // Items from index split_from on cover only a part of k of their tile (several per tile, to
+    // fill the last round of workgroups): they ADD into `out`, which zero_tiles_kernel cleared.
     // kWrite window: rows i < n_rows of the shadow against shadow rows j_base + [0, j_count);
     // j_count == 0 selects the triangle of one matrix (i < j < n_rows), otherwise the rectangle
     // A x B of a shadow holding [A ; B] (B from shadow row j_base), written at column j - j_base.
@@ -231,8 +233,13 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
                                        4 * (lane >> 5);
                     if (j_ok && (rect ? i < n_rows : i < j)) {
                         const uint32_t c = (uint32_t)acc[m][n][r];
-                        out[(uint64_t)i * ld + (j - j_base)] =
-                            row_counts ? row_counts[i] + nj - and_weight * c : c;
+                        uint32_t* dst = &out[(uint64_t)i * ld + (j - j_base)];
+                        if (blockIdx.x < split_from) {
+                            *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
+                        } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
+                            const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
+                            atomicAdd(dst, row_counts ? once - and_weight * c : c);
+                        }
                     }
                 }
             }
@@ -1108,6 +1115,67 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     return launch_fold_slots(ctx, d_total);
 }
 
+// Clears the output window of the tiles whose k range is split over several items (same write
+// predicate as pairw_fp4_kernel<., true>). One workgroup per tile, thread = column.
+__global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restrict__ items,
+                                                         uint32_t first, uint32_t parts,
+                                                         uint32_t* __restrict__ out, uint64_t ld,
+                                                         uint32_t n_rows, uint32_t j_base,
+                                                         uint32_t j_count) {
+    const MfmaItem it = items[first + blockIdx.x * parts];
+    const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
+    const bool rect = j_count != 0;
+    if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_rows)) return;
+    for (uint32_t r = 0; r < (uint32_t)kTile; ++r) {
+        const uint32_t i = (uint32_t)it.I * kTile + r;
+        if (rect ? i < n_rows : i < j) out[(uint64_t)i * ld + (j - j_base)] = 0;
+    }
+}
+
+// Runs the tile kernel in write mode over `tiles` (shadow already expanded). The kernel holds one
+// workgroup per CU, so n tiles take ceil(n / CUs) rounds and a nearly empty last round costs a
+// whole one (820 tiles on 256 CUs at the headline shape: 3.2 -> 4). The tiles of the last round
+// are therefore cut along k into as many parts as fill the CUs; the parts add into a cleared
+// window.
+static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
+                            uint32_t total_stages, uint64_t pitch, uint32_t* d_out, uint64_t ld,
+                            uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight,
+                            uint32_t j_base, uint32_t j_count) {
+    const size_t slots = (size_t)std::max(1, ctx->n_cus);
+    const size_t leftover = tiles.size() % slots;
+    uint32_t parts = 1;
+    if (leftover > 0 && ctx->k2_matrix_split)
+        parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(slots / leftover, total_stages / 32));
+    const size_t n_full = parts > 1 ? tiles.size() - leftover : tiles.size();
+    std::vector<MfmaItem> items;
+    for (size_t t = 0; t < n_full; ++t) items.push_back({tiles[t].first, tiles[t].second, 0, total_stages});
+    for (size_t t = n_full; t < tiles.size(); ++t)
+        for (uint32_t p = 0; p < parts; ++p) {
+            const uint32_t s0 = (uint32_t)((uint64_t)total_stages * p / parts);
+            const uint32_t s1 = (uint32_t)((uint64_t)total_stages * (p + 1) / parts);
+            items.push_back({tiles[t].first, tiles[t].second, s0, s1 - s0});
+        }
+    MfmaItem* d_items = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+    int rc = STORM_HIP_OK;
+    if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
+                       ctx->stream) != hipSuccess) {
+        rc = STORM_HIP_EHIP;
+    } else {
+        if (parts > 1)
+            hipLaunchKernelGGL(zero_tiles_kernel, dim3((uint32_t)leftover), dim3(256), 0, ctx->stream,
+                               d_items, (uint32_t)n_full, parts, d_out, ld, n_rows, j_base, j_count);
+        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
+                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
+                           ctx->d_slots, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           parts > 1 ? (uint32_t)n_full : 0xffffffffu);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = STORM_HIP_EHIP;
+    }
+    (void)hipFree(d_items);
+    return rc;
+}
+
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
@@ -1139,11 +1207,12 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
-    std::vector<MfmaItem> items;
-    for (uint32_t i = 0; i < nT; ++i)  // long rows of tiles first
-        for (uint32_t j = i; j < nT; ++j) items.push_back({(uint16_t)i, (uint16_t)j, 0, total_stages});
-    MfmaItem* d_items = nullptr;
-    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+    // off-diagonal tiles first; the diagonal ones (half of their window is written) go last,
+    // where run_matrix_tiles may cut them along k
+    std::vector<std::pair<uint16_t, uint16_t>> tiles;
+    for (uint32_t i = 0; i < nT; ++i)
+        for (uint32_t j = i + 1; j < nT; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
+    for (uint32_t i = 0; i < nT; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
     uint32_t* d_counts = nullptr;
     int rc = STORM_HIP_OK;
     if (op != STORM_HIP_OP_AND) {
@@ -1152,25 +1221,16 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         else
             rc = launch_row_counts(ctx, m, d_counts);
     }
-    if (rc != STORM_HIP_OK) {
-    } else if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
-                       ctx->stream) != hipSuccess) {
-        rc = STORM_HIP_EHIP;
-    } else {
+    if (rc == STORM_HIP_OK) {
         const uint64_t work = n_rows4 * m->stride_words * 2;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
-        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
-                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
-                           ctx->d_slots, d_out, ld, (uint32_t)m->n_rows, d_counts,
-                           op == STORM_HIP_OP_XOR ? 2u : 1u);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = STORM_HIP_EHIP;
+        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)m->n_rows, d_counts,
+                              op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u);
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
-    (void)hipFree(d_items);
     (void)hipFree(d_counts);
     return rc;
 }
@@ -1207,12 +1267,9 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
-    std::vector<MfmaItem> items;
+    std::vector<std::pair<uint16_t, uint16_t>> tiles;
     for (uint32_t i = 0; i < ta; ++i)
-        for (uint32_t j = 0; j < tb; ++j)
-            items.push_back({(uint16_t)i, (uint16_t)(ta + j), 0, total_stages});
-    MfmaItem* d_items = nullptr;
-    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
+        for (uint32_t j = 0; j < tb; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)(ta + j));
     uint32_t* d_counts = nullptr;  // per shadow row
     int rc = STORM_HIP_OK;
     if (op != STORM_HIP_OP_AND) {
@@ -1224,11 +1281,7 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
             if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
         }
     }
-    if (rc != STORM_HIP_OK) {
-    } else if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem),
-                              hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-        rc = STORM_HIP_EHIP;
-    } else {
+    if (rc == STORM_HIP_OK) {
         for (int side = 0; side < 2; ++side) {
             const storm_hip_matrix_s* m = side ? b : a;
             const uint64_t rows_dst = side ? rows_b : rows_a;
@@ -1239,15 +1292,10 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                                reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)), 0u,
                                1u, 2u, pitch / 16);
         }
-        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
-                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
-                           ctx->d_slots, d_out, ld, (uint32_t)a->n_rows, d_counts,
-                           op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = STORM_HIP_EHIP;
+        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)a->n_rows, d_counts,
+                              op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
     }
     if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
-    (void)hipFree(d_items);
     (void)hipFree(d_counts);
     return rc;
 }
