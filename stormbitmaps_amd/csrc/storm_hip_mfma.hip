@@ -414,10 +414,16 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
                                    : it.j1 - 1u - (t - D);
         const uint8_t* base = X4 + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
         uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
-        __builtin_amdgcn_global_load_lds((gptr_t)(base + goff0), (lptr_t)dst, 16, 0, 0);
+        // LDS-DMA as buffer loads (scalar descriptor of the stage + 32-bit lane offsets), not
+        // global_load_lds with 64-bit lane addresses: beside MFMA bursts the latter costs the
+        // wave 18.3 ns per MFMA at 3-4 waves per SIMD, the former 14.2 — as much as no load at
+        // all (tools/ubench_feed, profiles/r01_h_ubench_feed.txt).
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, (int)goff0, 0, 0, 0);
         if constexpr (kStripPieces == 2)
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + 32u * row_bytes + goff0),
-                                             (lptr_t)(dst + 4096u), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + 4096u), 16, (int)goff0,
+                                                     (int)(32u * (uint32_t)row_bytes), 0, 0);
     };
 
     // A fragments first (older in the VMEM queue than the DMAs, so waiting for them does not

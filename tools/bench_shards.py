@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--bits", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--worlds", default="1,2,4,8")
     args = ap.parse_args()
     import torch
     import stormbitmaps_amd as sb
@@ -30,7 +31,7 @@ def main():
     want = m.column_identity()
     total_t = torch.zeros(1, dtype=torch.int64, device="cuda:0")
     base = None
-    for world in (1, 2, 4, 8):
+    for world in [int(w) for w in args.worlds.split(",")]:
         worst, parts = 0.0, 0
         for rank in range(world):
             for _ in range(5):

@@ -2,7 +2,8 @@
 // (the strip kernel's stage) plus, per iteration, one of:
 //   0 nothing | 1 two global_load_lds (16 B/lane, LDS-DMA) | 2 two global_load_dwordx4 into
 //   registers | 3 mode 2 + two ds_write_b128 of the PREVIOUS iteration's registers |
-//   4 eight ds_read_b128 | 5 mode 1 + mode 4 | 6 mode 3 + mode 4
+//   4 eight ds_read_b128 | 5 mode 1 + mode 4 | 6 mode 3 + mode 4 |
+//   7 two buffer_load_dwordx4 ... lds (SRD + 32-bit offsets) | 8 mode 7 + mode 4
 // at W waves per SIMD (W workgroups of 256 threads per CU). Reports cycles-equivalents per
 // iteration from the wall time (the clock under load is not known exactly; compare modes).
 #include <hip/hip_runtime.h>
@@ -46,6 +47,15 @@ __global__ __launch_bounds__(256, WPS) void feed(const uint8_t* __restrict__ src
             __builtin_amdgcn_global_load_lds((gptr_t)(g + goff), (lptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(g + 32u * row_bytes + goff), (lptr_t)(dst + 4096u), 16, 0, 0);
         }
+        if constexpr (MODE == 7 || MODE == 8) {
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, 0x7fffffff, 0x00020000);
+            uint8_t* dst = lds[it & 3] + wave * 1024u;
+            const uint32_t so = (uint32_t)(it & 63) * 128u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, (int)goff, (int)so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + 4096u), 16,
+                                                 (int)(goff + 32u * (uint32_t)row_bytes), (int)so, 0, 0);
+        }
         if constexpr (MODE == 3 || MODE == 6) {  // registers loaded one iteration ago -> LDS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t w = lbase + (it & 3) * 8192u + wave * 1024u + lane * 16u;
@@ -57,7 +67,7 @@ __global__ __launch_bounds__(256, WPS) void feed(const uint8_t* __restrict__ src
                          : "v"(g + goff), "v"(g + 32u * row_bytes + goff)
                          : "memory");
         }
-        if constexpr (MODE >= 4) {
+        if constexpr (MODE >= 4 && MODE != 7) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
@@ -71,12 +81,12 @@ __global__ __launch_bounds__(256, WPS) void feed(const uint8_t* __restrict__ src
                 acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
                     v8i{a[n & 1].x, a[n & 1].y, a[n & 1].z, a[n & 1].w, 0, 0, 0, 0},
                     v8i{b[n >> 1].x, b[n >> 1].y, b[n >> 1].z, b[n >> 1].w, 0, 0, 0, 0}, acc[n], 4, 4, 0, 0, 0, 0);
-        if constexpr (MODE >= 4) {
+        if constexpr (MODE >= 4 && MODE != 7) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(rd[q]));
         }
-        if constexpr (MODE == 1 || MODE == 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (MODE == 1 || MODE == 5 || MODE == 7 || MODE == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     float s = 0;
@@ -125,6 +135,8 @@ int main() {
     ROW(4, "16 MFMA + 8 ds_read_b128")
     ROW(5, "16 MFMA + 2 global_load_lds + 8 ds_read")
     ROW(6, "16 MFMA + 2 gld + 2 ds_write + 8 ds_read")
+    ROW(7, "16 MFMA + 2 buffer_load_lds")
+    ROW(8, "16 MFMA + 2 buffer_load_lds + 8 ds_read")
     // the 4-wave code at lower residency: is the LDS-DMA cost a matter of code or of concurrency?
     if (run<1, 4, 2>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds")) return 1;
     if (run<1, 4, 1>(src, row_bytes, out, cus, "16 MFMA + 2 global_load_lds")) return 1;
