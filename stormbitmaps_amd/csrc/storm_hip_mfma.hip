@@ -93,14 +93,19 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
 __device__ __forceinline__ void stage_tile(uint8_t* lds_tile, const uint8_t* __restrict__ X4,
                                            uint64_t row_bytes, uint32_t row0, uint64_t kbyte,
                                            uint32_t wave, uint32_t lane) {
+    // buffer_load ... lds: scalar descriptor of the tile's k position + 32-bit lane offsets
+    // (global_load_lds with 64-bit lane addresses costs the wave far more beside MFMA bursts,
+    // tools/ubench_feed). 256 rows x row pitch < 2^32 is checked on the host.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(X4 + (uint64_t)row0 * row_bytes + kbyte), 0, -1, 0x00020000);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t n = (uint32_t)q * 8u + wave;  // wave-instruction index, 1 KiB each
         const uint32_t p = n * 64u + lane;           // 16-byte piece of the LDS image
         const uint32_t r = p >> 2;
         const uint32_t slot = (p & 3u) ^ ((r >> 2) & 3u);
-        const uint8_t* g = X4 + (uint64_t)(row0 + r) * row_bytes + kbyte + slot * 16u;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lds_tile + n * 1024u), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds_tile + n * 1024u), 16,
+                                                 (int)(r * (uint32_t)row_bytes + slot * 16u), 0, 0, 0);
     }
 }
 
@@ -900,8 +905,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     } else if (int rc = ensure_items(ctx, ranges, total_stages, shard_rank, shard_count, false)) {
         return rc;
     }
-    if (strips && pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
-        set_error("K2 strips: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 3",
+    if (pitch * (uint64_t)(strips ? kStripBRows : kTile) >= (1ull << 32)) {
+        set_error("K2: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 2",
                   (unsigned long long)row_bytes);
         return STORM_HIP_EINVAL;
     }
