@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shadow-resident", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (tuning)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal)")
     ap.add_argument("--all-on-device0", action="store_true",
@@ -164,6 +165,27 @@ def main():
     ctx.set_option("time_kernels", 0)
     kernel_ms = dom_sum_ms / dom_n if dom_n else launch_ms
 
+    # Secondary figure, never `value`: the same pass when the FP4 re-encoding of the (unchanged)
+    # matrix is kept in HBM between calls (library option keep_shadow, what the storm.h handles
+    # do) — i.e. without the O(N*M) expansion at the head of every pass.
+    shadow_resident = None
+    if not args.no_shadow_resident:
+        ctx.set_option("keep_shadow", 1)
+        step(); fence()
+        n2 = max(1, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        fence()
+        e2 = time.perf_counter() - t1
+        if collective:
+            t = torch.tensor([e2], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        ctx.set_option("keep_shadow", 0)
+        shadow_resident = {"ms_per_step": e2 * 1e3 / n2, "steps": n2,
+                           "total_matches": int(total_t.item()) == total}
+
     info = ctx.last_launch_info()
     pairs = N * (N - 1) // 2
     words = pairs * 2 * W
@@ -226,6 +248,11 @@ def main():
             "total": total, "verified_against_column_identity": ok,
             "roofline": roof,
         }
+        if shadow_resident is not None:
+            shadow_resident["value"] = words / (shadow_resident["ms_per_step"] * 1e-3)
+            shadow_resident["note"] = ("same pass with the FP4 shadow of the unchanged matrix kept resident "
+                                       "(option keep_shadow); informational, `value` always re-expands")
+            out["shadow_resident"] = shadow_resident
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lambda n: mat.download(0, min(n, N)), W)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

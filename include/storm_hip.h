@@ -141,14 +141,26 @@ int storm_hip_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                               uint64_t* h_total);
 
-/* kernel selection / tuning knobs (benchmarks; defaults are what ships)
- *   key "variant": -1 = auto (default): 4 for >= 1024 rows, else 2
+/* kernel selection / tuning knobs (benchmarks; defaults are what ships; none changes a result)
+ *   key "variant": -1 = auto (default): matrix-core strips (4) whenever 64 shadow rows fit 32-bit
+ *                  DMA offsets, else the popcount kernel (2)
  *                  0/1/2 = K1 popcount kernel, B operand direct / via VGPR->LDS / via LDS-DMA
- *                  3 = K2 FP4 matrix-core tiles, 4 = K2s FP4 matrix-core strips (+3 on the diagonal)
+ *                  3 = K2 FP4 matrix-core tiles, 4 = K2s FP4 matrix-core strips (256-row A tiles),
+ *                  5 = wide strips (512-row A tiles)
+ *   key "keep_shadow": 1 = keep the FP4 shadow of a dense matrix between all-pairs calls while the
+ *                  matrix is unchanged (default 0). Only valid when the matrix is modified through
+ *                  this library alone (upload / import / set_rows / fill / clear), never through
+ *                  storm_hip_matrix_device_ptr. storm.h handles use it.
+ *   key "time_kernels": see storm_hip_kernel_time
  *   key "seg_rows": K1 B rows per work item (default 256)
  *   key "chunks_per_item": K1 k-chunks (64 words each) per work item, 0 = auto
  *   key "k2_stages_per_item": K2 tile kernel k-slice length in 128-bit stages (default 32)
- *   key "k2_debug": timing probes only (results are then wrong), see storm_hip_mfma.hip
+ *   keys "k2_max_run" (128), "k2_tail_slices" (3), "k2_tail_run" (32): strip work-list shaping;
+ *        "k2_persistent" (0): per-XCD work queues; "k2_ring" (4): LDS ring depth 3..5;
+ *        "k2_pitch_pad" (-1 = auto): extra bytes per shadow row; "k2_lds_pad": cap workgroups per CU;
+ *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k
+ *   key "k2_debug", "k2_ring" >= 11: timing probes only (results may then be wrong), see
+ *        storm_hip_mfma.hip
  *   read-only "variant_used": what the last dense launch ran; "n_cus" */
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);

@@ -23,6 +23,7 @@
 #include "storm_hip_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -614,6 +615,9 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "keep_shadow")) {
+        ctx->keep_shadow = value != 0;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_matrix_split")) {
         ctx->k2_matrix_split = value != 0;
     } else if (!strcmp(key, "k2_pitch_pad")) {
@@ -733,6 +737,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     if (!m) return STORM_HIP_ENOMEM;
     m->n_rows = n_rows;
     m->n_words = n_words;
+    m->generation = next_matrix_generation();
     m->n_rows_pad = std::max<uint64_t>(kABlockRows,
                                        (n_rows + kABlockRows - 1) / kABlockRows * kABlockRows);
     m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
@@ -768,6 +773,7 @@ static int check_rows(const storm_hip_matrix_t* m, uint64_t row0, uint64_t n_row
 int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
                             uint64_t n_rows, const uint64_t* host_rows,
                             uint64_t src_stride_words) {
+    if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
     if (n_rows == 0) return STORM_HIP_OK;
     if (!host_rows || src_stride_words < m->n_words) {
@@ -785,6 +791,7 @@ int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_
 int storm_hip_matrix_import(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
                             uint64_t n_rows, const void* device_rows,
                             uint64_t src_stride_words) {
+    if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
     if (n_rows == 0) return STORM_HIP_OK;
     if (!device_rows || src_stride_words < m->n_words) {
@@ -819,6 +826,7 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
                                              uint64_t row0, uint64_t n_rows,
                                              const uint64_t* offsets,
                                              const uint32_t* positions) {
+    if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
     if (n_rows == 0) return STORM_HIP_OK;
     if (!offsets || (!positions && offsets[n_rows] != offsets[0])) {
@@ -866,6 +874,7 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
 
 int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
                                     uint64_t n_bits, uint32_t draws, uint64_t seed) {
+    if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || !m) return STORM_HIP_EINVAL;
     if (n_bits == 0 || (n_bits + 63) / 64 != m->n_words) {
         set_error("fill_synthetic: n_bits=%llu does not match %u words per row",
@@ -885,6 +894,7 @@ int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
 }
 
 int storm_hip_matrix_clear(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
+    if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || !m) return STORM_HIP_EINVAL;
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     STORM_HIP_TRY(hipMemsetAsync(m->d, 0, m->n_rows_pad * m->stride_words * 8, ctx->stream));
@@ -912,6 +922,11 @@ void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m) { return m ? m->d
 }  // extern "C"
 
 namespace storm {
+
+uint64_t next_matrix_generation() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1);
+}
 
 void kernel_time_mark(storm_hip_ctx_t* ctx) {
     if (!ctx->time_kernels) return;

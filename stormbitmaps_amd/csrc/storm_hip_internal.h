@@ -91,6 +91,10 @@ struct storm_hip_ctx_s {
     int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)
     uint32_t strip_queue_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t strip_queue_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // "keep_shadow": reuse the FP4 shadow across all-pairs calls while (matrix, generation, shard,
+    // layout) are unchanged. Only valid if the matrix is modified through the library alone.
+    int keep_shadow = 0;
+    uint64_t x4_key[4] = {0, 0, 0, 0};
     int k2_matrix_split = 1; // matrix output: cut the last round's tiles along k to fill the CUs
     int k2_pitch_pad = -1;  // K2/K2s: extra bytes per row of the FP4 shadow (multiple of 128; -1 = auto)
     int k2_lds_pad = 0;     // K2s: bytes of unused dynamic LDS per workgroup (caps workgroups per CU)
@@ -117,7 +121,8 @@ struct RowRange {
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
-                             uint32_t shard_count, int strip_mode, uint64_t* d_total);
+                             uint32_t shard_count, int strip_mode, uint64_t* d_total,
+                             uint64_t shadow_generation = 0);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld);
 int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
@@ -130,6 +135,7 @@ void release_mfma_state(storm_hip_ctx_t* ctx);
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
 // record the next event of the "time_kernels" series on the launch stream (no-op when off)
 void kernel_time_mark(storm_hip_ctx_t* ctx);
+uint64_t next_matrix_generation();
 }  // namespace storm
 
 struct storm_hip_matrix_s {
@@ -138,4 +144,5 @@ struct storm_hip_matrix_s {
     uint64_t n_rows_pad = 0;    // allocated rows (multiple of kABlockRows)
     uint32_t n_words = 0;       // logical words per row
     uint64_t stride_words = 0;  // allocated words per row (multiple of kChunkWords)
+    uint64_t generation = 0;    // changes with every mutation through the library (see "keep_shadow")
 };

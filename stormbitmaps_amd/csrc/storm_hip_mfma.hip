@@ -79,11 +79,11 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
         uint32_t w = 0;
         if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[t];
         uint4 o;
-        o.x = spread8_fp4(w & 0xFFu, nib);
-        o.y = spread8_fp4((w >> 8) & 0xFFu, nib);
-        o.z = spread8_fp4((w >> 16) & 0xFFu, nib);
-        o.w = spread8_fp4(w >> 24, nib);
-        X4[row * out_pitch_u4 + (t - row * halves_per_row)] = o;
+        o.x = spread8_fp4(w & 0xFFu, nib & 7u);
+        o.y = spread8_fp4((w >> 8) & 0xFFu, nib & 7u);
+        o.z = spread8_fp4((w >> 16) & 0xFFu, nib & 7u);
+        o.w = spread8_fp4(w >> 24, nib & 7u);
+        X4[row * out_pitch_u4 + (t - row * halves_per_row)] = o;  // (non-temporal stores: slower)
     }
 }
 
@@ -876,7 +876,10 @@ static uint64_t shadow_pitch(const storm_hip_ctx_t* ctx, uint64_t row_bytes, boo
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
-                             uint32_t shard_count, int strip_mode, uint64_t* d_total) {
+                             uint32_t shard_count, int strip_mode, uint64_t* d_total,
+                             uint64_t shadow_generation) {
+    // shadow_generation != 0 identifies the content of X (dense matrix + its generation): with
+    // "keep_shadow" an unchanged shadow of the same layout and shard is not rebuilt.
     // strip_mode: 0 = tile kernel, 1 = strips with 256-row A tiles, 2 = wide strips (512 rows;
     // n_rows_dst and every range start must then be multiples of 512)
     const bool strips = strip_mode != 0;
@@ -897,6 +900,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             return STORM_HIP_ENOMEM;
         }
         ctx->x4_capacity = x4_bytes;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     if (strips) {
@@ -920,14 +924,22 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
         return STORM_HIP_EINVAL;
     }
     const uint32_t n_strip = strips ? ctx->n_strip_items : 0;
+    const uint64_t key[4] = {(uint64_t)(uintptr_t)X, shadow_generation,
+                             ((uint64_t)shard_rank << 32) | shard_count,
+                             (pitch << 20) ^ (n_rows_dst << 2) ^ (uint64_t)strip_mode};
+    const bool shadow_valid = ctx->keep_shadow && shadow_generation != 0 &&
+                              !memcmp(key, ctx->x4_key, sizeof(key)) &&
+                              (ctx->k2_debug >> 8) == 0;
     if (ctx->n_items > 0 || n_strip > 0) {
         const uint64_t work = n_rows_dst * stride_words * 2;
         const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+        if (!shadow_valid)
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, stride_words,
                            std::min(n_rows_src, n_rows_dst), n_rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count,
-                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 7u : 2u, pitch / 16);
+                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
+        memcpy(ctx->x4_key, key, sizeof(key));
         if (n_strip > 0) {
             kernel_time_mark(ctx);
             const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
@@ -1080,7 +1092,9 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
             return STORM_HIP_ENOMEM;
         }
         ctx->x4_capacity = x4_bytes;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
+    memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // the shadow is about to hold [A ; B]
     const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
     const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
     const uint32_t jb0 = (uint32_t)(rows_a / kStripBRows);
@@ -1152,6 +1166,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<ui
                             uint32_t total_stages, uint64_t pitch, uint32_t* d_out, uint64_t ld,
                             uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight,
                             uint32_t j_base, uint32_t j_count) {
+    memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const size_t slots = (size_t)std::max(1, ctx->n_cus);
     const size_t leftover = tiles.size() % slots;
     uint32_t parts = 1;
@@ -1215,6 +1230,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
             return STORM_HIP_ENOMEM;
         }
         ctx->x4_capacity = x4_bytes;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
@@ -1275,6 +1291,7 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
             return STORM_HIP_ENOMEM;
         }
         ctx->x4_capacity = x4_bytes;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
@@ -1319,7 +1336,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
     std::vector<RowRange> ranges;
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     return launch_pairw_mfma_ranges(ctx, m->d, m->stride_words, m->n_rows_pad, n_rows4, ranges,
-                                    shard_rank, shard_count, strip_mode, d_total);
+                                    shard_rank, shard_count, strip_mode, d_total, m->generation);
 }
 
 }  // namespace storm

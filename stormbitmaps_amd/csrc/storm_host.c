@@ -102,6 +102,10 @@ static storm_hip_ctx_t* device_ctx(int slot) {
         if (storm_hip_ctx_create(g_device_ids[slot], NULL, &g_ctx[slot]) != STORM_HIP_OK) {
             device_error("storm_hip_ctx_create");
             g_ctx[slot] = NULL;
+        } else {
+            /* the device mirrors behind the storm.h handles are written by this file only, so a
+             * repeated all-pairs call on an unchanged handle may reuse the FP4 shadow */
+            (void)storm_hip_ctx_set_option(g_ctx[slot], "keep_shadow", 1);
         }
     }
     return g_ctx[slot];

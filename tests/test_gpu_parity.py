@@ -718,3 +718,40 @@ def test_rows_beyond_the_strips_reach_fall_back_to_the_popcount_kernel(hip_ctx, 
     finally:
         hip_ctx.set_option("variant", -1)
     m.close()
+
+
+def test_keep_shadow_follows_every_mutation(hip_ctx, orc):
+    """Option keep_shadow: the FP4 shadow is reused only while (matrix, generation, shard, layout)
+    are unchanged — every mutator, a second matrix on the same context, shard and variant changes
+    must each force a rebuild."""
+    M, N, d = 6000, 700, 2500
+    a = synth.dense_matrix_c(M, N, d, seed=1)
+    b = synth.dense_matrix_c(M, N, d, seed=2)
+    wa, wb = orc.wrapper_diag(a), orc.wrapper_diag(b)
+    try:
+        hip_ctx.set_option("keep_shadow", 1)
+        ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
+        assert [ma.pairw(), ma.pairw(), mb.pairw(), ma.pairw(), mb.pairw()] == [wa, wa, wb, wa, wb]
+        ma.upload(b)                                   # same buffer, new content
+        assert ma.pairw() == wb
+        ma.upload(a[:10], row0=5)                      # partial overwrite
+        mixed = b.copy(); mixed[5:15] = a[:10]
+        assert ma.pairw() == orc.wrapper_diag(mixed)
+        assert sum(ma.pairw(r, 3) for r in range(3)) == orc.wrapper_diag(mixed)   # shard change
+        assert ma.pairw() == orc.wrapper_diag(mixed)
+        for variant in (5, 3, 4):                      # layout change
+            hip_ctx.set_option("variant", variant)
+            assert ma.pairw() == orc.wrapper_diag(mixed), variant
+        hip_ctx.set_option("variant", -1)
+        assert ma.pairw_matrix().sum(dtype=np.uint64) == orc.wrapper_diag(mixed)  # tile layout in between
+        assert ma.pairw() == orc.wrapper_diag(mixed)
+        assert ma.square(mb) == orc.wrapper_square(mixed, b)                      # [A ; B] in between
+        assert ma.pairw() == orc.wrapper_diag(mixed)
+        ma.fill_synthetic(M, d, seed=1)
+        assert ma.pairw() == wa
+        ma.clear()
+        assert ma.pairw() == 0
+        ma.close(); mb.close()
+    finally:
+        hip_ctx.set_option("keep_shadow", 0)
+        hip_ctx.set_option("variant", -1)
