@@ -1,0 +1,123 @@
+/* device_stub.c — TEST ONLY. Stands in for libstorm_hip's device entry points so that the host
+ * side (stormbitmaps_amd/csrc/storm_host.c: the storm.h containers, their growth paths and the
+ * marshalling towards the device) can run under AddressSanitizer / UBSan on a machine without a
+ * GPU. It computes no pair counts: the "totals" it returns are the number of set bits that
+ * reached it, which the driver compares with what it fed in. Never linked into the product. */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "storm_hip.h"
+
+struct storm_hip_ctx_s { int device; uint64_t pending; };
+struct storm_hip_matrix_s { uint64_t n_rows; uint32_t n_words; uint64_t* rows; };
+struct storm_hip_sparse_s { uint64_t set_bits; };
+
+static const char* g_err = "";
+const char* storm_hip_last_error(void) { return g_err; }
+int storm_hip_device_count(void) { return 1; }
+
+int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
+    (void)stream;
+    *out = (storm_hip_ctx_t*)calloc(1, sizeof(**out));
+    if (!*out) return STORM_HIP_ENOMEM;
+    (*out)->device = device;
+    return STORM_HIP_OK;
+}
+void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) { free(ctx); }
+int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
+    (void)ctx; (void)key; (void)value;
+    return STORM_HIP_OK;
+}
+
+int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
+                            storm_hip_matrix_t** out) {
+    (void)ctx;
+    storm_hip_matrix_t* m = (storm_hip_matrix_t*)calloc(1, sizeof(*m));
+    if (!m) return STORM_HIP_ENOMEM;
+    m->n_rows = n_rows;
+    m->n_words = n_words;
+    m->rows = (uint64_t*)calloc((size_t)n_rows * n_words + 1, sizeof(uint64_t));
+    *out = m;
+    return m->rows ? STORM_HIP_OK : STORM_HIP_ENOMEM;
+}
+void storm_hip_matrix_destroy(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
+    (void)ctx;
+    if (m) free(m->rows);
+    free(m);
+}
+int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                            uint64_t n_rows, const uint64_t* host, uint64_t stride_words) {
+    (void)ctx;
+    if (row0 + n_rows > m->n_rows) return STORM_HIP_EINVAL;
+    for (uint64_t r = 0; r < n_rows; ++r) /* reads exactly what the real upload reads */
+        memcpy(m->rows + (row0 + r) * m->n_words, host + r * stride_words,
+               (size_t)m->n_words * sizeof(uint64_t));
+    return STORM_HIP_OK;
+}
+
+static uint64_t set_bits_of(const storm_hip_matrix_t* m) {
+    uint64_t n = 0;
+    for (uint64_t k = 0; k < m->n_rows * m->n_words; ++k) n += (uint64_t)__builtin_popcountll(m->rows[k]);
+    return n;
+}
+int storm_hip_pairw_dense_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
+                                uint32_t shard_rank, uint32_t shard_count) {
+    if (shard_rank >= shard_count) return STORM_HIP_EINVAL;
+    ctx->pending = shard_rank == 0 ? set_bits_of(m) : 0;
+    return STORM_HIP_OK;
+}
+int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    *h_total = ctx->pending;
+    return STORM_HIP_OK;
+}
+int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
+                           const storm_hip_matrix_t* b, uint64_t* h_total) {
+    (void)ctx;
+    *h_total = set_bits_of(a) + set_bits_of(b);
+    return STORM_HIP_OK;
+}
+int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op, uint32_t* h_out) {
+    (void)ctx; (void)op;
+    for (uint64_t i = 0; i < m->n_rows * m->n_rows; ++i) h_out[i] = 0; /* touches the whole output */
+    return STORM_HIP_OK;
+}
+
+int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                            const uint64_t* row_block_offset, const uint32_t* block_id,
+                            const uint8_t* block_kind, const uint64_t* block_data_offset,
+                            const uint32_t* block_n, const uint16_t* list_pool,
+                            uint64_t list_pool_len, const uint64_t* bitmap_pool,
+                            uint64_t bitmap_pool_words, storm_hip_sparse_t** out) {
+    (void)ctx;
+    if (row_block_offset[0] != 0 || row_block_offset[n_rows] != n_blocks) return STORM_HIP_EINVAL;
+    uint64_t bits = 0;
+    for (uint64_t r = 0; r < n_rows; ++r)
+        for (uint64_t b = row_block_offset[r]; b < row_block_offset[r + 1]; ++b) {
+            if (b > row_block_offset[r] && block_id[b] <= block_id[b - 1]) return STORM_HIP_EINVAL;
+            if (block_kind[b] == 0) {
+                if (block_data_offset[b] + block_n[b] > list_pool_len) return STORM_HIP_EINVAL;
+                for (uint32_t k = 0; k < block_n[b]; ++k) {
+                    const uint16_t v = list_pool[block_data_offset[b] + k];
+                    if (k && v <= list_pool[block_data_offset[b] + k - 1]) return STORM_HIP_EINVAL;
+                }
+                bits += block_n[b];
+            } else {
+                if (block_data_offset[b] + 1024 > bitmap_pool_words) return STORM_HIP_EINVAL;
+                for (int k = 0; k < 1024; ++k)
+                    bits += (uint64_t)__builtin_popcountll(bitmap_pool[block_data_offset[b] + k]);
+            }
+        }
+    *out = (storm_hip_sparse_t*)calloc(1, sizeof(**out));
+    if (!*out) return STORM_HIP_ENOMEM;
+    (*out)->set_bits = bits;
+    return STORM_HIP_OK;
+}
+void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) { (void)ctx; free(s); }
+int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s, uint32_t shard_rank,
+                           uint32_t shard_count, uint64_t* h_total) {
+    (void)ctx;
+    if (shard_rank >= shard_count) return STORM_HIP_EINVAL;
+    *h_total = shard_rank == 0 ? s->set_bits : 0;
+    return STORM_HIP_OK;
+}

@@ -1,0 +1,118 @@
+/* driver.c — TEST ONLY: runs the storm.h host side (containers, growth, marshalling, one-pair
+ * helpers) under ASan/UBSan against device_stub.c. The stub's "total" is the number of set bits
+ * that reached the device, so every all-pairs call doubles as an integrity check of what the
+ * containers stored: it must equal the distinct positions fed in. Exit code 0 = all good. */
+#include <inttypes.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "storm.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ULL;
+static uint64_t rnd(void) {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static int cmp_u32(const void* a, const void* b) {
+    const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return (x > y) - (x < y);
+}
+#define CHECK(cond)                                                             \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            fprintf(stderr, "%s:%d: check failed: %s\n", __FILE__, __LINE__, #cond); \
+            return 1;                                                           \
+        }                                                                       \
+    } while (0)
+
+/* one scenario: n_rows rows over [0, width), `draws` draws each (duplicates kept, sorted) */
+static int scenario(uint32_t n_rows, uint32_t width, uint32_t draws, int with_empty_rows) {
+    STORM_contiguous_t* dense = STORM_contig_new(width);
+    STORM_t* sparse = STORM_new();
+    CHECK(dense && sparse);
+    uint32_t* row = (uint32_t*)malloc((draws + 1) * sizeof(uint32_t));
+    const size_t words = (width + 63) / 64;
+    uint64_t* bits = (uint64_t*)calloc(words, sizeof(uint64_t));
+    uint64_t distinct_dense = 0, distinct_sparse = 0;
+    for (uint32_t i = 0; i < n_rows; ++i) {
+        const uint32_t n = (with_empty_rows && i % 7 == 3) ? 0 : draws;
+        memset(bits, 0, words * sizeof(uint64_t));
+        uint64_t distinct = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            row[j] = (uint32_t)(rnd() % width);
+            const uint64_t bit = 1ULL << (row[j] % 64);
+            if (!(bits[row[j] / 64] & bit)) ++distinct;
+            bits[row[j] / 64] |= bit;
+        }
+        qsort(row, n, sizeof(uint32_t), cmp_u32);
+        const int rc_d = STORM_contig_add(dense, row, n);
+        const int rc_s = STORM_add(sparse, row, n);
+        CHECK(rc_d == (int)n);              /* storm.c:1136 returns n_values, 0 for empty */
+        CHECK(rc_s == 1);                   /* storm.c:866 */
+        if (n) distinct_dense += distinct;  /* an empty row is not appended to the dense container */
+        distinct_sparse += distinct;
+        if (i % 97 == 0) { /* all-pairs in the middle of construction: mirror rebuilt afterwards */
+            CHECK(STORM_contig_pairw_intersect_cardinality(dense) == (dense->n_data < 2 ? 0 : distinct_dense));
+        }
+    }
+    /* the stub returns the set bits that reached the device */
+    if (dense->n_data >= 2) {
+        CHECK(STORM_contig_pairw_intersect_cardinality(dense) == distinct_dense);
+        CHECK(STORM_contig_pairw_intersect_cardinality_blocked(dense, 17) == distinct_dense);
+        CHECK(STORM_contig_pairw_intersect_cardinality_list(dense) == distinct_dense);
+        CHECK(STORM_contig_pairw_intersect_cardinality_blocked_list(dense, 3) == distinct_dense);
+        CHECK(STORM_wrapper_diag(dense->n_data, dense->data, dense->n_bitmaps_vector, NULL) == distinct_dense);
+        uint32_t* out = (uint32_t*)malloc((size_t)dense->n_data * dense->n_data * sizeof(uint32_t));
+        CHECK(out && STORM_contig_pairw_matrix(dense, 0, out) == 0);
+        free(out);
+    }
+    if (sparse->n_conts >= 2) {
+        CHECK(STORM_pairw_intersect_cardinality(sparse) == distinct_sparse);
+        CHECK(STORM_pairw_intersect_cardinality_blocked(sparse, 0) == distinct_sparse);
+    }
+    CHECK(STORM_serialized_size(sparse) >= 8);
+    /* one-pair helpers on the first two rows of the sparse container vs a naive count */
+    if (sparse->n_conts >= 2) {
+        const uint64_t got = STORM_bitmap_cont_intersect_cardinality(&sparse->conts[0], &sparse->conts[1]);
+        uint64_t want = 0;
+        for (size_t k = 0; k < dense->n_bitmaps_vector && dense->n_data >= 2 && !with_empty_rows; ++k)
+            want += (uint64_t)__builtin_popcountll(dense->data[k] & dense->data[dense->n_bitmaps_vector + k]);
+        if (!with_empty_rows && dense->n_data >= 2) CHECK(got == want);
+    }
+    /* clear keeps the handles usable */
+    CHECK(STORM_contig_clear(dense) == 1 && dense->n_data == 0);
+    CHECK(STORM_clear(sparse) == 1);
+    row[0] = 1 % width;
+    CHECK(STORM_contig_add(dense, row, 1) == 1 && STORM_add(sparse, row, 1) == 1);
+    CHECK(STORM_contig_pairw_intersect_cardinality(dense) == 0); /* one row: no pairs */
+    free(bits);
+    free(row);
+    STORM_free(sparse);
+    STORM_contig_free(dense);
+    return 0;
+}
+
+int main(void) {
+    /* error conventions (storm.c:878, :1032-1034, :1150) */
+    CHECK(STORM_contig_pairw_intersect_cardinality(NULL) == (uint64_t)-1);
+    CHECK(STORM_pairw_intersect_cardinality(NULL) == (uint64_t)-1);
+    CHECK(STORM_contig_add(NULL, NULL, 0) == -1);
+    {
+        STORM_contiguous_t* d = STORM_contig_new(100);
+        CHECK(STORM_contig_add(d, NULL, 3) == -2);
+        STORM_contig_free(d);
+    }
+    /* growth paths: > 512 rows (row regrow), > 16384 stored positions (list regrow), sparse rows
+     * below the list cutoff, dense blocks >= 4096 values, multi-block rows, width not % 64 */
+    if (scenario(1300, 4096, 40, 0)) return 1;      /* list path + both regrows            */
+    if (scenario(700, 65536, 13, 1)) return 1;      /* empty rows, tiny lists              */
+    if (scenario(40, 200000, 30000, 0)) return 1;   /* bitmap-kind blocks, 4 blocks / row  */
+    if (scenario(300, 131071, 4200, 0)) return 1;   /* per-block counts around 4096/2      */
+    if (scenario(3, 70, 5, 0)) return 1;
+    if (scenario(600, 1000, 128, 0)) return 1;      /* the README's shape (duplicates)     */
+    puts("host sanitize: ok");
+    return 0;
+}
