@@ -127,6 +127,14 @@ int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t
                                   uint32_t* d_out, uint64_t ld);
 int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                            uint32_t* h_out);
+/* A band of that triangle, for matrices whose n_rows^2 output does not fit at once: rows
+ * [row0, row0 + n_band_rows) only, written from output row 0:
+ *   d_out[(i - row0) * ld + j] = popcount(row_i OP row_j), row0 <= i < row0 + n_band_rows, i < j.
+ * `d_out` is a DEVICE pointer to n_band_rows x ld uint32, ld >= n_rows. Bands of a few thousand
+ * rows keep the matrix cores as busy as the whole triangle does. */
+int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                       uint64_t row0, uint64_t n_band_rows, uint32_t* d_out,
+                                       uint64_t ld);
 /* Materialised rectangle A x B (the two-matrix product XY^T):
  *   out[i * ld + j] = popcount(a_i OP b_j) for every row i of `a` and j of `b` (same row width).
  * _device: `d_out` is a DEVICE pointer, a->n_rows x ld uint32 with ld >= b->n_rows; synchronous.

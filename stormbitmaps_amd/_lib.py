@@ -49,6 +49,7 @@ SIGNATURES = {
     "storm_hip_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
     "storm_hip_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp]),
     "storm_hip_row_counts": (C.c_int, [vp, vp, vp]),
+    "storm_hip_pairw_matrix_band_device": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),

@@ -337,6 +337,13 @@ class HipMatrix:
               "storm_hip_square_matrix")
         return out
 
+    def pairw_matrix_band_device(self, d_out: int, ld: int, row0: int, n_band_rows: int,
+                                 op: str = "and") -> None:
+        """Rows [row0, row0 + n_band_rows) of the triangle into a device buffer (n_band_rows x ld)."""
+        check(self._lib.storm_hip_pairw_matrix_band_device(self.ctx._h, self._h, self.OPS[op], row0,
+                                                           n_band_rows, C.c_void_p(d_out), ld),
+              "storm_hip_pairw_matrix_band_device")
+
     def row_counts(self) -> np.ndarray:
         out = np.zeros(self.n_rows, dtype=np.uint32)
         check(self._lib.storm_hip_row_counts(self.ctx._h, self._h, _ptr(out)),

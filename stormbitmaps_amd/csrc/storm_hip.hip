@@ -1245,6 +1245,19 @@ int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t
     return launch_pairw_matrix(ctx, m, op, d_out, ld);
 }
 
+int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                       uint64_t row0, uint64_t n_band_rows, uint32_t* d_out,
+                                       uint64_t ld) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !d_out || ld < m->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR ||
+        row0 > m->n_rows || n_band_rows > m->n_rows - row0) {
+        set_error("pairw_matrix_band: NULL argument, unknown op, band outside the matrix or ld < rows");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_pairw_matrix(ctx, m, op, d_out, ld, row0, n_band_rows);
+}
+
 int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                            uint32_t* h_out) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;

@@ -124,7 +124,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
                              uint64_t shadow_generation = 0);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
-                        uint64_t ld);
+                        uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull);
 int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                        const storm_hip_matrix_s* b, uint64_t* d_total);
 int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,

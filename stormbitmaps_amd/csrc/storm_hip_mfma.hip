@@ -116,7 +116,10 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     unsigned long long* __restrict__ slots, uint32_t* __restrict__ out = nullptr, uint64_t ld = 0,
     uint32_t n_rows = 0, const uint32_t* __restrict__ row_counts = nullptr, uint32_t and_weight = 0,
-    uint32_t j_base = 0, uint32_t j_count = 0, uint32_t split_from = 0xffffffffu) {
+    uint32_t j_base = 0, uint32_t j_count = 0, uint32_t split_from = 0xffffffffu,
+    uint32_t i_lo = 0, uint32_t n_cols = 0) {
+    // rows i_lo <= i < n_rows are written, at output row i - i_lo (a band of the matrix); in
+    // triangle mode the columns run to n_cols (the matrix's row count)
     // Items from index split_from on cover only a part of k of their tile (several per tile, to
     // fill the last round of workgroups): they ADD into `out`, which zero_tiles_kernel cleared.
     // kWrite window: rows i < n_rows of the shadow against shadow rows j_base + [0, j_count);
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
             for (int n = 0; n < 2; ++n) {
                 const uint32_t j = b_row0 + wn * 64u + n * 32u + (lane & 31u);
                 const bool rect = j_count != 0;
-                const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_rows;
+                const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
                 // union / symmetric difference: n_i + n_j - and_weight * |i & j|
                 // (row_counts is indexed by shadow row)
                 const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
@@ -236,9 +239,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const uint32_t i = a_row0 + wm * 128u + m * 32u + (r & 3) + 8 * (r >> 2) +
                                        4 * (lane >> 5);
-                    if (j_ok && (rect ? i < n_rows : i < j)) {
+                    if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
                         const uint32_t c = (uint32_t)acc[m][n][r];
-                        uint32_t* dst = &out[(uint64_t)i * ld + (j - j_base)];
+                        uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
                         if (blockIdx.x < split_from) {
                             *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
                         } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
@@ -1146,14 +1149,15 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
                                                          uint32_t first, uint32_t parts,
                                                          uint32_t* __restrict__ out, uint64_t ld,
                                                          uint32_t n_rows, uint32_t j_base,
-                                                         uint32_t j_count) {
+                                                         uint32_t j_count, uint32_t i_lo,
+                                                         uint32_t n_cols) {
     const MfmaItem it = items[first + blockIdx.x * parts];
     const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
     const bool rect = j_count != 0;
-    if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_rows)) return;
+    if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_cols)) return;
     for (uint32_t r = 0; r < (uint32_t)kTile; ++r) {
         const uint32_t i = (uint32_t)it.I * kTile + r;
-        if (rect ? i < n_rows : i < j) out[(uint64_t)i * ld + (j - j_base)] = 0;
+        if (i >= i_lo && i < n_rows && (rect || i < j)) out[(uint64_t)(i - i_lo) * ld + (j - j_base)] = 0;
     }
 }
 
@@ -1165,7 +1169,8 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
 static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
                             uint32_t total_stages, uint64_t pitch, uint32_t* d_out, uint64_t ld,
                             uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight,
-                            uint32_t j_base, uint32_t j_count) {
+                            uint32_t j_base, uint32_t j_count, uint32_t i_lo = 0, uint32_t n_cols = 0) {
+    if (n_cols == 0) n_cols = n_rows;
     memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const size_t slots = (size_t)std::max(1, ctx->n_cus);
     const size_t leftover = tiles.size() % slots;
@@ -1190,11 +1195,11 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<ui
     } else {
         if (parts > 1)
             hipLaunchKernelGGL(zero_tiles_kernel, dim3((uint32_t)leftover), dim3(256), 0, ctx->stream,
-                               d_items, (uint32_t)n_full, parts, d_out, ld, n_rows, j_base, j_count);
+                               d_items, (uint32_t)n_full, parts, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
         hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
                            dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
                            ctx->d_slots, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           parts > 1 ? (uint32_t)n_full : 0xffffffffu);
+                           parts > 1 ? (uint32_t)n_full : 0xffffffffu, i_lo, n_cols);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = STORM_HIP_EHIP;
     }
@@ -1206,7 +1211,10 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<ui
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
-                        uint64_t ld) {
+                        uint64_t ld, uint64_t band_row0, uint64_t band_rows) {
+    // band: only rows [band_row0, band_row0 + band_rows) of the triangle, written from output row 0
+    const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
+    if (band_row0 >= band_end) return STORM_HIP_OK;
     if ((uint64_t)m->n_words * 64u >= (1ull << 24)) {
         set_error("pairw_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
                   (unsigned long long)m->n_words * 64u);
@@ -1237,9 +1245,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // off-diagonal tiles first; the diagonal ones (half of their window is written) go last,
     // where run_matrix_tiles may cut them along k
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
-    for (uint32_t i = 0; i < nT; ++i)
+    const uint32_t t_lo = (uint32_t)(band_row0 / kTile), t_hi = (uint32_t)((band_end + kTile - 1) / kTile);
+    for (uint32_t i = t_lo; i < t_hi; ++i)
         for (uint32_t j = i + 1; j < nT; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
-    for (uint32_t i = 0; i < nT; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
+    for (uint32_t i = t_lo; i < t_hi; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
     uint32_t* d_counts = nullptr;
     int rc = STORM_HIP_OK;
     if (op != STORM_HIP_OP_AND) {
@@ -1254,8 +1263,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
-        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)m->n_rows, d_counts,
-                              op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u);
+        // rows [band_row0, band_end) are written; the columns run over the whole matrix
+        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)band_end, d_counts,
+                              op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u, (uint32_t)band_row0,
+                              (uint32_t)m->n_rows);
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
     (void)hipFree(d_counts);
