@@ -105,6 +105,8 @@ struct storm_hip_ctx_s {
     int time_kernels = 0;
     std::vector<hipEvent_t> kernel_events;  // begin/end alternating
     size_t kernel_events_used = 0;
+    uint32_t* d_counts = nullptr;  // row-count scratch of the matrix-output paths
+    size_t counts_capacity = 0;
     unsigned long long* d_trace = nullptr;  // k2_ring = 18: per-item schedule trace of the strip kernel
     size_t trace_capacity = 0;
     uint32_t trace_items = 0;

@@ -652,6 +652,9 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_items) (void)hipFree(ctx->d_items);
     if (ctx->d_strip_items) (void)hipFree(ctx->d_strip_items);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    ctx->d_counts = nullptr;
+    ctx->counts_capacity = 0;
     ctx->d_trace = nullptr;
     ctx->trace_capacity = 0;
     ctx->d_strip_items = nullptr;
@@ -1143,6 +1146,22 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     return launch_fold_slots(ctx, d_total);
 }
 
+// Per-row set-bit counts for the OR / XOR epilogues: a scratch buffer kept in the context.
+static int ensure_counts_scratch(storm_hip_ctx_t* ctx, size_t n, uint32_t** out) {
+    if (n * sizeof(uint32_t) > ctx->counts_capacity) {
+        if (ctx->d_counts) STORM_HIP_TRY(hipFree(ctx->d_counts));
+        ctx->d_counts = nullptr;
+        ctx->counts_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_counts), n * sizeof(uint32_t)) != hipSuccess) {
+            set_error("matrix output: hipMalloc of the row-count scratch failed");
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->counts_capacity = n * sizeof(uint32_t);
+    }
+    *out = ctx->d_counts;
+    return STORM_HIP_OK;
+}
+
 // Clears the output window of the tiles whose k range is split over several items (same write
 // predicate as pairw_fp4_kernel<., true>). One workgroup per tile, thread = column.
 __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restrict__ items,
@@ -1166,12 +1185,14 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
 // whole one (820 tiles on 256 CUs at the headline shape: 3.2 -> 4). The tiles of the last round
 // are therefore cut along k into as many parts as fill the CUs; the parts add into a cleared
 // window.
-static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
-                            uint32_t total_stages, uint64_t pitch, uint32_t* d_out, uint64_t ld,
-                            uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight,
-                            uint32_t j_base, uint32_t j_count, uint32_t i_lo = 0, uint32_t n_cols = 0) {
-    if (n_cols == 0) n_cols = n_rows;
-    memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
+struct MatrixPlan {  // item table of one matrix-output launch, already in ctx->d_items
+    uint32_t n_items = 0, n_full = 0, parts = 1, leftover = 0;
+};
+
+// Builds and uploads the item table (before the caller launches the expansion, so that the one
+// host wait for the pageable upload does not sit between the kernels).
+static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
+                             uint32_t total_stages, MatrixPlan* plan) {
     const size_t slots = (size_t)std::max(1, ctx->n_cus);
     const size_t leftover = tiles.size() % slots;
     uint32_t parts = 1;
@@ -1186,25 +1207,50 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<ui
             const uint32_t s1 = (uint32_t)((uint64_t)total_stages * (p + 1) / parts);
             items.push_back({tiles[t].first, tiles[t].second, s0, s1 - s0});
         }
-    MfmaItem* d_items = nullptr;
-    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_items), items.size() * sizeof(MfmaItem)));
-    int rc = STORM_HIP_OK;
-    if (hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(MfmaItem), hipMemcpyHostToDevice,
-                       ctx->stream) != hipSuccess) {
-        rc = STORM_HIP_EHIP;
-    } else {
-        if (parts > 1)
-            hipLaunchKernelGGL(zero_tiles_kernel, dim3((uint32_t)leftover), dim3(256), 0, ctx->stream,
-                               d_items, (uint32_t)n_full, parts, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
-        hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3((uint32_t)items.size()),
-                           dim3(kMfmaThreads), 0, ctx->stream, ctx->d_x4, pitch, d_items,
-                           ctx->d_slots, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           parts > 1 ? (uint32_t)n_full : 0xffffffffu, i_lo, n_cols);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = STORM_HIP_EHIP;
+    // the context's item buffer (shared with the tile kernel's sum mode, whose cached table is
+    // dropped here); hipMalloc / hipFree per call would cost more than the kernel's tail
+    if (items.size() > ctx->items_capacity) {
+        if (ctx->d_items) STORM_HIP_TRY(hipFree(ctx->d_items));
+        ctx->d_items = nullptr;
+        ctx->items_capacity = 0;
+        const size_t cap = std::max<size_t>(items.size(), 4096);
+        STORM_HIP_TRY(hipMalloc(&ctx->d_items, cap * sizeof(MfmaItem)));
+        ctx->items_capacity = cap;
     }
-    (void)hipFree(d_items);
-    return rc;
+    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    ctx->n_items = 0;
+    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, items.data(), items.size() * sizeof(MfmaItem),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` is pageable and leaves scope
+    plan->n_items = (uint32_t)items.size();
+    plan->n_full = (uint32_t)n_full;
+    plan->parts = parts;
+    plan->leftover = parts > 1 ? (uint32_t)leftover : 0;
+    return STORM_HIP_OK;
+}
+
+// Runs the tile kernel in write mode over the planned items (shadow already expanded). The kernel
+// holds one workgroup per CU, so n tiles take ceil(n / CUs) rounds and a nearly empty last round
+// costs a whole one (820 tiles on 256 CUs at the headline shape: 3.2 -> 4). The tiles of the last
+// round are therefore cut along k into as many parts as fill the CUs; the parts add into a
+// cleared window.
+static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64_t pitch,
+                            uint32_t* d_out, uint64_t ld, uint32_t n_rows, const uint32_t* d_counts,
+                            uint32_t and_weight, uint32_t j_base, uint32_t j_count, uint32_t i_lo = 0,
+                            uint32_t n_cols = 0) {
+    if (n_cols == 0) n_cols = n_rows;
+    memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
+    const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
+    if (plan.parts > 1)
+        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.leftover), dim3(256), 0, ctx->stream, d_items,
+                           plan.n_full, plan.parts, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
+    hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3(plan.n_items), dim3(kMfmaThreads), 0,
+                       ctx->stream, ctx->d_x4, pitch, d_items, ctx->d_slots, d_out, ld, n_rows,
+                       d_counts, and_weight, j_base, j_count,
+                       plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return STORM_HIP_EHIP;
+    return STORM_HIP_OK;
 }
 
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
@@ -1250,12 +1296,11 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         for (uint32_t j = i + 1; j < nT; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
     for (uint32_t i = t_lo; i < t_hi; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
     uint32_t* d_counts = nullptr;
-    int rc = STORM_HIP_OK;
-    if (op != STORM_HIP_OP_AND) {
-        if (hipMalloc(reinterpret_cast<void**>(&d_counts), m->n_rows * sizeof(uint32_t)) != hipSuccess)
-            rc = STORM_HIP_ENOMEM;
-        else
-            rc = launch_row_counts(ctx, m, d_counts);
+    MatrixPlan plan;
+    int rc = plan_matrix_tiles(ctx, tiles, total_stages, &plan);
+    if (rc == STORM_HIP_OK && op != STORM_HIP_OP_AND) {
+        rc = ensure_counts_scratch(ctx, m->n_rows, &d_counts);
+        if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, m, d_counts);
     }
     if (rc == STORM_HIP_OK) {
         const uint64_t work = n_rows4 * m->stride_words * 2;
@@ -1264,12 +1309,11 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
         // rows [band_row0, band_end) are written; the columns run over the whole matrix
-        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)band_end, d_counts,
+        rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)band_end, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u, (uint32_t)band_row0,
                               (uint32_t)m->n_rows);
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
-    (void)hipFree(d_counts);
     return rc;
 }
 
@@ -1310,15 +1354,12 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     for (uint32_t i = 0; i < ta; ++i)
         for (uint32_t j = 0; j < tb; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)(ta + j));
     uint32_t* d_counts = nullptr;  // per shadow row
-    int rc = STORM_HIP_OK;
-    if (op != STORM_HIP_OP_AND) {
-        if (hipMalloc(reinterpret_cast<void**>(&d_counts), (rows_a + rows_b) * sizeof(uint32_t)) !=
-            hipSuccess) {
-            rc = STORM_HIP_ENOMEM;
-        } else {
-            rc = launch_row_counts(ctx, a, d_counts);
-            if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
-        }
+    MatrixPlan plan;
+    int rc = plan_matrix_tiles(ctx, tiles, total_stages, &plan);
+    if (rc == STORM_HIP_OK && op != STORM_HIP_OP_AND) {
+        rc = ensure_counts_scratch(ctx, rows_a + rows_b, &d_counts);
+        if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, a, d_counts);
+        if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
     }
     if (rc == STORM_HIP_OK) {
         for (int side = 0; side < 2; ++side) {
@@ -1331,11 +1372,10 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                                reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)), 0u,
                                1u, 2u, pitch / 16);
         }
-        rc = run_matrix_tiles(ctx, tiles, total_stages, pitch, d_out, ld, (uint32_t)a->n_rows, d_counts,
+        rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)a->n_rows, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
     }
     if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
-    (void)hipFree(d_counts);
     return rc;
 }
 
