@@ -634,6 +634,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_lds_pad = (int)value;
     } else if (!strcmp(key, "k2_persistent")) {
         ctx->k2_persistent = value != 0;
+    } else if (!strcmp(key, "k2_lpt_rounds")) {
+        if (value < 0 || value > 63) {
+            set_error("k2_lpt_rounds must be 0..63");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_lpt_rounds = (int)value;
     } else if (!strcmp(key, "k2_tail_slices")) {
         if (value < 0 || value > 255) {
             set_error("k2_tail_slices must be 0..255");

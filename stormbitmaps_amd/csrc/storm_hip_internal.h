@@ -98,6 +98,7 @@ struct storm_hip_ctx_s {
     int k2_matrix_split = 1; // matrix output: cut the last round's tiles along k to fill the CUs
     int k2_pitch_pad = -1;  // K2/K2s: extra bytes per row of the FP4 shadow (multiple of 128; -1 = auto)
     int k2_lds_pad = 0;     // K2s: bytes of unused dynamic LDS per workgroup (caps workgroups per CU)
+    int k2_lpt_rounds = 6;  // K2s: XCD lists of at most this many rounds of 128 items are sorted longest-first
     int k2_tail_slices = 3; // K2s: last slices of every XCD's list are cut into short runs ...
     int k2_tail_run = 32;   //      ... of at most this many stages, merged longest-first
     // "time_kernels" option: HIP event pairs around the dominant kernel of every pairwise launch

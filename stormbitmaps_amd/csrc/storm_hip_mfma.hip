@@ -761,6 +761,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
                              ((uint64_t)shard_rank << 32) | shard_count,
                              ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
                                  ((uint64_t)(ctx->k2_persistent != 0) << 47) |
+                                 ((uint64_t)(ctx->k2_lpt_rounds & 0x3f) << 41) |
                                  ((uint64_t)(ctx->k2_tail_slices & 0xff) << 32) |
                                  ((uint64_t)(ctx->k2_tail_run & 0xffff) << 16) |
                                  (uint64_t)(ctx->k2_max_run & 0xffff)};
@@ -827,6 +828,15 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
             return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
         });
         per_xcd[x].insert(per_xcd[x].end(), tail.begin(), tail.end());
+        // A short list (a few rounds of the XCD's ~128 slots: small N, or a 1/8 shard) is all
+        // tail: order the whole of it longest-first. The L2 locality that slice-major order buys
+        // is worth 1-2 %, the tail of a 2-round launch a third of its time (N = 2048: the
+        // schedule trace showed the launch draining for 24 of its 66 us).
+        if (per_xcd[x].size() <= (size_t)128 * (size_t)std::max(0, ctx->k2_lpt_rounds))
+            std::stable_sort(per_xcd[x].begin(), per_xcd[x].end(),
+                             [&](const StripItem& p, const StripItem& q) {
+                                 return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
+                             });
     }
     std::vector<StripItem> items;
     if (ctx->k2_persistent) {  // one contiguous queue per XCD
