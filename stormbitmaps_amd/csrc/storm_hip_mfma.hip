@@ -10,18 +10,23 @@
 //
 // Pipeline per all-pairs call
 //   1. expand_fp4_kernel: bit-packed rows -> nibble rows (4 bits per bit), once per call:
-//      an O(N*M) pass, ~2 % of the O(N^2*M) product at the headline shape.
-//   2. pairw_fp4_kernel: work item = (256x256 row-block tile with I <= J, k-slice).
+//      an O(N*M) pass, HBM-bound, 8-9 % of a pass at the headline shape ("keep_shadow" keeps
+//      the result while the matrix is unchanged).
+//   2. strip_fp4_kernel (K2s, the default): A-stationary strips, see below.
+//      pairw_fp4_kernel (K2 tiles: variant 3 and every materialised-output entry point):
+//      work item = (256x256 row-block tile with I <= J, k-slice).
 //      512 threads = 8 waves as 2 (M) x 4 (N); each wave owns 128x64 of the tile = 4x2
 //      MFMA blocks (128 accumulator registers). Per stage (128 bits of k = 64 B per row) the
-//      A and B row blocks go global -> LDS by global_load_lds (16 B/lane, double-buffered,
-//      one barrier per stage), XOR-swizzled through the SOURCE address so that the
+//      A and B row blocks go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, ring of 4
+//      stages, one barrier per stage), XOR-swizzled through the SOURCE address so that the
 //      ds_read_b128 operand fetches are bank-conflict free; 2 k-steps x 8 MFMAs per stage.
-//      Off-diagonal tiles add every entry; diagonal tiles add (all - trace) / 2, which is the
-//      strict upper triangle because the tile is symmetric — no global correction term, so
-//      any subset of items (a multi-GPU shard) yields an exact partial.
-//   3. items are ordered k-slice-major and dealt to the 8 XCDs in groups of 32 neighbouring
-//      tiles (4 x 8 row blocks), so the 32 CUs of one XCD share 12 row-block slices in L2.
+//      Sum mode: off-diagonal tiles add every entry; diagonal tiles add (all - trace) / 2,
+//      the strict upper triangle because the tile is symmetric — no global correction term,
+//      so any subset of items (a multi-GPU shard) yields an exact partial. Write mode: the
+//      accumulators go to the output matrix (AND / OR / XOR counts, triangle, band, rectangle).
+//   3. tile items are ordered k-slice-major and dealt to the 8 XCDs in groups of 32
+//      neighbouring tiles (4 x 8 row blocks), so the 32 CUs of one XCD share 12 row-block
+//      slices in L2.
 #include "storm_hip_internal.h"
 
 #include <algorithm>
@@ -306,23 +311,26 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
 // K2s "strip" kernel: the off-diagonal part of the triangle, A-stationary.
 //
 // Ablating the tile kernel above (k2_debug probes, profiles/r01_d_*) showed that its limit is
-// operand delivery, not the matrix cores: an LDS-DMA instruction occupies its wave for ~100
-// cycles, the two waves of a SIMD run in lockstep, and 32 KiB of DMA + 96 KiB of ds_read per
-// stage left the MFMA pipe 55 % busy. Only the grand total is wanted, so the accumulators never
-// have to be flushed per B block — which allows K1's dataflow on the matrix cores:
-//   work item = (A row block I of 256 rows, k-slice of 256 bits, run of later 64-row B blocks).
+// operand delivery, not the matrix cores (its two waves per SIMD run in lockstep behind one
+// barrier, and 32 KiB of DMA + 96 KiB of ds_read per stage left the MFMA pipe 55 % busy). Only
+// the grand total is wanted, so the accumulators never have to be flushed per B block — which
+// allows K1's dataflow on the matrix cores:
+//   work item = (A row block I of 256 rows, k-slice of 256 bits, the A tile's own 4 blocks
+//               and/or a run of later 64-row B blocks).
 //   A operand : this wave's 64 rows x 256 bits live in 32 VGPRs for the whole item
 //               (8 fragment loads straight from global memory, once per item).
 //   B operand : one stage = 64 B rows x the k-slice = 64 rows x 128 B, FULL 128-byte lines,
-//               2 LDS-DMA instructions per wave; ring of 4 stages (3 in flight) = 32 KiB.
+//               2 LDS-DMA instructions per wave (buffer_load_dwordx4 ... lds); ring of 4
+//               stages (3 in flight) = 32 KiB.
 //   per stage : 4 k-steps x (2 ds_read_b128 + 4 MFMA) per wave into 4 accumulator blocks that
 //               are never flushed (f32 exact: <= 256 bits x 4096 stages < 2^24).
-//   occupancy : 4 waves (one per SIMD, 64 A rows each), <= 168 VGPRs -> THREE workgroups per
-//               CU, i.e. 3 waves per SIMD from three independent barrier domains: while one
-//               wave issues DMA or sits at its barrier, the others feed the matrix pipe.
+//   occupancy : 4 waves (one per SIMD, 64 A rows each), 126 VGPRs -> FOUR workgroups per CU,
+//               i.e. 4 waves per SIMD from four independent barrier domains: while one wave
+//               sits at its barrier or in an item's prologue, the others feed the matrix pipe.
 // Per MFMA this moves half the DMA bytes of the tile kernel. Items of one k-slice are dealt to
-// one XCD, whose L2 then holds that slice of all rows (N x 128 B = 1.3 MB at N = 10000), so HBM
-// sees each byte about once.
+// one XCD (longest first within the slice), whose L2 then holds that slice of all rows
+// (N x 128 B = 1.3 MB at N = 10000); the shadow's row pitch is padded off powers of two, so the
+// strips miss L2 for only ~2.6x the shadow's size per launch.
 // ------------------------------------------------------------------------------------------
 constexpr int kStripRowBytes = 128;                      // 256 bits of k as nibbles
 constexpr int kStripBRows = 64;                          // B rows per stage
