@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--draws", type=int, default=0, help="0 = bits/2 (dense)")
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed passes for this long before the warmup steps (clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shadow-resident", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="ctx option key=value (tuning)")
@@ -139,6 +141,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The chip needs ~30 passes (~30 ms) from idle to settle (tools/bench_ramp.py: passes 3..25
+    # run 1.17 -> 0.92 ms, steady 0.88): an untimed pre-warm in front of the W warmup steps makes
+    # the figure independent of how small W is. Same work as a step, results discarded.
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     fence()
