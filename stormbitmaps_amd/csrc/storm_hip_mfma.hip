@@ -75,21 +75,30 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
     // out_pitch_u4: row pitch of the shadow in 16-byte units (0 = dense, stride_words * 2)
     if (out_pitch_u4 == 0) out_pitch_u4 = stride_words * 2;
     const uint64_t halves_per_row = stride_words * 2;
-    const uint64_t total = n_rows_dst * halves_per_row;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total;
-         t += (uint64_t)gridDim.x * 256) {
-        const uint64_t row = t / halves_per_row;
-        const uint32_t group = (uint32_t)((t - row * halves_per_row) >> 7);  // 128 halves = 64 words
-        if (shard_count > 1 && group % shard_count != shard_rank) continue;
-        uint32_t w = 0;
-        if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[t];
-        uint4 o;
-        o.x = spread8_fp4(w & 0xFFu, nib & 7u);
-        o.y = spread8_fp4((w >> 8) & 0xFFu, nib & 7u);
-        o.z = spread8_fp4((w >> 16) & 0xFFu, nib & 7u);
-        o.w = spread8_fp4(w >> 24, nib & 7u);
-        X4[row * out_pitch_u4 + (t - row * halves_per_row)] = o;  // (non-temporal stores: slower)
-    }
+    // grid = (column chunks of 256 halves, rows): no division per element (a 64-bit divide per
+    // 16 output bytes made the first version VALU-bound just below the HBM rate)
+    for (uint64_t row = blockIdx.y; row < n_rows_dst; row += gridDim.y)
+        for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < halves_per_row;
+             h += (uint64_t)gridDim.x * 256) {
+            const uint32_t group = (uint32_t)(h >> 7);  // 128 halves = 64 words
+            if (shard_count > 1 && group % shard_count != shard_rank) continue;
+            uint32_t w = 0;
+            if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[row * halves_per_row + h];
+            uint4 o;
+            o.x = spread8_fp4(w & 0xFFu, nib & 7u);
+            o.y = spread8_fp4((w >> 8) & 0xFFu, nib & 7u);
+            o.z = spread8_fp4((w >> 16) & 0xFFu, nib & 7u);
+            o.w = spread8_fp4(w >> 24, nib & 7u);
+            X4[row * out_pitch_u4 + h] = o;  // (non-temporal stores: slower)
+        }
+}
+
+// Launch geometry of expand_fp4_kernel for n_rows_dst rows of stride_words words.
+static inline dim3 expand_grid(uint64_t n_rows_dst, uint64_t stride_words) {
+    const uint64_t chunks = (stride_words * 2 + 255) / 256;
+    const uint64_t cx = std::min<uint64_t>(chunks, 1024);
+    // ~8192 workgroups in all, each walking down the rows of its column chunk
+    return dim3((uint32_t)cx, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_rows_dst, 8192 / cx)));
 }
 
 // LDS image of one operand stage: 256 rows x 64 B, the 16-byte slot s of row r stored at
@@ -955,10 +964,9 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                               !memcmp(key, ctx->x4_key, sizeof(key)) &&
                               (ctx->k2_debug >> 8) == 0;
     if (ctx->n_items > 0 || n_strip > 0) {
-        const uint64_t work = n_rows_dst * stride_words * 2;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
+        const dim3 grid = expand_grid(n_rows_dst, stride_words);
         if (!shadow_valid)
-        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, stride_words,
+        hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, X, stride_words,
                            std::min(n_rows_src, n_rows_dst), n_rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count,
                            (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u, pitch / 16);
@@ -1148,9 +1156,8 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     for (int side = 0; side < 2; ++side) {
         const storm_hip_matrix_s* m = side ? b : a;
         const uint64_t rows_dst = side ? rows_b : rows_a;
-        const uint64_t work = rows_dst * stride_words * 2;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
-        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+        const dim3 grid = expand_grid(rows_dst, stride_words);
+        hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                            stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)),
                            0u, 1u, 2u, pitch / 16);
@@ -1321,9 +1328,8 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, m, d_counts);
     }
     if (rc == STORM_HIP_OK) {
-        const uint64_t work = n_rows4 * m->stride_words * 2;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
-        hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+        const dim3 grid = expand_grid(n_rows4, m->stride_words);
+        hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
                            reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
         // rows [band_row0, band_end) are written; the columns run over the whole matrix
@@ -1383,9 +1389,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
         for (int side = 0; side < 2; ++side) {
             const storm_hip_matrix_s* m = side ? b : a;
             const uint64_t rows_dst = side ? rows_b : rows_a;
-            const uint64_t work = rows_dst * stride_words * 2;
-            const uint32_t grid = (uint32_t)std::min<uint64_t>((work + 255) / 256, 256u * 32u);
-            hipLaunchKernelGGL(expand_fp4_kernel, dim3(grid), dim3(256), 0, ctx->stream, m->d,
+            const dim3 grid = expand_grid(rows_dst, stride_words);
+            hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                                stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
                                reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)), 0u,
                                1u, 2u, pitch / 16);
