@@ -41,6 +41,13 @@ def test_hand_computed_matrices(case):
     assert c.pairw_intersect_cardinality_blocked_list(5) == want
     assert s.pairw_intersect_cardinality() == want
     assert s.pairw_intersect_cardinality_blocked(0) == want
+    # per-pair matrices (AND / OR / XOR) against the fixture's set arithmetic
+    n = sum(1 for r in case["rows"] if len(r))       # empty rows are not appended (storm.c:1034)
+    if n == len(case["rows"]) and n >= 1:
+        for name in ("and", "or", "xor"):
+            got = c.pairw_matrix(n, name)
+            for i, j, cnt in case["pair_counts"][name]:
+                assert got[i, j] == cnt and got[j, i] == 0, (name, i, j)
 
 
 @pytest.mark.parametrize("case", _load("survey_totals.json")["agree"],

@@ -75,6 +75,14 @@ def test_oracle_hand_computed(orc, case):
     assert s.pairw_blocked(0) == case["total"]
     nonempty = [r for r in case["rows"] if len(r)]
     assert orc.truth_naive(_dense_from_rows(case["M"], nonempty)) == case["total"]
+    # per-pair AND / OR / XOR counts against plain set arithmetic (all rows, empty ones included)
+    dense = _dense_from_rows(case["M"], case["rows"])
+    n = len(case["rows"])
+    for op, name in enumerate(("and", "or", "xor")):
+        got = orc.tile_counts_op(dense, 0, n, 0, n, op)
+        for i, j, want in case["pair_counts"][name]:
+            assert got[i, j] == want == got[j, i], (name, i, j)
+        assert orc.truth_naive_op(dense, op) == sum(x[2] for x in case["pair_counts"][name])
 
 
 def test_leaves_agree_on_random_words(orc):
