@@ -144,11 +144,21 @@ def main():
     # The chip needs ~30 passes (~30 ms) from idle to settle (tools/bench_ramp.py: passes 3..25
     # run 1.17 -> 0.92 ms, steady 0.88): an untimed pre-warm in front of the W warmup steps makes
     # the figure independent of how small W is. Same work as a step, results discarded.
+    # Every rank must run the SAME number of steps (each step carries a collective): the ranks
+    # agree on "long enough" through a MAX all-reduce of their elapsed time after each batch.
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+    while True:
         for _ in range(10):
             step()
         torch.cuda.synchronize(dev)
+        waited = (time.perf_counter() - t_pre) * 1e3
+        if collective:
+            w = torch.tensor([waited], dtype=torch.float64,
+                             device=dev if args.backend != "gloo" else "cpu")
+            dist.all_reduce(w, op=dist.ReduceOp.MAX)
+            waited = float(w.item())
+        if waited >= args.prewarm_ms:
+            break
     for _ in range(args.warmup):
         step()
     fence()
