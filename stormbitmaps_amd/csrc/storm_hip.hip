@@ -615,6 +615,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "k2_shape")) {
+        if (value != 16 && value != 32) {
+            set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_shape = (int)value;
     } else if (!strcmp(key, "keep_shadow")) {
         ctx->keep_shadow = value != 0;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
@@ -678,6 +684,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
+    if (!strcmp(key, "k2_shape")) return ctx->k2_shape;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     return -1;
 }

@@ -664,6 +664,219 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     }  // items
 }
 
+// ------------------------------------------------------------------------------------------
+// K2s16: the same strips on v_mfma_scale_f32_16x16x128_f8f6f4.
+//
+// Same work items, same B stages and LDS image, same ring protocol as strip_fp4_kernel; only the
+// matrix instruction differs. The chip is power-limited in this loop (tools/ubench_shape,
+// profiles/r02_ubench_shape.txt): with the strip kernel's stage traffic beside the MFMAs the
+// 32x32x64 form holds 2.04 GHz and the 16x16x128 form 2.21 GHz at nearly the same cycles per
+// bit-MAC, 8.0 against 8.26 PFLOP/s in the bare loop (MI355X_MICROARCH.md "DVFS give-back" (7)
+// reports the same for bf16).
+//   wave tile : 64 A rows = 4 blocks of 16, k-slice of 256 bits = 2 k-steps of 128 bits;
+//               A = 8 fragments of 4 VGPRs (as before), accumulators 4 x 4 blocks of 4 VGPRs.
+//   operands  : lane l holds row l & 15 and the 16-byte quarter l >> 4 of a 64-byte k-step
+//               (tools/mfma_fp4_probe checks both lane maps); C/D: col = l & 15,
+//               row = 4 * (l >> 4) + reg.
+//   B reads   : one ds_read_b128 per (k-step, 16-row B block) = 8 per stage, each feeding 4 MFMAs
+//               (64 cycles); issued THREE steps ahead into a rotation of 4 fragment registers,
+//               retired by lgkmcnt(3). The stage image's XOR swizzle (slot ^ (row / 2) % 8) is
+//               conflict free for this fragment shape too: a 16-lane group of ds_read_b128 holds
+//               rows {0-3, 12-15} at quarter q and rows {4-11} at quarter q + 1 (or the mirror
+//               image), which lands on 16 different 16-byte bank groups.
+// ------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int kStripRing>
+__global__ __launch_bounds__(kStripThreads, 4) void strip16_fp4_kernel(
+    const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
+    unsigned long long* __restrict__ slots) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripRing * kStripStageBytes];
+    auto lds = reinterpret_cast<uint8_t(*)[kStripStageBytes]>(lds_raw);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave;
+    const uint32_t item_idx = blockIdx.x;
+    const StripItem it = items[item_idx];
+    const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
+    const uint32_t D = it.diag ? (uint32_t)(kStripATile / kStripBRows) : 0u;
+    const uint32_t T = D + (it.j1 - it.j0);
+
+    // B stage DMA: identical to strip_fp4_kernel (see there)
+    const uint32_t r0 = (wave * 64u + lane) >> 3;
+    const uint32_t goff0 = r0 * (uint32_t)row_bytes + (((lane & 7u) ^ ((r0 >> 1) & 7u)) * 16u);
+    auto issue = [&](uint32_t t) {
+        const uint32_t blk = t < D ? it.a_row0 / (uint32_t)kStripBRows + t : it.j1 - 1u - (t - D);
+        const uint8_t* base = X4 + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
+        uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, (int)goff0, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + 4096u), 16, (int)goff0,
+                                                 (int)(32u * (uint32_t)row_bytes), 0, 0);
+    };
+
+    // A fragments: a[kk][m] = rows wm*64 + m*16 + (lane & 15), bytes kk*64 + (lane >> 4)*16 .. +16
+    v4i a[2][4];
+    {
+        const uint8_t* ap = X4 + (uint64_t)(it.a_row0 + wm * 64u + (lane & 15u)) * row_bytes + kbyte +
+                            (lane >> 4) * 16u;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                a[kk][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 16u * row_bytes + kk * 64);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kStripRing - 1; ++t)
+        if (t < T) issue(t);
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = v4f{};
+
+    // fragment (kk, n) of a stage: row n*16 + (lane & 15), 16-byte slot kk*4 + (lane >> 4), swizzled
+    const uint32_t swz = ((lane & 15u) >> 1) & 7u;
+    const uint32_t lds_base =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    uint32_t boff[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+        boff[kk] = lds_base + (lane & 15u) * kStripRowBytes +
+                   ((((uint32_t)kk * 4u + (lane >> 4)) ^ swz) * 16u);
+
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[kk][m]));  // retire the A loads here
+
+    auto retire = [&](uint32_t t, uint32_t newest_issued) {
+        const uint32_t younger = min(T - 1u, newest_issued) - t;
+        if (younger >= 3u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (younger == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(kStripRing >= 3 && kStripRing <= 5, "vmcnt cases above cover rings of 3..5");
+
+    // step s of a stage = (k-step s >> 2, B block s & 3): 1 fragment read, 4 MFMAs
+#define STORM_FETCH16(dst, stage_base, s)                                                 \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                          \
+                 : "=&v"(dst)                                                             \
+                 : "v"(boff[(s) >> 2] + (stage_base)), "n"(((s) & 3) * 16 * kStripRowBytes))
+#define STORM_MUL16(s, frag)                                                              \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                         \
+        acc[m][(s) & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
+            v8i{a[(s) >> 2][m].x, a[(s) >> 2][m].y, a[(s) >> 2][m].z, a[(s) >> 2][m].w, 0, 0, 0, 0}, \
+            v8i{frag.x, frag.y, frag.z, frag.w, 0, 0, 0, 0}, acc[m][(s) & 3], 4, 4, 0, 0, 0, 0)
+#define STORM_LGKM(n)                                       \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+
+    v4i b0 = {}, b1 = {}, b2 = {}, b3 = {};
+    uint32_t t = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    // ---- the A tile's own 4 blocks: wave wm skips the blocks before its own rows, keeps the
+    //      strict upper triangle of its own 64 x 64 block and takes the later blocks whole
+#pragma unroll 1
+    for (; t < D; ++t) {
+        retire(t, t + kStripRing - 2);
+        if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= wm) {
+            const uint32_t sb = (t % kStripRing) * kStripStageBytes;
+            STORM_FETCH16(b0, sb, 0);
+            STORM_FETCH16(b1, sb, 1);
+            STORM_FETCH16(b2, sb, 2);
+            STORM_FETCH16(b3, sb, 3);
+            STORM_LGKM(3); STORM_MUL16(0, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b0, sb, 4);
+            STORM_LGKM(3); STORM_MUL16(1, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b1, sb, 5);
+            STORM_LGKM(3); STORM_MUL16(2, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b2, sb, 6);
+            STORM_LGKM(3); STORM_MUL16(3, b3); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b3, sb, 7);
+            STORM_LGKM(3); STORM_MUL16(4, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(2); STORM_MUL16(5, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(1); STORM_MUL16(6, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(0); STORM_MUL16(7, b3); __builtin_amdgcn_sched_barrier(0);
+            if (t == wm) {
+                // The accumulators hold exactly this wave's own 64 x 64 block (earlier stages were
+                // skipped): clear the pairs i >= j in place. Block (m, n) covers rows m*16.. and
+                // columns n*16..; C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg.
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (m > n) acc[m][n] = v4f{};
+                        if (m == n) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t row = 4u * (lane >> 4) + (uint32_t)r;
+                                acc[m][n][r] = row < (lane & 15u) ? acc[m][n][r] : 0.0f;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    // ---- later blocks, software-pipelined three steps ahead across stage boundaries: iteration t
+    //      retires stage t+1 before its own MFMAs, so its last three steps may already fetch the
+    //      first three fragments of stage t+1
+    if (t < T) {
+        retire(t, t + kStripRing - 2);
+        {
+            const uint32_t sb = (t % kStripRing) * kStripStageBytes;
+            STORM_FETCH16(b0, sb, 0);
+            STORM_FETCH16(b1, sb, 1);
+            STORM_FETCH16(b2, sb, 2);
+        }
+        for (; t < T; ++t) {
+            if (t + 1 < T) retire(t + 1, t + kStripRing - 2);
+            else __builtin_amdgcn_s_barrier();
+            if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t sb = (t % kStripRing) * kStripStageBytes;
+            // (after the last stage this re-reads the same stage: never consumed; keeps the body branch-free)
+            const uint32_t sn = ((t + 1 < T ? t + 1 : t) % kStripRing) * kStripStageBytes;
+            STORM_FETCH16(b3, sb, 3); STORM_LGKM(3); STORM_MUL16(0, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b0, sb, 4); STORM_LGKM(3); STORM_MUL16(1, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b1, sb, 5); STORM_LGKM(3); STORM_MUL16(2, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b2, sb, 6); STORM_LGKM(3); STORM_MUL16(3, b3); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b3, sb, 7); STORM_LGKM(3); STORM_MUL16(4, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b0, sn, 0); STORM_LGKM(3); STORM_MUL16(5, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b1, sn, 1); STORM_LGKM(3); STORM_MUL16(6, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16(b2, sn, 2); STORM_LGKM(3); STORM_MUL16(7, b3); __builtin_amdgcn_sched_barrier(0);
+        }
+        STORM_LGKM(0);
+    }
+#undef STORM_FETCH16
+#undef STORM_MUL16
+#undef STORM_LGKM
+
+    uint64_t mine = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // 16 x 64 entries below 2^24 each: a uint32 cannot overflow
+        uint32_t part = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += (uint32_t)acc[m][n][r];
+        mine += part;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0 && mine != 0)
+        atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+                  (unsigned long long)mine);
+}
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
@@ -1062,9 +1275,14 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                 }
                 default:
                     // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
-                    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
-                                       (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
-                                       ctx->d_slots);
+                    if (ctx->k2_shape == 16)
+                        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, sgrid, sblock,
+                                           (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
+                                           ctx->d_slots);
+                    else
+                        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
+                                           (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
+                                           ctx->d_slots);
                     break;
             }
             kernel_time_mark(ctx);
@@ -1163,9 +1381,14 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                            0u, 1u, 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
-                       dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
-                       static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+    if (ctx->k2_shape == 16)
+        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
+                           dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
+                           static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+    else
+        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
+                           dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
+                           static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
     STORM_HIP_TRY(hipGetLastError());
     ctx->last_info[0] = (uint32_t)items.size();
     return launch_fold_slots(ctx, d_total);

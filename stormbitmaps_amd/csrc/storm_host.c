@@ -299,6 +299,35 @@ uint64_t STORM_wrapper_diag_blocked(const uint32_t n_vectors, const uint64_t* va
     return STORM_wrapper_diag(n_vectors, vals, n_ints, f);
 }
 
+/* The list wrappers hand every pair with a "sparse" row (n_alts <= cutoff at storm.c:207,
+ * < cutoff at :309) to the list leaf, which probes the shorter position list against the other
+ * row's bitmap (storm.c:108-129). When every list holds exactly the set bits of its row that is
+ * popcount(row_i & row_j) for every pair under either cutoff convention, which is what the
+ * device computes from the bitmaps alone. A list that disagrees with its row has no such
+ * meaning; the check below (rows the reference could route to the list leaf: n_alts <= cutoff,
+ * the wider of the two conventions) makes the call fail loudly instead of answering a
+ * different question. O(listed positions + words of the listed rows) on the host. */
+static int alt_lists_match_rows(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints,
+                                const uint32_t* n_alts, const uint32_t* alt_positions,
+                                const uint32_t* alt_offsets, uint32_t cutoff) {
+    if (!vals || !n_alts) return 0;
+    for (uint32_t i = 0; i < n_vectors; ++i) {
+        if (n_alts[i] > cutoff) continue; /* never reaches the list leaf through this row alone */
+        const uint64_t* row = vals + (uint64_t)i * n_ints;
+        uint64_t bits = 0;
+        for (uint32_t k = 0; k < n_ints; ++k) bits += (uint64_t)__builtin_popcountll(row[k]);
+        if (bits != n_alts[i]) return 0;
+        if (n_alts[i] == 0) continue;
+        if (!alt_positions || !alt_offsets) return 0;
+        const uint32_t* l = alt_positions + alt_offsets[i];
+        for (uint32_t k = 0; k < n_alts[i]; ++k) {
+            if (l[k] >= (uint64_t)n_ints * 64u || !probe(row, l[k])) return 0;
+            if (k != 0 && l[k] <= l[k - 1]) return 0; /* sorted, duplicate-free (storm.h:227) */
+        }
+    }
+    return 1;
+}
+
 /* reference storm.c:190-219 */
 uint64_t STORM_wrapper_diag_list(const uint32_t n_vectors, const uint64_t* STORM_RESTRICT vals,
                                  const uint32_t n_ints, const uint32_t* STORM_RESTRICT n_alts,
@@ -306,9 +335,14 @@ uint64_t STORM_wrapper_diag_list(const uint32_t n_vectors, const uint64_t* STORM
                                  const uint32_t* STORM_RESTRICT alt_offsets,
                                  const STORM_compute_func f, const STORM_compute_lfunc fl,
                                  const uint32_t cutoff) {
-    (void)n_alts; (void)alt_positions; (void)alt_offsets; (void)cutoff;
     if (!leaf_is_ours(f) || !lleaf_is_ours(fl)) {
         host_error("STORM_wrapper_diag_list: foreign leaf cannot run on the device");
+        return ALL_PAIRS_FAILED;
+    }
+    if (n_vectors >= 2 && n_ints != 0 &&
+        !alt_lists_match_rows(n_vectors, vals, n_ints, n_alts, alt_positions, alt_offsets, cutoff)) {
+        host_error("STORM_wrapper_diag_list: a position list does not describe its bitmap row; "
+                   "the device path counts the bitmaps and refuses inconsistent lists");
         return ALL_PAIRS_FAILED;
     }
     return raw_pairw(n_vectors, vals, n_ints);

@@ -12,6 +12,7 @@
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 // one wave: lane l supplies 4 dwords of A (row l&31, k-half l>>5) and 4 dwords of B
 __global__ void one_mfma(const uint32_t* a, const uint32_t* b, float* d) {
@@ -21,6 +22,16 @@ __global__ void one_mfma(const uint32_t* a, const uint32_t* b, float* d) {
     v16f acc = {};
     acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(va, vb, acc, 4, 4, 0, 0, 0, 0);
     for (int r = 0; r < 16; ++r) d[l * 16 + r] = acc[r];
+}
+
+// the 16x16x128 form: lane l supplies 4 dwords of A (row l&15, k-quarter l>>4) and 4 dwords of B
+__global__ void one_mfma16(const uint32_t* a, const uint32_t* b, float* d) {
+    const int l = threadIdx.x;
+    v8i va = {}, vb = {};
+    for (int i = 0; i < 4; ++i) { va[i] = (int)a[l * 4 + i]; vb[i] = (int)b[l * 4 + i]; }
+    v4f acc = {};
+    acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, vb, acc, 4, 4, 0, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) d[l * 4 + r] = acc[r];
 }
 
 template <int NACC>
@@ -74,6 +85,38 @@ int main() {
         }
     for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) want_sum += __builtin_popcountll(rowsA[i] & rowsB[j]);
     printf("semantics: %d of 1024 entries differ from popcount(A_row & B_col) under the guide's C/D map; tile sum %.0f (want %.0f)\n", bad, sum, want_sum);
+
+    // ---- semantics of the 16x16x128 form (the strip kernel's default shape) ----
+    {
+        unsigned __int128 ra[16], rb[16];
+        auto r128 = [&]() { return ((unsigned __int128)r64() << 64) | r64(); };
+        for (int i = 0; i < 16; ++i) { ra[i] = r128(); rb[i] = r128() & r128(); }
+        std::vector<uint32_t> ha16(64 * 4), hb16(64 * 4);
+        for (int l = 0; l < 64; ++l)
+            for (int dw = 0; dw < 4; ++dw) {
+                uint32_t wa = 0, wb = 0;
+                for (int n = 0; n < 8; ++n) {
+                    const int k = (l >> 4) * 32 + dw * 8 + n;
+                    if ((uint64_t)(ra[l & 15] >> k) & 1) wa |= 0x2u << (4 * n);
+                    if ((uint64_t)(rb[l & 15] >> k) & 1) wb |= 0x2u << (4 * n);
+                }
+                ha16[l * 4 + dw] = wa; hb16[l * 4 + dw] = wb;
+            }
+        CHECK(hipMemcpy(da, ha16.data(), ha16.size() * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(db, hb16.data(), hb16.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(one_mfma16, dim3(1), dim3(64), 0, 0, da, db, dd);
+        std::vector<float> h16(64 * 4);
+        CHECK(hipMemcpy(h16.data(), dd, h16.size() * 4, hipMemcpyDeviceToHost));
+        // C/D map: col = lane & 15, row = 4 * (lane >> 4) + reg
+        int bad16 = 0;
+        auto pc = [](unsigned __int128 v) { return __builtin_popcountll((uint64_t)v) + __builtin_popcountll((uint64_t)(v >> 64)); };
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) {
+                const int col = l & 15, row = 4 * (l >> 4) + r;
+                if (h16[l * 4 + r] != (float)pc(ra[row] & rb[col])) ++bad16;
+            }
+        printf("semantics 16x16x128: %d of 256 entries differ from popcount(A_row & B_col) under col = lane & 15, row = 4 * (lane >> 4) + reg\n", bad16);
+    }
 
     // ---- rate ----
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
