@@ -222,10 +222,14 @@ uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_
                                                                uint32_t bsize);
 
 /* Extension: the per-pair matrix the reference only sums (README.md:41). op: 0 = intersect,
- * 1 = union, 2 = symmetric difference. `out` is n_data x n_data uint32, row-major; entry (i, j)
- * = popcount(row_i OP row_j) for i < j, 0 elsewhere. Returns 0; -1 NULL handle, -2 NULL out,
- * -3 device failure (see STORM_hip_error). */
-int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out);
+ * 1 = union, 2 = symmetric difference. `out` holds out_rows x out_ld uint32, row-major; entry
+ * (i, j) = popcount(row_i OP row_j) for i < j < n_data at out[i * out_ld + j], 0 for i >= j.
+ * Returns 0; -1 NULL handle, -2 NULL out, -3 device failure (see STORM_hip_error), -4 when
+ * out_rows or out_ld is smaller than the number of rows the handle holds (nothing is written).
+ * STORM_contig_n_rows: rows appended so far (empty inputs append none, storm.c:1034). */
+uint64_t STORM_contig_n_rows(const STORM_contiguous_t* bitmap);
+int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out, uint64_t out_rows,
+                              uint64_t out_ld);
 
 /* ------------------------------------------------------------- extensions (not in ref) ---
  * Device selection for the entry points above. By default device 0 computes everything.

@@ -135,6 +135,15 @@ int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, in
 int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                        uint64_t row0, uint64_t n_band_rows, uint32_t* d_out,
                                        uint64_t ld);
+/* The same band into HOST memory: h_out[(i - row0) * ld + j], n_band_rows x ld uint32 with
+ * ld >= n_rows; entries i >= j come back as 0. _begin only enqueues (one band per GPU can be in
+ * flight from one host thread), _end waits for the context's stream. */
+int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                      uint64_t row0, uint64_t n_band_rows, uint32_t* h_out,
+                                      uint64_t ld);
+int storm_hip_pairw_matrix_band_end(storm_hip_ctx_t* ctx);
+int storm_hip_pairw_matrix_band(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                uint64_t row0, uint64_t n_band_rows, uint32_t* h_out, uint64_t ld);
 /* Materialised rectangle A x B (the two-matrix product XY^T):
  *   out[i * ld + j] = popcount(a_i OP b_j) for every row i of `a` and j of `b` (same row width).
  * _device: `d_out` is a DEVICE pointer, a->n_rows x ld uint32 with ld >= b->n_rows; synchronous.

@@ -50,6 +50,9 @@ SIGNATURES = {
     "storm_hip_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp]),
     "storm_hip_row_counts": (C.c_int, [vp, vp, vp]),
     "storm_hip_pairw_matrix_band_device": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
+    "storm_hip_pairw_matrix_band": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
+    "storm_hip_pairw_matrix_band_begin": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
+    "storm_hip_pairw_matrix_band_end": (C.c_int, [vp]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),
@@ -97,7 +100,8 @@ SIGNATURES = {
     "STORM_get_intersect_count_func": (vp, [sz]),
     "STORM_get_alignment": (u32, []),
     "STORM_get_cpuid": (C.c_int, []),
-    "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp]),
+    "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
+    "STORM_contig_n_rows": (u64, [vp]),
     "STORM_hip_set_devices": (C.c_int, [C.c_int, vp]),
     "STORM_hip_set_shard": (C.c_int, [u32, u32]),
     "STORM_hip_error": (cp, []),

@@ -70,12 +70,19 @@ class StormContig:
             self._lib.STORM_contig_pairw_intersect_cardinality_blocked(self._h, bsize),
             "STORM_contig_pairw_intersect_cardinality_blocked")  # storm.c:1175
 
-    def pairw_matrix(self, n_rows: int, op: str = "and") -> np.ndarray:
+    @property
+    def n_rows(self) -> int:
+        """Rows the handle holds (STORM_contig_n_rows; an empty add appends none, storm.c:1034)."""
+        return int(self._lib.STORM_contig_n_rows(self._h))
+
+    def pairw_matrix(self, op: str = "and") -> np.ndarray:
         """STORM_contig_pairw_matrix (extension): [n_rows, n_rows] uint32 per-pair counts, i < j.
-        `n_rows` = rows added so far (the handle's n_data)."""
-        out = np.zeros((n_rows, n_rows), dtype=np.uint32)
+        The buffer is sized from the handle's own row count and its extent is passed down, so a
+        miscount cannot overrun it (the C entry point returns -4 instead)."""
+        n = self.n_rows
+        out = np.zeros((n, n), dtype=np.uint32)
         rc = int(self._lib.STORM_contig_pairw_matrix(self._h, {"and": 0, "or": 1, "xor": 2}[op],
-                                                     _ptr(out)))
+                                                     _ptr(out), n, n))
         if rc != 0:
             raise RuntimeError(f"STORM_contig_pairw_matrix -> {rc}: "
                                f"{self._lib.STORM_hip_error().decode()}")

@@ -1271,6 +1271,53 @@ int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_mat
     return launch_pairw_matrix(ctx, m, op, d_out, ld, row0, n_band_rows);
 }
 
+// Host-output band: the band is computed into a staging buffer of the context (kept between
+// calls) and copied out row by row (ld may exceed n_rows). _begin only enqueues, so that one host
+// thread can keep one band per GPU in flight; _end waits.
+int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                      uint64_t row0, uint64_t n_band_rows, uint32_t* h_out,
+                                      uint64_t ld) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !h_out || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR || ld < m->n_rows ||
+        row0 > m->n_rows || n_band_rows > m->n_rows - row0) {
+        set_error("pairw_matrix_band: NULL argument, unknown op, band outside the matrix or ld < rows");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t n = m->n_rows;
+    if (n == 0 || n_band_rows == 0) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t need = (size_t)n_band_rows * n * sizeof(uint32_t);
+    if (need > ctx->band_capacity) {
+        if (ctx->d_band) STORM_HIP_TRY(hipFree(ctx->d_band));
+        ctx->d_band = nullptr;
+        ctx->band_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_band), need) != hipSuccess) {
+            set_error("pairw_matrix_band: hipMalloc of %zu bytes for the output band failed", need);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->band_capacity = need;
+    }
+    STORM_HIP_TRY(hipMemsetAsync(ctx->d_band, 0, need, ctx->stream));
+    if (int rc = launch_pairw_matrix(ctx, m, op, ctx->d_band, n, row0, n_band_rows, false)) return rc;
+    STORM_HIP_TRY(hipMemcpy2DAsync(h_out, ld * sizeof(uint32_t), ctx->d_band, n * sizeof(uint32_t),
+                                   n * sizeof(uint32_t), n_band_rows, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_pairw_matrix_band_end(storm_hip_ctx_t* ctx) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+int storm_hip_pairw_matrix_band(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                uint64_t row0, uint64_t n_band_rows, uint32_t* h_out, uint64_t ld) {
+    if (int rc = storm_hip_pairw_matrix_band_begin(ctx, m, op, row0, n_band_rows, h_out, ld)) return rc;
+    return storm_hip_pairw_matrix_band_end(ctx);
+}
+
 int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                            uint32_t* h_out) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
@@ -1278,23 +1325,7 @@ int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, in
         set_error("pairw_matrix: NULL argument or unknown op");
         return STORM_HIP_EINVAL;
     }
-    const uint64_t n = m->n_rows;
-    if (n == 0) return STORM_HIP_OK;
-    STORM_HIP_TRY(hipSetDevice(ctx->device));
-    uint32_t* d_out = nullptr;
-    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * n * sizeof(uint32_t)));
-    int rc = STORM_HIP_OK;
-    if (hipMemsetAsync(d_out, 0, n * n * sizeof(uint32_t), ctx->stream) != hipSuccess) {
-        rc = STORM_HIP_EHIP;
-    } else if ((rc = launch_pairw_matrix(ctx, m, op, d_out, n)) == STORM_HIP_OK) {
-        if (hipMemcpyAsync(h_out, d_out, n * n * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                           ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = STORM_HIP_EHIP;
-    }
-    if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
-    (void)hipFree(d_out);
-    return rc;
+    return storm_hip_pairw_matrix_band(ctx, m, op, 0, m->n_rows, h_out, m->n_rows);
 }
 
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,

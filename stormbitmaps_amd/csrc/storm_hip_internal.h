@@ -107,6 +107,8 @@ struct storm_hip_ctx_s {
     int time_kernels = 0;
     std::vector<hipEvent_t> kernel_events;  // begin/end alternating
     size_t kernel_events_used = 0;
+    uint32_t* d_band = nullptr;    // device staging of the host-output matrix calls (band x n_rows uint32)
+    size_t band_capacity = 0;
     uint32_t* d_counts = nullptr;  // row-count scratch of the matrix-output paths
     size_t counts_capacity = 0;
     unsigned long long* d_trace = nullptr;  // k2_ring = 18: per-item schedule trace of the strip kernel
@@ -128,7 +130,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
                              uint64_t shadow_generation = 0);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
-                        uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull);
+                        uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull,
+                        bool sync = true);
 int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                        const storm_hip_matrix_s* b, uint64_t* d_total);
 int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,

@@ -883,6 +883,9 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_strip_items) (void)hipFree(ctx->d_strip_items);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_band) (void)hipFree(ctx->d_band);
+    ctx->d_band = nullptr;
+    ctx->band_capacity = 0;
     ctx->d_counts = nullptr;
     ctx->counts_capacity = 0;
     ctx->d_trace = nullptr;
@@ -1485,7 +1488,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
 static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64_t pitch,
                             uint32_t* d_out, uint64_t ld, uint32_t n_rows, const uint32_t* d_counts,
                             uint32_t and_weight, uint32_t j_base, uint32_t j_count, uint32_t i_lo = 0,
-                            uint32_t n_cols = 0) {
+                            uint32_t n_cols = 0, bool sync = true) {
     if (n_cols == 0) n_cols = n_rows;
     memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
@@ -1496,8 +1499,8 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
                        ctx->stream, ctx->d_x4, pitch, d_items, ctx->d_slots, d_out, ld, n_rows,
                        d_counts, and_weight, j_base, j_count,
                        plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return STORM_HIP_EHIP;
+    if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
+    if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
     return STORM_HIP_OK;
 }
 
@@ -1505,7 +1508,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
-                        uint64_t ld, uint64_t band_row0, uint64_t band_rows) {
+                        uint64_t ld, uint64_t band_row0, uint64_t band_rows, bool sync) {
     // band: only rows [band_row0, band_row0 + band_rows) of the triangle, written from output row 0
     const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
     if (band_row0 >= band_end) return STORM_HIP_OK;
@@ -1558,7 +1561,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         // rows [band_row0, band_end) are written; the columns run over the whole matrix
         rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)band_end, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u, (uint32_t)band_row0,
-                              (uint32_t)m->n_rows);
+                              (uint32_t)m->n_rows, sync);
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
     return rc;

@@ -40,6 +40,7 @@ struct storm_hip_sparse_s {
 namespace {
 
 constexpr uint32_t kBlockWords = 1024;  // 65536 bits
+constexpr uint32_t kMaxBlockId = 65536;  // uint32 positions / 65536 bits per block
 
 // list-kind block -> pool row: one workgroup per block
 __global__ __launch_bounds__(kThreads) void expand_lists_kernel(
@@ -100,6 +101,16 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
         return STORM_HIP_EINVAL;
     }
     // ---- validate + count blocks per column ----
+    if (n_blocks > 0 && n_rows == 0) {
+        set_error("sparse_create: %llu blocks but no rows", (unsigned long long)n_blocks);
+        return STORM_HIP_EINVAL;
+    }
+    if (n_rows > 0 && (!row_block_offset || row_block_offset[0] != 0 ||
+                       row_block_offset[n_rows] != n_blocks)) {
+        set_error("sparse_create: row_block_offset must run from 0 to n_blocks = %llu",
+                  (unsigned long long)n_blocks);
+        return STORM_HIP_EINVAL;
+    }
     uint32_t max_id = 0;
     for (uint64_t r = 0; r < n_rows; ++r) {
         if (row_block_offset[r] > row_block_offset[r + 1] ||
@@ -112,6 +123,10 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
             if (b > row_block_offset[r] && block_id[b] <= block_id[b - 1]) {
                 set_error("sparse_create: block ids of row %llu are not ascending",
                           (unsigned long long)r);
+                return STORM_HIP_EINVAL;
+            }
+            if (block_id[b] >= kMaxBlockId) {  // positions are uint32: ids stop at 2^32 / 65536
+                set_error("sparse_create: block id %u out of range", block_id[b]);
                 return STORM_HIP_EINVAL;
             }
             if (block_kind[b] > 1) {
@@ -130,10 +145,6 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
             }
             max_id = std::max(max_id, block_id[b]);
         }
-    }
-    if (n_rows > 0 && n_blocks > 0 && row_block_offset[0] != 0) {
-        set_error("sparse_create: row_block_offset[0] must be 0");
-        return STORM_HIP_EINVAL;
     }
     std::vector<uint64_t> per_col((size_t)max_id + 2, 0), n_list_col((size_t)max_id + 2, 0);
     for (uint64_t b = 0; b < n_blocks; ++b) {

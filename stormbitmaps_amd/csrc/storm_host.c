@@ -563,20 +563,52 @@ static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
     return st ? dense_state_pairw(st) : ALL_PAIRS_FAILED;
 }
 
+uint64_t STORM_contig_n_rows(const STORM_contiguous_t* h) { return h ? h->n_data : 0; }
+
 /* Extension (storm.h): the per-pair matrix the reference only sums (README.md:41). `op`:
- * 0 intersect, 1 union, 2 symmetric difference. out = n_data x n_data uint32, row-major;
- * entries i >= j are 0. Returns 0, -1 for a NULL handle, -2 for NULL out, -3 on device failure. */
-int STORM_contig_pairw_matrix(STORM_contiguous_t* h, int op, uint32_t* out) {
+ * 0 intersect, 1 union, 2 symmetric difference. `out` holds out_rows x out_ld uint32, row-major;
+ * the n_data x n_data result is written at leading dimension out_ld, entries i >= j are 0.
+ * Returns 0, -1 for a NULL handle, -2 for NULL out, -3 on device failure, -4 when the buffer is
+ * too small for the rows the handle holds (out_rows < n_data or out_ld < n_data).
+ * With several devices configured every GPU writes one band of rows; the bands are cut so that
+ * each holds the same number of pairs (row i has n - 1 - i of them). */
+int STORM_contig_pairw_matrix(STORM_contiguous_t* h, int op, uint32_t* out, uint64_t out_rows,
+                              uint64_t out_ld) {
     if (!h) return -1;
     if (!out) return -2;
-    if (h->n_data == 0) return 0;
+    const uint64_t n = h->n_data;
+    if (out_rows < n || out_ld < n) return -4;
+    if (n == 0) return 0;
     dense_state_t* st = contig_mirror(h);
     if (!st) return -3;
-    if (storm_hip_pairw_matrix(g_ctx[0], st->m[0], op, out) != STORM_HIP_OK) {
-        device_error("storm_hip_pairw_matrix");
-        return -3;
+    const uint64_t pairs = n * (n - 1) / 2;
+    uint64_t row0 = 0;
+    int launched = 0, rc = 0;
+    for (int d = 0; d < g_n_devices; ++d) {
+        uint64_t row1 = n;
+        if (d + 1 < g_n_devices) { /* first row r (multiple of 256) with pairs above r >= share */
+            const uint64_t share = pairs / (uint64_t)g_n_devices * (uint64_t)(d + 1);
+            row1 = row0;
+            while (row1 < n && row1 * (n - 1) - row1 * (row1 - 1) / 2 < share) row1 += 256;
+            if (row1 > n) row1 = n;
+        }
+        if (row1 > row0) {
+            if (storm_hip_pairw_matrix_band_begin(g_ctx[d], st->m[d], op, row0, row1 - row0,
+                                                  out + row0 * out_ld, out_ld) != STORM_HIP_OK) {
+                device_error("storm_hip_pairw_matrix_band_begin");
+                rc = -3;
+                break;
+            }
+        }
+        launched = d + 1;
+        row0 = row1;
     }
-    return 0;
+    for (int d = 0; d < launched; ++d)
+        if (storm_hip_pairw_matrix_band_end(g_ctx[d]) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_matrix_band_end");
+            rc = -3;
+        }
+    return rc;
 }
 
 uint64_t STORM_contig_pairw_intersect_cardinality(STORM_contiguous_t* h) { /* :1149-1173 */

@@ -77,11 +77,15 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     *h_total = set_bits_of(a) + set_bits_of(b);
     return STORM_HIP_OK;
 }
-int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op, uint32_t* h_out) {
+int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
+                                      uint64_t row0, uint64_t n_band_rows, uint32_t* h_out, uint64_t ld) {
     (void)ctx; (void)op;
-    for (uint64_t i = 0; i < m->n_rows * m->n_rows; ++i) h_out[i] = 0; /* touches the whole output */
+    if (ld < m->n_rows || row0 + n_band_rows > m->n_rows) return STORM_HIP_EINVAL;
+    for (uint64_t i = 0; i < n_band_rows; ++i) /* touches the whole band of the output */
+        for (uint64_t j = 0; j < m->n_rows; ++j) h_out[i * ld + j] = 0;
     return STORM_HIP_OK;
 }
+int storm_hip_pairw_matrix_band_end(storm_hip_ctx_t* ctx) { (void)ctx; return STORM_HIP_OK; }
 
 int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                             const uint64_t* row_block_offset, const uint32_t* block_id,

@@ -66,7 +66,9 @@ static int scenario(uint32_t n_rows, uint32_t width, uint32_t draws, int with_em
         CHECK(STORM_contig_pairw_intersect_cardinality_blocked_list(dense, 3) == distinct_dense);
         CHECK(STORM_wrapper_diag(dense->n_data, dense->data, dense->n_bitmaps_vector, NULL) == distinct_dense);
         uint32_t* out = (uint32_t*)malloc((size_t)dense->n_data * dense->n_data * sizeof(uint32_t));
-        CHECK(out && STORM_contig_pairw_matrix(dense, 0, out) == 0);
+        CHECK(out && STORM_contig_pairw_matrix(dense, 0, out, dense->n_data, dense->n_data) == 0);
+        CHECK(STORM_contig_n_rows(dense) == dense->n_data);
+        CHECK(dense->n_data < 2 || STORM_contig_pairw_matrix(dense, 0, out, dense->n_data - 1, dense->n_data) == -4);
         free(out);
     }
     if (sparse->n_conts >= 2) {

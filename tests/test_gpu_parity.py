@@ -45,7 +45,8 @@ def test_hand_computed_matrices(case):
     n = sum(1 for r in case["rows"] if len(r))       # empty rows are not appended (storm.c:1034)
     if n == len(case["rows"]) and n >= 1:
         for name in ("and", "or", "xor"):
-            got = c.pairw_matrix(n, name)
+            assert c.n_rows == n
+            got = c.pairw_matrix(name)
             for i, j, cnt in case["pair_counts"][name]:
                 assert got[i, j] == cnt and got[j, i] == 0, (name, i, j)
 
@@ -659,13 +660,13 @@ def test_storm_h_matrix_extension(orc):
     try:
         for r in rows[:250]:
             h.add(r)
-        assert np.array_equal(h.pairw_matrix(250), np.triu(orc.tile_counts(mat[:250], 0, 250, 0, 250), k=1))
+        assert np.array_equal(h.pairw_matrix(), np.triu(orc.tile_counts(mat[:250], 0, 250, 0, 250), k=1))
         for r in rows[250:]:
             h.add(r)
         for name, op in (("and", 0), ("or", 1), ("xor", 2)):
-            assert np.array_equal(h.pairw_matrix(N, name),
+            assert np.array_equal(h.pairw_matrix(name),
                                   np.triu(orc.tile_counts_op(mat, 0, N, 0, N, op), k=1)), name
-        assert int(h.pairw_matrix(N).sum(dtype=np.uint64)) == h.pairw_intersect_cardinality()
+        assert int(h.pairw_matrix().sum(dtype=np.uint64)) == h.pairw_intersect_cardinality()
     finally:
         h.free()
 
