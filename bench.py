@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_WORDPAIRS = 256 * 4 * 32 * 2.4e9 / 4  # 4 VALU lane-ops per 64-bit word pair
 FP4_PEAK_TFLOPS = 10000.0  # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense
-FP4_MEASURED_WORDPAIRS = 6.4e13  # tools/mfma_fp4_probe: back-to-back v_mfma_f32_32x32x64_f8f6f4
+FP4_MEASURED_WORDPAIRS = 7.48e13  # tools/ubench_shape: bare v_mfma_scale_f32_16x16x128_f8f6f4 loop, random 0/1 operands (9.57 PFLOP/s)
 
 
 def cpu_baseline(head_rows_fn, n_words, budget_s=12.0):
@@ -175,6 +175,7 @@ def main():
         reduce_total()
     fence()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -184,6 +185,26 @@ def main():
     dom_sum_ms, dom_n = ctx.kernel_time()
     ctx.set_option("time_kernels", 0)
     kernel_ms = dom_sum_ms / dom_n if dom_n else launch_ms
+
+    # N > 1 diagnostics (outside the timed region): the 8-byte all-reduce alone, and every rank's
+    # own kernel / pass / wall time, so that a scaling run can be read rank by rank
+    per_rank = None
+    if collective:
+        n_ar = 20
+        reduce_total(); fence()
+        t_ar = time.perf_counter()
+        for _ in range(n_ar):
+            reduce_total()
+        torch.cuda.synchronize(dev)
+        allreduce_us = (time.perf_counter() - t_ar) * 1e6 / n_ar
+        mine = torch.tensor([kernel_ms, launch_ms, my_elapsed * 1e3 / args.steps, allreduce_us,
+                             float(ctx.last_launch_info()["items"])], dtype=torch.float64,
+                            device=dev if args.backend != "gloo" else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [{"rank": r, "kernel_ms": round(float(g[0]), 4), "pass_ms": round(float(g[1]), 4),
+                     "wall_ms_per_step": round(float(g[2]), 4), "allreduce_us": round(float(g[3]), 1),
+                     "work_items": int(g[4])} for r, g in enumerate(gathered)]
 
     # Secondary figure, never `value`: the same pass when the FP4 re-encoding of the (unchanged)
     # matrix is kept in HBM between calls (library option keep_shadow, what the storm.h handles
@@ -220,29 +241,46 @@ def main():
         alg_bytes_launch = pairs * W * 16 / world                # 16 B / word pair
         alg_flop_launch = pairs * W * 64 * 2 / world             # 64 bit-MACs per word pair
         hbm_gbs = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM-side bytes of the dominant kernel per launch: measured with rocprofv3 PMC passes
+        # (tools/profile_default.sh -> tools/pmc_traffic.py) and only quoted while the device
+        # sources are the ones it was measured on
+        traffic, traffic_note = None, "no PMC summary for this kernel variant under profiles/"
         pmc = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"variant{used}", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                from stormbitmaps_amd._lib import kernel_source_hash
+                entry = json.load(open(pmc)).get(f"variant{used}", {})
+                if entry.get("source_hash") == kernel_source_hash():
+                    traffic = entry.get("hbm_bytes_per_launch")
+                    traffic_note = (f"rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of {entry.get('dominant_kernel')} "
+                                    f"at 1 GPU, sources {entry.get('source_hash')}")
+                elif entry:
+                    traffic_note = ("stale: the PMC summary was measured on other device sources "
+                                    f"({entry.get('source_hash')}); re-run tools/profile_default.sh")
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"unreadable PMC summary: {e}"
+        step_ms = elapsed * 1e3 / args.steps
         if used >= 3:
             # K2/K2s: the bits are multiplied as FP4 on the matrix cores -> MFMA-bound
             achieved = alg_flop_launch / (kernel_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP4_PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "storm::strip_fp4_kernel" if used >= 4 else "storm::pairw_fp4_kernel",
+                    "frac": achieved / FP4_PEAK_TFLOPS, "traffic": traffic if world == 1 else None,
+                    "traffic_note": traffic_note,
+                    # the same FLOPs over everything one step contains (expansion, fold, launch
+                    # gaps, all-reduce): wall time of the timed loop / steps
+                    "frac_whole_pass": alg_flop_launch / (step_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS,
+                    "kernel": ("storm::strip16_fp4_kernel<4>" if ctx.get_option("k2_shape") == 16 else
+                               "storm::strip_fp4_kernel") if used >= 4 else "storm::pairw_fp4_kernel",
                     "kernel_ms": kernel_ms, "launch_ms": launch_ms,
                     "algorithmic_flop_per_launch": alg_flop_launch,
                     "measured_fp4_mfma_peak_frac": (pairs * W / world / (kernel_ms * 1e-3)) / FP4_MEASURED_WORDPAIRS,
                     "hbm_algorithmic_gb_s": hbm_gbs, "hbm_algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
-                    "note": "1 word pair = 64 bit-MACs = 128 FLOP on v_mfma_f32_32x32x64_f8f6f4 (FP4). The "
+                    "note": "1 word pair = 64 bit-MACs = 128 FLOP on v_mfma_scale_f32_16x16x128_f8f6f4 (FP4). The "
                             "reference's no-reuse byte accounting (16 B per word pair, benchmark.cpp:131) is "
                             "kept as hbm_algorithmic_*; on-chip reuse puts it far above the HBM peak."}
         else:
             roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"storm::pairw_dense_kernel<{used}>", "kernel_ms": kernel_ms,
                     "launch_ms": launch_ms,
                     "algorithmic_bytes_per_launch": alg_bytes_launch,
@@ -262,12 +300,16 @@ def main():
             "config": {"workload": f"STORM_contiguous_t N={N} M={M} dense draws={draws} seed={args.seed} "
                                    "(BASELINE configs[1], README `benchmark 65536 10000`)",
                        "entry_point": "storm_hip_pairw_dense_launch == STORM_contig_pairw_intersect_cardinality_blocked",
-                       "parallelism": f"pair-space shard x{world}, X replicated, uint64 all-reduce",
+                       "parallelism": f"work shard x{world} (whole k-slices per rank + leftover slices cut along the "
+                                      "pair space), X replicated, one uint64 all-reduce per step",
                        "kernel_variant": used, "work_items": info["items"]},
             "gb_per_s_algorithmic": value * 8 / 1e9,
             "total": total, "verified_against_column_identity": ok,
             "roofline": roof,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["slowest_rank_kernel_ms"] = max(r["kernel_ms"] for r in per_rank)
         if shadow_resident is not None:
             shadow_resident["value"] = words / (shadow_resident["ms_per_step"] * 1e-3)
             shadow_resident["note"] = ("same pass with the FP4 shadow of the unchanged matrix kept resident "

@@ -125,9 +125,10 @@ struct STORM_s {
     STORM_bitmap_cont_t* conts;
     uint32_t n_conts, m_conts;
     /* private */
-    void* hip_arena;        /* storm_hip_sparse_t*, rebuilt when dirty */
+    void* hip_arena;        /* device replicas of the flattened arena, rebuilt when dirty */
     uint32_t hip_dirty;
     uint32_t hip_generation; /* device configuration the arena was built for */
+    uint64_t hip_fingerprint; /* rows / blocks / set-bit counts the arena was built from */
 };
 
 /* one row of the dense container (reference storm.h:181-186) */
@@ -238,6 +239,15 @@ int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out,
  * sums are added on the host. Multi-PROCESS runs (one rank per GPU, RCCL all-reduce) use
  * STORM_hip_set_shard(rank, world): each process then returns only its shard's partial. */
 int STORM_hip_set_devices(int n_devices, const int* device_ids);
+/* The containers keep a device copy of their rows between all-pairs calls. It follows every
+ * change made through STORM_add / STORM_clear / STORM_contig_add / STORM_contig_clear, and for
+ * STORM_t also edits made with the public per-row / per-block adders directly on h->conts[i]
+ * (a fingerprint of rows, blocks and set-bit counts is compared on every call). What it cannot
+ * see is a caller writing into the public buffers in place (h->data, bitmaps[i].data: the
+ * reference structs are not opaque): after such an edit call the matching function below, or the
+ * next all-pairs call answers for the rows as they were. Returns 0, -1 for a NULL handle. */
+int STORM_hip_invalidate(STORM_t* bitmap);
+int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
 const char* STORM_hip_error(void);
 

@@ -175,7 +175,11 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *   keys "k2_max_run" (128), "k2_tail_slices" (3), "k2_tail_run" (32): strip work-list shaping;
  *        "k2_persistent" (0): per-XCD work queues; "k2_ring" (4): LDS ring depth 3..5;
  *        "k2_pitch_pad" (-1 = auto): extra bytes per shadow row; "k2_lds_pad": cap workgroups per CU;
- *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k
+ *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k;
+ *        "k2_shape" (16): MFMA form of the default strips, 16 = 16x16x128, 32 = 32x32x64;
+ *        "k2_shadow_budget_mb" (98304): when the FP4 shadow (4 x the bits) of a matrix would exceed
+ *        this many MiB the pass runs k-chunk by k-chunk over a compact shadow of one chunk
+ *        (HBM-tiled: bounded footprint for any M x N; 0 = never chunk)
  *   key "k2_debug", "k2_ring" >= 11: timing probes only (results may then be wrong), see
  *        storm_hip_mfma.hip
  *   read-only "variant_used": what the last dense launch ran; "n_cus" */
@@ -196,8 +200,23 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
  * starts a new series. */
 int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launches);
 /* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,
- * [2]=word-pairs executed (including zero padding), [3]=segments */
+ * [2]=word-pairs executed incl. zero padding (popcount kernel) / k-chunks of the pass (matrix-core
+ * strips: 1 unless the shadow budget forced HBM tiling), [3]=segments */
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);
+
+/* ---- multi-GPU work split of the default (matrix-core strip) path, host-only ---------------
+ * The work list shard `shard_rank` of `shard_count` would multiply for an n_rows x n_words
+ * matrix, as 5 uint32 per item: {a_row0, diag, j0, j1, ks} =
+ *   A tile rows [a_row0, a_row0 + 256) x k-slice ks (bits [256 ks, 256 ks + 256) of every row) x
+ *   (diag ? the strict upper triangle inside the A tile : nothing) + the 64-row B blocks
+ *   [j0, j1) (rows [64 j0, 64 j1)), i.e. the pairs (i, j), i in the A tile, j in those blocks.
+ * Ownership: whole k-slices go to shard ks % shard_count; the n_kslices %
+ * shard_count leftover slices are cut along the pair space, longest item first onto the least
+ * loaded shard. The lists of all shards tile (pair, k-slice) space exactly once. Touches no
+ * device; `out` may be NULL to query the item count. Shards the reference loop storm.c:1199-1238. */
+int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                         uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
+                         uint64_t* n_items);
 
 /* ---- sparse (STORM_t) arena: flattened rows -> blocks (storm.h:157-178) --------------
  * Host-side flat description of all rows' 65536-bit blocks:
@@ -218,6 +237,11 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
                            uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);
+/* split form (one host thread, one arena replica per GPU): _begin launches this shard into the
+ * context's result word, _end waits for it and copies it to the host */
+int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
+                                 uint32_t shard_rank, uint32_t shard_count);
+int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total);
 /* work census of the last sparse call: out[0]=list×list block pairs, [1]=list×bitmap,
  * [2]=bitmap×bitmap, [3]=block columns */
 int storm_hip_sparse_last_census(storm_hip_ctx_t* ctx, uint64_t out[4]);

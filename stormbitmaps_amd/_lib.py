@@ -53,6 +53,7 @@ SIGNATURES = {
     "storm_hip_pairw_matrix_band": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
     "storm_hip_pairw_matrix_band_begin": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
     "storm_hip_pairw_matrix_band_end": (C.c_int, [vp]),
+    "storm_hip_strip_plan": (C.c_int, [u64, u32, u32, u32, vp, u64, vp]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),
@@ -65,6 +66,8 @@ SIGNATURES = {
                                           P(vp)]),
     "storm_hip_sparse_destroy": (None, [vp, vp]),
     "storm_hip_pairw_sparse": (C.c_int, [vp, vp, u32, u32, P(u64)]),
+    "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
+    "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_sparse_last_census": (C.c_int, [vp, P(u64 * 4)]),
     # storm_synth.h
     "storm_synth_fill_row": (None, [vp, u64, u64, u32, u64]),
@@ -102,6 +105,8 @@ SIGNATURES = {
     "STORM_get_cpuid": (C.c_int, []),
     "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
     "STORM_contig_n_rows": (u64, [vp]),
+    "STORM_hip_invalidate": (C.c_int, [vp]),
+    "STORM_contig_hip_invalidate": (C.c_int, [vp]),
     "STORM_hip_set_devices": (C.c_int, [C.c_int, vp]),
     "STORM_hip_set_shard": (C.c_int, [u32, u32]),
     "STORM_hip_error": (cp, []),
@@ -146,3 +151,17 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise StormHipError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def kernel_source_hash() -> str:
+    """Fingerprint of the device sources (csrc/*.hip + the shared internal header): what a
+    profile summary under profiles/ was measured on. bench.py only quotes measured HBM traffic
+    whose fingerprint equals the current one."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(".hip") or name == "storm_hip_internal.h":
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]

@@ -88,6 +88,11 @@ class StormContig:
                                f"{self._lib.STORM_hip_error().decode()}")
         return out
 
+    def hip_invalidate(self) -> None:
+        """STORM_contig_hip_invalidate: forget the device copy after an in-place edit of the
+        handle's public buffers (storm.h extension)."""
+        self._lib.STORM_contig_hip_invalidate(self._h)
+
     def pairw_intersect_cardinality_list(self) -> int:
         return int(self._lib.STORM_contig_pairw_intersect_cardinality_list(self._h))  # :1243
 
@@ -130,6 +135,10 @@ class Storm:
 
     def serialized_size(self) -> int:
         return int(self._lib.STORM_serialized_size(self._h))  # storm.c:963
+
+    def hip_invalidate(self) -> None:
+        """STORM_hip_invalidate (storm.h extension)."""
+        self._lib.STORM_hip_invalidate(self._h)
 
     def pairw_intersect_cardinality(self) -> int:
         return _all_pairs(self._lib.STORM_pairw_intersect_cardinality(self._h),

@@ -615,6 +615,13 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_ring = (int)value;
+    } else if (!strcmp(key, "k2_shadow_budget_mb")) {
+        if (value < 0 || value > (1 << 22)) {
+            set_error("k2_shadow_budget_mb must be 0 (unbounded) .. 4194304");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_shadow_budget_mb = (int)value;
+        memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
@@ -685,6 +692,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
     if (!strcmp(key, "k2_shape")) return ctx->k2_shape;
+    if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     return -1;
 }

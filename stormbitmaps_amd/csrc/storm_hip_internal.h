@@ -88,6 +88,7 @@ struct storm_hip_ctx_s {
     int k2_stages_per_item = 32;
     int k2_max_run = 128;   // K2s: B stages per strip item
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
+    int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
     int k2_shape = 16;      // K2s: MFMA shape of the default strip kernel: 16 = 16x16x128 (default), 32 = 32x32x64
     int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)
     uint32_t strip_queue_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -128,7 +129,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
-                             uint64_t shadow_generation = 0);
+                             uint64_t shadow_generation = 0, uint32_t n_words_logical = 0);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull,
                         bool sync = true);

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 
 namespace storm {
 
@@ -62,41 +63,55 @@ __device__ __forceinline__ uint32_t spread8_fp4(uint32_t b, uint32_t nib = 2u) {
     return x * nib;
 }
 
+// Which columns a shard (multi-GPU rank) expands: the ownership unit is a run of 2^unit_shift
+// 32-bit half words of a row (3: one strip k-slice = 4 words; 7: one k-group = 64 words, the tile
+// kernel's k-slice). Units below modulo_units belong to shard unit % count; the units from there on
+// (the strips' leftover slices, whose ITEMS are dealt to the shards) are expanded by every shard.
+struct ExpandOwn {
+    uint32_t rank, count, unit_shift, modulo_units;
+};
+constexpr ExpandOwn kExpandAll = {0u, 1u, 7u, 0u};
+
 // One thread per 32-bit half word: 16 output bytes, fully coalesced on both sides.
-// Rows >= n_rows_src (padding up to a multiple of 256) are written as zeros.
-// A shard (multi-GPU rank) only multiplies its own k-groups (64 words = 16 strip slices = one
-// tile-kernel k-slice, owner = group % shard_count), so it only expands those columns.
+// Rows >= n_rows_src (padding up to a multiple of 256) are written as zeros. The half words
+// [h_begin, h_end) of every row are expanded (default: the whole row) and land at shadow column
+// h - h_dst0, so that a k-chunk of a matrix whose full shadow would not fit gets a compact shadow of
+// its own; half words beyond the end of the row read as zero (the last chunk may overhang).
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restrict__ X,
                                                          uint64_t stride_words,
                                                          uint64_t n_rows_src, uint64_t n_rows_dst,
-                                                         uint4* __restrict__ X4,
-                                                         uint32_t shard_rank, uint32_t shard_count,
-                                                         uint32_t nib = 2u, uint64_t out_pitch_u4 = 0) {
+                                                         uint4* __restrict__ X4, ExpandOwn own,
+                                                         uint32_t nib = 2u, uint64_t out_pitch_u4 = 0,
+                                                         uint64_t h_begin = 0, uint64_t h_end = 0,
+                                                         uint64_t h_dst0 = 0) {
     // out_pitch_u4: row pitch of the shadow in 16-byte units (0 = dense, stride_words * 2)
     if (out_pitch_u4 == 0) out_pitch_u4 = stride_words * 2;
     const uint64_t halves_per_row = stride_words * 2;
+    if (h_end == 0) h_end = halves_per_row;
     // grid = (column chunks of 256 halves, rows): no division per element (a 64-bit divide per
     // 16 output bytes made the first version VALU-bound just below the HBM rate)
     for (uint64_t row = blockIdx.y; row < n_rows_dst; row += gridDim.y)
-        for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < halves_per_row;
+        for (uint64_t h = h_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x; h < h_end;
              h += (uint64_t)gridDim.x * 256) {
-            const uint32_t group = (uint32_t)(h >> 7);  // 128 halves = 64 words
-            if (shard_count > 1 && group % shard_count != shard_rank) continue;
+            const uint32_t unit = (uint32_t)((h - h_dst0) >> own.unit_shift);
+            if (own.count > 1 && unit < own.modulo_units && unit % own.count != own.rank) continue;
             uint32_t w = 0;
-            if (row < n_rows_src) w = reinterpret_cast<const uint32_t*>(X)[row * halves_per_row + h];
+            if (row < n_rows_src && h < halves_per_row)
+                w = reinterpret_cast<const uint32_t*>(X)[row * halves_per_row + h];
             uint4 o;
             o.x = spread8_fp4(w & 0xFFu, nib & 7u);
             o.y = spread8_fp4((w >> 8) & 0xFFu, nib & 7u);
             o.z = spread8_fp4((w >> 16) & 0xFFu, nib & 7u);
             o.w = spread8_fp4(w >> 24, nib & 7u);
-            X4[row * out_pitch_u4 + h] = o;  // (non-temporal stores: slower)
+            X4[row * out_pitch_u4 + (h - h_dst0)] = o;  // (non-temporal stores: slower)
         }
 }
 
-// Launch geometry of expand_fp4_kernel for n_rows_dst rows of stride_words words.
-static inline dim3 expand_grid(uint64_t n_rows_dst, uint64_t stride_words) {
-    const uint64_t chunks = (stride_words * 2 + 255) / 256;
-    const uint64_t cx = std::min<uint64_t>(chunks, 1024);
+// Launch geometry of expand_fp4_kernel for n_rows_dst rows of `halves` half words each.
+static inline dim3 expand_grid(uint64_t n_rows_dst, uint64_t stride_words, uint64_t halves = 0) {
+    if (halves == 0) halves = stride_words * 2;
+    const uint64_t chunks = (halves + 255) / 256;
+    const uint64_t cx = std::max<uint64_t>(1, std::min<uint64_t>(chunks, 1024));
     // ~8192 workgroups in all, each walking down the rows of its column chunk
     return dim3((uint32_t)cx, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_rows_dst, 8192 / cx)));
 }
@@ -984,36 +999,52 @@ static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& range
     return STORM_HIP_OK;
 }
 
-// Strip items for this shard: k-slice ks belongs to the rank that owns its k-group; the shard's
-// slices are dealt to the 8 XCDs (block b runs on XCD b % 8 — observed, speed only), and inside
-// an XCD's list the items of one slice are consecutive, longest run first.
-static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
+// Ownership of the strip work among shard_count shards (multi-GPU ranks; reference loop being
+// sharded: storm.c:1199-1238). Two levels:
+//   * whole k-slices (256 bits of every row): the first (n_kslices / G) * G slices go to shard
+//     ks % G, so a shard expands and multiplies only its own columns — 1/G of the O(N*M) expansion
+//     and of the pair work, equal shares whatever N is;
+//   * the remaining n_kslices % G slices ("leftover") are cut along the PAIR space: their items
+//     (A tile x run of B blocks) are dealt to the shards longest-first onto the least loaded one
+//     (deterministic, every shard computes the same deal), every shard expands those few slices.
+// Hence any G balances to within one short item per leftover slice (c2 at G = 3: 85 1/3 slices
+// each), and a matrix with fewer slices than shards (M <= 256 * G bits) still splits G ways.
+static inline uint32_t strip_modulo_slices(uint32_t n_kslices, uint32_t shard_count) {
+    return n_kslices / shard_count * shard_count;
+}
+static inline uint32_t strip_item_cost(const StripItem& it, uint32_t per_tile) {
+    return (it.j1 - it.j0) + it.diag * per_tile + 10u;  // stages + ~10 stages' worth of prologue
+}
+
+// Strip items for this shard; the shard's slices are dealt to the 8 XCDs (block b runs on XCD
+// b % 8 — observed, speed only), and inside an XCD's list the items of one slice are consecutive,
+// longest run first.
+struct StripShaping {  // work-list shaping knobs (context options of the same names)
+    int max_run = 128, tail_run = 32, tail_slices = 3, lpt_rounds = 6;
+    bool persistent = false, one_slice_probe = false;
+};
+// Pure host computation (no device): the list, in launch order, and for the persistent form the
+// per-XCD queue bounds.
+static void build_strip_items(const StripShaping& sh, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
-                              uint32_t a_tile) {
-    const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
-                             ((uint64_t)shard_rank << 32) | shard_count,
-                             ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
-                                 ((uint64_t)(ctx->k2_persistent != 0) << 47) |
-                                 ((uint64_t)(ctx->k2_lpt_rounds & 0x3f) << 41) |
-                                 ((uint64_t)(ctx->k2_tail_slices & 0xff) << 32) |
-                                 ((uint64_t)(ctx->k2_tail_run & 0xffff) << 16) |
-                                 (uint64_t)(ctx->k2_max_run & 0xffff)};
-    if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
+                              uint32_t a_tile, std::vector<StripItem>& items,
+                              uint32_t queue_base[8], uint32_t queue_count[8]) {
     // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
     // load per run for a shorter tail at the end of the launch
-    const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
-    const uint32_t kTailRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_tail_run));
+    const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, sh.max_run));
+    const uint32_t kTailRun = (uint32_t)std::min(4096, std::max(1, sh.tail_run));
     const uint32_t kPerTile = a_tile / kStripBRows;
     // The slices of this shard, dealt to the XCDs in turn.
     std::vector<std::vector<uint32_t>> slices_of(8);
     uint32_t local = 0;
-    for (uint32_t ks = 0; ks < n_kslices; ++ks)
-        if ((ks / 16u) % shard_count == shard_rank) slices_of[local++ % 8].push_back(ks);  // 16 slices = one k-group
+    const uint32_t modulo_slices = strip_modulo_slices(n_kslices, shard_count);
+    for (uint32_t ks = 0; ks < modulo_slices; ++ks)
+        if (ks % shard_count == shard_rank) slices_of[local++ % 8].push_back(ks);
     // One slice = every A tile against the B blocks behind it; `max_run` caps the stages per item.
     auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
         // k2_debug & 16 (timing probe, wrong results): every XCD re-reads one k-slice, i.e. the
         // launch as it would run if nothing ever missed in L2
-        const uint32_t ks_data = (ctx->k2_debug & 16) ? ks % 8u : ks;
+        const uint32_t ks_data = sh.one_slice_probe ? ks % 8u : ks;
         for (const RowRange& rg : ranges) {
             // A tiles of a_tile rows from the start of the range (the rows between r1 and
             // the end of its last A tile are zero: the caller pads ranges accordingly)
@@ -1038,7 +1069,25 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     // up to one 157-stage item (10 % of the launch at the headline shape, by list-scheduling
     // simulation and by measurement). So the LAST k2_tail_slices slices of every XCD are cut into
     // short runs and merged longest-first, which lets the list end on many small items.
-    const uint32_t kTail = (uint32_t)std::max(0, ctx->k2_tail_slices);
+    // leftover slices: short runs, dealt to the shards by longest-processing-time-first
+    std::vector<std::vector<StripItem>> leftover_of(8);
+    if (modulo_slices < n_kslices) {
+        std::vector<uint64_t> load(shard_count, 0);
+        for (uint32_t ks = modulo_slices; ks < n_kslices; ++ks) {
+            std::vector<StripItem> all;
+            emit_slice(ks, std::min(kMaxRun, kTailRun), all);
+            std::stable_sort(all.begin(), all.end(), [&](const StripItem& p, const StripItem& q) {
+                return strip_item_cost(p, kPerTile) > strip_item_cost(q, kPerTile);
+            });
+            const uint32_t xcd = local++ % 8;  // one slice stays on one XCD's L2
+            for (const StripItem& it : all) {
+                const uint32_t r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+                load[r] += strip_item_cost(it, kPerTile);
+                if (r == shard_rank) leftover_of[xcd].push_back(it);
+            }
+        }
+    }
+    const uint32_t kTail = (uint32_t)std::max(0, sh.tail_slices);
     std::vector<std::vector<StripItem>> per_xcd(8);
     for (int x = 0; x < 8; ++x) {
         const std::vector<uint32_t>& sl = slices_of[x];
@@ -1057,6 +1106,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
         }
         std::vector<StripItem> tail;
         for (size_t k = n_main; k < sl.size(); ++k) emit_slice(sl[k], std::min(kMaxRun, kTailRun), tail);
+        tail.insert(tail.end(), leftover_of[x].begin(), leftover_of[x].end());
         std::stable_sort(tail.begin(), tail.end(), [&](const StripItem& p, const StripItem& q) {
             return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
         });
@@ -1065,17 +1115,17 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
         // tail: order the whole of it longest-first. The L2 locality that slice-major order buys
         // is worth 1-2 %, the tail of a 2-round launch a third of its time (N = 2048: the
         // schedule trace showed the launch draining for 24 of its 66 us).
-        if (per_xcd[x].size() <= (size_t)128 * (size_t)std::max(0, ctx->k2_lpt_rounds))
+        if (per_xcd[x].size() <= (size_t)128 * (size_t)std::max(0, sh.lpt_rounds))
             std::stable_sort(per_xcd[x].begin(), per_xcd[x].end(),
                              [&](const StripItem& p, const StripItem& q) {
                                  return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
                              });
     }
-    std::vector<StripItem> items;
-    if (ctx->k2_persistent) {  // one contiguous queue per XCD
+    items.clear();
+    if (sh.persistent) {  // one contiguous queue per XCD
         for (int x = 0; x < 8; ++x) {
-            ctx->strip_queue_base[x] = (uint32_t)items.size();
-            ctx->strip_queue_count[x] = (uint32_t)per_xcd[x].size();
+            queue_base[x] = (uint32_t)items.size();
+            queue_count[x] = (uint32_t)per_xcd[x].size();
             items.insert(items.end(), per_xcd[x].begin(), per_xcd[x].end());
         }
     } else {  // dispatcher order: block b runs on XCD b % 8
@@ -1085,6 +1135,30 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
             for (int x = 0; x < 8; ++x)
                 if (pos < per_xcd[x].size()) items.push_back(per_xcd[x][pos]);
     }
+}
+
+static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
+                              uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
+                              uint32_t a_tile) {
+    const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
+                             ((uint64_t)shard_rank << 32) | shard_count,
+                             ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
+                                 ((uint64_t)(ctx->k2_persistent != 0) << 47) |
+                                 ((uint64_t)(ctx->k2_lpt_rounds & 0x3f) << 41) |
+                                 ((uint64_t)(ctx->k2_tail_slices & 0xff) << 32) |
+                                 ((uint64_t)(ctx->k2_tail_run & 0xffff) << 16) |
+                                 (uint64_t)(ctx->k2_max_run & 0xffff)};
+    if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
+    StripShaping sh;
+    sh.max_run = ctx->k2_max_run;
+    sh.tail_run = ctx->k2_tail_run;
+    sh.tail_slices = ctx->k2_tail_slices;
+    sh.lpt_rounds = ctx->k2_lpt_rounds;
+    sh.persistent = ctx->k2_persistent != 0;
+    sh.one_slice_probe = (ctx->k2_debug & 16) != 0;
+    std::vector<StripItem> items;
+    build_strip_items(sh, ranges, n_kslices, shard_rank, shard_count, a_tile, items,
+                      ctx->strip_queue_base, ctx->strip_queue_count);
     if (items.size() >= (1ull << 31)) {
         set_error("K2s: %zu strip items exceed the grid limit", items.size());
         return STORM_HIP_EINVAL;
@@ -1126,7 +1200,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
-                             uint64_t shadow_generation) {
+                             uint64_t shadow_generation, uint32_t n_words_logical) {
     // shadow_generation != 0 identifies the content of X (dense matrix + its generation): with
     // "keep_shadow" an unchanged shadow of the same layout and shard is not rebuilt.
     // strip_mode: 0 = tile kernel, 1 = strips with 256-row A tiles, 2 = wide strips (512 rows;
@@ -1134,8 +1208,31 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     const bool strips = strip_mode != 0;
     const uint32_t a_tile = strip_mode == 2 ? 512u : (uint32_t)kStripATile;
     const uint64_t row_bytes = stride_words * 32;  // 64 bits -> 64 nibbles = 32 bytes
-    const uint64_t pitch = shadow_pitch(ctx, row_bytes, strip_mode != 0);
-    const size_t x4_bytes = (size_t)std::max<uint64_t>(n_rows_dst, kTile) * pitch;
+    // k-slices that hold data: the zero padding of the rows up to 64 words is never multiplied
+    // (a 256-bit matrix is one slice, not sixteen)
+    const uint32_t n_kslices = n_words_logical
+                                   ? (n_words_logical + 3u) / 4u
+                                   : (uint32_t)(row_bytes / kStripRowBytes);
+    // HBM tiling along k: the FP4 shadow is 4 x the bits. When the whole of it would exceed the
+    // context's budget ("k2_shadow_budget_mb") the strips run k-chunk by k-chunk over a compact
+    // shadow of one chunk — expand chunk, multiply chunk, partial sums accumulate in the slots —
+    // so the footprint is bounded whatever M * N is. Every chunk has the same number of slices
+    // (the last one overhangs into zero columns), hence one work list serves all of them.
+    const uint64_t rows_alloc = std::max<uint64_t>(n_rows_dst, kTile);
+    uint32_t n_chunks = 1, chunk_slices = n_kslices;
+    uint64_t shadow_row_bytes = row_bytes;
+    if (strips && ctx->k2_shadow_budget_mb > 0) {
+        const uint64_t budget = (uint64_t)ctx->k2_shadow_budget_mb << 20;
+        const uint64_t full = rows_alloc * shadow_pitch(ctx, row_bytes, true);
+        if (full > budget && n_kslices > 8) {
+            const uint64_t want = (full + budget - 1) / budget;
+            chunk_slices = (uint32_t)(((uint64_t)n_kslices + want - 1) / want + 7u) / 8u * 8u;
+            n_chunks = (n_kslices + chunk_slices - 1) / chunk_slices;
+            shadow_row_bytes = (uint64_t)chunk_slices * kStripRowBytes;
+        }
+    }
+    const uint64_t pitch = shadow_pitch(ctx, shadow_row_bytes, strip_mode != 0);
+    const size_t x4_bytes = (size_t)rows_alloc * pitch;
     if (n_rows_dst / kTile >= 65535) {
         set_error("K2: too many row blocks");
         return STORM_HIP_EINVAL;
@@ -1160,12 +1257,11 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     }
     if (pitch * (uint64_t)(strips ? kStripBRows : kTile) >= (1ull << 32)) {
         set_error("K2: rows of %llu nibble bytes exceed the 32-bit DMA offsets; use variant 2",
-                  (unsigned long long)row_bytes);
+                  (unsigned long long)shadow_row_bytes);
         return STORM_HIP_EINVAL;
     }
-    const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
     if (strips)
-        if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, a_tile))
+        if (int rc = ensure_strip_items(ctx, ranges, chunk_slices, shard_rank, shard_count, a_tile))
             return rc;
     // accumulators are f32: a k-slice must stay below 2^24 bits
     if ((uint64_t)ctx->k2_stages_per_item * 128u >= (1u << 24)) {
@@ -1176,18 +1272,33 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     const uint64_t key[4] = {(uint64_t)(uintptr_t)X, shadow_generation,
                              ((uint64_t)shard_rank << 32) | shard_count,
                              (pitch << 20) ^ (n_rows_dst << 2) ^ (uint64_t)strip_mode};
-    const bool shadow_valid = ctx->keep_shadow && shadow_generation != 0 &&
+    const bool shadow_valid = ctx->keep_shadow && shadow_generation != 0 && n_chunks == 1 &&
                               !memcmp(key, ctx->x4_key, sizeof(key)) &&
                               (ctx->k2_debug >> 8) == 0;
-    if (ctx->n_items > 0 || n_strip > 0) {
-        const dim3 grid = expand_grid(n_rows_dst, stride_words);
-        if (!shadow_valid)
-        hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, X, stride_words,
-                           std::min(n_rows_src, n_rows_dst), n_rows_dst,
-                           reinterpret_cast<uint4*>(ctx->d_x4), shard_rank, shard_count,
-                           (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u, pitch / 16);
+    // what this shard expands: its own k-slices + the leftover slices (strips; within a chunk
+    // the rule runs over the chunk's own slice numbers, as its work list does), or its own
+    // k-groups (tile kernel)
+    const ExpandOwn own = strips ? ExpandOwn{shard_rank, shard_count, 3u,
+                                             strip_modulo_slices(chunk_slices, shard_count)}
+                                 : ExpandOwn{shard_rank, shard_count, 7u, 0xffffffffu};
+    const uint32_t nib = (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u;
+    const uint64_t n_src = std::min(n_rows_src, n_rows_dst);
+    for (uint32_t chunk = 0; chunk < n_chunks && (ctx->n_items > 0 || n_strip > 0); ++chunk) {
+        if (!shadow_valid) {
+            if (n_chunks == 1) {
+                hipLaunchKernelGGL(expand_fp4_kernel, expand_grid(n_rows_dst, stride_words), dim3(256), 0,
+                                   ctx->stream, X, stride_words, n_src, n_rows_dst,
+                                   reinterpret_cast<uint4*>(ctx->d_x4), own, nib, pitch / 16);
+            } else {
+                const uint64_t h0 = (uint64_t)chunk * chunk_slices * 8u, h1 = h0 + (uint64_t)chunk_slices * 8u;
+                hipLaunchKernelGGL(expand_fp4_kernel, expand_grid(n_rows_dst, stride_words, h1 - h0),
+                                   dim3(256), 0, ctx->stream, X, stride_words, n_src, n_rows_dst,
+                                   reinterpret_cast<uint4*>(ctx->d_x4), own, nib, pitch / 16, h0, h1, h0);
+            }
+        }
         STORM_HIP_TRY(hipGetLastError());
-        memcpy(ctx->x4_key, key, sizeof(key));
+        if (n_chunks == 1) memcpy(ctx->x4_key, key, sizeof(key));
+        else memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
         if (n_strip > 0) {
             kernel_time_mark(ctx);
             const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
@@ -1315,7 +1426,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     }
     ctx->last_info[0] = ctx->n_items + n_strip;
     ctx->last_info[1] = ctx->k2_stages_per_item;
-    ctx->last_info[2] = 0;
+    ctx->last_info[2] = n_chunks;
     ctx->last_info[3] = 0;
     return launch_fold_slots(ctx, d_total);
 }
@@ -1381,7 +1492,7 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
         hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                            stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
                            reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)),
-                           0u, 1u, 2u, pitch / 16);
+                           kExpandAll, 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
     }
     if (ctx->k2_shape == 16)
@@ -1557,7 +1668,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         const dim3 grid = expand_grid(n_rows4, m->stride_words);
         hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                            m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
-                           reinterpret_cast<uint4*>(ctx->d_x4), 0u, 1u, 2u, pitch / 16);
+                           reinterpret_cast<uint4*>(ctx->d_x4), kExpandAll, 2u, pitch / 16);
         // rows [band_row0, band_end) are written; the columns run over the whole matrix
         rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)band_end, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u, (uint32_t)band_row0,
@@ -1618,8 +1729,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
             const dim3 grid = expand_grid(rows_dst, stride_words);
             hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
                                stride_words, std::min<uint64_t>(m->n_rows_pad, rows_dst), rows_dst,
-                               reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)), 0u,
-                               1u, 2u, pitch / 16);
+                               reinterpret_cast<uint4*>(ctx->d_x4 + (side ? rows_a * pitch : 0)),
+                               kExpandAll, 2u, pitch / 16);
         }
         rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)a->n_rows, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
@@ -1636,7 +1747,43 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
     std::vector<RowRange> ranges;
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     return launch_pairw_mfma_ranges(ctx, m->d, m->stride_words, m->n_rows_pad, n_rows4, ranges,
-                                    shard_rank, shard_count, strip_mode, d_total, m->generation);
+                                    shard_rank, shard_count, strip_mode, d_total, m->generation,
+                                    m->n_words);
 }
 
 }  // namespace storm
+
+// Host-only view of the default path's work decomposition (no device is touched): what a shard
+// of a multi-GPU run multiplies, so that the partition of the pair space can be checked — and
+// rehearsed with CPU partials — without a GPU (tests/test_dist_cpu.py).
+extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                                    uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
+                                    uint64_t* n_items) {
+    using namespace storm;
+    if (!n_items || shard_count == 0 || shard_rank >= shard_count || n_words == 0) {
+        set_error("strip_plan: bad arguments");
+        return STORM_HIP_EINVAL;
+    }
+    try {
+        const uint32_t n_kslices = (n_words + 3u) / 4u;  // slices that hold data (launch_pairw_mfma_ranges)
+        std::vector<RowRange> ranges;
+        if (n_rows > 1) ranges.push_back({0, n_rows});
+        std::vector<StripItem> items;
+        uint32_t qb[8], qc[8];
+        build_strip_items(StripShaping{}, ranges, n_kslices, shard_rank, shard_count,
+                          (uint32_t)kStripATile, items, qb, qc);
+        *n_items = items.size();
+        if (out)
+            for (uint64_t i = 0; i < std::min<uint64_t>(capacity_items, items.size()); ++i) {
+                out[i * 5 + 0] = items[i].a_row0;
+                out[i * 5 + 1] = items[i].diag;
+                out[i * 5 + 2] = items[i].j0;
+                out[i * 5 + 3] = items[i].j1;
+                out[i * 5 + 4] = items[i].ks;
+            }
+    } catch (const std::exception& e) {
+        set_error("strip_plan: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+    return STORM_HIP_OK;
+}

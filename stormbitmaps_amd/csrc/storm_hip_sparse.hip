@@ -284,9 +284,32 @@ void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
     delete s;
 }
 
+int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    if (!ctx || !h_total) {
+        set_error("pairw_sparse_end: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
                            uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total) {
-    if (!ctx || !cs || !h_total) {
+    if (!h_total) {
+        set_error("pairw_sparse: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    if (int rc = storm_hip_pairw_sparse_begin(ctx, cs, shard_rank, shard_count)) return rc;
+    return storm_hip_pairw_sparse_end(ctx, h_total);
+}
+
+// Launches this shard's share into the context's result word; _end fetches it.
+int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
+                                 uint32_t shard_rank, uint32_t shard_count) {
+    if (!ctx || !cs) {
         set_error("pairw_sparse: NULL argument");
         return STORM_HIP_EINVAL;
     }
@@ -313,9 +336,6 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;
-        STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t),
-                                     hipMemcpyDeviceToHost, ctx->stream));
-        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         return STORM_HIP_OK;
     }
     const uint32_t seg_len = (uint32_t)ctx->seg_rows;
@@ -355,9 +375,6 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
                                        s->seg_row_sum,
                                        reinterpret_cast<uint64_t*>(ctx->d_scalar)))
         return rc;
-    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STORM_HIP_OK;
 }
 

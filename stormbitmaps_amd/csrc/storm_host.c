@@ -901,9 +901,17 @@ uint64_t STORM_bitmap_cont_intersect_cardinality(
  * ---------------------------------------------------------------------------------------- */
 STORM_t* STORM_new() { return (STORM_t*)calloc(1, sizeof(STORM_t)); }
 
+/* device state of a STORM_t handle: one replica of the flattened arena per configured GPU */
+typedef struct {
+    storm_hip_sparse_t* a[MAX_DEVICES];
+} sparse_state_t;
+
 static void storm_drop_device(STORM_t* h) {
     if (h->hip_arena) {
-        storm_hip_sparse_destroy(g_ctx[0], (storm_hip_sparse_t*)h->hip_arena);
+        sparse_state_t* st = (sparse_state_t*)h->hip_arena;
+        for (int d = 0; d < MAX_DEVICES; ++d)
+            if (st->a[d]) storm_hip_sparse_destroy(g_ctx[d], st->a[d]);
+        free(st);
         h->hip_arena = NULL;
     }
     h->hip_dirty = 1;
@@ -949,8 +957,29 @@ uint64_t STORM_serialized_size(const STORM_t* h) { /* storm.c:963-973 */
     return bytes + 2 * sizeof(uint32_t);
 }
 
-/* Flatten rows -> blocks into the arrays storm_hip_sparse_create() takes (storm_hip.h). */
-static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
+/* Fingerprint of what the device arena was built from: rows, blocks per row, and per block its
+ * id, kind and set-bit count. STORM_bitmap_cont_add / STORM_bitmap_add are public (storm.h:203-222)
+ * and a caller may use them on h->conts[i] directly, behind STORM_add's back; O(blocks) per call
+ * makes such an edit rebuild the arena instead of returning the old total. (In-place edits of a
+ * block's words that keep its set-bit count are not seen: call STORM_hip_invalidate.) */
+static uint64_t storm_fingerprint(const STORM_t* h) {
+    uint64_t f = 1469598103934665603ull ^ h->n_conts;
+    for (uint32_t i = 0; i < h->n_conts; ++i) {
+        const STORM_bitmap_cont_t* r = &h->conts[i];
+        f = (f ^ r->n_bitmaps) * 1099511628211ull;
+        for (uint32_t b = 0; b < r->n_bitmaps; ++b) {
+            const STORM_bitmap_t* blk = &r->bitmaps[b];
+            f = (f ^ blk->id) * 1099511628211ull;
+            f = (f ^ (((uint64_t)blk->n_bitmap << 32) | blk->n_scalar)) * 1099511628211ull;
+            f = (f ^ blk->n_bits_set) * 1099511628211ull;
+        }
+    }
+    return f;
+}
+
+/* Flatten rows -> blocks into the arrays storm_hip_sparse_create() takes (storm_hip.h), once, and
+ * build one arena replica per configured device. */
+static int storm_build_arena(STORM_t* h) {
     uint64_t n_blocks = 0, n_list = 0, n_dense = 0;
     for (uint32_t i = 0; i < h->n_conts; ++i)
         for (uint32_t b = 0; b < h->conts[i].n_bitmaps; ++b) {
@@ -958,6 +987,7 @@ static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
             ++n_blocks;
             if (blk->n_bitmap) ++n_dense; else n_list += blk->n_scalar;
         }
+    sparse_state_t* st = (sparse_state_t*)calloc(1, sizeof(*st));
     uint64_t* row_off = (uint64_t*)malloc((h->n_conts + 1ull) * sizeof(uint64_t));
     uint32_t* ids = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
     uint8_t* kinds = (uint8_t*)malloc(n_blocks + 1);
@@ -966,7 +996,7 @@ static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
     uint16_t* lists = (uint16_t*)malloc((n_list + 1) * sizeof(uint16_t));
     uint64_t* words = (uint64_t*)malloc((n_dense * BLOCK_WORDS + 1) * sizeof(uint64_t));
     int rc = -1;
-    if (row_off && ids && kinds && offs && lens && lists && words) {
+    if (st && row_off && ids && kinds && offs && lens && lists && words) {
         uint64_t nb = 0, nl = 0, nw = 0;
         for (uint32_t i = 0; i < h->n_conts; ++i) {
             row_off[i] = nb;
@@ -989,41 +1019,74 @@ static int storm_build_arena(STORM_t* h, storm_hip_ctx_t* ctx) {
             }
         }
         row_off[h->n_conts] = nb;
-        storm_hip_sparse_t* arena = NULL;
-        if (storm_hip_sparse_create(ctx, h->n_conts, n_blocks, row_off, ids, kinds, offs, lens,
-                                    lists, n_list, words, n_dense * BLOCK_WORDS,
-                                    &arena) == STORM_HIP_OK) {
-            h->hip_arena = arena;
-            h->hip_dirty = 0;
-            h->hip_generation = g_config_generation;
-            rc = 0;
-        } else {
-            device_error("storm_hip_sparse_create");
+        rc = 0;
+        for (int d = 0; d < g_n_devices && rc == 0; ++d) {
+            storm_hip_ctx_t* ctx = device_ctx(d);
+            if (!ctx || storm_hip_sparse_create(ctx, h->n_conts, n_blocks, row_off, ids, kinds, offs,
+                                                lens, lists, n_list, words, n_dense * BLOCK_WORDS,
+                                                &st->a[d]) != STORM_HIP_OK) {
+                device_error("storm_hip_sparse_create");
+                rc = -1;
+            }
         }
     }
     free(row_off); free(ids); free(kinds); free(offs); free(lens); free(lists); free(words);
+    if (rc == 0) {
+        h->hip_arena = st;
+        h->hip_dirty = 0;
+        h->hip_generation = g_config_generation;
+        h->hip_fingerprint = storm_fingerprint(h);
+    } else if (st) {
+        for (int d = 0; d < MAX_DEVICES; ++d)
+            if (st->a[d]) storm_hip_sparse_destroy(g_ctx[d], st->a[d]);
+        free(st);
+    }
     return rc;
 }
 
+/* all configured devices work concurrently on disjoint shards; the host adds the partials */
 static uint64_t storm_pairw_device(STORM_t* h) {
     if (h->n_conts < 2) return 0;
-    storm_hip_ctx_t* ctx = device_ctx(0);
-    if (!ctx) return ALL_PAIRS_FAILED;
-    if (!h->hip_arena || h->hip_dirty || h->hip_dirty != 0 ||
-        h->hip_generation != g_config_generation) {
-        if (h->hip_arena) {
-            storm_hip_sparse_destroy(ctx, (storm_hip_sparse_t*)h->hip_arena);
-            h->hip_arena = NULL;
+    configure_from_env();
+    if (!h->hip_arena || h->hip_dirty || h->hip_generation != g_config_generation ||
+        h->hip_fingerprint != storm_fingerprint(h)) {
+        storm_drop_device(h);
+        if (storm_build_arena(h)) return ALL_PAIRS_FAILED;
+    }
+    sparse_state_t* st = (sparse_state_t*)h->hip_arena;
+    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
+    for (int d = 0; d < g_n_devices; ++d) {
+        const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+        if (storm_hip_pairw_sparse_begin(g_ctx[d], st->a[d], rank, world) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_sparse_begin");
+            return ALL_PAIRS_FAILED;
         }
-        if (storm_build_arena(h, ctx)) return ALL_PAIRS_FAILED;
     }
     uint64_t total = 0;
-    if (storm_hip_pairw_sparse(ctx, (storm_hip_sparse_t*)h->hip_arena, g_shard_rank,
-                               g_shard_count, &total) != STORM_HIP_OK) {
-        device_error("storm_hip_pairw_sparse");
-        return ALL_PAIRS_FAILED;
+    for (int d = 0; d < g_n_devices; ++d) {
+        uint64_t part = 0;
+        if (storm_hip_pairw_sparse_end(g_ctx[d], &part) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_sparse_end");
+            return ALL_PAIRS_FAILED;
+        }
+        total += part;
     }
     return total;
+}
+
+/* Extensions (storm.h): forget the device copy of a handle whose public members were edited
+ * in place (the reference structs are not opaque, storm.h:157-200); the next all-pairs call
+ * uploads again. */
+int STORM_hip_invalidate(STORM_t* h) {
+    if (!h) return -1;
+    storm_drop_device(h);
+    return 0;
+}
+
+int STORM_contig_hip_invalidate(STORM_contiguous_t* h) {
+    if (!h) return -1;
+    contig_drop_device(h);
+    return 0;
 }
 
 uint64_t STORM_pairw_intersect_cardinality(STORM_t* h) { /* storm.c:877-895 */

@@ -1,10 +1,18 @@
-"""One process per GPU: shard the pair space, all-reduce the 8-byte total.
+"""One process per GPU: shard the all-pairs work, all-reduce the 8-byte total.
 
-The pair space N(N-1)/2 is cut into segments (A block x run of B rows) and rank r of G takes
-every G-th segment (storm_hip_pairw_dense's shard arguments). X is replicated on every GPU,
-so the only inter-GPU exchange is one uint64 sum: ``torch.distributed.all_reduce`` on a
-1-element int64 tensor — backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU
-tests. Integer addition makes the result independent of G.
+X is replicated on every GPU and rank r of G multiplies its share of the work of the default
+(matrix-core strip) path — ``storm_hip_pairw_dense(..., shard_rank, shard_count)``. The share is
+two-level (``storm_hip_strip_plan`` in include/storm_hip.h):
+
+  * whole k-slices (256 bits of every row): slice ks goes to rank ks % G, so a rank expands and
+    multiplies 1/G of the columns against the whole pair space;
+  * the n_kslices % G leftover slices are cut along the PAIR space (A tile x run of B blocks),
+    longest item first onto the least loaded rank.
+
+The only inter-GPU exchange is one uint64 sum: ``torch.distributed.all_reduce`` on a 1-element
+int64 tensor — backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+Integer addition makes the result independent of G. (The popcount fallback kernel, used only for
+rows beyond the strips' reach, shards its segment list cyclically instead.)
 """
 from __future__ import annotations
 
@@ -28,9 +36,24 @@ def init_process_group(backend: str):
     return dist
 
 
-def shard_segments(n_segments: int, rank: int, world: int):
-    """Indices of the segments rank `rank` owns (cyclic, as ensure_segments() in storm_hip.hip)."""
-    return range(rank, n_segments, world)
+def strip_plan(n_rows: int, n_words: int, rank: int, world: int):
+    """The work items rank `rank` of `world` multiplies on the default path, as an [n, 5] uint32
+    array of {a_row0, diag, j0, j1, ks} (see storm_hip_strip_plan in include/storm_hip.h).
+    Host-only: computed by libstorm_hip.so without touching a device."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    lib = _lib.load()
+    n = C.c_uint64(0)
+    _lib.check(lib.storm_hip_strip_plan(n_rows, n_words, rank, world, None, 0, C.byref(n)),
+               "storm_hip_strip_plan")
+    out = np.zeros((int(n.value), 5), dtype=np.uint32)
+    if n.value:
+        _lib.check(lib.storm_hip_strip_plan(n_rows, n_words, rank, world, out.ctypes.data_as(C.c_void_p),
+                                            n.value, C.byref(n)), "storm_hip_strip_plan")
+    return out
 
 
 def allreduce_total(partial: int, device=None) -> int:

@@ -118,10 +118,13 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     return STORM_HIP_OK;
 }
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) { (void)ctx; free(s); }
-int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s, uint32_t shard_rank,
-                           uint32_t shard_count, uint64_t* h_total) {
-    (void)ctx;
+int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s, uint32_t shard_rank,
+                                 uint32_t shard_count) {
     if (shard_rank >= shard_count) return STORM_HIP_EINVAL;
-    *h_total = shard_rank == 0 ? s->set_bits : 0;
+    ctx->pending = shard_rank == 0 ? s->set_bits : 0;
+    return STORM_HIP_OK;
+}
+int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    *h_total = ctx->pending;
     return STORM_HIP_OK;
 }

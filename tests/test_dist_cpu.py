@@ -1,53 +1,107 @@
-"""The multi-rank path on CPU (gloo, world_size 2): shards partition the segment list and the
-all-reduced partial totals equal the single-rank total. The per-segment partials here come
-from the ORACLE (checker) because the product kernels need a GPU; what is under test is the
-host-side sharding + all-reduce plumbing of stormbitmaps_amd/dist.py, which bench.py uses
-unchanged with backend "nccl" (RCCL)."""
+"""The multi-rank path on CPU (gloo, world_size 2) with the ownership rule the DEFAULT device
+path uses: every rank asks libstorm_hip.so for its strip work list (storm_hip_strip_plan —
+host-only, the same planner the launch uses), the lists of all ranks must tile (pair, k-slice)
+space exactly once and balance, and the all-reduced partial totals must equal the single-rank
+total. The per-item partials here come from the ORACLE (checker) because the product kernels
+need a GPU; what is under test is the ownership rule and the all-reduce plumbing of
+stormbitmaps_amd/dist.py, which bench.py uses unchanged with backend "nccl" (RCCL)."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 from stormbitmaps_amd import dist as sdist
 from stormbitmaps_amd import synth
 
-A_BLOCK, SEG_ROWS = 128, 256
+A_TILE, B_BLOCK, SLICE_WORDS = 256, 64, 4
 
 
-def segments(n_rows):
-    """Same construction as ensure_segments() in csrc/storm_hip.hip: full segments, then diagonals."""
-    full, diag = [], []
-    for a0 in range(0, n_rows, A_BLOCK):
-        a_end = min(a0 + A_BLOCK, n_rows)
-        if a_end - a0 > 1:
-            diag.append((a0, a_end, a0, a_end))
-        for j in range(a0 + A_BLOCK, n_rows, SEG_ROWS):
-            full.append((a0, a_end, j, min(j + SEG_ROWS, n_rows)))
-    return full, diag
+def _n_kslices(n_words):
+    return (n_words + SLICE_WORDS - 1) // SLICE_WORDS   # slices that hold data (padding is never multiplied)
 
 
-def _segment_total(orc, mat, seg):
-    a0, a_end, j_lo, j_hi = seg
-    t = orc.tile_counts(mat, a0, a_end, j_lo, j_hi)
-    if j_lo == a0:
-        t = np.triu(t, k=1)
-    return int(t.sum())
+def _cover(n_rows, n_words, world):
+    """cover[ks][i, j] = how many items of all ranks count pair (i, j) in k-slice ks; per-rank cost."""
+    pad = (n_rows + A_TILE - 1) // A_TILE * A_TILE
+    ks_n = _n_kslices(n_words)
+    cover = np.zeros((ks_n, pad, pad), dtype=np.uint8)
+    cost = []
+    for r in range(world):
+        items = sdist.strip_plan(n_rows, n_words, r, world)
+        c = 0
+        for a0, diag, j0, j1, ks in items.tolist():
+            if diag:
+                cover[ks, a0:a0 + A_TILE, a0:a0 + A_TILE] += np.triu(np.ones((A_TILE, A_TILE), np.uint8), k=1)
+            cover[ks, a0:a0 + A_TILE, j0 * B_BLOCK:min(j1 * B_BLOCK, pad)] += 1
+            c += (j1 - j0) + 4 * diag
+        cost.append(c)
+    return cover, cost
 
 
-def _worker(rank, world, port, n_rows, want, q):
+@pytest.mark.parametrize("n_rows,n_words,worlds", [
+    (700, 32, (1, 2, 3, 8)),      # 8 k-slices: whole slices + leftover mix
+    (1500, 4, (1, 2, 3, 5, 8)),   # ONE k-slice: fewer slices than ranks -> pure pair-space split
+    (300, 100, (2, 3, 7)),        # 25 slices, 7 ranks: 3 whole each + 4 leftover
+])
+def test_strip_plans_of_all_ranks_tile_the_work_exactly_once(n_rows, n_words, worlds):
+    pad = (n_rows + A_TILE - 1) // A_TILE * A_TILE
+    want = np.zeros((pad, pad), dtype=np.uint8)
+    want[:n_rows, :] = np.triu(np.ones((n_rows, pad), np.uint8), k=1)   # B blocks run to the padded edge
+    for world in worlds:
+        cover, cost = _cover(n_rows, n_words, world)
+        for ks in range(cover.shape[0]):
+            # every real pair i < j < n_rows exactly once; padded (all-zero) rows may be visited, never twice
+            assert np.array_equal(cover[ks][:n_rows, :n_rows], want[:n_rows, :n_rows]), (world, ks)
+            assert cover[ks].max() <= 1
+        assert sum(cost) == _cover(n_rows, n_words, 1)[1][0] or world == 1
+
+
+def test_headline_shape_balances_within_three_percent_for_any_world():
+    """c2 (N = 10000, W = 1024: 256 k-slices): stage counts per rank for G = 2..8."""
+    for world in (2, 3, 4, 5, 6, 7, 8):
+        cost = []
+        for r in range(world):
+            it = sdist.strip_plan(10000, 1024, r, world)
+            cost.append(int((it[:, 3] - it[:, 2]).sum() + 4 * it[:, 1].sum()))
+        assert max(cost) <= 1.03 * (sum(cost) / world), (world, cost)
+    # a matrix with a single k-slice still splits 8 ways (pair-space sharding)
+    cost = []
+    for r in range(8):
+        it = sdist.strip_plan(10000, 4, r, 8)
+        cost.append(int((it[:, 3] - it[:, 2]).sum() + 4 * it[:, 1].sum()))
+    assert min(cost) > 0 and max(cost) <= 1.03 * (sum(cost) / 8), cost
+
+
+def _item_total(orc, mat, item):
+    """Oracle partial of one strip item: pairs (A tile x B blocks [+ own triangle]) on k-slice ks."""
+    a0, diag, j0, j1, ks = (int(x) for x in item)
+    n = mat.shape[0]
+    w0 = ks * SLICE_WORDS
+    sl = np.ascontiguousarray(mat[:, w0:w0 + SLICE_WORDS])
+    if sl.shape[1] == 0:
+        return 0
+    a1 = min(a0 + A_TILE, n)
+    total = 0
+    if diag and a1 - a0 > 1:
+        total += int(np.triu(orc.tile_counts(sl, a0, a1, a0, a1), k=1).sum())
+    b0, b1 = min(j0 * B_BLOCK, n), min(j1 * B_BLOCK, n)
+    if b1 > b0 and a1 > a0:
+        total += int(orc.tile_counts(sl, a0, a1, b0, b1).sum())
+    return total
+
+
+def _worker(rank, world, port, n_rows, n_bits, want, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from tests._orc import Oracle
     orc = Oracle()
     d = sdist.init_process_group("gloo")
-    mat = synth.dense_matrix(2048, n_rows, 700, seed=42)
-    full, diag = segments(n_rows)
+    mat = synth.dense_matrix(n_bits, n_rows, 700, seed=42)
 
     def partial(r, w):
-        mine = [full[i] for i in sdist.shard_segments(len(full), r, w)] + \
-               [diag[i] for i in sdist.shard_segments(len(diag), r, w)]
-        return sum(_segment_total(orc, mat, s) for s in mine)
+        return sum(_item_total(orc, mat, it) for it in sdist.strip_plan(n_rows, mat.shape[1], r, w))
 
     total = sdist.sharded_pairw(partial)
     q.put((rank, total, partial(rank, world)))
@@ -56,31 +110,17 @@ def _worker(rank, world, port, n_rows, want, q):
     assert total == want
 
 
-def test_two_rank_gloo_allreduce_equals_single_rank(orc):
+@pytest.mark.parametrize("n_bits", (2048, 700))   # 8 k-slices: whole slices only | 3 slices: 1 whole each + 1 leftover
+def test_two_rank_gloo_allreduce_equals_single_rank(orc, n_bits):
     n_rows = 700
-    mat = synth.dense_matrix(2048, n_rows, 700, seed=42)
+    mat = synth.dense_matrix(n_bits, n_rows, 700, seed=42)
     want = orc.wrapper_diag(mat)
-    full, diag = segments(n_rows)
-    # the shards partition the segment list for any world size
-    for w in (1, 2, 3, 8):
-        for lst in (full, diag):
-            got = sorted(i for r in range(w) for i in sdist.shard_segments(len(lst), r, w))
-            assert got == list(range(len(lst)))
-    # ...and the segments tile the strict upper triangle exactly once
-    cover = np.zeros((n_rows, n_rows), dtype=np.int32)
-    for a0, a_end, j_lo, j_hi in full + diag:
-        if j_lo == a0:
-            cover[a0:a_end, j_lo:j_hi] += np.triu(np.ones((a_end - a0, j_hi - j_lo), dtype=np.int32), k=1)
-        else:
-            cover[a0:a_end, j_lo:j_hi] += 1
-    assert np.array_equal(cover, np.triu(np.ones((n_rows, n_rows), dtype=np.int32), k=1))
-
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, want, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_bits, want, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(2))

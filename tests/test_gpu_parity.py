@@ -440,8 +440,12 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sock:   # a free port: fixed ones collide with concurrent runs / TIME_WAIT
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(29540 + ranks), os.path.join(root, "bench.py"),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", str(ranks), "--backend", "gloo", "--all-on-device0", "--steps", "3", "--warmup", "1",
            "--rows", "3000", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
@@ -452,6 +456,10 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     assert out["n_gpus"] == ranks and out["verified_against_column_identity"] is True
     assert out["config"]["kernel_variant"] == 4
     assert out["shadow_resident"]["total_matches"] is True
+    # the per-rank diagnostics a scaling run is read by
+    assert [r["rank"] for r in out["per_rank"]] == list(range(ranks))
+    assert all(r["kernel_ms"] > 0 and r["work_items"] > 0 for r in out["per_rank"])
+    assert 0 < out["roofline"]["frac_whole_pass"] <= out["roofline"]["frac"] * 1.05
 
 
 def test_benchmark_cli_rows_agree_with_golden_totals():

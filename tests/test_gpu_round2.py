@@ -164,3 +164,112 @@ def test_strip_kernel_mfma_shapes_agree(hip_ctx, orc):
     finally:
         hip_ctx.set_option("k2_shape", 16)
     assert hip_ctx.get_option("k2_shape") == 16
+
+
+@pytest.mark.parametrize("M,N,worlds", [(256, 3000, (2, 8)), (4096, 1500, (3, 5, 7)), (65536, 2600, (3, 6, 16)),
+                                        (700, 513, (2, 3))])
+def test_two_level_ownership_partitions_for_any_world(hip_ctx, orc, M, N, worlds):
+    """Shards of the default path: whole k-slices per rank + leftover slices cut along the pair
+    space (storm_hip_strip_plan). Also with fewer k-slices than ranks (M = 256: one slice, pure
+    pair-space split) and world sizes that do not divide the slice count."""
+    mat = synth.dense_matrix_c(M, N, max(1, M // 3), seed=M + N)
+    want = orc.truth_columns(mat)
+    m = hip_ctx.matrix_from_host(mat)
+    assert m.pairw() == want
+    for w in worlds:
+        parts = [m.pairw(r, w) for r in range(w)]
+        assert sum(parts) == want, (w, parts)
+        if M <= 256 * w and N >= 2000:   # fewer slices than ranks: every rank still gets work
+            assert min(parts) > 0, (w, parts)
+    m.close()
+
+
+def test_hbm_tiled_passes_under_a_shadow_budget(hip_ctx, orc):
+    """Option k2_shadow_budget_mb: a matrix whose FP4 shadow (4 x the bits) exceeds the budget is
+    multiplied k-chunk by k-chunk over a compact shadow of one chunk (bounded footprint for any
+    M x N). Same totals as the one-piece pass, also per shard, with chunk counts that do and do not
+    divide the slice count (the last chunk overhangs into zero columns)."""
+    cases = (((70000, 1029, 20000), (4, 2, 1)),      # 274 slices, shadow 36 MiB
+             ((65536, 6000, 32768), (64, 20)))       # 256 slices, shadow 192 MiB
+    try:
+        for (M, N, d), budgets in cases:
+            m = hip_ctx.matrix(N, (M + 63) // 64)
+            m.fill_synthetic(M, d, seed=N)
+            want = m.column_identity()
+            hip_ctx.set_option("k2_shadow_budget_mb", 0)
+            assert m.pairw() == want and hip_ctx.last_launch_info()["word_pairs_executed"] == 1
+            if N < 2000:
+                assert want == orc.truth_columns(m.download())
+            for mb in budgets:
+                hip_ctx.set_option("k2_shadow_budget_mb", mb)
+                assert m.pairw() == want, (M, N, mb)
+                chunks = hip_ctx.last_launch_info()["word_pairs_executed"]   # out[2]: k-chunks of the pass
+                assert chunks > 1, (M, N, mb, chunks)
+                assert sum(m.pairw(r, 3) for r in range(3)) == want, (M, N, mb)
+                hip_ctx.set_option("keep_shadow", 1)     # a chunked pass keeps nothing: must still be right
+                assert m.pairw() == want and m.pairw() == want
+                hip_ctx.set_option("keep_shadow", 0)
+            m.close()
+    finally:
+        hip_ctx.set_option("k2_shadow_budget_mb", 96 * 1024)
+        hip_ctx.set_option("keep_shadow", 0)
+
+
+def test_device_copies_follow_direct_edits_and_invalidate(lib, orc):
+    """the reference structs are public. STORM_t: rows edited with the public per-row
+    adder behind STORM_add's back are caught by the fingerprint; in-place edits of the dense
+    buffer need STORM_contig_hip_invalidate."""
+    M, N, d = 131072, 300, 900
+    rows = synth.positions(M, N + 1, d, seed=21)
+    s = sb.Storm()
+    for r in rows[:N]:
+        s.add(r)
+    first = s.pairw_intersect_cardinality()
+    assert first == orc.storm(rows[:N]).pairw()
+    s.add(np.zeros(0, dtype=np.uint32))                       # an empty row (storm.c:864) ...
+    assert s.pairw_intersect_cardinality() == first
+    # ... filled directly through the public per-row API on h->conts[N]
+    conts = C.cast(s._h, C.POINTER(C.c_void_p))[0]            # STORM_s.conts
+    cont_size = 32                                            # sizeof(STORM_bitmap_cont_t): 2 ptrs + 3 u32 (+pad)
+    extra = np.ascontiguousarray(rows[N], dtype=np.uint32)
+    lib.STORM_bitmap_cont_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    assert lib.STORM_bitmap_cont_add(C.c_void_p(conts + N * cont_size), _p(extra), extra.size) == 1
+    assert s.pairw_intersect_cardinality() == orc.storm(rows).pairw()
+    s.free()
+    # dense: flip bits in h->data in place
+    c = sb.StormContig(4096)
+    mat = synth.dense_matrix_c(4096, 200, 1000, seed=3)
+    for r in synth.positions_from_dense(mat):
+        c.add(r)
+    assert c.pairw_intersect_cardinality() == orc.truth_columns(mat)
+    data_ptr = C.cast(c._h, C.POINTER(C.c_void_p))[0]         # STORM_contiguous_s.data
+    host = np.ctypeslib.as_array(C.cast(data_ptr, C.POINTER(C.c_uint64)), shape=(200, 64))
+    host[:] = ~host
+    c.hip_invalidate()
+    assert c.pairw_intersect_cardinality() == orc.truth_columns(~mat)
+    c.free()
+
+
+def test_per_pair_matrix_in_bands_over_several_devices(lib, orc):
+    """STORM_contig_pairw_matrix with [0, 0, 0] configured: three contexts, each writes one band of
+    rows (bands cut for equal pair counts); buffer extent checked by the C entry point."""
+    M, N, d = 9000, 1100, 3000
+    mat = synth.dense_matrix_c(M, N, d, seed=5)
+    want = np.triu(orc.tile_counts(mat, 0, N, 0, N), k=1)
+    ids = (C.c_int * 3)(0, 0, 0)
+    try:
+        assert lib.STORM_hip_set_devices(3, ids) == 0
+        c = sb.StormContig(M)
+        for r in synth.positions_from_dense(mat):
+            c.add(r)
+        assert c.n_rows == N
+        assert np.array_equal(c.pairw_matrix(), want)
+        wide = np.full((N + 3, N + 7), 77, dtype=np.uint32)     # leading dimension > n_rows
+        assert lib.STORM_contig_pairw_matrix(c._h, 0, _p(wide), N + 3, N + 7) == 0
+        assert np.array_equal(wide[:N, :N], want) and (wide[N:] == 77).all() and (wide[:, N:] == 77).all()
+        small = np.zeros((N - 1, N), dtype=np.uint32)
+        assert lib.STORM_contig_pairw_matrix(c._h, 0, _p(small), N - 1, N) == -4
+        c.free()
+    finally:
+        one_dev = (C.c_int * 1)(0)
+        assert lib.STORM_hip_set_devices(1, one_dev) == 0

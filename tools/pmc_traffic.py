@@ -9,7 +9,11 @@ and writes the 4x larger FP4 shadow exactly once."""
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stormbitmaps_amd._lib import kernel_source_hash  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -38,7 +42,8 @@ def main():
                      "passes; tools/profile_default.sh + tools/pmc_traffic.py), headline shape. FETCH_SIZE "
                      "is KiB and on gfx950 reports half of a 16 B/lane stream: doubled here, checked on "
                      "expand_fp4_kernel (reads the bit matrix once, writes the 4x FP4 shadow once).")
-    entry = {"dominant_kernel": dominant,
+    entry = {"source_hash": kernel_source_hash(),  # bench.py ignores traffic measured on other sources
+             "dominant_kernel": dominant,
              "hbm_bytes_per_launch": sum(kernels[dominant].values()),
              "all_kernels_bytes_per_launch": sum(sum(v.values()) for v in kernels.values()),
              "kernels": kernels}
