@@ -160,7 +160,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 2, wn = wave & 3u;
-    const MfmaItem it = items[blockIdx.x];
+    const uint32_t item_idx = blockIdx.x;
+    const MfmaItem it = items[item_idx];
     const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
 
     // per-lane byte offset of its 16-byte operand piece inside a 32-row block, per k-step
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void pairw_fp4_kernel(
                     if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
                         const uint32_t c = (uint32_t)acc[m][n][r];
                         uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
-                        if (blockIdx.x < split_from) {
+                        if (item_idx < split_from) {
                             *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
                         } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
                             const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
@@ -1183,15 +1184,18 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
 }
 
 // Row pitch of the FP4 shadow. Rows whose byte length is a multiple of a large power of two put
-// every B block of a k-slice 2^21+ bytes apart, i.e. onto few L2 / memory channels; a few extra
-// 128-byte lines per row break the pattern (strip kernel 0.866 -> 0.835 ms at the headline
-// shape, its L2 misses 3.4 -> 0.86 GB per launch; 3 lines also suit the expansion's writes
-// better than 1). k2_pitch_pad: -1 = that rule, otherwise the pad in bytes.
-// The tile kernel (64-byte row pieces, A and B tiles) measured the other way round — 1.96 ms
-// dense, 2.25 ms padded for the materialised matrix — so the rule is for the strips only.
+// every row block of a k-slice 2^15+ bytes apart, i.e. into a handful of L2 sets and memory
+// channels; a few extra 128-byte lines per row break the pattern (strip kernel 0.866 -> 0.835 ms at
+// the headline shape, its L2 misses 3.4 -> 0.86 GB per launch; 3 lines also suit the expansion's
+// writes better than 1). k2_pitch_pad: -1 = that rule, otherwise the pad in bytes.
+// The tile kernel wants the same pad once its tiles are launched in XCD groups
+// (xcd_grouped_tiles): materialised matrix 1.72 ms dense, 1.56 ms with 384 B, 1.99 ms with 128 B
+// (profiles/r02_e_matrix_order_pad.txt). In round 1's row-major tile order it had measured the
+// other way round (1.96 dense, 2.25 padded).
 static uint64_t shadow_pitch(const storm_hip_ctx_t* ctx, uint64_t row_bytes, bool strips) {
+    (void)strips;
     if (ctx->k2_pitch_pad >= 0) return row_bytes + (uint64_t)ctx->k2_pitch_pad;
-    return row_bytes + (strips && row_bytes % 1024 == 0 ? 384u : 0u);
+    return row_bytes + (row_bytes % 1024 == 0 ? 384u : 0u);
 }
 
 // X: bit rows (stride_words per row), n_rows_src of them readable; the FP4 shadow gets
@@ -1615,6 +1619,34 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     return STORM_HIP_OK;
 }
 
+// Launch order of write-mode tiles for L2 reuse. A tile item streams 8 MiB per operand at the
+// headline shape (256 rows x all of k), twice an XCD's L2: in row-major order the 32 tiles an
+// XCD works on at a time share their A rows and nothing else, and the kernel fetched 12.6 GB per
+// launch from beyond L2 (47 % of its L2 requests missed; it ran at the HBM rate with the matrix
+// pipe 44 % busy: profiles/r02_d_*). Here the tiles [i0, i1) x [j0, j1) (upper triangle only when
+// `triangle`) are cut into groups of 4 x 8, group g goes to XCD g % 8 (block b runs on XCD b % 8:
+// observed, speed only), so the 32 workgroups of an XCD — which start together and advance along k
+// at the same pace — fetch 12 row-block slices per k-stage instead of 33.
+static void xcd_grouped_tiles(uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1, bool triangle,
+                              std::vector<std::pair<uint16_t, uint16_t>>& out) {
+    std::vector<std::vector<std::pair<uint16_t, uint16_t>>> per_xcd(8);
+    uint32_t g = 0;
+    for (uint32_t gi = i0; gi < i1; gi += 4)
+        for (uint32_t gj = triangle ? std::max(j0, gi / 8 * 8) : j0; gj < j1; gj += 8) {
+            std::vector<std::pair<uint16_t, uint16_t>>& dst = per_xcd[g % 8];
+            const size_t before = dst.size();
+            for (uint32_t i = gi; i < std::min(gi + 4, i1); ++i)
+                for (uint32_t j = std::max(gj, triangle ? i + 1 : gj); j < std::min(gj + 8, j1); ++j)
+                    dst.emplace_back((uint16_t)i, (uint16_t)j);
+            if (dst.size() != before) ++g;
+        }
+    size_t longest = 0;
+    for (auto& v : per_xcd) longest = std::max(longest, v.size());
+    for (size_t pos = 0; pos < longest; ++pos)
+        for (int x = 0; x < 8; ++x)
+            if (pos < per_xcd[x].size()) out.push_back(per_xcd[x][pos]);
+}
+
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
@@ -1654,8 +1686,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // where run_matrix_tiles may cut them along k
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
     const uint32_t t_lo = (uint32_t)(band_row0 / kTile), t_hi = (uint32_t)((band_end + kTile - 1) / kTile);
-    for (uint32_t i = t_lo; i < t_hi; ++i)
-        for (uint32_t j = i + 1; j < nT; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)j);
+    xcd_grouped_tiles(t_lo, t_hi, 0, nT, true, tiles);
     for (uint32_t i = t_lo; i < t_hi; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
     uint32_t* d_counts = nullptr;
     MatrixPlan plan;
@@ -1712,8 +1743,7 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
-    for (uint32_t i = 0; i < ta; ++i)
-        for (uint32_t j = 0; j < tb; ++j) tiles.emplace_back((uint16_t)i, (uint16_t)(ta + j));
+    xcd_grouped_tiles(0, ta, ta, ta + tb, false, tiles);
     uint32_t* d_counts = nullptr;  // per shadow row
     MatrixPlan plan;
     int rc = plan_matrix_tiles(ctx, tiles, total_stages, &plan);
