@@ -202,6 +202,16 @@ int STORM_clear(STORM_t* bitmap);
 uint64_t STORM_pairw_intersect_cardinality(STORM_t* bitmap);
 uint64_t STORM_pairw_intersect_cardinality_blocked(STORM_t* bitmap, uint32_t bsize);
 uint64_t STORM_serialized_size(const STORM_t* bitmap);
+/* Extension: the serialized form whose SIZE the reference defines (STORM_serialized_size,
+ * storm.c:372-394, :963-973) but never writes. STORM_serialize writes exactly
+ * STORM_serialized_size(h) bytes (layout: storm_host.c) and returns that count, 0 if `capacity`
+ * is too small. STORM_deserialize returns NULL on a malformed stream.
+ * STORM_serialized_pairw_intersect_cardinality computes the all-pairs total of a serialized
+ * container without building it on the host: the bytes are uploaded as they are and unpacked into
+ * the block arena by the device (`buf` 2-byte aligned; (uint64_t)-1 on failure). */
+uint64_t STORM_serialize(const STORM_t* bitmap, void* buf, uint64_t capacity);
+STORM_t* STORM_deserialize(const void* buf, uint64_t n_bytes);
+uint64_t STORM_serialized_pairw_intersect_cardinality(const void* buf, uint64_t n_bytes);
 /* (reference storm.h:231 declares STORM_intersect_cardinality_square but never defines it,
  *  storm.c:975; nothing to stand in for.) */
 

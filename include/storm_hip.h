@@ -52,6 +52,9 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx);
 /* ---- dense matrix lifecycle (device mirror of STORM_contiguous_t, storm.c:1001-1147) ---- */
 int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
                             storm_hip_matrix_t** out); /* zero-filled */
+/* change the logical row count (device mirror of a container that grows row by row, storm.c:1078):
+ * growing reallocates with amortised doubling and keeps the rows; new rows are zero until uploaded */
+int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t n_rows);
 /* copy n_rows host rows (row stride = src_stride_words) into rows [row0, row0+n_rows) */
 int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
                             uint64_t n_rows, const uint64_t* host_rows,
@@ -234,6 +237,11 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
                             const uint32_t* block_n, const uint16_t* list_pool,
                             uint64_t list_pool_len, const uint64_t* bitmap_pool,
                             uint64_t bitmap_pool_words, storm_hip_sparse_t** out);
+/* the same arena from a serialized STORM_t (STORM_serialize, storm.h; sizes as reference
+ * storm.c:372-394): the host walks the headers only, the payload bytes go up as they are and both
+ * block kinds are unpacked on the device. `buf` 2-byte aligned. */
+int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
+                                       storm_hip_sparse_t** out);
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
                            uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);

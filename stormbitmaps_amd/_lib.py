@@ -29,6 +29,7 @@ SIGNATURES = {
     "storm_hip_ctx_destroy": (None, [vp]),
     "storm_hip_matrix_create": (C.c_int, [vp, u64, u32, P(vp)]),
     "storm_hip_matrix_upload": (C.c_int, [vp, vp, u64, u64, vp, u64]),
+    "storm_hip_matrix_resize": (C.c_int, [vp, vp, u64]),
     "storm_hip_matrix_import": (C.c_int, [vp, vp, u64, u64, vp, u64]),
     "storm_hip_matrix_download": (C.c_int, [vp, vp, u64, u64, vp, u64]),
     "storm_hip_matrix_set_rows_from_positions": (C.c_int, [vp, vp, u64, u64, vp, vp]),
@@ -66,6 +67,7 @@ SIGNATURES = {
                                           P(vp)]),
     "storm_hip_sparse_destroy": (None, [vp, vp]),
     "storm_hip_pairw_sparse": (C.c_int, [vp, vp, u32, u32, P(u64)]),
+    "storm_hip_sparse_create_serialized": (C.c_int, [vp, vp, u64, P(vp)]),
     "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_sparse_last_census": (C.c_int, [vp, P(u64 * 4)]),
@@ -105,6 +107,9 @@ SIGNATURES = {
     "STORM_get_cpuid": (C.c_int, []),
     "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
     "STORM_contig_n_rows": (u64, [vp]),
+    "STORM_serialize": (u64, [vp, vp, u64]),
+    "STORM_deserialize": (vp, [vp, u64]),
+    "STORM_serialized_pairw_intersect_cardinality": (u64, [vp, u64]),
     "STORM_hip_invalidate": (C.c_int, [vp]),
     "STORM_contig_hip_invalidate": (C.c_int, [vp]),
     "STORM_hip_set_devices": (C.c_int, [C.c_int, vp]),

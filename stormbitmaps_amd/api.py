@@ -140,6 +140,34 @@ class Storm:
         """STORM_hip_invalidate (storm.h extension)."""
         self._lib.STORM_hip_invalidate(self._h)
 
+    def serialize(self) -> np.ndarray:
+        """STORM_serialize: exactly STORM_serialized_size(h) bytes (uint8 array)."""
+        n = self.serialized_size()
+        buf = np.zeros(n + (n & 1), dtype=np.uint8)
+        got = int(self._lib.STORM_serialize(self._h, _ptr(buf), n))
+        if got != n:
+            raise RuntimeError(f"STORM_serialize wrote {got} of {n} bytes")
+        return buf[:n]
+
+    @classmethod
+    def deserialize(cls, data) -> "Storm":
+        """STORM_deserialize; ValueError on a malformed stream."""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = self._lib.STORM_deserialize(_ptr(buf), buf.size)
+        if not self._h:
+            raise ValueError("STORM_deserialize: malformed stream")
+        return self
+
+    @staticmethod
+    def serialized_pairw_intersect_cardinality(data) -> int:
+        """All-pairs total of a serialized container, arena built on the device from the bytes."""
+        buf = np.ascontiguousarray(np.frombuffer(bytes(data), dtype=np.uint8))
+        lib = _lib.load()
+        return _all_pairs(lib.STORM_serialized_pairw_intersect_cardinality(_ptr(buf), buf.size),
+                          "STORM_serialized_pairw_intersect_cardinality")
+
     def pairw_intersect_cardinality(self) -> int:
         return _all_pairs(self._lib.STORM_pairw_intersect_cardinality(self._h),
                           "STORM_pairw_intersect_cardinality")  # storm.c:877

@@ -778,6 +778,48 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     return STORM_HIP_OK;
 }
 
+// Changes the logical row count. Growing beyond the allocation reallocates (at least doubling, so
+// that a container streamed in batch by batch copies O(n) rows in all) and carries the rows over
+// device to device; rows [old, new) are zero until uploaded; shrinking zeroes the dropped rows, so
+// "rows >= n_rows are zero" — what the kernels' padding relies on — always holds.
+int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t n_rows) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || n_rows >= (1ull << 32) - kABlockRows) {
+        set_error("matrix_resize: NULL matrix or row count out of range");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t row_bytes = m->stride_words * sizeof(uint64_t);
+    if (n_rows > m->n_rows_pad) {
+        const uint64_t want = (n_rows + kABlockRows - 1) / kABlockRows * kABlockRows;
+        const uint64_t new_pad = std::max<uint64_t>(want, 2 * m->n_rows_pad);
+        uint64_t* nd = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&nd), new_pad * row_bytes) != hipSuccess) {
+            set_error("matrix_resize: hipMalloc of %llu bytes failed",
+                      (unsigned long long)(new_pad * row_bytes));
+            return STORM_HIP_ENOMEM;
+        }
+        if (hipMemcpyAsync(nd, m->d, m->n_rows_pad * row_bytes, hipMemcpyDeviceToDevice,
+                           ctx->stream) != hipSuccess ||
+            hipMemsetAsync(nd + m->n_rows_pad * m->stride_words, 0,
+                           (new_pad - m->n_rows_pad) * row_bytes, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            (void)hipFree(nd);
+            set_error("matrix_resize: device copy failed");
+            return STORM_HIP_EHIP;
+        }
+        (void)hipFree(m->d);
+        m->d = nd;
+        m->n_rows_pad = new_pad;
+    } else if (n_rows < m->n_rows) {
+        STORM_HIP_TRY(hipMemsetAsync(m->d + n_rows * m->stride_words, 0,
+                                     (m->n_rows - n_rows) * row_bytes, ctx->stream));
+    }
+    m->n_rows = n_rows;
+    m->generation = next_matrix_generation();
+    return STORM_HIP_OK;
+}
+
 static int check_rows(const storm_hip_matrix_t* m, uint64_t row0, uint64_t n_rows) {
     if (!m) {
         set_error("NULL matrix");

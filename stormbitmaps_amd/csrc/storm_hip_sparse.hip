@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <exception>
 
 using namespace storm;
 
@@ -41,6 +42,7 @@ namespace {
 
 constexpr uint32_t kBlockWords = 1024;  // 65536 bits
 constexpr uint32_t kMaxBlockId = 65536;  // uint32 positions / 65536 bits per block
+constexpr uint32_t kSerialMagic = 0x314d5453u;  // "STM1": second header word of STORM_serialize
 
 // list-kind block -> pool row: one workgroup per block
 __global__ __launch_bounds__(kThreads) void expand_lists_kernel(
@@ -67,6 +69,20 @@ __global__ __launch_bounds__(kThreads) void place_bitmaps_kernel(
     for (uint32_t k = threadIdx.x; k < kBlockWords / 2; k += kThreads) dst[k] = src[k];
 }
 
+// bitmap-kind block whose 1024 words sit in a byte stream at 2-byte alignment only (a serialized
+// STORM_t, see STORM_serialize): assembled from uint16 loads
+__global__ __launch_bounds__(kThreads) void place_bitmaps_u16_kernel(
+    uint64_t* __restrict__ pool, const uint32_t* __restrict__ pool_row,
+    const uint64_t* __restrict__ src_off_u16, const uint16_t* __restrict__ stream) {
+    const uint32_t b = blockIdx.x;
+    const uint16_t* src = stream + src_off_u16[b];
+    uint64_t* dst = pool + (uint64_t)pool_row[b] * kBlockWords;
+    for (uint32_t k = threadIdx.x; k < kBlockWords; k += kThreads) {
+        const uint16_t* q = src + 4u * k;
+        dst[k] = (uint64_t)q[0] | ((uint64_t)q[1] << 16) | ((uint64_t)q[2] << 32) | ((uint64_t)q[3] << 48);
+    }
+}
+
 template <typename T>
 int upload(T** d, const T* h, size_t n, hipStream_t stream) {
     *d = nullptr;
@@ -78,14 +94,17 @@ int upload(T** d, const T* h, size_t n, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" {
-
-int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
-                            const uint64_t* row_block_offset, const uint32_t* block_id,
-                            const uint8_t* block_kind, const uint64_t* block_data_offset,
-                            const uint32_t* block_n, const uint16_t* list_pool,
-                            uint64_t list_pool_len, const uint64_t* bitmap_pool,
-                            uint64_t bitmap_pool_words, storm_hip_sparse_t** out) {
+// Builds the device arena from the flat block description of storm_hip.h. `bitmaps_in_stream`:
+// the bitmap blocks' words are not in `bitmap_pool` but inside `list_pool` itself (then a byte
+// stream viewed as uint16, block_data_offset of a bitmap block in uint16 units): the whole stream
+// is uploaded once and both block kinds are unpacked from it on the device.
+static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                       const uint64_t* row_block_offset, const uint32_t* block_id,
+                       const uint8_t* block_kind, const uint64_t* block_data_offset,
+                       const uint32_t* block_n, const uint16_t* list_pool,
+                       uint64_t list_pool_len, const uint64_t* bitmap_pool,
+                       uint64_t bitmap_pool_words, bool bitmaps_in_stream,
+                       storm_hip_sparse_t** out) {
     if (!ctx || !out) {
         set_error("sparse_create: NULL context or output");
         return STORM_HIP_EINVAL;
@@ -137,6 +156,11 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
                 if (block_data_offset[b] + block_n[b] > list_pool_len ||
                     (block_n[b] && !list_pool)) {
                     set_error("sparse_create: list block outside the list pool");
+                    return STORM_HIP_EINVAL;
+                }
+            } else if (bitmaps_in_stream) {
+                if (block_data_offset[b] + 4ull * kBlockWords > list_pool_len || !list_pool) {
+                    set_error("sparse_create: bitmap block outside the serialized stream");
                     return STORM_HIP_EINVAL;
                 }
             } else if (block_data_offset[b] + kBlockWords > bitmap_pool_words || !bitmap_pool) {
@@ -213,20 +237,37 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
             rc = STORM_HIP_EHIP;
             break;
         }
+        // the list pool (or the whole serialized stream) goes up once
+        if (!list_row.empty() || (bitmaps_in_stream && !dense_row.empty()))
+            if ((rc = upload(&d_lists, list_pool, (size_t)list_pool_len, ctx->stream))) break;
         // list-kind blocks: expand on the device
         if (!list_row.empty()) {
             if ((rc = upload(&d_lrow, list_row.data(), list_row.size(), ctx->stream)) ||
                 (rc = upload(&d_loff, list_off.data(), list_off.size(), ctx->stream)) ||
-                (rc = upload(&d_llen, list_len.data(), list_len.size(), ctx->stream)) ||
-                (rc = upload(&d_lists, list_pool, (size_t)list_pool_len, ctx->stream)))
+                (rc = upload(&d_llen, list_len.data(), list_len.size(), ctx->stream)))
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
                                dim3(kThreads), 0, ctx->stream, s->d_pool, d_lrow, d_loff, d_llen,
                                d_lists);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
+        // bitmap-kind blocks of a serialized stream: unpacked where they lie in the uploaded bytes
+        if (!dense_row.empty() && bitmaps_in_stream) {
+            uint64_t* d_doff = nullptr;
+            if ((rc = upload(&d_drow, dense_row.data(), dense_row.size(), ctx->stream)) ||
+                (rc = upload(&d_doff, dense_src.data(), dense_src.size(), ctx->stream))) {
+                (void)hipFree(d_doff);
+                break;
+            }
+            hipLaunchKernelGGL(place_bitmaps_u16_kernel, dim3((uint32_t)dense_row.size()),
+                               dim3(kThreads), 0, ctx->stream, s->d_pool, d_drow, d_doff, d_lists);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = STORM_HIP_EHIP;
+            (void)hipFree(d_doff);
+            if (rc != STORM_HIP_OK) break;
+        }
         // bitmap-kind blocks: staged through a bounded buffer (<= 64 MiB per round)
-        if (!dense_row.empty()) {
+        if (!dense_row.empty() && !bitmaps_in_stream) {
             const size_t round = std::min<size_t>(dense_row.size(), 8192);
             h_stage = static_cast<uint64_t*>(malloc(round * kBlockWords * sizeof(uint64_t)));
             if (!h_stage) { rc = STORM_HIP_ENOMEM; break; }
@@ -271,6 +312,81 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     }
     *out = s;
     return STORM_HIP_OK;
+}
+
+extern "C" {
+
+int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                            const uint64_t* row_block_offset, const uint32_t* block_id,
+                            const uint8_t* block_kind, const uint64_t* block_data_offset,
+                            const uint32_t* block_n, const uint16_t* list_pool,
+                            uint64_t list_pool_len, const uint64_t* bitmap_pool,
+                            uint64_t bitmap_pool_words, storm_hip_sparse_t** out) {
+    try {
+        return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind,
+                           block_data_offset, block_n, list_pool, list_pool_len, bitmap_pool,
+                           bitmap_pool_words, false, out);
+    } catch (const std::exception& e) {
+        set_error("sparse_create: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+}
+
+// Arena straight from a serialized STORM_t (byte layout: STORM_serialize in storm.h / storm_host.c;
+// sizes as reference storm.c:372-394, :963-973). Only the headers are walked on the host
+// (O(blocks)); the payload bytes are uploaded as they are and unpacked by the device.
+int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
+                                       storm_hip_sparse_t** out) {
+    if (!ctx || !out || !buf) {
+        set_error("sparse_create_serialized: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    *out = nullptr;
+    try {
+        const uint8_t* p = static_cast<const uint8_t*>(buf);
+        auto u32_at = [&](uint64_t off) { uint32_t v; memcpy(&v, p + off, 4); return v; };
+        const char* bad = "sparse_create_serialized: truncated or malformed stream";
+        if (n_bytes < 8 || (n_bytes & 1) || u32_at(4) != kSerialMagic) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+        const uint64_t n_rows = u32_at(0);
+        std::vector<uint64_t> row_off(n_rows + 1, 0), offs;
+        std::vector<uint32_t> ids, lens;
+        std::vector<uint8_t> kinds;
+        uint64_t at = 8;
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            if (at + 12 > n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+            const uint32_t nb = u32_at(at);
+            at += 12;
+            if (at + 4ull * nb > n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+            at += 4ull * nb;  // block_ids[] (repeated in the block headers)
+            for (uint32_t b = 0; b < nb; ++b) {
+                if (at + 16 > n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+                const uint32_t n_bitmap = u32_at(at) & 0x3fffffffu;
+                const uint32_t w2 = u32_at(at + 8), id = u32_at(at + 12);
+                const uint32_t n_scalar = w2 & 0x7fffffffu, has_list = w2 >> 31;
+                at += 16;
+                const uint64_t words = 8ull * n_bitmap, list = has_list ? 2ull * n_scalar : 0;
+                if ((n_bitmap != 0 && n_bitmap != kBlockWords) || at + words + list > n_bytes) {
+                    set_error("%s", bad);
+                    return STORM_HIP_EINVAL;
+                }
+                ids.push_back(id);
+                if (n_bitmap) {  // bitmap kind (storm.c:745-749: a block is one kind or the other)
+                    kinds.push_back(1); offs.push_back(at / 2); lens.push_back(0);
+                } else {
+                    kinds.push_back(0); offs.push_back((at + words) / 2); lens.push_back(has_list ? n_scalar : 0);
+                }
+                at += words + list;
+            }
+            row_off[r + 1] = ids.size();
+        }
+        if (at != n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+        return build_arena(ctx, n_rows, ids.size(), row_off.data(), ids.data(), kinds.data(), offs.data(),
+                           lens.data(), reinterpret_cast<const uint16_t*>(p), n_bytes / 2, nullptr, 0,
+                           true, out);
+    } catch (const std::exception& e) {
+        set_error("sparse_create_serialized: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
 }
 
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {

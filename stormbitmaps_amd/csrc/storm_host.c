@@ -12,6 +12,7 @@
  * about two host-resident blocks and are never called by the all-pairs functions.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -95,12 +96,14 @@ static void configure_from_env(void) {
     }
 }
 
+static int g_quiet_ctx = 0; /* 1 while a best-effort caller (row streaming) asks for a context */
+
 static storm_hip_ctx_t* device_ctx(int slot) {
     configure_from_env();
     if (slot < 0 || slot >= g_n_devices) return NULL;
     if (!g_ctx[slot]) {
         if (storm_hip_ctx_create(g_device_ids[slot], NULL, &g_ctx[slot]) != STORM_HIP_OK) {
-            device_error("storm_hip_ctx_create");
+            if (!g_quiet_ctx) device_error("storm_hip_ctx_create");
             g_ctx[slot] = NULL;
         } else {
             /* the device mirrors behind the storm.h handles are written by this file only, so a
@@ -409,6 +412,9 @@ STORM_contiguous_t* STORM_contig_new(size_t vector_length) {
     return h;
 }
 
+#define CONTIG_STREAM_ROWS 256u /* batch of finished rows STORM_contig_add streams to the device */
+static void contig_stream_rows(STORM_contiguous_t* h);
+
 static void contig_drop_device(STORM_contiguous_t* h) {
     if (h->hip_matrix) {
         dense_state_release((dense_state_t*)h->hip_matrix);
@@ -524,6 +530,7 @@ int STORM_contig_add(STORM_contiguous_t* h, const uint32_t* values, const uint32
     h->n_scalar[h->n_data] = distinct; /* storm.c:1132-1134 */
     h->bitmaps[h->n_data].n_scalar = distinct;
     ++h->n_data;
+    if (h->n_data % CONTIG_STREAM_ROWS == 0) contig_stream_rows(h);
     return (int)n_values;
 }
 
@@ -537,21 +544,73 @@ int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
     return 1;
 }
 
+/* Rows [hip_rows_synced, upto) of `h` go to every replica of its device mirror (created on first
+ * use, grown with storm_hip_matrix_resize). Rows of a STORM_contiguous_t never change once added,
+ * so what has been uploaded stays valid. Returns 0 on success. */
+static int contig_upload_rows(STORM_contiguous_t* h, uint64_t upto) {
+    configure_from_env();
+    dense_state_t* st = (dense_state_t*)h->hip_matrix;
+    if (st && st->config_generation != g_config_generation) {
+        contig_drop_device(h);
+        st = NULL;
+    }
+    if (!st) {
+        st = (dense_state_t*)calloc(1, sizeof(*st));
+        if (!st) return -1;
+        st->config_generation = g_config_generation;
+        h->hip_matrix = st;
+        h->hip_rows_synced = 0;
+    }
+    for (int d = 0; d < g_n_devices; ++d) {
+        storm_hip_ctx_t* ctx = device_ctx(d);
+        if (!ctx) return -1;
+        if (!st->m[d] &&
+            storm_hip_matrix_create(ctx, h->m_data, h->n_bitmaps_vector, &st->m[d]) != STORM_HIP_OK)
+            return -1;
+        if (storm_hip_matrix_resize(ctx, st->m[d], upto) != STORM_HIP_OK) return -1;
+        if (upto > h->hip_rows_synced &&
+            storm_hip_matrix_upload(ctx, st->m[d], h->hip_rows_synced, upto - h->hip_rows_synced,
+                                    h->data + h->hip_rows_synced * h->n_bitmaps_vector,
+                                    h->n_bitmaps_vector) != STORM_HIP_OK)
+            return -1;
+    }
+    h->hip_rows_synced = upto;
+    h->hip_rows_capacity = h->m_data;
+    return 0;
+}
+
+/* Streaming: STORM_contig_add sends every finished batch of CONTIG_STREAM_ROWS rows to the device
+ * while the host builds the next ones (PCIe beside the host's bit setting), so that the first
+ * all-pairs call only has the last partial batch left to copy. Best effort: without a usable
+ * device the adds still succeed and the failure surfaces at the all-pairs call, as before.
+ * STORM_HIP_STREAM_ROWS=0 in the environment turns it off. */
+static int g_stream_state = 0; /* 0 unknown, 1 on, -1 off (no device, or disabled) */
+
+static void contig_stream_rows(STORM_contiguous_t* h) {
+    if (g_stream_state == 0) {
+        const char* e = getenv("STORM_HIP_STREAM_ROWS");
+        g_stream_state = (e && e[0] == '0') ? -1 : 1;
+    }
+    if (g_stream_state < 0) return;
+    g_quiet_ctx = 1;
+    const int rc = contig_upload_rows(h, h->n_data);
+    g_quiet_ctx = 0;
+    if (rc != 0) {
+        contig_drop_device(h);
+        g_stream_state = -1;
+    }
+}
+
 /* make sure the device mirror of `h` is current; NULL on failure */
 static dense_state_t* contig_mirror(STORM_contiguous_t* h) {
-    if (!h->hip_matrix || h->hip_rows_synced != h->n_data ||
-        ((dense_state_t*)h->hip_matrix)->config_generation != g_config_generation) {
-        contig_drop_device(h);
-        dense_state_t* st = (dense_state_t*)calloc(1, sizeof(*st));
-        if (!st) return NULL;
-        h->hip_matrix = st;
-        if (dense_state_upload(st, h->data, h->n_data, h->n_bitmaps_vector,
-                               h->n_bitmaps_vector) != 0) {
+    dense_state_t* st = (dense_state_t*)h->hip_matrix;
+    if (!st || h->hip_rows_synced != h->n_data || st->config_generation != g_config_generation) {
+        if (h->hip_rows_synced > h->n_data) contig_drop_device(h);
+        if (contig_upload_rows(h, h->n_data) != 0) {
+            device_error("dense upload");
             contig_drop_device(h);
             return NULL;
         }
-        h->hip_rows_synced = h->n_data;
-        h->hip_rows_capacity = h->n_data;
     }
     return (dense_state_t*)h->hip_matrix;
 }
@@ -955,6 +1014,159 @@ uint64_t STORM_serialized_size(const STORM_t* h) { /* storm.c:963-973 */
     for (uint32_t i = 0; i < h->n_conts; ++i)
         bytes += STORM_bitmap_cont_serialized_size(&h->conts[i]);
     return bytes + 2 * sizeof(uint32_t);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Serialized form of a STORM_t. The reference defines only its SIZE (storm.c:372-394, :963-973:
+ * 2 words per container, 3 + n_bitmaps words per row, 4 words + 8 n_bitmap + 2 n_scalar bytes per
+ * block); this is a byte layout with exactly those sizes, little endian, fields at 2-byte
+ * alignment (lists of odd length shift what follows), so STORM_serialize writes exactly
+ * STORM_serialized_size(h) bytes:
+ *   container : u32 n_rows, u32 magic "STM1"
+ *   row       : u32 n_blocks, u32 prev_inserted_value, u32 bytes of this row's blocks,
+ *               u32 block_ids[n_blocks]
+ *   block     : u32 n_bitmap (0 or 1024; bits 30-31 zero), u32 n_bits_set,
+ *               u32 n_scalar | n_scalar_set << 31, u32 id,
+ *               u64 data[n_bitmap], u16 scalar[n_scalar] (only if n_scalar_set)
+ * ---------------------------------------------------------------------------------------- */
+#define STORM_SERIAL_MAGIC 0x314d5453u
+
+static uint8_t* put_u32(uint8_t* p, uint32_t v) { memcpy(p, &v, 4); return p + 4; }
+static uint32_t get_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+uint64_t STORM_serialize(const STORM_t* h, void* buf, uint64_t capacity) {
+    if (!h || !buf) return 0;
+    const uint64_t need = STORM_serialized_size(h);
+    if (capacity < need) return 0;
+    uint8_t* p = (uint8_t*)buf;
+    p = put_u32(p, h->n_conts);
+    p = put_u32(p, STORM_SERIAL_MAGIC);
+    for (uint32_t i = 0; i < h->n_conts; ++i) {
+        STORM_bitmap_cont_t* r = &h->conts[i];
+        uint32_t payload = 0;
+        for (uint32_t b = 0; b < r->n_bitmaps; ++b) payload += STORM_bitmap_serialized_size(&r->bitmaps[b]);
+        p = put_u32(p, r->n_bitmaps);
+        p = put_u32(p, r->prev_inserted_value);
+        p = put_u32(p, payload);
+        for (uint32_t b = 0; b < r->n_bitmaps; ++b) p = put_u32(p, r->block_ids[b]);
+        for (uint32_t b = 0; b < r->n_bitmaps; ++b) {
+            const STORM_bitmap_t* blk = &r->bitmaps[b];
+            p = put_u32(p, blk->n_bitmap);
+            p = put_u32(p, blk->n_bits_set);
+            p = put_u32(p, (uint32_t)blk->n_scalar | ((uint32_t)blk->n_scalar_set << 31));
+            p = put_u32(p, blk->id);
+            if (blk->n_bitmap) {
+                memcpy(p, blk->data, (size_t)blk->n_bitmap * 8);
+                p += (size_t)blk->n_bitmap * 8;
+            }
+            if (blk->n_scalar_set && blk->n_scalar) {
+                memcpy(p, blk->scalar, (size_t)blk->n_scalar * 2);
+                p += (size_t)blk->n_scalar * 2;
+            }
+        }
+    }
+    return (uint64_t)(p - (uint8_t*)buf) == need ? need : 0;
+}
+
+/* NULL on a truncated or malformed stream (nothing is leaked) */
+STORM_t* STORM_deserialize(const void* buf, uint64_t n_bytes) {
+    const uint8_t* p = (const uint8_t*)buf;
+    if (!p || n_bytes < 8 || get_u32(p + 4) != STORM_SERIAL_MAGIC) return NULL;
+    const uint32_t n_rows = get_u32(p);
+    STORM_t* h = STORM_new();
+    if (!h) return NULL;
+    uint64_t at = 8;
+    int ok = 1;
+    h->conts = (STORM_bitmap_cont_t*)calloc(n_rows ? n_rows : 1, sizeof(*h->conts));
+    if (!h->conts) ok = 0;
+    h->m_conts = ok ? (n_rows ? n_rows : 1) : 0;
+    for (uint32_t i = 0; ok && i < n_rows; ++i) {
+        STORM_bitmap_cont_t* r = &h->conts[i];
+        if (at + 12 > n_bytes) { ok = 0; break; }
+        const uint32_t nb = get_u32(p + at);
+        r->prev_inserted_value = get_u32(p + at + 4);
+        at += 12;
+        if (at + 4ull * nb > n_bytes) { ok = 0; break; }
+        h->n_conts = i + 1; /* rows up to here are released by STORM_free on failure */
+        if (nb) {
+            r->bitmaps = (STORM_bitmap_t*)STORM_aligned_malloc(64, (size_t)nb * sizeof(*r->bitmaps));
+            r->block_ids = (uint32_t*)malloc((size_t)nb * sizeof(uint32_t));
+            if (!r->bitmaps || !r->block_ids) { ok = 0; break; }
+            r->m_bitmaps = nb;
+            for (uint32_t b = 0; b < nb; ++b) STORM_bitmap_init(&r->bitmaps[b]);
+            memcpy(r->block_ids, p + at, 4ull * nb);
+        }
+        at += 4ull * nb;
+        for (uint32_t b = 0; ok && b < nb; ++b) {
+            STORM_bitmap_t* blk = &r->bitmaps[b];
+            if (at + 16 > n_bytes) { ok = 0; break; }
+            const uint32_t n_bitmap = get_u32(p + at), w2 = get_u32(p + at + 8);
+            const uint32_t n_scalar = w2 & 0x7fffffffu, has_list = w2 >> 31;
+            blk->n_bits_set = get_u32(p + at + 4);
+            blk->id = get_u32(p + at + 12);
+            at += 16;
+            if ((n_bitmap != 0 && n_bitmap != BLOCK_WORDS) || blk->id != r->block_ids[b] ||
+                at + 8ull * n_bitmap + (has_list ? 2ull * n_scalar : 0) > n_bytes ||
+                (b && blk->id <= r->block_ids[b - 1])) { ok = 0; break; }
+            if (n_bitmap) {
+                blk->data = (uint64_t*)STORM_aligned_malloc(STORM_get_alignment(), BLOCK_WORDS * 8);
+                if (!blk->data) { ok = 0; break; }
+                memcpy(blk->data, p + at, BLOCK_WORDS * 8);
+                blk->n_bitmap = BLOCK_WORDS;
+                at += BLOCK_WORDS * 8;
+            }
+            if (has_list) {
+                blk->n_scalar_set = 1;
+                blk->m_scalar = n_scalar ? n_scalar : 1;
+                blk->scalar = (uint16_t*)STORM_aligned_malloc(STORM_get_alignment(), (size_t)blk->m_scalar * 2);
+                if (!blk->scalar) { ok = 0; break; }
+                memcpy(blk->scalar, p + at, (size_t)n_scalar * 2);
+                blk->n_scalar = n_scalar;
+                at += (uint64_t)n_scalar * 2;
+            }
+            r->n_bitmaps = b + 1;
+        }
+    }
+    if (ok && at != n_bytes) ok = 0;
+    if (!ok) {
+        STORM_free(h);
+        return NULL;
+    }
+    h->hip_dirty = 1;
+    return h;
+}
+
+/* All-pairs total straight from a serialized STORM_t: the bytes are uploaded as they are and the
+ * block arena is built on the device (storm_hip_sparse_create_serialized) — no host containers,
+ * no per-bit host work. `buf` must be 2-byte aligned. (uint64_t)-1 on a malformed stream or a
+ * device failure. */
+uint64_t STORM_serialized_pairw_intersect_cardinality(const void* buf, uint64_t n_bytes) {
+    if (!buf || n_bytes < 8 || ((uintptr_t)buf & 1)) return ALL_PAIRS_FAILED;
+    if (get_u32((const uint8_t*)buf) < 2) return get_u32((const uint8_t*)buf + 4) == STORM_SERIAL_MAGIC ? 0 : ALL_PAIRS_FAILED;
+    configure_from_env();
+    storm_hip_sparse_t* arena[MAX_DEVICES] = {0};
+    uint64_t total = 0;
+    int ok = 1, launched = 0;
+    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
+    for (int d = 0; ok && d < g_n_devices; ++d) {
+        storm_hip_ctx_t* ctx = device_ctx(d);
+        if (!ctx || storm_hip_sparse_create_serialized(ctx, buf, n_bytes, &arena[d]) != STORM_HIP_OK ||
+            storm_hip_pairw_sparse_begin(ctx, arena[d], g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d,
+                                         world) != STORM_HIP_OK) {
+            device_error("serialized all-pairs");
+            ok = 0;
+        } else {
+            launched = d + 1;
+        }
+    }
+    for (int d = 0; d < launched; ++d) {
+        uint64_t part = 0;
+        if (storm_hip_pairw_sparse_end(g_ctx[d], &part) != STORM_HIP_OK) ok = 0;
+        total += part;
+    }
+    for (int d = 0; d < MAX_DEVICES; ++d)
+        if (arena[d]) storm_hip_sparse_destroy(g_ctx[d], arena[d]);
+    return ok ? total : ALL_PAIRS_FAILED;
 }
 
 /* Fingerprint of what the device arena was built from: rows, blocks per row, and per block its

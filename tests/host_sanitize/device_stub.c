@@ -46,6 +46,17 @@ void storm_hip_matrix_destroy(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
     if (m) free(m->rows);
     free(m);
 }
+int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t n_rows) {
+    (void)ctx;
+    uint64_t* nr = (uint64_t*)calloc((size_t)n_rows * m->n_words + 1, sizeof(uint64_t));
+    if (!nr) return STORM_HIP_ENOMEM;
+    const uint64_t keep = n_rows < m->n_rows ? n_rows : m->n_rows;
+    memcpy(nr, m->rows, (size_t)keep * m->n_words * sizeof(uint64_t));
+    free(m->rows);
+    m->rows = nr;
+    m->n_rows = n_rows;
+    return STORM_HIP_OK;
+}
 int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
                             uint64_t n_rows, const uint64_t* host, uint64_t stride_words) {
     (void)ctx;
@@ -115,6 +126,17 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     *out = (storm_hip_sparse_t*)calloc(1, sizeof(**out));
     if (!*out) return STORM_HIP_ENOMEM;
     (*out)->set_bits = bits;
+    return STORM_HIP_OK;
+}
+int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
+                                       storm_hip_sparse_t** out) {
+    (void)ctx;
+    const uint8_t* p = (const uint8_t*)buf;
+    uint64_t touched = 0;
+    for (uint64_t i = 0; i < n_bytes; ++i) touched += p[i]; /* reads every byte handed over */
+    *out = (storm_hip_sparse_t*)calloc(1, sizeof(**out));
+    if (!*out) return STORM_HIP_ENOMEM;
+    (*out)->set_bits = touched;
     return STORM_HIP_OK;
 }
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) { (void)ctx; free(s); }

@@ -76,6 +76,22 @@ static int scenario(uint32_t n_rows, uint32_t width, uint32_t draws, int with_em
         CHECK(STORM_pairw_intersect_cardinality_blocked(sparse, 0) == distinct_sparse);
     }
     CHECK(STORM_serialized_size(sparse) >= 8);
+    { /* serialized form: exact size, round trip, truncations rejected, nothing leaked */
+        const uint64_t n = STORM_serialized_size(sparse);
+        uint8_t* buf = (uint8_t*)malloc(n + 2);
+        CHECK(buf && STORM_serialize(sparse, buf, n) == n);
+        CHECK(STORM_serialize(sparse, buf, n - 1) == 0);
+        STORM_t* back = STORM_deserialize(buf, n);
+        CHECK(back && STORM_serialized_size(back) == n && back->n_conts == sparse->n_conts);
+        uint8_t* again = (uint8_t*)malloc(n + 2);
+        CHECK(again && STORM_serialize(back, again, n) == n && memcmp(buf, again, n) == 0);
+        if (sparse->n_conts >= 2) CHECK(STORM_pairw_intersect_cardinality(back) == distinct_sparse);
+        STORM_free(back);
+        for (uint64_t cut = 0; cut < n; cut += (n / 37) + 1) CHECK(STORM_deserialize(buf, cut) == NULL);
+        if (sparse->n_conts >= 2) CHECK(STORM_serialized_pairw_intersect_cardinality(buf, n) != (uint64_t)-1);
+        free(again);
+        free(buf);
+    }
     /* one-pair helpers on the first two rows of the sparse container vs a naive count */
     if (sparse->n_conts >= 2) {
         const uint64_t got = STORM_bitmap_cont_intersect_cardinality(&sparse->conts[0], &sparse->conts[1]);

@@ -273,3 +273,58 @@ def test_per_pair_matrix_in_bands_over_several_devices(lib, orc):
     finally:
         one_dev = (C.c_int * 1)(0)
         assert lib.STORM_hip_set_devices(1, one_dev) == 0
+
+
+@pytest.mark.parametrize("M,N,d", [(196608, 1300, 12690), (524288, 2000, 524), (524288, 1200, 131072), (70000, 300, 7)])
+def test_device_arena_from_a_serialized_container(hip_ctx, orc, M, N, d):
+    """STORM_serialize -> bytes -> arena built on the device from the bytes
+    (storm_hip_sparse_create_serialized: both block kinds unpacked from the uploaded stream) ->
+    all-pairs total, against the container path and the column identity of the same bits."""
+    s = sb.Storm()
+    assert s.add_synthetic(M, N, d, seed=M + N) == N
+    want = s.pairw_intersect_cardinality()
+    m = hip_ctx.matrix(N, (M + 63) // 64)
+    m.fill_synthetic(M, d, seed=M + N)
+    assert want == m.column_identity()
+    if N <= 300:
+        assert want == orc.truth_columns(m.download())
+    m.close()
+    data = s.serialize()
+    assert data.size == s.serialized_size()
+    assert sb.Storm.serialized_pairw_intersect_cardinality(data) == want
+    back = sb.Storm.deserialize(data)
+    assert back.pairw_intersect_cardinality() == want
+    back.free()
+    s.free()
+    with pytest.raises(sb.StormHipError):
+        sb.Storm.serialized_pairw_intersect_cardinality(data[: data.size // 2 * 2 - 2])
+
+
+def test_rows_stream_to_the_device_while_the_container_is_built(lib, orc):
+    """STORM_contig_add sends every finished batch of 256 rows to the device mirror, so the first
+    all-pairs call at the headline shape has < 256 rows left to copy: first call within 2 x the
+    resident call. Totals against the raw-buffer wrapper and, on a subset, the
+    oracle; rows added after a call extend the mirror instead of rebuilding it."""
+    import time
+    M, N, d = 65536, 10000, 32768
+    c = sb.StormContig(M)
+    assert c.add_synthetic(N - 300, d, seed=42) == N - 300
+    t0 = time.perf_counter(); a = c.pairw_intersect_cardinality_blocked(31); t1 = time.perf_counter()
+    b = c.pairw_intersect_cardinality_blocked(31); t2 = time.perf_counter()
+    assert a == b
+    first, resident = t1 - t0, t2 - t1
+    print(f"first call {1e3 * first:.2f} ms, resident call {1e3 * resident:.2f} ms")
+    assert c.add_synthetic(300, d, seed=42, row0=N - 300) == 300      # grows the mirror
+    total = c.pairw_intersect_cardinality()
+    ctx = sb.HipContext(0)
+    m = ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, d, seed=42)
+    assert total == m.column_identity()
+    head = ctx.matrix(N - 300, M // 64)
+    head.import_device(m.device_ptr, N - 300, m.stride_words)
+    assert a == head.pairw()
+    for x in (m, head):
+        x.close()
+    ctx.close()
+    c.free()
+    assert first < 2.0 * resident + 1e-3, (first, resident)
