@@ -125,7 +125,8 @@ int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, 
  *   out[i * ld + j] = popcount(row_i OP row_j) for i < j; other entries are left untouched.
  * _device: `d_out` is a DEVICE pointer to n_rows x ld uint32 (ld >= n_rows); synchronous.
  * plain  : `h_out` is a HOST n_rows x n_rows uint32 buffer; entries i >= j come back as 0.
- * Rows must be shorter than 2^24 bits (exact f32 accumulation). */
+ * Rows of 2^24 bits and more (beyond exact f32 accumulation in one go) are cut along k and the
+ * parts added; the limit is 2^25 bits per row (32-bit DMA offsets of the tile kernel). */
 int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                   uint32_t* d_out, uint64_t ld);
 int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstorm_hip.so")
+# STORM_HIP_LIB: another build of the same library (the tools' probes build, `make probes`)
+LIB_PATH = os.environ.get("STORM_HIP_LIB") or os.path.join(_HERE, "libstorm_hip.so")
 
 u64, u32, u16, u8, i64 = C.c_uint64, C.c_uint32, C.c_uint16, C.c_uint8, C.c_int64
 vp, cp, sz = C.c_void_p, C.c_char_p, C.c_size_t

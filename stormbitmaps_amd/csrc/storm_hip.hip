@@ -610,10 +610,18 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_max_run = (int)value;
     } else if (!strcmp(key, "k2_ring")) {
+#ifdef STORM_HIP_PROBES
         if ((value < 3 || value > 5) && (value < 11 || value > 18) && value != 26) {
             set_error("k2_ring must be 3, 4 or 5 (10 + bits = timing probes)");
             return STORM_HIP_EINVAL;
         }
+#else
+        if (value != 4) {
+            set_error("k2_ring: this build ships the 4-deep ring only (other depths and the timing "
+                      "probes: build with STORM_HIP_PROBES, `make probes`)");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->k2_ring = (int)value;
     } else if (!strcmp(key, "k2_shadow_budget_mb")) {
         if (value < 0 || value > (1 << 22)) {
@@ -666,7 +674,15 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_tail_run = (int)value;
     } else if (!strcmp(key, "k2_debug")) {
+#ifdef STORM_HIP_PROBES
         ctx->k2_debug = (int)value;
+#else
+        if (value != 0) {
+            set_error("k2_debug: timing probes (wrong results by design) are not in this build "
+                      "(STORM_HIP_PROBES, `make probes`)");
+            return STORM_HIP_EINVAL;
+        }
+#endif
     } else if (!strcmp(key, "time_kernels")) {
         ctx->time_kernels = value != 0;
         ctx->kernel_events_used = 0;
@@ -694,6 +710,11 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_shape")) return ctx->k2_shape;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
+#ifdef STORM_HIP_PROBES
+    if (!strcmp(key, "probes_built")) return 1;
+#else
+    if (!strcmp(key, "probes_built")) return 0;
+#endif
     return -1;
 }
 
@@ -715,7 +736,13 @@ int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launch
 
 int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t capacity_items,
                                 uint64_t* n_items) {
+    return guarded("storm_hip_debug_strip_trace", [&]() -> int {
     if (check_ctx(ctx) || !n_items) return STORM_HIP_EINVAL;
+#ifndef STORM_HIP_PROBES
+    set_error("strip trace: not in this build (STORM_HIP_PROBES, `make probes`)");
+    *n_items = 0;
+    return STORM_HIP_EINVAL;
+#endif
     *n_items = ctx->trace_items;
     if (!out || ctx->trace_items == 0) return STORM_HIP_OK;
     STORM_HIP_TRY(hipSetDevice(ctx->device));
@@ -735,6 +762,7 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
         out[i * 8 + 7] = items[i * 5 + 4];
     }
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]) {
@@ -746,6 +774,7 @@ int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]) {
 // ---- dense matrix ----
 int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
                             storm_hip_matrix_t** out) {
+    return guarded("storm_hip_matrix_create", [&]() -> int {
     if (check_ctx(ctx) || !out) return STORM_HIP_EINVAL;
     *out = nullptr;
     if (n_words == 0 || n_rows >= (1ull << 32) - kABlockRows) {
@@ -776,6 +805,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     }
     *out = m;
     return STORM_HIP_OK;
+    });
 }
 
 // Changes the logical row count. Growing beyond the allocation reallocates (at least doubling, so
@@ -783,6 +813,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
 // device to device; rows [old, new) are zero until uploaded; shrinking zeroes the dropped rows, so
 // "rows >= n_rows are zero" — what the kernels' padding relies on — always holds.
 int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t n_rows) {
+    return guarded("storm_hip_matrix_resize", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || n_rows >= (1ull << 32) - kABlockRows) {
         set_error("matrix_resize: NULL matrix or row count out of range");
@@ -818,6 +849,7 @@ int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_
     m->n_rows = n_rows;
     m->generation = next_matrix_generation();
     return STORM_HIP_OK;
+    });
 }
 
 static int check_rows(const storm_hip_matrix_t* m, uint64_t row0, uint64_t n_rows) {
@@ -889,6 +921,7 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
                                              uint64_t row0, uint64_t n_rows,
                                              const uint64_t* offsets,
                                              const uint32_t* positions) {
+    return guarded("storm_hip_matrix_set_rows_from_positions", [&]() -> int {
     if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || check_rows(m, row0, n_rows)) return STORM_HIP_EINVAL;
     if (n_rows == 0) return STORM_HIP_OK;
@@ -933,10 +966,12 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
     (void)hipFree(d_off);
     (void)hipFree(d_pos);
     return rc;
+    });
 }
 
 int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
                                     uint64_t n_bits, uint32_t draws, uint64_t seed) {
+    return guarded("storm_hip_matrix_fill_synthetic", [&]() -> int {
     if (m) m->generation = next_matrix_generation();  // any cached FP4 shadow is stale now
     if (check_ctx(ctx) || !m) return STORM_HIP_EINVAL;
     if (n_bits == 0 || (n_bits + 63) / 64 != m->n_words) {
@@ -954,6 +989,7 @@ int storm_hip_matrix_fill_synthetic(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m,
                        m->stride_words, m->n_rows, n_bits, draws, seed);
     STORM_HIP_TRY(hipGetLastError());
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_matrix_clear(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m) {
@@ -1071,6 +1107,7 @@ extern "C" {
 
 int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                                  uint32_t shard_rank, uint32_t shard_count, uint64_t* d_total) {
+    return guarded("storm_hip_pairw_dense_launch", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !d_total) {
         set_error("pairw_dense: NULL matrix or result pointer");
@@ -1097,6 +1134,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
     if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
     return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
                                  ctx->seg_row_sum, d_total);
+    });
 }
 
 int storm_hip_pairw_dense_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
@@ -1127,6 +1165,7 @@ int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
 
 int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                            const storm_hip_matrix_t* b, uint64_t* h_total) {
+    return guarded("storm_hip_square_dense", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!a || !b || !h_total) {
         set_error("square_dense: NULL argument");
@@ -1173,10 +1212,12 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                                  ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint64_t i0,
                           uint64_t i1, uint64_t j0, uint64_t j1, uint32_t* h_out) {
+    return guarded("storm_hip_tile_counts", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !h_out || i1 < i0 || j1 < j0 || i1 > m->n_rows || j1 > m->n_rows) {
         set_error("tile_counts: bad tile");
@@ -1204,6 +1245,7 @@ int storm_hip_tile_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uin
     }
     (void)hipFree(d_out);
     return rc;
+    });
 }
 
 }  // extern "C"
@@ -1222,6 +1264,7 @@ int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 extern "C" {
 
 int storm_hip_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint32_t* h_counts) {
+    return guarded("storm_hip_row_counts", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !h_counts) {
         set_error("row_counts: NULL argument");
@@ -1241,10 +1284,12 @@ int storm_hip_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, uint
     }
     (void)hipFree(d_counts);
     return rc;
+    });
 }
 
 int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                              uint64_t* h_total) {
+    return guarded("storm_hip_pairw_dense_op", [&]() -> int {
     if (op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR) {
         set_error("pairw_dense_op: unknown op %d", op);
         return STORM_HIP_EINVAL;
@@ -1259,10 +1304,12 @@ int storm_hip_pairw_dense_op(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, 
     const uint64_t both = (m->n_rows - 1) * set_bits;
     *h_total = both - (op == STORM_HIP_OP_XOR ? 2 * *h_total : *h_total);
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_square_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                                    const storm_hip_matrix_t* b, int op, uint32_t* d_out, uint64_t ld) {
+    return guarded("storm_hip_square_matrix_device", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!a || !b || !d_out || ld < b->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR ||
         a->n_words != b->n_words) {
@@ -1271,10 +1318,12 @@ int storm_hip_square_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_square_matrix(ctx, a, b, op, d_out, ld);
+    });
 }
 
 int storm_hip_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                             const storm_hip_matrix_t* b, int op, uint32_t* h_out) {
+    return guarded("storm_hip_square_matrix", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!a || !b || !h_out) {
         set_error("square_matrix: NULL argument");
@@ -1295,10 +1344,12 @@ int storm_hip_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     }
     (void)hipFree(d_out);
     return rc;
+    });
 }
 
 int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                   uint32_t* d_out, uint64_t ld) {
+    return guarded("storm_hip_pairw_matrix_device", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !d_out || ld < m->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR) {
         set_error("pairw_matrix: NULL argument, unknown op or leading dimension < rows");
@@ -1306,11 +1357,13 @@ int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_pairw_matrix(ctx, m, op, d_out, ld);
+    });
 }
 
 int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                        uint64_t row0, uint64_t n_band_rows, uint32_t* d_out,
                                        uint64_t ld) {
+    return guarded("storm_hip_pairw_matrix_band_device", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !d_out || ld < m->n_rows || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR ||
         row0 > m->n_rows || n_band_rows > m->n_rows - row0) {
@@ -1319,6 +1372,7 @@ int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_mat
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     return launch_pairw_matrix(ctx, m, op, d_out, ld, row0, n_band_rows);
+    });
 }
 
 // Host-output band: the band is computed into a staging buffer of the context (kept between
@@ -1327,6 +1381,7 @@ int storm_hip_pairw_matrix_band_device(storm_hip_ctx_t* ctx, const storm_hip_mat
 int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                       uint64_t row0, uint64_t n_band_rows, uint32_t* h_out,
                                       uint64_t ld) {
+    return guarded("storm_hip_pairw_matrix_band_begin", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !h_out || op < STORM_HIP_OP_AND || op > STORM_HIP_OP_XOR || ld < m->n_rows ||
         row0 > m->n_rows || n_band_rows > m->n_rows - row0) {
@@ -1353,6 +1408,7 @@ int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matr
                                    n * sizeof(uint32_t), n_band_rows, hipMemcpyDeviceToHost,
                                    ctx->stream));
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_pairw_matrix_band_end(storm_hip_ctx_t* ctx) {
@@ -1380,6 +1436,7 @@ int storm_hip_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, in
 
 int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                               uint64_t* h_total) {
+    return guarded("storm_hip_column_identity", [&]() -> int {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
     if (!m || !h_total) {
         set_error("column_identity: NULL argument");
@@ -1397,6 +1454,7 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                                  ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STORM_HIP_OK;
+    });
 }
 
 }  // extern "C"

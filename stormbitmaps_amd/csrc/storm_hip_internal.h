@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "storm_hip.h"
@@ -26,6 +28,24 @@ void set_error(const char* fmt, ...);
             return STORM_HIP_EHIP;                                                           \
         }                                                                                    \
     } while (0)
+
+// No C++ exception may cross the C boundary: every extern "C" entry point that can reach a
+// std::vector or operator new runs its body through this (bad_alloc -> STORM_HIP_ENOMEM).
+template <typename Fn>
+static inline int guarded(const char* what, Fn&& fn) noexcept {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        set_error("%s: out of host memory", what);
+        return STORM_HIP_ENOMEM;
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return STORM_HIP_EHIP;
+    } catch (...) {
+        set_error("%s: unknown C++ exception", what);
+        return STORM_HIP_EHIP;
+    }
+}
 
 // Geometry of the dense kernel (see DESIGN.md "K1").
 constexpr int kLanes = 64;                           // gfx950 wavefront

@@ -1323,6 +1323,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                                        (size_t)ctx->k2_lds_pad, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, nullptr, queues, heads);
                     break;
+#ifdef STORM_HIP_PROBES  // timing probes and the schedule trace: tools build (make probes)
                 case 218: {
                     const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
                     if (need > ctx->trace_capacity) {
@@ -1341,10 +1342,12 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
+#endif
                 case 104:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
+#ifdef STORM_HIP_PROBES
                 case 105:
                     hipLaunchKernelGGL((strip_fp4_kernel<5, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
@@ -1391,6 +1394,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                                        ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace);
                     break;
                 }
+#endif  // STORM_HIP_PROBES
                 default:
                     // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
                     if (ctx->k2_shape == 16)
@@ -1411,6 +1415,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             const dim3 kgrid(ctx->n_items), block(kMfmaThreads);
             const MfmaItem* items = static_cast<const MfmaItem*>(ctx->d_items);
             switch (ctx->k2_debug & 12) {  // 4 / 8: timing probes without DMA / without MFMA
+#ifdef STORM_HIP_PROBES
                 case 4:
                     hipLaunchKernelGGL(pairw_fp4_kernel<4>, kgrid, block, 0, ctx->stream, ctx->d_x4,
                                        pitch, items, ctx->d_slots);
@@ -1419,6 +1424,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     hipLaunchKernelGGL(pairw_fp4_kernel<8>, kgrid, block, 0, ctx->stream, ctx->d_x4,
                                        pitch, items, ctx->d_slots);
                     break;
+#endif
                 default:
                     hipLaunchKernelGGL(pairw_fp4_kernel<0>, kgrid, block, 0, ctx->stream, ctx->d_x4,
                                        pitch, items, ctx->d_slots);
@@ -1560,10 +1566,18 @@ struct MatrixPlan {  // item table of one matrix-output launch, already in ctx->
 static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
                              uint32_t total_stages, MatrixPlan* plan) {
     const size_t slots = (size_t)std::max(1, ctx->n_cus);
-    const size_t leftover = tiles.size() % slots;
+    size_t leftover = tiles.size() % slots;
     uint32_t parts = 1;
     if (leftover > 0 && ctx->k2_matrix_split)
         parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(slots / leftover, total_stages / 32));
+    // f32 accumulators hold exact integers below 2^24: an item may span at most kMaxExactStages
+    // stages (128 bits each). Rows of 2^24 bits and more are therefore cut along k for EVERY tile;
+    // the parts add into the cleared window like the parts of the last round do.
+    constexpr uint32_t kMaxExactStages = (1u << 24) / 128u - 1u;
+    if (total_stages > kMaxExactStages) {
+        leftover = tiles.size();
+        parts = std::max(parts, (total_stages + kMaxExactStages - 1) / kMaxExactStages);
+    }
     const size_t n_full = parts > 1 ? tiles.size() - leftover : tiles.size();
     std::vector<MfmaItem> items;
     for (size_t t = 0; t < n_full; ++t) items.push_back({tiles[t].first, tiles[t].second, 0, total_stages});
@@ -1655,11 +1669,6 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // band: only rows [band_row0, band_row0 + band_rows) of the triangle, written from output row 0
     const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
     if (band_row0 >= band_end) return STORM_HIP_OK;
-    if ((uint64_t)m->n_words * 64u >= (1ull << 24)) {
-        set_error("pairw_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
-                  (unsigned long long)m->n_words * 64u);
-        return STORM_HIP_EINVAL;
-    }
     if (m->n_rows < 2) return STORM_HIP_OK;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
@@ -1667,6 +1676,11 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     const size_t x4_bytes = (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
         set_error("pairw_matrix: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    if (pitch * (uint64_t)kTile > (1ull << 32)) {  // rows of 2^25 bits and more
+        set_error("pairw_matrix: rows of %llu nibble bytes exceed the tile kernel's 32-bit DMA offsets",
+                  (unsigned long long)row_bytes);
         return STORM_HIP_EINVAL;
     }
     if (x4_bytes > ctx->x4_capacity) {
@@ -1713,11 +1727,6 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
 // (device pointer, uint32, ld >= b->n_rows): the tile kernel over a shadow holding [A ; B].
 int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                          const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld) {
-    if ((uint64_t)a->n_words * 64u >= (1ull << 24)) {
-        set_error("square_matrix: rows of %llu bits exceed exact f32 accumulation (2^24)",
-                  (unsigned long long)a->n_words * 64u);
-        return STORM_HIP_EINVAL;
-    }
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
@@ -1726,6 +1735,11 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;
     if ((rows_a + rows_b) / kTile >= 65535) {
         set_error("square_matrix: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    if (pitch * (uint64_t)kTile > (1ull << 32)) {
+        set_error("square_matrix: rows of %llu nibble bytes exceed the tile kernel's 32-bit DMA offsets",
+                  (unsigned long long)row_bytes);
         return STORM_HIP_EINVAL;
     }
     const size_t x4_bytes = (size_t)(rows_a + rows_b) * pitch;

@@ -425,6 +425,7 @@ int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
 // Launches this shard's share into the context's result word; _end fetches it.
 int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,
                                  uint32_t shard_rank, uint32_t shard_count) {
+    return guarded("storm_hip_pairw_sparse_begin", [&]() -> int {
     if (!ctx || !cs) {
         set_error("pairw_sparse: NULL argument");
         return STORM_HIP_EINVAL;
@@ -492,6 +493,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                                        reinterpret_cast<uint64_t*>(ctx->d_scalar)))
         return rc;
     return STORM_HIP_OK;
+    });
 }
 
 int storm_hip_sparse_last_census(storm_hip_ctx_t* ctx, uint64_t out[4]) {

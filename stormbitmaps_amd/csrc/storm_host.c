@@ -902,10 +902,13 @@ int STORM_bitmap_cont_add(STORM_bitmap_cont_t* r, const uint32_t* values,
         STORM_bitmap_t* b = &r->bitmaps[r->n_bitmaps];
         b->id = block;
         r->block_ids[r->n_bitmaps] = block;
-        if (stop - start < STORM_DEFAULT_SCALAR_THRESHOLD)
-            STORM_bitmap_add_scalar_only(b, values + start, stop - start);
-        else
-            STORM_bitmap_add(b, values + start, stop - start);
+        const int added = stop - start < STORM_DEFAULT_SCALAR_THRESHOLD
+                              ? STORM_bitmap_add_scalar_only(b, values + start, stop - start)
+                              : STORM_bitmap_add(b, values + start, stop - start);
+        if (added < 0) { /* allocation failed: the block is not counted, the row stays consistent */
+            STORM_bitmap_clear(b);
+            return -3;
+        }
         ++r->n_bitmaps;
         r->prev_inserted_value = values[stop - 1];
         start = stop;
@@ -995,7 +998,13 @@ int STORM_add(STORM_t* h, const uint32_t* values, const uint32_t n_values) { /* 
         h->conts = nc;
         h->m_conts = new_m;
     }
-    STORM_bitmap_cont_add(&h->conts[h->n_conts++], values, n_values);
+    /* NULL or empty `values` still append an (empty) row and return 1, as storm.c:864 does; only an
+     * allocation failure inside the row (-3) undoes the add */
+    if (STORM_bitmap_cont_add(&h->conts[h->n_conts], values, n_values) == -3) {
+        STORM_bitmap_cont_clear(&h->conts[h->n_conts]);
+        return -3;
+    }
+    ++h->n_conts;
     h->hip_dirty = 1;
     return 1;
 }
@@ -1225,7 +1234,7 @@ static int storm_build_arena(STORM_t* h) {
                     kinds[nb] = 0;
                     offs[nb] = nl;
                     lens[nb] = blk->n_scalar;
-                    memcpy(lists + nl, blk->scalar, blk->n_scalar * sizeof(uint16_t));
+                    if (blk->n_scalar) memcpy(lists + nl, blk->scalar, blk->n_scalar * sizeof(uint16_t));
                     nl += blk->n_scalar;
                 }
             }

@@ -1,0 +1,70 @@
+"""No allocation failure may unwind or crash through the C boundary.
+
+1. C++ side: an extern "C" entry point whose std::vector cannot grow (address space capped with
+   RLIMIT_AS in a child process) must return STORM_HIP_ENOMEM and set the error text — not abort
+   with an uncaught std::bad_alloc.
+2. C side: tests/host_sanitize/alloc_inject.h makes the k-th allocation of storm_host.c fail, for
+   every k a scenario reaches, under AddressSanitizer: every failure must surface as the documented
+   return code (NULL / -3 / 0 / (uint64_t)-1), without a crash, leak or use of freed memory."""
+import os
+import shutil
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "stormbitmaps_amd", "libstorm_hip.so")
+
+
+def test_bad_alloc_in_the_strip_planner_becomes_enomem():
+    child = textwrap.dedent(f"""
+        import ctypes as C, resource
+        resource.setrlimit(resource.RLIMIT_AS, (2 << 30, 2 << 30))
+        try:
+            C.CDLL("/opt/rocm/lib/libamdhip64.so", mode=C.RTLD_GLOBAL)
+        except OSError:
+            import torch  # noqa: F401  (the wheel's HIP runtime)
+        lib = C.CDLL({LIB!r})
+        lib.storm_hip_strip_plan.restype = C.c_int
+        lib.storm_hip_strip_plan.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                             C.c_uint64, C.c_void_p]
+        lib.storm_hip_last_error.restype = C.c_char_p
+        n = C.c_uint64(0)
+        # ~1.2e8 work items x 20 B: cannot be built inside 2 GiB of address space
+        rc = lib.storm_hip_strip_plan(1_000_000, 2048, 0, 1, None, 0, C.byref(n))
+        print("rc", rc, lib.storm_hip_last_error().decode())
+        ok = lib.storm_hip_strip_plan(3000, 64, 0, 1, None, 0, C.byref(n))   # the library is still usable
+        print("after", ok, n.value)
+    """)
+    res = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "rc -4" in res.stdout and "bad_alloc" in res.stdout or "out of host memory" in res.stdout, res.stdout
+    assert "after 0" in res.stdout, res.stdout
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_every_failing_allocation_of_the_host_side_is_survived(tmp_path):
+    exe = tmp_path / "alloc_inject"
+    inc = os.path.join(ROOT, "tests", "host_sanitize", "alloc_inject.h")
+    srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
+            os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c")]
+    common = ["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+              "-fno-omit-frame-pointer", "-Wall", "-I" + os.path.join(ROOT, "include")]
+    objs = []
+    for src in srcs:   # only the product's host code sees the failing allocator
+        obj = tmp_path / (os.path.basename(src) + ".o")
+        build = subprocess.run(common + ["-include", inc, "-c", src, "-o", str(obj)], capture_output=True, text=True)
+        if build.returncode != 0 and "asan" in build.stderr.lower() and "cannot find" in build.stderr.lower():
+            pytest.skip("libasan not installed")
+        assert build.returncode == 0, build.stderr
+        objs.append(str(obj))
+    build = subprocess.run(common + objs + [os.path.join(ROOT, "tests", "host_sanitize", "device_stub.c"),
+                                            os.path.join(ROOT, "tests", "host_sanitize", "alloc_inject.c"),
+                                            "-o", str(exe), "-lm"], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "alloc inject: ok" in run.stdout, run.stdout[-2000:]

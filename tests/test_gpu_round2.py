@@ -328,3 +328,19 @@ def test_rows_stream_to_the_device_while_the_container_is_built(lib, orc):
     ctx.close()
     c.free()
     assert first < 2.0 * resident + 1e-3, (first, resident)
+
+
+def test_materialised_output_for_rows_beyond_exact_f32_range(hip_ctx, orc):
+    """Rows of 2^24 bits and more: one f32 accumulator cannot hold a whole row's count exactly, so
+    every tile of the materialised output is cut along k and the parts are added.
+    Dense enough that pair counts exceed 2^22, so a k-uncut f32 sum would be inexact."""
+    M, N = (1 << 24) + 4096, 70
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, M, seed=3)            # ~63 % density: pair counts ~ 6.7e6
+    host = m.download()
+    want = np.triu(orc.tile_counts(host, 0, N, 0, N), k=1)
+    assert want.max() > (1 << 22)
+    assert np.array_equal(m.pairw_matrix("and"), want)
+    assert np.array_equal(m.pairw_matrix("xor"), np.triu(orc.tile_counts_op(host, 0, N, 0, N, 2), k=1))
+    assert m.pairw() == int(want.sum(dtype=np.uint64)) == m.column_identity()
+    m.close()
