@@ -476,7 +476,11 @@ def test_benchmark_cli_rows_agree_with_golden_totals():
         assert res.returncode == 0, res.stderr
         lines = res.stdout.strip().splitlines()
         assert lines[0].startswith("Samples\tAlts\tMethod")
-        rows = [l.split("\t") for l in lines[1:]]
+        assert lines[1].startswith("#Method\tAlts\t") and lines[1].endswith("fp4_mfma_frac")
+        rows = [l.split("\t") for l in lines[2:]]
+        n_cols = len(lines[1].split("\t"))
+        assert all(len(r) == n_cols for r in rows), [len(r) for r in rows]
+        assert all(0.0 < float(r[-1]) < 1.0 and float(r[-3]) > 0 for r in rows)   # FP4 fraction, GB/s
         for load in (int(x) for x in loads.split(",")):
             totals = {int(r[2]) for r in rows if int(r[1]) == load}
             names = [r[0] for r in rows if int(r[1]) == load]

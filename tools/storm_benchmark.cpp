@@ -11,8 +11,12 @@
 // (storm_synth.h) instead of std::random_device (:756-757); the CPU PMU fields (cycles,
 // instructions, branch/cache misses) are printed as 0 — there is no perf_event on the device;
 // time is printed in ms with 3 decimals (a pass takes ~1 ms, the reference prints whole ms);
-// CRoaring and the direct-to-SIMD rows do not exist; two extra columns are appended:
-// GPUs used and 64-bit words/s.
+// CRoaring and the direct-to-SIMD rows do not exist; five extra columns are appended:
+// GPUs used, 64-bit words/s, algorithmic GB/s (the reference's no-reuse accounting, 8 B per word,
+// benchmark.cpp:131), that rate as a fraction of the GPUs' HBM peak (8 TB/s each; on-chip reuse
+// puts it far above 1) and the fraction of the GPUs' dense FP4 matrix-core peak (10 PFLOP/s each;
+// one word pair = 128 FLOP) — every figure over the WALL time of the call, host synchronisation and
+// (bitmap-hip row) the PCIe copy included. `--describe` prints one line per column.
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -50,10 +54,32 @@ static void print_row(const std::string& name, uint32_t load, const char* extra,
     const double n_comps = (double)n_variants * (n_variants - 1) / 2.0;
     const double words = n_comps * 2.0 * (double)n_ints;
     const double mbs = words * 8.0 / (1024.0 * 1024.0) / (r.ms / 1000.0);
-    printf("%s\t%u\t%s%llu\t%.2f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.2f\t%.3f\t%d\t%.4e\n",
+    const double secs = r.ms / 1000.0;
+    const double gbs = words * 8.0 / 1e9 / secs;                  // algorithmic (no reuse credit)
+    const double hbm_frac = gbs / (8000.0 * gpus);                // of 8 TB/s per GPU
+    const double fp4_frac = words / 2.0 * 128.0 / secs / (1e16 * gpus);  // of 10 PFLOP/s per GPU
+    printf("%s\t%u\t%s%llu\t%.2f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.2f\t%.3f\t%d\t%.4e\t%.1f\t%.3f\t%.3e\n",
            name.c_str(), load, extra, (unsigned long long)r.total, 0.0, 0.0, 0.0, 0ull, 0ull, 0ull,
-           0ull, 0ull, mbs, r.ms, gpus, words / (r.ms / 1000.0));
+           0ull, 0ull, mbs, r.ms, gpus, words / secs, gbs, hbm_frac, fp4_frac);
     fflush(stdout);
+}
+
+static void describe_columns() {
+    fprintf(stderr,
+            "columns of a result row (tab separated; reference row = name, load, [size], then bench_t::PrintPretty, benchmark.cpp:74-87):\n"
+            "  1 Method                 row name of the reference (storm, storm-blocked, STORM-contig, STORM-contig-<b>); bitmap-hip-blocked-<b> = STORM_wrapper_diag_blocked on the raw buffer\n"
+            "  2 Alts                   values drawn per row (the load)\n"
+            "  [3 size]                 STORM_serialized_size, only in the M >= 256000 form (benchmark.cpp:609)\n"
+            "  + total                  bench_t.total: sum over row pairs of popcount(A & B)\n"
+            "  + instructions_cycle, cycles_word, instructions_word, cycles, instructions, MinBranchMiss, MinCacheRef, MinCacheMiss\n"
+            "                           CPU PMU fields of bench_t (:76-84): printed as 0, the work runs on the GPU\n"
+            "  + throughput             bench_t.throughput: pairs * 2 * W * 8 B / 2^20 / s (:129-131), MiB/s\n"
+            "  + time_ms                bench_t.time_ms, best of --reps calls, 3 decimals (the reference prints whole ms)\n"
+            "  + GPUs                   devices the call was sharded over (--gpus)\n"
+            "  + words_per_s            pairs * 2 * W / s: the BASELINE metric\n"
+            "  + GB_per_s_algorithmic   words_per_s * 8 / 1e9 (no-reuse accounting of the reference)\n"
+            "  + hbm_frac_algorithmic   that over 8 TB/s per GPU (exceeds 1: operands are reused on chip)\n"
+            "  + fp4_mfma_frac          pairs * W * 128 FLOP / s over 10 PFLOP/s per GPU (the binding roof of the default path)\n");
 }
 
 static std::vector<uint32_t> default_loads(uint32_t M) {
@@ -65,7 +91,7 @@ int main(int argc, char** argv) {
         fprintf(stderr,
                 "\nAbout:   Computes sum(popcnt(A & B)) for the all-vs-all comparison of N integer\n"
                 "         lists bounded by [0, M) on the MI355X.\n"
-                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G] [--seed S] [--reps R]\n\n");
+                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G] [--seed S] [--reps R] [--describe]\n\n");
         return EXIT_FAILURE;
     }
     int64_t n_samples = 0, n_vals = 10000;  // one-argument form uses N = 10000 (benchmark.cpp:1102)
@@ -76,6 +102,7 @@ int main(int argc, char** argv) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--describe")) { describe_columns(); return EXIT_SUCCESS; }
         else if (positional == 0) { n_samples = atoll(argv[i]); ++positional; }
         else if (positional == 1) { n_vals = atoll(argv[i]); ++positional; }
         else {
@@ -97,7 +124,11 @@ int main(int argc, char** argv) {
     for (int g = 0; g < gpus; ++g) ids[g] = g;
     STORM_hip_set_devices(gpus, ids.data());
 
+    // the reference's header line as it stands (benchmark.cpp:506, :671; it does not match its own rows),
+    // then the names of the columns actually printed
     printf("Samples\tAlts\tMethod\tTime(ms)\tCPUCycles\tCount\tThroughput(MB/s)\tInts/s(1e6)\tIntersect/s(1e6)\tActualThroughput(MB/s)\tCycles/int\tCycles/intersect\n");
+    printf("#Method\tAlts\t%stotal\tinstructions_cycle\tcycles_word\tinstructions_word\tcycles\tinstructions\tMinBranchMiss\tMinCacheRef\tMinCacheMiss\tthroughput(MiB/s)\ttime_ms\tGPUs\twords_per_s\tGB_per_s_algorithmic\thbm_frac_algorithmic\tfp4_mfma_frac\n",
+           n_samples >= 256000 ? "size\t" : "");
     const uint32_t n_ints = (uint32_t)std::ceil(M / 64.0);
     uint32_t optimal_b = (uint32_t)(STORM_CACHE_BLOCK_SIZE / (n_ints * 8));  // :823-824
     if (optimal_b < 5) optimal_b = 5;
