@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-rank cost of the k-group sharding on ONE GPU (rehearsal for the multi-GPU bench): time
+"""Per-rank cost of the two-level work split (storm_hip_strip_plan) on ONE GPU (rehearsal for the multi-GPU bench): time
 storm_hip_pairw_dense_launch for rank r of `world` at the headline shape, for several worlds.
 Ideal is t(1)/world; prints the launch time of the slowest rank and the implied scaling."""
 import argparse
