@@ -630,6 +630,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
+    } else if (!strcmp(key, "k2_tile_shape")) {
+        if (value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 16 or 32");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_tile_shape = (int)value;
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
