@@ -173,6 +173,9 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *                  this library alone (upload / import / set_rows / fill / clear), never through
  *                  storm_hip_matrix_device_ptr. storm.h handles use it.
  *   key "time_kernels": see storm_hip_kernel_time
+ *   key "sparse_probe": sparse container, block columns whose blocks are all lists: -1 = auto (the
+ *                  list-probe kernel K4 when the mean list has <= 400 positions, else the dense path),
+ *                  0 = never, 1 = every eligible column
  *   key "seg_rows": K1 B rows per work item (default 256)
  *   key "chunks_per_item": K1 k-chunks (64 words each) per work item, 0 = auto
  *   key "k2_stages_per_item": K2 tile kernel k-slice length in 128-bit stages (default 32)
@@ -205,7 +208,8 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
 int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launches);
 /* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,
  * [2]=word-pairs executed incl. zero padding (popcount kernel) / k-chunks of the pass (matrix-core
- * strips: 1 unless the shadow budget forced HBM tiling), [3]=segments */
+ * strips: 1 unless the shadow budget forced HBM tiling), [3]=segments (popcount kernel) / block columns
+ * counted by the list-probe kernel (sparse container) */
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);
 
 /* ---- multi-GPU work split of the default (matrix-core strip) path, host-only ---------------

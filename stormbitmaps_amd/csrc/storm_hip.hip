@@ -591,6 +591,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->variant = (int)value;
+    } else if (!strcmp(key, "sparse_probe")) {
+        if (value < -1 || value > 1) {
+            set_error("sparse_probe must be -1 (auto), 0 (never) or 1 (every eligible column)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->sparse_probe = (int)value;
     } else if (!strcmp(key, "seg_rows")) {
         if (value < 1 || value > (1 << 20)) {
             set_error("seg_rows out of range");

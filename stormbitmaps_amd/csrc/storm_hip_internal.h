@@ -89,6 +89,7 @@ struct storm_hip_ctx_s {
     // options
     int variant = -1;       // -1 auto, 0/1/2 popcount kernel (B path), 3 MFMA tiles, 4 MFMA strips
     int variant_used = 2;   // what the last dense launch ran
+    int sparse_probe = -1;  // sparse container: list-probe kernel for columns of short lists (-1 auto, 0 never, 1 always)
     int seg_rows = 256;
     int chunks_per_item = 0;
     // info of the last dense launch

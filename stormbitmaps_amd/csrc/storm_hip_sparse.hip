@@ -31,6 +31,16 @@ struct storm_hip_sparse_s {
     std::vector<RowRange> cols;      // pool-row range [r0, r1) of each non-empty column; every r0
                                      // is a multiple of 512 and the gap up to it is zero rows
     uint64_t census[4] = {0, 0, 0, 0};
+    // list-probe path (K4): columns whose blocks are all short lists
+    std::vector<uint8_t> col_probe;  // per entry of `cols`: 1 = has probe data
+    std::vector<uint32_t> col_avg_len;  // per entry of `cols`: mean list length (probe columns)
+    uint32_t* d_probe_elems = nullptr;  // (row in column) << 16 | position in block, column by column, row order
+    struct ProbeItemHost { uint32_t a_begin, a_end, b_begin, b_end, a0, col; };
+    std::vector<ProbeItemHost> probe_items;  // all eligible columns; filtered per launch
+    void* d_probe_items = nullptr;
+    size_t probe_items_capacity = 0;
+    uint64_t probe_key = ~0ull;
+    uint32_t n_probe_launch = 0, n_probe_cols_launch = 0;
     // segment table cache (per shard)
     Seg* d_segs = nullptr;
     uint32_t n_segs = 0;
@@ -81,6 +91,68 @@ __global__ __launch_bounds__(kThreads) void place_bitmaps_u16_kernel(
         const uint16_t* q = src + 4u * k;
         dst[k] = (uint64_t)q[0] | ((uint64_t)q[1] << 16) | ((uint64_t)q[2] << 32) | ((uint64_t)q[3] << 48);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 — list probe kernel for block columns whose blocks are all short sorted lists (the reference's
+// "extremely fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached
+// through the kind dispatch :618-656). The dense path multiplies 8 KiB per present block whatever
+// its density; here the work is proportional to the listed positions.
+//   data  : per column the lists of its rows, concatenated in row order, one uint32 per listed
+//           position: (row in column) << 16 | position in block;
+//   item  : 16 consecutive A rows of a column x a chunk of the elements of the LATER rows;
+//   LDS   : the 16 A rows as a TRANSPOSED bitmap — T[position] = 16-bit mask of the A rows that have
+//           that position set (65536 x 16 bit = 128 KiB) — zeroed and scattered per item;
+//   stream: every element of the later rows is ONE LDS read: popcount(T[pos] & rows_before(j)) is that
+//           element's contribution against all 16 A rows at once; 16-byte coalesced loads of the
+//           element array (an XCD's L2 holds a column's few MB), 1024 threads per workgroup.
+// Pairs i < j: B rows inside the A group mask off the A rows that are not before them.
+// ------------------------------------------------------------------------------------------
+struct ProbeItem {
+    uint32_t a_begin, a_end;  // elements of the A rows [a0, a0 + 16)
+    uint32_t b_begin, b_end;  // chunk of the elements of rows > a0
+    uint32_t a0;              // first A row (row index within the column)
+};
+constexpr int kProbeThreads = 1024;
+constexpr uint32_t kProbeChunk = 1u << 17;  // elements per item
+
+__global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
+    const uint32_t* __restrict__ elems, const ProbeItem* __restrict__ items, uint32_t item_stride,
+    uint32_t item_first, unsigned long long* __restrict__ slots) {
+    __shared__ __attribute__((aligned(16))) uint32_t T[32768];  // two 16-bit masks per word
+    const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t w = tid * 4u; w < 32768u; w += kProbeThreads * 4u)
+        *reinterpret_cast<uint4*>(&T[w]) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    for (uint32_t e = it.a_begin + tid; e < it.a_end; e += kProbeThreads) {
+        const uint32_t v = elems[e];
+        const uint32_t pos = v & 0xffffu, r = (v >> 16) - it.a0;  // r in 0..15
+        atomicOr(&T[pos >> 1], 1u << (r + 16u * (pos & 1u)));
+    }
+    __syncthreads();
+    uint32_t count = 0;
+    auto visit = [&](uint32_t v) {
+        const uint32_t pos = v & 0xffffu, jr = (v >> 16) - it.a0;  // >= 1
+        const uint32_t mask = jr >= 16u ? 0xffffu : (1u << jr) - 1u;
+        count += __popc((T[pos >> 1] >> (16u * (pos & 1u))) & mask);
+    };
+    // head up to a 16-byte boundary, body in uint4, tail
+    uint32_t e = it.b_begin;
+    const uint32_t head_end = min(it.b_end, (it.b_begin + 3u) & ~3u);
+    if (e + tid < head_end) visit(elems[e + tid]);
+    e = head_end;
+    const uint32_t body_end = e + ((it.b_end - e) & ~3u);
+    for (uint32_t q = e + tid * 4u; q < body_end; q += kProbeThreads * 4u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&elems[q]);
+        visit(v.x); visit(v.y); visit(v.z); visit(v.w);
+    }
+    if (body_end + tid < it.b_end) visit(elems[body_end + tid]);
+    uint64_t mine = count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if ((tid & 63u) == 0 && mine != 0)
+        atomicAdd(&slots[(blockIdx.x * 16u + (tid >> 6)) & (kSlots - 1)], (unsigned long long)mine);
 }
 
 template <typename T>
@@ -218,6 +290,73 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
     }
 
+    // ---- probe data (K4): columns whose blocks are all lists, at most 65535 rows, mean list length
+    //      <= kProbeMaxAvgLen (beyond that the dense path is faster anyway: DESIGN.md §4)
+    std::vector<uint32_t> probe_elems;
+    {
+        constexpr uint64_t kProbeMaxAvgLen = 1024;
+        std::vector<uint64_t> col_elems((size_t)max_id + 2, 0);
+        for (uint64_t b = 0; b < n_blocks; ++b)
+            if (block_kind[b] == 0) col_elems[block_id[b]] += block_n[b];
+        std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
+        std::vector<uint64_t> elem_base((size_t)max_id + 2, 0);
+        s->col_probe.assign(s->cols.size(), 0);
+        s->col_avg_len.assign(s->cols.size(), 0);
+        uint64_t total = 0;
+        size_t entry = 0;
+        for (uint32_t c = 0; c <= max_id; ++c) {
+            if (!per_col[c]) continue;
+            col_entry[c] = (int64_t)entry;
+            const uint64_t n_c = per_col[c];
+            if (n_list_col[c] == n_c && n_c >= 2 && n_c <= 65535 && col_elems[c] > 0 &&
+                col_elems[c] <= n_c * kProbeMaxAvgLen && total + col_elems[c] < (1ull << 32) - 8) {
+                s->col_probe[entry] = 1;
+                s->col_avg_len[entry] = (uint32_t)(col_elems[c] / n_c);
+                total = (total + 3) & ~3ull;  // columns start on 16-byte boundaries
+                elem_base[c] = total;
+                total += col_elems[c];
+            }
+            ++entry;
+        }
+        if (total > 0) {
+            probe_elems.assign((size_t)total + 4, 0);
+            std::vector<uint64_t> cursor(elem_base);
+            std::vector<uint64_t> next(start);
+            // per probe column: element offset of every row (rows are visited in order)
+            std::vector<std::vector<uint32_t>> row_start(s->cols.size());
+            for (size_t e = 0; e < s->cols.size(); ++e)
+                if (s->col_probe[e]) row_start[e].reserve((size_t)(s->cols[e].r1 - s->cols[e].r0) + 1);
+            for (uint64_t b = 0; b < n_blocks; ++b) {
+                const uint32_t c = block_id[b];
+                const uint64_t local = next[c]++ - start[c];
+                const int64_t e = col_entry[c];
+                if (e < 0 || !s->col_probe[(size_t)e]) continue;
+                row_start[(size_t)e].push_back((uint32_t)cursor[c]);
+                const uint16_t* l = list_pool + block_data_offset[b];
+                for (uint32_t k = 0; k < block_n[b]; ++k)
+                    probe_elems[(size_t)cursor[c]++] = ((uint32_t)local << 16) | l[k];
+            }
+            for (size_t e = 0; e < s->cols.size(); ++e) {
+                if (!s->col_probe[e]) continue;
+                std::vector<uint32_t>& rs = row_start[e];
+                const uint32_t n_c = (uint32_t)rs.size();
+                rs.push_back(n_c ? rs[0] + 0u : 0u);  // placeholder, fixed below
+                // end offset of the column = start of its first row + its element count
+                uint64_t cnt = 0;
+                for (uint32_t c = 0; c <= max_id; ++c)
+                    if (col_entry[c] == (int64_t)e) { cnt = col_elems[c]; break; }
+                rs[n_c] = rs[0] + (uint32_t)cnt;
+                for (uint32_t a0 = 0; a0 + 1 < n_c; a0 += 16) {
+                    const uint32_t a1 = std::min(a0 + 16u, n_c);
+                    if (rs[a1] == rs[a0]) continue;  // no listed position in the A rows
+                    for (uint32_t b0 = rs[a0 + 1]; b0 < rs[n_c]; b0 += kProbeChunk)
+                        s->probe_items.push_back({rs[a0], rs[a1], b0, std::min(rs[n_c], b0 + kProbeChunk),
+                                                  a0, (uint32_t)e});
+                }
+            }
+        }
+    }
+
     // ---- device pool ----
     int rc = STORM_HIP_OK;
     uint32_t *d_lrow = nullptr, *d_llen = nullptr, *d_drow = nullptr;
@@ -237,6 +376,9 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             rc = STORM_HIP_EHIP;
             break;
         }
+        if (!probe_elems.empty() &&
+            (rc = upload(&s->d_probe_elems, probe_elems.data(), probe_elems.size(), ctx->stream)))
+            break;
         // the list pool (or the whole serialized stream) goes up once
         if (!list_row.empty() || (bitmaps_in_stream && !dense_row.empty()))
             if ((rc = upload(&d_lists, list_pool, (size_t)list_pool_len, ctx->stream))) break;
@@ -397,6 +539,8 @@ void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
     }
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_segs) (void)hipFree(s->d_segs);
+    if (s->d_probe_elems) (void)hipFree(s->d_probe_elems);
+    if (s->d_probe_items) (void)hipFree(s->d_probe_items);
     delete s;
 }
 
@@ -445,14 +589,59 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     if (variant < 0) variant = widest >= 64 ? 4 : 2;
     ctx->variant_used = variant;
     if (variant >= 3) {
+        // K4: columns of short lists go to the probe kernel ("sparse_probe": -1 = when the mean list
+        // has at most 400 positions — measured at c4 (profiles/r02_j_sparse_probe.jsonl): 31x faster
+        // than the dense path at 13 positions per list, 7.5x at 65, 1.2x at 393, 0.67x at 655 —,
+        // 1 = every eligible column, 0 = never); what it counts lands in the same slots the strips'
+        // fold sums up
+        std::vector<uint8_t> use_probe(s->cols.size(), 0);
+        if (ctx->sparse_probe != 0 && s->d_probe_elems)
+            for (size_t e = 0; e < s->cols.size(); ++e)
+                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 400u);
+        {
+            uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
+            for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;
+            if (key != s->probe_key) {
+                std::vector<ProbeItem> mine;
+                uint32_t cols_used = 0;
+                for (size_t e = 0; e < use_probe.size(); ++e) cols_used += use_probe[e];
+                for (const auto& pi : s->probe_items)
+                    if (use_probe[pi.col]) mine.push_back({pi.a_begin, pi.a_end, pi.b_begin, pi.b_end, pi.a0});
+                if (mine.size() > s->probe_items_capacity) {
+                    if (s->d_probe_items) STORM_HIP_TRY(hipFree(s->d_probe_items));
+                    s->d_probe_items = nullptr;
+                    s->probe_items_capacity = 0;
+                    STORM_HIP_TRY(hipMalloc(&s->d_probe_items, std::max<size_t>(mine.size(), 1024) * sizeof(ProbeItem)));
+                    s->probe_items_capacity = std::max<size_t>(mine.size(), 1024);
+                }
+                if (!mine.empty()) {
+                    STORM_HIP_TRY(hipMemcpyAsync(s->d_probe_items, mine.data(), mine.size() * sizeof(ProbeItem),
+                                                 hipMemcpyHostToDevice, ctx->stream));
+                    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                }
+                // shard r of G takes items r, r + G, ...: the grid covers ceil((n - r) / G) of them
+                s->n_probe_launch = mine.size() > shard_rank
+                                        ? (uint32_t)((mine.size() - shard_rank + shard_count - 1) / shard_count)
+                                        : 0u;
+                s->n_probe_cols_launch = cols_used;
+                s->probe_key = key;
+            }
+        }
+        if (s->n_probe_launch > 0) {
+            hipLaunchKernelGGL(probe_lists_kernel, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
+                               s->d_probe_elems, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
+                               shard_rank, ctx->d_slots);
+            STORM_HIP_TRY(hipGetLastError());
+        }
         std::vector<RowRange> ranges;
-        for (const RowRange& c : s->cols)
-            if (c.r1 - c.r0 > 1) ranges.push_back(c);
+        for (size_t e = 0; e < s->cols.size(); ++e)
+            if (!use_probe[e] && s->cols[e].r1 - s->cols[e].r0 > 1) ranges.push_back(s->cols[e]);
         if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 512,
                                               std::max<uint64_t>(s->n_pool_rows, 512), ranges,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;
+        ctx->last_info[3] = s->n_probe_cols_launch;  // block columns counted by the list-probe kernel
         return STORM_HIP_OK;
     }
     const uint32_t seg_len = (uint32_t)ctx->seg_rows;

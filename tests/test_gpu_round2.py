@@ -344,3 +344,48 @@ def test_materialised_output_for_rows_beyond_exact_f32_range(hip_ctx, orc):
     assert np.array_equal(m.pairw_matrix("xor"), np.triu(orc.tile_counts_op(host, 0, N, 0, N, 2), k=1))
     assert m.pairw() == int(want.sum(dtype=np.uint64)) == m.column_identity()
     m.close()
+
+
+@pytest.mark.parametrize("M,N,d", [(524288, 3000, 524), (524288, 1037, 104), (196608, 2100, 40), (262144, 517, 1500),
+                                   (65536, 300, 3)])
+def test_list_probe_kernel_for_columns_of_short_lists(hip_ctx, orc, M, N, d):
+    """K4 (reference regime: list x list blocks, storm.c:4-73 through the kind dispatch :618-656):
+    block columns whose blocks are all short lists are counted by the probe kernel (transposed 16-row
+    bitmap in the LDS, streamed (row, position) elements) instead of being expanded to dense pool
+    rows. Same totals as the dense-on-present-blocks path and the oracle, per shard too; rows with
+    no values and row counts that are not multiples of 16 included."""
+    rows = synth.positions(M, N, d, seed=M + N + d)
+    rows[7] = np.zeros(0, dtype=np.uint32)
+    rows[N - 1] = rows[N - 1][:1]
+    s = sb.Storm()
+    for r in rows:
+        s.add(r)
+    ctx = sb.HipContext(0)                     # option changes must not leak into other tests' context
+    lib = sb.load()
+    want = orc.storm(rows).pairw_blocked(0) if N * d <= 2_000_000 else None
+    data = s.serialize()
+    h = C.c_void_p()
+    assert lib.storm_hip_sparse_create_serialized(ctx._h, data.ctypes.data_as(C.c_void_p), data.size, C.byref(h)) == 0
+    out = C.c_uint64()
+    got = {}
+    try:
+        for probe in (0, 1, -1):
+            ctx.set_option("sparse_probe", probe)
+            assert lib.storm_hip_pairw_sparse(ctx._h, h, 0, 1, C.byref(out)) == 0, lib.storm_hip_last_error()
+            got[probe] = out.value
+            used = ctx.last_launch_info()["segments"]            # out[3]: columns the probe kernel counted
+            auto = d * 65536 // M <= 400                         # mean list length per block vs the auto rule
+            assert (used > 0) == (probe == 1 or (probe == -1 and auto)), (probe, used)
+            parts = []
+            for r in range(3):
+                assert lib.storm_hip_pairw_sparse(ctx._h, h, r, 3, C.byref(out)) == 0
+                parts.append(out.value)
+            assert sum(parts) == got[probe], (probe, parts)
+    finally:
+        lib.storm_hip_sparse_destroy(ctx._h, h)
+        ctx.close()
+    assert got[0] == got[1] == got[-1], got
+    if want is not None:
+        assert got[0] == want
+    assert s.pairw_intersect_cardinality() == got[0]
+    s.free()
