@@ -1130,11 +1130,12 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    // variant -1 = auto: the matrix-core strips at every size they can address (their 64-row B
-    // stages need 64 * row_bytes < 2^32). Measured (tools/bench_crossover.py): they beat the
-    // popcount kernel from N = 64 up (10-37 us vs its 42-84 us latency floor at N <= 256).
+    // variant -1 = auto: the matrix-core strips at every size (rows beyond their 32-bit DMA offsets
+    // are multiplied k-chunk by k-chunk over a compact shadow). Measured (tools/bench_crossover.py):
+    // they beat the popcount kernel from N = 64 up (10-37 us vs its 42-84 us latency floor at
+    // N <= 256).
     int variant = ctx->variant;
-    if (variant < 0) variant = (m->stride_words * 32ull * 64ull < (1ull << 32)) ? 4 : 2;
+    if (variant < 0) variant = 4;
     ctx->variant_used = variant;
     if (variant >= 3) {
         const int saved = ctx->variant;

@@ -1457,12 +1457,21 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     const uint64_t rows_alloc = std::max<uint64_t>(n_rows_dst, kTile);
     uint32_t n_chunks = 1, chunk_slices = n_kslices;
     uint64_t shadow_row_bytes = row_bytes;
-    if (strips && ctx->k2_shadow_budget_mb > 0) {
-        const uint64_t budget = (uint64_t)ctx->k2_shadow_budget_mb << 20;
-        const uint64_t full = rows_alloc * shadow_pitch(ctx, row_bytes, true);
-        if (full > budget && n_kslices > 8) {
-            const uint64_t want = (full + budget - 1) / budget;
+    if (strips) {
+        uint64_t want = 1;  // chunks needed
+        if (ctx->k2_shadow_budget_mb > 0) {
+            const uint64_t budget = (uint64_t)ctx->k2_shadow_budget_mb << 20;
+            const uint64_t full = rows_alloc * shadow_pitch(ctx, row_bytes, true);
+            if (full > budget && n_kslices > 8) want = (full + budget - 1) / budget;
+        }
+        // the strips address a B stage (64 shadow rows) with 32-bit DMA offsets: a chunk's row pitch
+        // stays below 2^26 bytes. Rows of more than 2^27 bits are therefore ALWAYS chunked (round 1
+        // sent them to the popcount kernel at a fifth of the rate).
+        constexpr uint32_t kDmaCapSlices = ((1u << 26) - 1024u) / kStripRowBytes / 8u * 8u;
+        want = std::max<uint64_t>(want, ((uint64_t)n_kslices + kDmaCapSlices - 1) / kDmaCapSlices);
+        if (want > 1) {
             chunk_slices = (uint32_t)(((uint64_t)n_kslices + want - 1) / want + 7u) / 8u * 8u;
+            chunk_slices = std::min(chunk_slices, kDmaCapSlices);
             n_chunks = (n_kslices + chunk_slices - 1) / chunk_slices;
             shadow_row_bytes = (uint64_t)chunk_slices * kStripRowBytes;
         }

@@ -229,24 +229,6 @@ static void dense_state_release(dense_state_t* st) {
     }
 }
 
-/* replicate `n_rows` host rows on every configured device (one replica per GPU) */
-static int dense_state_upload(dense_state_t* st, const uint64_t* rows, uint64_t n_rows,
-                              uint32_t n_words, uint64_t stride_words) {
-    configure_from_env();
-    st->config_generation = g_config_generation;
-    for (int d = 0; d < g_n_devices; ++d) {
-        storm_hip_ctx_t* ctx = device_ctx(d);
-        if (!ctx) return -1;
-        if (storm_hip_matrix_create(ctx, n_rows, n_words, &st->m[d]) != STORM_HIP_OK ||
-            storm_hip_matrix_upload(ctx, st->m[d], 0, n_rows, rows, stride_words) !=
-                STORM_HIP_OK) {
-            device_error("dense upload");
-            return -1;
-        }
-    }
-    return 0;
-}
-
 /* all configured devices work concurrently on disjoint shards; the host adds the partials */
 static uint64_t dense_state_pairw(dense_state_t* st) {
     const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
@@ -269,19 +251,37 @@ static uint64_t dense_state_pairw(dense_state_t* st) {
     return total;
 }
 
+/* The raw-buffer wrappers (STORM_wrapper_*) get the caller's matrix anew on every call; what can be
+ * kept between calls is the device allocation: one replica set per process, resized and re-uploaded
+ * (a hipMalloc + zero fill + hipFree of the matrix per call cost more than the copy at small sizes). */
+static dense_state_t g_wrapper_state;
+static uint32_t g_wrapper_words = 0;
+
 static uint64_t raw_pairw(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints) {
     if (n_vectors < 2 || n_ints == 0) return 0;
     if (!vals) {
         host_error("all-pairs wrapper: NULL buffer");
         return ALL_PAIRS_FAILED;
     }
-    dense_state_t st;
-    memset(&st, 0, sizeof(st));
-    uint64_t total = ALL_PAIRS_FAILED;
-    if (dense_state_upload(&st, vals, n_vectors, n_ints, n_ints) == 0)
-        total = dense_state_pairw(&st);
-    dense_state_release(&st);
-    return total;
+    configure_from_env();
+    dense_state_t* st = &g_wrapper_state;
+    if (st->config_generation != g_config_generation || g_wrapper_words != n_ints) {
+        dense_state_release(st);
+        st->config_generation = g_config_generation;
+        g_wrapper_words = n_ints;
+    }
+    for (int d = 0; d < g_n_devices; ++d) {
+        storm_hip_ctx_t* ctx = device_ctx(d);
+        if (!ctx ||
+            (!st->m[d] && storm_hip_matrix_create(ctx, n_vectors, n_ints, &st->m[d]) != STORM_HIP_OK) ||
+            storm_hip_matrix_resize(ctx, st->m[d], n_vectors) != STORM_HIP_OK ||
+            storm_hip_matrix_upload(ctx, st->m[d], 0, n_vectors, vals, n_ints) != STORM_HIP_OK) {
+            device_error("all-pairs wrapper: upload");
+            dense_state_release(st);
+            return ALL_PAIRS_FAILED;
+        }
+    }
+    return dense_state_pairw(st);
 }
 
 /* reference storm.c:132-150 */

@@ -735,18 +735,23 @@ def test_materialised_rectangle(hip_ctx, orc):
         ma.close(); mb.close()
 
 
-def test_rows_beyond_the_strips_reach_fall_back_to_the_popcount_kernel(hip_ctx, orc):
-    """Rows longer than 2^27 bits do not fit the strip kernel's 32-bit DMA offsets: auto must pick
-    the popcount kernel and still be exact; forcing the strips must fail loudly, not wrongly."""
+def test_rows_beyond_the_dma_offsets_are_multiplied_in_k_chunks(hip_ctx, orc):
+    """Rows longer than 2^27 bits do not fit the strip kernel's 32-bit DMA offsets in one piece: the
+    pass runs k-chunk by k-chunk over a compact shadow (round 1 fell back to the popcount kernel);
+    the popcount kernel and the tile kernel's refusal stay as cross-checks."""
     M, N = 140_000_000, 3
     rng = np.random.default_rng(5)
     mat = rng.integers(0, 1 << 63, size=(N, (M + 63) // 64), dtype=np.uint64)
     mat[:, -1] &= np.uint64((1 << (M % 64)) - 1) if M % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
     m = hip_ctx.matrix_from_host(mat)
-    assert m.pairw() == orc.wrapper_diag(mat)
-    assert hip_ctx.get_option("variant_used") == 2
+    want = orc.wrapper_diag(mat)
+    assert m.pairw() == want
+    assert hip_ctx.get_option("variant_used") == 4
+    assert hip_ctx.last_launch_info()["word_pairs_executed"] >= 2      # out[2]: k-chunks of the pass
     try:
-        hip_ctx.set_option("variant", 4)
+        hip_ctx.set_option("variant", 2)
+        assert m.pairw() == want
+        hip_ctx.set_option("variant", 3)
         with pytest.raises(RuntimeError):
             m.pairw()
     finally:
