@@ -8,7 +8,8 @@ the reference's README headline `benchmark 65536 10000` (benchmark.cpp:906-918).
     words/s = N(N-1)/2 * 2 * ceil(M/64) / t          (benchmark.cpp:128-129)
 
 One step = one full all-pairs pass with the matrix already resident in HBM: the dense kernel
-over this rank's shard of the pair space + the 8-byte all-reduce of the partial totals.
+over this rank's shard of the work + the 8-byte all-reduce of the partial totals (issued async on
+RCCL's stream, so it overlaps the next step's pass; all of them complete inside the timed region).
 At --gpus N>1 (launched by torch.distributed.run, one rank per GPU, RCCL) the SAME total work
 is sharded over the ranks (strong scaling); `value` is whole-job words/s.
 
@@ -118,47 +119,84 @@ def main():
         ctx.set_option(k, int(v))
     mat = ctx.matrix(N, W)
     mat.fill_synthetic(M, draws, seed=args.seed)  # resident in HBM before any timing
-    total_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    # Two result words used in turn: the 8-byte all-reduce of step i runs on RCCL's own stream while
+    # the pass of step i+1 is already being computed (async_op); a word is only rewritten after the
+    # all-reduce that last used it has been ordered in front of the compute stream. Every step still
+    # carries its collective, and all of them have completed before the timed region's closing fence.
+    totals = torch.zeros(2, dtype=torch.int64, device=dev)
+    barrier_word = torch.zeros(1, dtype=torch.int64, device=dev)
+    pending = [None, None]
+    state = {"n": 0}
 
     collective = dist.is_initialized()
 
-    def reduce_total():
+    def launch_pass():
+        k = state["n"] & 1
+        if pending[k] is not None:
+            pending[k].wait()   # stream-level: orders the compute stream behind that collective
+            pending[k] = None
+        mat.pairw_launch(totals[k:].data_ptr(), rank, world)
+        return k
+
+    def reduce_total(k):
         if not collective:
             return
         if args.backend == "gloo":  # CPU transport (rehearsal only)
-            host = total_t.cpu()
+            host = totals[k:k + 1].cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            total_t.copy_(host)
+            totals[k:k + 1].copy_(host)
         else:
-            dist.all_reduce(total_t, op=dist.ReduceOp.SUM)
+            pending[k] = dist.all_reduce(totals[k:k + 1], op=dist.ReduceOp.SUM, async_op=True)
 
     def step():
-        mat.pairw_launch(total_t.data_ptr(), rank, world)
-        reduce_total()
+        k = launch_pass()
+        reduce_total(k)
+        state["n"] += 1
+
+    def last_total():
+        return int(totals[(state["n"] - 1) & 1].item())
 
     def fence():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if collective:
-            dist.barrier()
+            # barrier: no rank gets past it before every rank has reached it. With RCCL it is an
+            # all-reduce on a resident word followed by the ONE host wait below (dist.barrier()
+            # makes its own tensor and its own host wait: a longer idle gap in front of the timed
+            # steps, and idle time is what costs clock: profiles/r02_k_bench_nccl_ramp.txt)
+            if args.backend == "gloo":
+                dist.barrier()
+            else:
+                dist.all_reduce(barrier_word, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
 
     # The chip needs ~30 passes (~30 ms) from idle to settle (tools/bench_ramp.py: passes 3..25
     # run 1.17 -> 0.92 ms, steady 0.88): an untimed pre-warm in front of the W warmup steps makes
     # the figure independent of how small W is. Same work as a step, results discarded.
-    # Every rank must run the SAME number of steps (each step carries a collective): the ranks
-    # agree on "long enough" through a MAX all-reduce of their elapsed time after each batch.
+    # Every rank must run the SAME number of steps (each step carries a collective).
+    # One calibration batch, then ONE agreement on how many more passes make up the pre-warm (the
+    # slowest rank's estimate), then those passes back to back with no host round trip in between: a
+    # synchronise + all-reduce + .item() after every batch leaves the GPU idle each time, and a few
+    # milliseconds of idle cost ~10 % on the next 10-20 passes (profiles/r02_k_bench_nccl_ramp.txt).
+    # (the very first step pays for the RCCL communicator — seconds —, the shadow allocation and the
+    #  work list: it must not be part of the calibration, or the pre-warm collapses to nothing; that is
+    #  what made every N > 1 run of round 1's bench.py start its timed steps on a cold chip)
+    step()
+    fence()
     t_pre = time.perf_counter()
-    while True:
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize(dev)
-        waited = (time.perf_counter() - t_pre) * 1e3
-        if collective:
-            w = torch.tensor([waited], dtype=torch.float64,
-                             device=dev if args.backend != "gloo" else "cpu")
-            dist.all_reduce(w, op=dist.ReduceOp.MAX)
-            waited = float(w.item())
-        if waited >= args.prewarm_ms:
-            break
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize(dev)
+    per_step_ms = (time.perf_counter() - t_pre) * 1e3 / 10
+    n_pre = max(0, int(args.prewarm_ms / max(per_step_ms, 1e-3)) - 10)
+    if collective:
+        w = torch.tensor([n_pre], dtype=torch.int64, device=dev if args.backend != "gloo" else "cpu")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        n_pre = int(w.item())
+    for _ in range(n_pre):
+        step()
     for _ in range(args.warmup):
         step()
     fence()
@@ -168,11 +206,15 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
     t0 = time.perf_counter()
+    host_us = []
     for a, b in ev:
+        th = time.perf_counter()
         a.record(stream)
-        mat.pairw_launch(total_t.data_ptr(), rank, world)
+        k = launch_pass()
         b.record(stream)
-        reduce_total()
+        reduce_total(k)
+        state["n"] += 1
+        host_us.append((time.perf_counter() - th) * 1e6)
     fence()
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
@@ -180,8 +222,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total = int(total_t.item())
-    launch_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)   # expand + dominant kernel + fold
+    total = last_total()
+    per_step_pass_ms = [a.elapsed_time(b) for a, b in ev]
+    launch_ms = sum(per_step_pass_ms) / len(ev)   # expand + dominant kernel + fold
     dom_sum_ms, dom_n = ctx.kernel_time()
     ctx.set_option("time_kernels", 0)
     kernel_ms = dom_sum_ms / dom_n if dom_n else launch_ms
@@ -191,10 +234,11 @@ def main():
     per_rank = None
     if collective:
         n_ar = 20
-        reduce_total(); fence()
+        scratch = torch.zeros(1, dtype=torch.int64, device=dev if args.backend != "gloo" else "cpu")
+        dist.all_reduce(scratch); fence()
         t_ar = time.perf_counter()
         for _ in range(n_ar):
-            reduce_total()
+            dist.all_reduce(scratch, op=dist.ReduceOp.SUM)   # blocking form: latency of one collective
         torch.cuda.synchronize(dev)
         allreduce_us = (time.perf_counter() - t_ar) * 1e6 / n_ar
         mine = torch.tensor([kernel_ms, launch_ms, my_elapsed * 1e3 / args.steps, allreduce_us,
@@ -225,7 +269,7 @@ def main():
             e2 = float(t.item())
         ctx.set_option("keep_shadow", 0)
         shadow_resident = {"ms_per_step": e2 * 1e3 / n2, "steps": n2,
-                           "total_matches": int(total_t.item()) == total}
+                           "total_matches": last_total() == total}
 
     info = ctx.last_launch_info()
     pairs = N * (N - 1) // 2
@@ -307,6 +351,8 @@ def main():
             "total": total, "verified_against_column_identity": ok,
             "roofline": roof,
         }
+        out["pass_ms_first_steps"] = [round(x, 4) for x in per_step_pass_ms[:24]]  # rank 0: ramp after the fence?
+        out["host_enqueue_us_first_steps"] = [round(x, 1) for x in host_us[:24]]
         if per_rank is not None:
             out["per_rank"] = per_rank
             out["slowest_rank_kernel_ms"] = max(r["kernel_ms"] for r in per_rank)
