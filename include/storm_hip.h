@@ -218,9 +218,9 @@ int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);
  *   A tile rows [a_row0, a_row0 + 256) x k-slice ks (bits [256 ks, 256 ks + 256) of every row) x
  *   (diag ? the strict upper triangle inside the A tile : nothing) + the 64-row B blocks
  *   [j0, j1) (rows [64 j0, 64 j1)), i.e. the pairs (i, j), i in the A tile, j in those blocks.
- * Ownership: whole k-slices go to shard ks % shard_count; the n_kslices %
- * shard_count leftover slices are cut along the pair space, longest item first onto the least
- * loaded shard. The lists of all shards tile (pair, k-slice) space exactly once. Touches no
+ * Ownership: whole k-slices, in units of 4 (one 128-byte line of the bit matrix), go
+ * to shard (ks / 4) % shard_count; the leftover slices (fewer than 4 x shard_count) are cut along
+ * the pair space, longest item first onto the least loaded shard. The lists of all shards tile (pair, k-slice) space exactly once. Touches no
  * device; `out` may be NULL to query the item count. Shards the reference loop storm.c:1199-1238. */
 int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
                          uint32_t shard_count, uint32_t* out, uint64_t capacity_items,

@@ -64,19 +64,25 @@ __device__ __forceinline__ uint32_t spread8_fp4(uint32_t b, uint32_t nib = 2u) {
 }
 
 // Which columns a shard (multi-GPU rank) expands: the ownership unit is a run of 2^unit_shift
-// 32-bit half words of a row (3: one strip k-slice = 4 words; 7: one k-group = 64 words, the tile
-// kernel's k-slice). Units below modulo_units belong to shard unit % count; the units from there on
-// (the strips' leftover slices, whose ITEMS are dealt to the shards) are expanded by every shard.
+// 32-bit half words of a row (5: four strip k-slices = one 128-byte line of the bit matrix, so that a
+// shard reads whole lines; 7: one k-group = 64 words, the tile kernel's k-slice), numbered from
+// h_begin. Units below modulo_units (a multiple of count) belong to shard unit % count; the units from
+// there on (the strips' leftover slices, whose ITEMS are dealt to the shards) are expanded by every
+// shard.
 struct ExpandOwn {
     uint32_t rank, count, unit_shift, modulo_units;
 };
 constexpr ExpandOwn kExpandAll = {0u, 1u, 7u, 0u};
+constexpr uint32_t kOwnSlices = 4;  // strips: k-slices per ownership unit
 
 // One thread per 32-bit half word: 16 output bytes, fully coalesced on both sides.
 // Rows >= n_rows_src (padding up to a multiple of 256) are written as zeros. The half words
 // [h_begin, h_end) of every row are expanded (default: the whole row) and land at shadow column
 // h - h_dst0, so that a k-chunk of a matrix whose full shadow would not fit gets a compact shadow of
 // its own; half words beyond the end of the row read as zero (the last chunk may overhang).
+// A shard walks a COMPACT index over the units it owns, so that its expansion costs 1 / count of the
+// whole (round 2's first version tested ownership per element: 37 us for a 1/8 shard of the headline
+// matrix where 69 / 8 were due).
 __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restrict__ X,
                                                          uint64_t stride_words,
                                                          uint64_t n_rows_src, uint64_t n_rows_dst,
@@ -88,13 +94,20 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
     if (out_pitch_u4 == 0) out_pitch_u4 = stride_words * 2;
     const uint64_t halves_per_row = stride_words * 2;
     if (h_end == 0) h_end = halves_per_row;
+    const uint32_t shift = own.unit_shift;
+    const uint64_t units = (h_end - h_begin + (1ull << shift) - 1) >> shift;      // in [h_begin, h_end)
+    const uint64_t modulo = own.count > 1 ? min((uint64_t)own.modulo_units, units / own.count * own.count) : 0;
+    const uint64_t whole = own.count > 1 ? modulo / own.count : 0;                // units owned outright
+    const uint64_t compact = (whole + (units - modulo)) << shift;                 // half words this shard expands
     // grid = (column chunks of 256 halves, rows): no division per element (a 64-bit divide per
     // 16 output bytes made the first version VALU-bound just below the HBM rate)
     for (uint64_t row = blockIdx.y; row < n_rows_dst; row += gridDim.y)
-        for (uint64_t h = h_begin + (uint64_t)blockIdx.x * 256 + threadIdx.x; h < h_end;
-             h += (uint64_t)gridDim.x * 256) {
-            const uint32_t unit = (uint32_t)((h - h_dst0) >> own.unit_shift);
-            if (own.count > 1 && unit < own.modulo_units && unit % own.count != own.rank) continue;
+        for (uint64_t hc = (uint64_t)blockIdx.x * 256 + threadIdx.x; hc < compact;
+             hc += (uint64_t)gridDim.x * 256) {
+            const uint64_t uc = hc >> shift;
+            const uint64_t unit = uc < whole ? uc * own.count + own.rank : modulo + (uc - whole);
+            const uint64_t h = h_begin + (unit << shift) + (hc & ((1ull << shift) - 1));
+            if (h >= h_end) continue;  // the last unit may be cut short
             uint32_t w = 0;
             if (row < n_rows_src && h < halves_per_row)
                 w = reinterpret_cast<const uint32_t*>(X)[row * halves_per_row + h];
@@ -105,6 +118,14 @@ __global__ __launch_bounds__(256) void expand_fp4_kernel(const uint64_t* __restr
             o.w = spread8_fp4(w >> 24, nib & 7u);
             X4[row * out_pitch_u4 + (h - h_dst0)] = o;  // (non-temporal stores: slower)
         }
+}
+
+// Half words a shard expands in a range of `halves` (host mirror of the kernel's arithmetic: grid size).
+static inline uint64_t expand_compact_halves(const ExpandOwn& own, uint64_t halves) {
+    const uint64_t units = (halves + (1ull << own.unit_shift) - 1) >> own.unit_shift;
+    if (own.count <= 1) return units << own.unit_shift;
+    const uint64_t modulo = std::min<uint64_t>(own.modulo_units, units / own.count * own.count);
+    return (modulo / own.count + (units - modulo)) << own.unit_shift;
 }
 
 // Launch geometry of expand_fp4_kernel for n_rows_dst rows of `halves` half words each.
@@ -1234,16 +1255,20 @@ static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& range
 
 // Ownership of the strip work among shard_count shards (multi-GPU ranks; reference loop being
 // sharded: storm.c:1199-1238). Two levels:
-//   * whole k-slices (256 bits of every row): the first (n_kslices / G) * G slices go to shard
-//     ks % G, so a shard expands and multiplies only its own columns — 1/G of the O(N*M) expansion
-//     and of the pair work, equal shares whatever N is;
-//   * the remaining n_kslices % G slices ("leftover") are cut along the PAIR space: their items
+//   * whole k-slices (256 bits of every row), in units of 4 (1024 bits = one 128-byte line of the bit
+//     matrix, so that a shard's expansion reads whole lines): the first (n_units / G) * G units go
+//     to shard unit % G, so a shard expands and multiplies only its own columns — 1/G of the O(N*M)
+//     expansion and of the pair work, equal shares whatever N is;
+//   * the remaining slices ("leftover", fewer than 4 G) are cut along the PAIR space: their items
 //     (A tile x run of B blocks) are dealt to the shards longest-first onto the least loaded one
 //     (deterministic, every shard computes the same deal), every shard expands those few slices.
 // Hence any G balances to within one short item per leftover slice (c2 at G = 3: 85 1/3 slices
 // each), and a matrix with fewer slices than shards (M <= 256 * G bits) still splits G ways.
 static inline uint32_t strip_modulo_slices(uint32_t n_kslices, uint32_t shard_count) {
-    return n_kslices / shard_count * shard_count;
+    return n_kslices / kOwnSlices / shard_count * shard_count * kOwnSlices;  // whole units, a multiple of G
+}
+static inline bool strip_owns_slice(uint32_t ks, uint32_t shard_rank, uint32_t shard_count) {
+    return (ks / kOwnSlices) % shard_count == shard_rank;
 }
 static inline uint32_t strip_item_cost(const StripItem& it, uint32_t per_tile) {
     return (it.j1 - it.j0) + it.diag * per_tile + 10u;  // stages + ~10 stages' worth of prologue
@@ -1272,7 +1297,7 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
     uint32_t local = 0;
     const uint32_t modulo_slices = strip_modulo_slices(n_kslices, shard_count);
     for (uint32_t ks = 0; ks < modulo_slices; ++ks)
-        if (ks % shard_count == shard_rank) slices_of[local++ % 8].push_back(ks);
+        if (strip_owns_slice(ks, shard_rank, shard_count)) slices_of[local++ % 8].push_back(ks);
     // One slice = every A tile against the B blocks behind it; `max_run` caps the stages per item.
     auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
         // k2_debug & 16 (timing probe, wrong results): every XCD re-reads one k-slice, i.e. the
@@ -1523,20 +1548,22 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     // what this shard expands: its own k-slices + the leftover slices (strips; within a chunk
     // the rule runs over the chunk's own slice numbers, as its work list does), or its own
     // k-groups (tile kernel)
-    const ExpandOwn own = strips ? ExpandOwn{shard_rank, shard_count, 3u,
-                                             strip_modulo_slices(chunk_slices, shard_count)}
+    const ExpandOwn own = strips ? ExpandOwn{shard_rank, shard_count, 5u,
+                                             strip_modulo_slices(chunk_slices, shard_count) / kOwnSlices}
                                  : ExpandOwn{shard_rank, shard_count, 7u, 0xffffffffu};
     const uint32_t nib = (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u;
     const uint64_t n_src = std::min(n_rows_src, n_rows_dst);
     for (uint32_t chunk = 0; chunk < n_chunks && (ctx->n_items > 0 || n_strip > 0); ++chunk) {
         if (!shadow_valid) {
             if (n_chunks == 1) {
-                hipLaunchKernelGGL(expand_fp4_kernel, expand_grid(n_rows_dst, stride_words), dim3(256), 0,
-                                   ctx->stream, X, stride_words, n_src, n_rows_dst,
+                hipLaunchKernelGGL(expand_fp4_kernel,
+                                   expand_grid(n_rows_dst, stride_words, expand_compact_halves(own, stride_words * 2)),
+                                   dim3(256), 0, ctx->stream, X, stride_words, n_src, n_rows_dst,
                                    reinterpret_cast<uint4*>(ctx->d_x4), own, nib, pitch / 16);
             } else {
                 const uint64_t h0 = (uint64_t)chunk * chunk_slices * 8u, h1 = h0 + (uint64_t)chunk_slices * 8u;
-                hipLaunchKernelGGL(expand_fp4_kernel, expand_grid(n_rows_dst, stride_words, h1 - h0),
+                hipLaunchKernelGGL(expand_fp4_kernel,
+                                   expand_grid(n_rows_dst, stride_words, expand_compact_halves(own, h1 - h0)),
                                    dim3(256), 0, ctx->stream, X, stride_words, n_src, n_rows_dst,
                                    reinterpret_cast<uint4*>(ctx->d_x4), own, nib, pitch / 16, h0, h1, h0);
             }

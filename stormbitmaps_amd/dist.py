@@ -4,9 +4,10 @@ X is replicated on every GPU and rank r of G multiplies its share of the work of
 (matrix-core strip) path — ``storm_hip_pairw_dense(..., shard_rank, shard_count)``. The share is
 two-level (``storm_hip_strip_plan`` in include/storm_hip.h):
 
-  * whole k-slices (256 bits of every row): slice ks goes to rank ks % G, so a rank expands and
-    multiplies 1/G of the columns against the whole pair space;
-  * the n_kslices % G leftover slices are cut along the PAIR space (A tile x run of B blocks),
+  * whole k-slices (256 bits of every row), in units of 4 (one 128-byte line of the bit matrix):
+    slice ks goes to rank (ks / 4) % G, so a rank expands and multiplies 1/G of the columns against
+    the whole pair space;
+  * the leftover slices (fewer than 4 G) are cut along the PAIR space (A tile x run of B blocks),
     longest item first onto the least loaded rank.
 
 The only inter-GPU exchange is one uint64 sum: ``torch.distributed.all_reduce`` on a 1-element
