@@ -1581,10 +1581,14 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             unsigned int* heads = reinterpret_cast<unsigned int*>(ctx->d_slots + kSlots);
             // persistent form: one workgroup per resident slot
             const dim3 pgrid(std::min<uint32_t>(n_strip, (uint32_t)ctx->n_cus * (strip_mode == 2 ? 2u : 4u)));
+            // (the persistent form's queue heads are re-zeroed by the fold at the END of a pass: a
+            //  k-chunked pass launches the strips several times in front of it, so it runs the plain
+            //  form — found by the randomised soak, a second chunk saw exhausted queues)
+            const bool persist = ctx->k2_persistent && n_chunks == 1;
             const int sel = strip_mode == 2 ? 100 + ctx->k2_ring
-                                            : (ctx->k2_persistent && ctx->k2_ring == 4) ? 204
-                                            : (ctx->k2_persistent && ctx->k2_ring == 18) ? 218
-                                                                                         : ctx->k2_ring;
+                                            : (persist && ctx->k2_ring == 4) ? 204
+                                            : (persist && ctx->k2_ring == 18) ? 218
+                                                                              : ctx->k2_ring;
             switch (sel) {  // ring depth: tuning probe
                 case 204:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock,

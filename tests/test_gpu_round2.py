@@ -209,10 +209,21 @@ def test_hbm_tiled_passes_under_a_shadow_budget(hip_ctx, orc):
                 hip_ctx.set_option("keep_shadow", 1)     # a chunked pass keeps nothing: must still be right
                 assert m.pairw() == want and m.pairw() == want
                 hip_ctx.set_option("keep_shadow", 0)
+                # the persistent-queue forms (32-row and wide strips) under chunks: their queue heads
+                # are only re-zeroed at the end of a pass (soak seed 397310033 caught a lost chunk)
+                for shape in (32, 16):
+                    hip_ctx.set_option("k2_shape", shape)
+                    hip_ctx.set_option("k2_persistent", 1)
+                    assert m.pairw() == want and m.pairw() == want, (M, N, mb, shape)
+                    hip_ctx.set_option("k2_persistent", 0)
+                    assert m.pairw() == want, (M, N, mb, shape)
+                hip_ctx.set_option("k2_shape", 16)
             m.close()
     finally:
         hip_ctx.set_option("k2_shadow_budget_mb", 96 * 1024)
         hip_ctx.set_option("keep_shadow", 0)
+        hip_ctx.set_option("k2_shape", 16)
+        hip_ctx.set_option("k2_persistent", 0)
 
 
 def test_device_copies_follow_direct_edits_and_invalidate(lib, orc):

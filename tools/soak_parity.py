@@ -38,7 +38,11 @@ def main():
                 "k2_tail_slices": int(rng.choice([3, 0, 1, 8])),
                 "k2_tail_run": int(rng.choice([32, 1, 5, 64])),
                 "k2_persistent": int(rng.choice([0, 0, 1])),
-                "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640]))}
+                "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
+                "k2_shape": int(rng.choice([16, 16, 32])),
+                "k2_tile_shape": int(rng.choice([16, 16, 32])),
+                "k2_shadow_budget_mb": int(rng.choice([98304, 98304, 1, 8])),
+                "sparse_probe": int(rng.choice([-1, -1, 0, 1]))}
         for k, v in opts.items():
             ctx.set_option(k, v)
         try:
@@ -90,10 +94,26 @@ def main():
                     s.add(r)
                 want = orc.storm(rows).pairw()
                 ok = s.pairw_intersect_cardinality() == want == s.pairw_intersect_cardinality_blocked(0)
+                # the same container as a serialized stream on THIS context (random sparse_probe / shards)
+                import ctypes as C
+                data = s.serialize()
+                h = C.c_void_p()
+                lib = sb.load()
+                ok = ok and lib.storm_hip_sparse_create_serialized(ctx._h, data.ctypes.data_as(C.c_void_p),
+                                                                   data.size, C.byref(h)) == 0
+                if ok:
+                    world = int(rng.choice([1, 2, 5]))
+                    out, got = C.c_uint64(), 0
+                    for r in range(world):
+                        ok = ok and lib.storm_hip_pairw_sparse(ctx._h, h, r, world, C.byref(out)) == 0
+                        got += out.value
+                    ok = ok and got == want
+                    lib.storm_hip_sparse_destroy(ctx._h, h)
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1}.items():
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 16,
+                         "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
         n_cases += 1
         kinds[kind] = kinds.get(kind, 0) + 1
