@@ -637,8 +637,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
-        if (value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 16 or 32");
+        if (value != 1 && value != 2 && value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 1 (bit operands), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_tile_shape = (int)value;

@@ -1146,6 +1146,829 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tile16_fp4_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// K2t-bits: the materialised-output kernel on the BIT matrix itself (default, option k2_tile_shape = 1).
+//
+// tile16_fp4_kernel above pulls 64 KiB of FP4 operands into the CU per 256 x 256 x 256 tile step
+// (13.8 GB per headline call). The operands are 4 x inflated bits, so this kernel moves the bits and
+// inflates them in registers, where it costs ONE v_and_b32 per operand dword instead of the ~10-op bit
+// spread of expand_fp4_kernel:
+//   * a sum over k does not care in which order k is walked, as long as A and B agree. A lane
+//     holds 128 consecutive bits of its row as four dwords w0..w3 (one ds_read_b128). MFMA "class" c
+//     takes the operand {w0 & K_c, .., w3 & K_c} with K_c = 0x11111111 << c: bit 4 n + c of each word
+//     sits in nibble n ALREADY, as E2M1 code 1 << c = 0.5, 1.0, 2.0 for c = 0, 1, 2. Bit 3 of a nibble
+//     is the sign, so class 3 is shifted down once: (w >> 1) & K_2. Four MFMAs (one per class)
+//     consume the 128 bits of each lane; with the two k-halves of the 32x32x64 form, 256 bits of k.
+//   * both operands of class c carry the same value v_c, so a set pair contributes v_c^2; the
+//     block scale of the scaled MFMA (E8M0, 2^(s - 127), applied to both operands) restores 1:
+//     s = 128, 127, 126, 126. Every partial sum is a small multiple of 1/4: exact in f32.
+// There is no FP4 shadow and no expansion pass for this path: the operands are the matrix rows.
+// What shapes the kernel is ISSUE bandwidth, not bytes (first version, 8 waves of 64 x 128 with
+// 16x16x128 MFMAs, two per SIMD: 1.36 ms, matrix pipe 57 % busy — a 16-cycle MFMA holds the SIMD's
+// vector issue for 8 cycles and each v_and costs 4, MI355X_MICROARCH.md "vector-instruction ISSUE
+// cost"; 1.9 inflation ops per MFMA did not fit beside it). Hence:
+//   * ONE wave per SIMD with the whole register file: 4 waves, wave w owns A rows 128 (w % 2) .. + 127
+//     against B rows 128 (w / 2) .. + 127 = 4 x 4 blocks of 32 x 32 (256 accumulator registers).
+//     Inflation work goes with operand rows per MFMA: (4 + 4) blocks x 5 ops per 16 MFMAs of
+//     32 cycles each = 2.5 ops (10 issue cycles) + the MFMA's own 8 per 32-cycle slot.
+//   * stage = 512 bits of k: 256 A rows + 256 B rows x 64 B = 32 KiB by LDS-DMA (8 pieces per wave,
+//     one per class phase), ring of 4; k-group = 256 bits = one ds_read_b128 per lane and block, read
+//     one k-group ahead; per class phase 16 MFMAs with the next B operand and the next phase's A
+//     operands inflated between them.
+// LDS image: row r at 64 r, 16-byte slot s at s ^ ((r / 4) % 4) (conflict free for 16 consecutive rows).
+// Rows beyond the matrix read as zero through the buffer descriptor's range (num_records = valid
+// rows x pitch, rebuilt per stage with the k offset folded into the base).
+// ------------------------------------------------------------------------------------------
+constexpr int kTbThreads = 256;
+constexpr int kTbRing = 4;
+constexpr int kTbRowBytes = 64;                          // 512 bits of k per stage
+constexpr int kTbImageBytes = kTile * kTbRowBytes;       // 16 KiB per operand
+constexpr int kTbStageBytes = 2 * kTbImageBytes;         // A image, then B image
+
+template <int C>
+__device__ __forceinline__ v4i tb_inflate(v4i w) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    if constexpr (C == 3) return (v4i)(((v4u)w >> 1u) & 0x44444444u);
+    else return w & (int)(0x11111111u << C);
+}
+template <int C>
+__device__ __forceinline__ int tb_scale() {  // E8M0 block scale undoing v_c on each operand
+    return C == 0 ? 128 : C == 1 ? 127 : 126;
+}
+
+struct TileOperands {       // where the virtual rows of the item table live
+    const uint8_t* xa;      // virtual rows [0, split): matrix A (or the only matrix)
+    const uint8_t* xb;      // virtual rows [split, ..): matrix B
+    uint64_t pitch;         // bytes per row of both
+    uint32_t split;         // first virtual row of matrix B (0xffffffff: none)
+    uint32_t rows_a, rows_b;  // allocated rows behind xa / xb (reads beyond return zero)
+};
+
+// Epilogue of the bit-operand kernels for a tile that lies wholly inside the output (no diagonal,
+// no edge, no k-parts, 16-byte aligned rows): the accumulators hold 16 ROWS of one column per
+// lane, so storing them directly costs one 4-byte store per element, two 128-byte runs per
+// wave-instruction (measured: 16 us per tile item, 5 % of the call). Here each wave turns its block
+// through a private 16 KiB of the (now idle) ring, 32 rows x 128 columns at a time, and stores
+// 16 bytes per lane: two 512-byte runs per instruction, a quarter of the instructions.
+template <int MB>
+__device__ __forceinline__ void tb_store_interior(const v16f (&acc)[MB][4], uint8_t* lds_wave,
+                                                  uint32_t* __restrict__ out_tile, uint64_t ld,
+                                                  uint32_t lane, const uint32_t* __restrict__ row_counts,
+                                                  uint32_t i0, uint32_t j0, uint32_t and_weight) {
+    uint32_t* w32 = reinterpret_cast<uint32_t*>(lds_wave);
+    const uint4* r128 = reinterpret_cast<const uint4*>(lds_wave);
+    uint32_t nj[4] = {0u, 0u, 0u, 0u};
+    if (row_counts) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) nj[n] = row_counts[j0 + (uint32_t)n * 32u + (lane & 31u)];
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t il = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+            const uint32_t ni = row_counts ? row_counts[i0 + (uint32_t)m * 32u + il] : 0u;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint32_t c = (uint32_t)acc[m][n][r];
+                w32[il * 128u + (uint32_t)n * 32u + (lane & 31u)] = row_counts ? ni + nj[n] - and_weight * c : c;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t row = (uint32_t)q * 2u + (lane >> 5);
+            const uint4 v = r128[row * 32u + (lane & 31u)];
+            *reinterpret_cast<uint4*>(&out_tile[(uint64_t)((uint32_t)m * 32u + row) * ld + 4u * (lane & 31u)]) = v;
+        }
+    }
+}
+
+
+__global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
+    TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
+    uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
+    uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbRing][kTbStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wa = wave & 1u, wb = wave >> 1;
+    const uint32_t item_idx = blockIdx.x;
+    const MfmaItem it = items[item_idx];
+    const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
+    const uint32_t S = it.n_stages / 4u;                  // items count 128-bit stages; cuts fall on 4
+    const uint32_t kbyte0 = it.stage0 * 16u;              // byte of the row where this item starts
+    const uint32_t pitch = (uint32_t)ops.pitch;
+
+    // operand windows: base of the tile's first row and the bytes of it that exist
+    auto window = [&](uint32_t v0, const uint8_t*& base, uint32_t& bytes) {
+        const bool second = v0 >= ops.split;
+        const uint32_t r0 = second ? v0 - ops.split : v0;
+        const uint32_t have = second ? ops.rows_b : ops.rows_a;
+        const uint32_t rows = have > r0 ? min(have - r0, (uint32_t)kTile) : 0u;
+        base = (second ? ops.xb : ops.xa) + (uint64_t)r0 * ops.pitch;
+        bytes = rows * pitch;
+    };
+    const uint8_t *a_base, *b_base;
+    uint32_t a_bytes, b_bytes;
+    window(a_row0, a_base, a_bytes);
+    window(b_row0, b_base, b_bytes);
+
+    // DMA: an image is 16 wave-instructions of 1 KiB (16 rows each). Piece p of a stage (one per class
+    // phase): instruction w + 4 (p % 4) of the A image (p < 4) or of the B image. Lane L fills row
+    // L / 4 of the instruction, physical slot L % 4 = logical slot (L % 4) ^ ((L / 16) % 4).
+    const uint32_t voff0 = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
+    auto issue_piece = [&](uint32_t s, uint32_t p) {
+        const uint32_t koff = kbyte0 + s * kTbRowBytes;
+        const bool second = p >= 4u;
+        // (past the last stage the piece is still issued, with an empty range: a branch-free loop
+        //  body keeps every piece where it is written, and the count below stays the same)
+        const uint32_t bytes = s < S ? (second ? b_bytes : a_bytes) : 0u;
+        // (a window with rows has koff < pitch <= bytes; written as a select on `bytes != 0`, not as
+        //  a saturating subtraction, which has no scalar form and turns the descriptor divergent)
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>((second ? b_base : a_base) + koff), 0, bytes ? bytes - koff : 0u, 0x00020000);
+        uint8_t* dst = lds[s % kTbRing] + (second ? kTbImageBytes : 0) + (wave + 4u * (p & 3u)) * 1024u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst, 16, (int)(voff0 + (p & 3u) * 64u * pitch), 0, 0, 0);
+    };
+    auto issue = [&](uint32_t s) {
+#pragma unroll
+        for (uint32_t p = 0; p < 8; ++p) issue_piece(s, p);
+    };
+
+    v16f acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = v16f{};
+
+    // fragment of block t in k-group g: row 32 t + (lane & 31), logical slot 2 g + (lane >> 5)
+    const uint32_t lds_base =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    const uint32_t slot = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
+    const uint32_t a_frag0 = lds_base + (wa * 128u + (lane & 31u)) * kTbRowBytes + slot * 16u;
+    const uint32_t a_frag1 = lds_base + (wa * 128u + (lane & 31u)) * kTbRowBytes + (slot ^ 2u) * 16u;
+    const uint32_t b_delta = kTbImageBytes + wb * 128u * kTbRowBytes - wa * 128u * kTbRowBytes;
+
+    issue(0);
+    issue(1);
+    issue(2);
+
+#define STORM_TB_FETCH(dst, addr, n) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
+#define STORM_TB_MUL(C, m, n, av, bv)                                                               \
+    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
+        v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
+        acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
+
+    v4i xa[4], xb[4], ya[4], yb[4];  // bits of the k-group in use / of the next one (x: even groups)
+    v4i ao[4], an[4], bo, bn = {};   // inflated A blocks of the running / next class phase, B block
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const uint32_t b0 = a_frag0 + b_delta;
+        STORM_TB_FETCH(xa[0], a_frag0, 0);
+        STORM_TB_FETCH(xa[1], a_frag0, 1);
+        STORM_TB_FETCH(xa[2], a_frag0, 2);
+        STORM_TB_FETCH(xa[3], a_frag0, 3);
+        STORM_TB_FETCH(xb[0], b0, 0);
+        STORM_TB_FETCH(xb[1], b0, 1);
+        STORM_TB_FETCH(xb[2], b0, 2);
+        STORM_TB_FETCH(xb[3], b0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ao[m] = tb_inflate<0>(xa[m]);
+        bo = tb_inflate<0>(xb[0]);
+    }
+    // At the top of stage s the wave's DMA pieces of stage s + 1 must have landed (only stage
+    // s + 2's eight may stay in flight): the second k-group reads one k-group ahead, into it. The
+    // barrier makes that true of every wave's share and says that every wave is done with stage
+    // s - 1, whose slot stage s + 3 takes.
+    for (uint32_t s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // (after the last stage the look-ahead re-reads the same stage: never consumed)
+        const uint32_t cur = (s % kTbRing) * kTbStageBytes;
+        const uint32_t nxs = ((s + 1 < S ? s + 1 : s) % kTbRing) * kTbStageBytes;
+        const uint32_t a1 = a_frag1 + cur, b1 = a1 + b_delta;
+        const uint32_t a0n = a_frag0 + nxs, b0n = a0n + b_delta;
+        const uint32_t dma_stage = s + kTbRing - 1;
+        // k-group 0, class 0
+        issue_piece(dma_stage, 0);
+        STORM_TB_FETCH(ya[0], a1, 0);
+        STORM_TB_FETCH(ya[1], a1, 1);
+        STORM_TB_FETCH(ya[2], a1, 2);
+        STORM_TB_FETCH(ya[3], a1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 0, ao, bo);
+        bn = tb_inflate<0>(xb[1]);
+        STORM_TB_MUL(0, 1, 0, ao, bo);
+        an[0] = tb_inflate<1>(xa[0]);
+        STORM_TB_MUL(0, 2, 0, ao, bo);
+        STORM_TB_MUL(0, 3, 0, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 1, ao, bn);
+        bo = tb_inflate<0>(xb[2]);
+        STORM_TB_MUL(0, 1, 1, ao, bn);
+        an[1] = tb_inflate<1>(xa[1]);
+        STORM_TB_MUL(0, 2, 1, ao, bn);
+        STORM_TB_MUL(0, 3, 1, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 2, ao, bo);
+        bn = tb_inflate<0>(xb[3]);
+        STORM_TB_MUL(0, 1, 2, ao, bo);
+        an[2] = tb_inflate<1>(xa[2]);
+        STORM_TB_MUL(0, 2, 2, ao, bo);
+        STORM_TB_MUL(0, 3, 2, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 3, ao, bn);
+        bo = tb_inflate<1>(xb[0]);
+        STORM_TB_MUL(0, 1, 3, ao, bn);
+        an[3] = tb_inflate<1>(xa[3]);
+        STORM_TB_MUL(0, 2, 3, ao, bn);
+        STORM_TB_MUL(0, 3, 3, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 1
+        issue_piece(dma_stage, 1);
+        STORM_TB_FETCH(yb[0], b1, 0);
+        STORM_TB_FETCH(yb[1], b1, 1);
+        STORM_TB_FETCH(yb[2], b1, 2);
+        STORM_TB_FETCH(yb[3], b1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 0, an, bo);
+        bn = tb_inflate<1>(xb[1]);
+        STORM_TB_MUL(1, 1, 0, an, bo);
+        ao[0] = tb_inflate<2>(xa[0]);
+        STORM_TB_MUL(1, 2, 0, an, bo);
+        STORM_TB_MUL(1, 3, 0, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 1, an, bn);
+        bo = tb_inflate<1>(xb[2]);
+        STORM_TB_MUL(1, 1, 1, an, bn);
+        ao[1] = tb_inflate<2>(xa[1]);
+        STORM_TB_MUL(1, 2, 1, an, bn);
+        STORM_TB_MUL(1, 3, 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 2, an, bo);
+        bn = tb_inflate<1>(xb[3]);
+        STORM_TB_MUL(1, 1, 2, an, bo);
+        ao[2] = tb_inflate<2>(xa[2]);
+        STORM_TB_MUL(1, 2, 2, an, bo);
+        STORM_TB_MUL(1, 3, 2, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 3, an, bn);
+        bo = tb_inflate<2>(xb[0]);
+        STORM_TB_MUL(1, 1, 3, an, bn);
+        ao[3] = tb_inflate<2>(xa[3]);
+        STORM_TB_MUL(1, 2, 3, an, bn);
+        STORM_TB_MUL(1, 3, 3, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 2
+        issue_piece(dma_stage, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 0, ao, bo);
+        bn = tb_inflate<2>(xb[1]);
+        STORM_TB_MUL(2, 1, 0, ao, bo);
+        an[0] = tb_inflate<3>(xa[0]);
+        STORM_TB_MUL(2, 2, 0, ao, bo);
+        STORM_TB_MUL(2, 3, 0, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 1, ao, bn);
+        bo = tb_inflate<2>(xb[2]);
+        STORM_TB_MUL(2, 1, 1, ao, bn);
+        an[1] = tb_inflate<3>(xa[1]);
+        STORM_TB_MUL(2, 2, 1, ao, bn);
+        STORM_TB_MUL(2, 3, 1, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 2, ao, bo);
+        bn = tb_inflate<2>(xb[3]);
+        STORM_TB_MUL(2, 1, 2, ao, bo);
+        an[2] = tb_inflate<3>(xa[2]);
+        STORM_TB_MUL(2, 2, 2, ao, bo);
+        STORM_TB_MUL(2, 3, 2, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 3, ao, bn);
+        bo = tb_inflate<3>(xb[0]);
+        STORM_TB_MUL(2, 1, 3, ao, bn);
+        an[3] = tb_inflate<3>(xa[3]);
+        STORM_TB_MUL(2, 2, 3, ao, bn);
+        STORM_TB_MUL(2, 3, 3, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 3
+        issue_piece(dma_stage, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 0, an, bo);
+        bn = tb_inflate<3>(xb[1]);
+        STORM_TB_MUL(3, 1, 0, an, bo);
+        ao[0] = tb_inflate<0>(ya[0]);
+        STORM_TB_MUL(3, 2, 0, an, bo);
+        STORM_TB_MUL(3, 3, 0, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 1, an, bn);
+        bo = tb_inflate<3>(xb[2]);
+        STORM_TB_MUL(3, 1, 1, an, bn);
+        ao[1] = tb_inflate<0>(ya[1]);
+        STORM_TB_MUL(3, 2, 1, an, bn);
+        STORM_TB_MUL(3, 3, 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 2, an, bo);
+        bn = tb_inflate<3>(xb[3]);
+        STORM_TB_MUL(3, 1, 2, an, bo);
+        ao[2] = tb_inflate<0>(ya[2]);
+        STORM_TB_MUL(3, 2, 2, an, bo);
+        STORM_TB_MUL(3, 3, 2, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 3, an, bn);
+        bo = tb_inflate<0>(yb[0]);
+        STORM_TB_MUL(3, 1, 3, an, bn);
+        ao[3] = tb_inflate<0>(ya[3]);
+        STORM_TB_MUL(3, 2, 3, an, bn);
+        STORM_TB_MUL(3, 3, 3, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 0
+        issue_piece(dma_stage, 4);
+        STORM_TB_FETCH(xa[0], a0n, 0);
+        STORM_TB_FETCH(xa[1], a0n, 1);
+        STORM_TB_FETCH(xa[2], a0n, 2);
+        STORM_TB_FETCH(xa[3], a0n, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 0, ao, bo);
+        bn = tb_inflate<0>(yb[1]);
+        STORM_TB_MUL(0, 1, 0, ao, bo);
+        an[0] = tb_inflate<1>(ya[0]);
+        STORM_TB_MUL(0, 2, 0, ao, bo);
+        STORM_TB_MUL(0, 3, 0, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 1, ao, bn);
+        bo = tb_inflate<0>(yb[2]);
+        STORM_TB_MUL(0, 1, 1, ao, bn);
+        an[1] = tb_inflate<1>(ya[1]);
+        STORM_TB_MUL(0, 2, 1, ao, bn);
+        STORM_TB_MUL(0, 3, 1, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 2, ao, bo);
+        bn = tb_inflate<0>(yb[3]);
+        STORM_TB_MUL(0, 1, 2, ao, bo);
+        an[2] = tb_inflate<1>(ya[2]);
+        STORM_TB_MUL(0, 2, 2, ao, bo);
+        STORM_TB_MUL(0, 3, 2, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 3, ao, bn);
+        bo = tb_inflate<1>(yb[0]);
+        STORM_TB_MUL(0, 1, 3, ao, bn);
+        an[3] = tb_inflate<1>(ya[3]);
+        STORM_TB_MUL(0, 2, 3, ao, bn);
+        STORM_TB_MUL(0, 3, 3, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 1
+        issue_piece(dma_stage, 5);
+        STORM_TB_FETCH(xb[0], b0n, 0);
+        STORM_TB_FETCH(xb[1], b0n, 1);
+        STORM_TB_FETCH(xb[2], b0n, 2);
+        STORM_TB_FETCH(xb[3], b0n, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 0, an, bo);
+        bn = tb_inflate<1>(yb[1]);
+        STORM_TB_MUL(1, 1, 0, an, bo);
+        ao[0] = tb_inflate<2>(ya[0]);
+        STORM_TB_MUL(1, 2, 0, an, bo);
+        STORM_TB_MUL(1, 3, 0, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 1, an, bn);
+        bo = tb_inflate<1>(yb[2]);
+        STORM_TB_MUL(1, 1, 1, an, bn);
+        ao[1] = tb_inflate<2>(ya[1]);
+        STORM_TB_MUL(1, 2, 1, an, bn);
+        STORM_TB_MUL(1, 3, 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 2, an, bo);
+        bn = tb_inflate<1>(yb[3]);
+        STORM_TB_MUL(1, 1, 2, an, bo);
+        ao[2] = tb_inflate<2>(ya[2]);
+        STORM_TB_MUL(1, 2, 2, an, bo);
+        STORM_TB_MUL(1, 3, 2, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 3, an, bn);
+        bo = tb_inflate<2>(yb[0]);
+        STORM_TB_MUL(1, 1, 3, an, bn);
+        ao[3] = tb_inflate<2>(ya[3]);
+        STORM_TB_MUL(1, 2, 3, an, bn);
+        STORM_TB_MUL(1, 3, 3, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 2
+        issue_piece(dma_stage, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 0, ao, bo);
+        bn = tb_inflate<2>(yb[1]);
+        STORM_TB_MUL(2, 1, 0, ao, bo);
+        an[0] = tb_inflate<3>(ya[0]);
+        STORM_TB_MUL(2, 2, 0, ao, bo);
+        STORM_TB_MUL(2, 3, 0, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 1, ao, bn);
+        bo = tb_inflate<2>(yb[2]);
+        STORM_TB_MUL(2, 1, 1, ao, bn);
+        an[1] = tb_inflate<3>(ya[1]);
+        STORM_TB_MUL(2, 2, 1, ao, bn);
+        STORM_TB_MUL(2, 3, 1, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 2, ao, bo);
+        bn = tb_inflate<2>(yb[3]);
+        STORM_TB_MUL(2, 1, 2, ao, bo);
+        an[2] = tb_inflate<3>(ya[2]);
+        STORM_TB_MUL(2, 2, 2, ao, bo);
+        STORM_TB_MUL(2, 3, 2, ao, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 3, ao, bn);
+        bo = tb_inflate<3>(yb[0]);
+        STORM_TB_MUL(2, 1, 3, ao, bn);
+        an[3] = tb_inflate<3>(ya[3]);
+        STORM_TB_MUL(2, 2, 3, ao, bn);
+        STORM_TB_MUL(2, 3, 3, ao, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 3
+        issue_piece(dma_stage, 7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 0, an, bo);
+        bn = tb_inflate<3>(yb[1]);
+        STORM_TB_MUL(3, 1, 0, an, bo);
+        ao[0] = tb_inflate<0>(xa[0]);
+        STORM_TB_MUL(3, 2, 0, an, bo);
+        STORM_TB_MUL(3, 3, 0, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 1, an, bn);
+        bo = tb_inflate<3>(yb[2]);
+        STORM_TB_MUL(3, 1, 1, an, bn);
+        ao[1] = tb_inflate<0>(xa[1]);
+        STORM_TB_MUL(3, 2, 1, an, bn);
+        STORM_TB_MUL(3, 3, 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 2, an, bo);
+        bn = tb_inflate<3>(yb[3]);
+        STORM_TB_MUL(3, 1, 2, an, bo);
+        ao[2] = tb_inflate<0>(xa[2]);
+        STORM_TB_MUL(3, 2, 2, an, bo);
+        STORM_TB_MUL(3, 3, 2, an, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 3, an, bn);
+        bo = tb_inflate<0>(xb[0]);
+        STORM_TB_MUL(3, 1, 3, an, bn);
+        ao[3] = tb_inflate<0>(xa[3]);
+        STORM_TB_MUL(3, 2, 3, an, bn);
+        STORM_TB_MUL(3, 3, 3, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the empty pieces of the tail, too
+#undef STORM_TB_MUL
+#undef STORM_TB_FETCH
+
+    // ---- epilogue: C/D map of the 32x32 form: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const bool rect = j_count != 0;
+    {
+        const uint32_t col0 = b_row0 - j_base;  // rect: j_base <= b_row0 is implied by the range test
+        const bool interior =
+            item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
+            (rect ? (b_row0 >= j_base && col0 + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
+            (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
+        if (interior) {
+            __builtin_amdgcn_s_barrier();  // every wave has left the ring
+            tb_store_interior<4>(acc, &lds[0][0] + wave * 16384u,
+                                 &out[(uint64_t)(a_row0 + wa * 128u - i_lo) * ld + col0 + wb * 128u], ld, lane,
+                                 row_counts, a_row0 + wa * 128u, b_row0 + wb * 128u, and_weight);
+            return;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t j = b_row0 + wb * 128u + (uint32_t)n * 32u + (lane & 31u);
+        const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
+        const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t i = a_row0 + wa * 128u + (uint32_t)m * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) +
+                                   4u * (lane >> 5);
+                if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
+                    const uint32_t c = (uint32_t)acc[m][n][r];
+                    uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
+                    if (item_idx < split_from) {
+                        *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
+                    } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
+                        const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
+                        atomicAdd(dst, row_counts ? once - and_weight * c : c);
+                    }
+                }
+            }
+    }
+}
+
+// The same with TWO waves per SIMD (option k2_tile_shape = 2): 8 waves, wave w owns A rows
+// 64 (w % 4) .. + 63 against B rows 128 (w / 4) .. + 127 = 2 x 4 blocks of 32 x 32 (128 accumulator
+// registers); 3.75 inflation ops per MFMA instead of 2.5, but a wave's DMA issue and waits overlap
+// with its SIMD partner's MFMAs. Waves 4-7 issue their four DMA pieces one class phase later than
+// waves 0-3.
+__global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
+    TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
+    uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
+    uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbRing][kTbStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wa = wave & 3u, wb = wave >> 2;
+    const uint32_t item_idx = blockIdx.x;
+    const MfmaItem it = items[item_idx];
+    const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
+    const uint32_t S = it.n_stages / 4u;
+    const uint32_t kbyte0 = it.stage0 * 16u;
+    const uint32_t pitch = (uint32_t)ops.pitch;
+
+    auto window = [&](uint32_t v0, const uint8_t*& base, uint32_t& bytes) {
+        const bool second = v0 >= ops.split;
+        const uint32_t r0 = second ? v0 - ops.split : v0;
+        const uint32_t have = second ? ops.rows_b : ops.rows_a;
+        const uint32_t rows = have > r0 ? min(have - r0, (uint32_t)kTile) : 0u;
+        base = (second ? ops.xb : ops.xa) + (uint64_t)r0 * ops.pitch;
+        bytes = rows * pitch;
+    };
+    const uint8_t *a_base, *b_base;
+    uint32_t a_bytes, b_bytes;
+    window(a_row0, a_base, a_bytes);
+    window(b_row0, b_base, b_bytes);
+
+    // piece p of a stage: instruction w + 8 (p % 2) of the A image (p < 2) or of the B image
+    const uint32_t voff0 = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
+    auto issue_piece = [&](uint32_t s, uint32_t p) {
+        const uint32_t koff = kbyte0 + s * kTbRowBytes;
+        const bool second = p >= 2u;
+        const uint32_t bytes = s < S ? (second ? b_bytes : a_bytes) : 0u;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>((second ? b_base : a_base) + koff), 0, bytes ? bytes - koff : 0u, 0x00020000);
+        uint8_t* dst = lds[s % kTbRing] + (second ? kTbImageBytes : 0) + (wave + 8u * (p & 1u)) * 1024u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst, 16, (int)(voff0 + (p & 1u) * 128u * pitch), 0, 0, 0);
+    };
+    auto issue = [&](uint32_t s) {
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) issue_piece(s, p);
+    };
+
+    v16f acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = v16f{};
+
+    const uint32_t lds_base =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    const uint32_t slot = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
+    const uint32_t a_frag0 = lds_base + (wa * 64u + (lane & 31u)) * kTbRowBytes + slot * 16u;
+    const uint32_t a_frag1 = lds_base + (wa * 64u + (lane & 31u)) * kTbRowBytes + (slot ^ 2u) * 16u;
+    const uint32_t b_delta = kTbImageBytes + wb * 128u * kTbRowBytes - wa * 64u * kTbRowBytes;
+
+    issue(0);
+    issue(1);
+    issue(2);
+
+#define STORM_TB_FETCH(dst, addr, n) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
+#define STORM_TB_MUL(C, m, n, av, bv)                                                               \
+    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
+        v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
+        acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
+
+    v4i xa[2], xb[4], ya[2], yb[4];
+    v4i ao[2], an[2], bo, bn = {};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const uint32_t b0 = a_frag0 + b_delta;
+        STORM_TB_FETCH(xa[0], a_frag0, 0);
+        STORM_TB_FETCH(xa[1], a_frag0, 1);
+        STORM_TB_FETCH(xb[0], b0, 0);
+        STORM_TB_FETCH(xb[1], b0, 1);
+        STORM_TB_FETCH(xb[2], b0, 2);
+        STORM_TB_FETCH(xb[3], b0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ao[0] = tb_inflate<0>(xa[0]);
+        ao[1] = tb_inflate<0>(xa[1]);
+        bo = tb_inflate<0>(xb[0]);
+    }
+    for (uint32_t s = 0; s < S; ++s) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t cur = (s % kTbRing) * kTbStageBytes;
+        const uint32_t nxs = ((s + 1 < S ? s + 1 : s) % kTbRing) * kTbStageBytes;
+        const uint32_t a1 = a_frag1 + cur, b1 = a1 + b_delta;
+        const uint32_t a0n = a_frag0 + nxs, b0n = a0n + b_delta;
+        const uint32_t dma_stage = s + kTbRing - 1;
+        // k-group 0, class 0
+        issue_piece(dma_stage, 0);
+        STORM_TB_FETCH(ya[0], a1, 0);
+        STORM_TB_FETCH(ya[1], a1, 1);
+        STORM_TB_FETCH(yb[0], b1, 0);
+        STORM_TB_FETCH(yb[1], b1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 0, ao, bo);
+        bn = tb_inflate<0>(xb[1]);
+        STORM_TB_MUL(0, 1, 0, ao, bo);
+        STORM_TB_MUL(0, 0, 1, ao, bn);
+        bo = tb_inflate<0>(xb[2]);
+        STORM_TB_MUL(0, 1, 1, ao, bn);
+        STORM_TB_MUL(0, 0, 2, ao, bo);
+        bn = tb_inflate<0>(xb[3]);
+        STORM_TB_MUL(0, 1, 2, ao, bo);
+        an[0] = tb_inflate<1>(xa[0]);
+        STORM_TB_MUL(0, 0, 3, ao, bn);
+        bo = tb_inflate<1>(xb[0]);
+        STORM_TB_MUL(0, 1, 3, ao, bn);
+        an[1] = tb_inflate<1>(xa[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 1
+        STORM_TB_FETCH(yb[2], b1, 2);
+        STORM_TB_FETCH(yb[3], b1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 0, an, bo);
+        bn = tb_inflate<1>(xb[1]);
+        STORM_TB_MUL(1, 1, 0, an, bo);
+        STORM_TB_MUL(1, 0, 1, an, bn);
+        bo = tb_inflate<1>(xb[2]);
+        STORM_TB_MUL(1, 1, 1, an, bn);
+        STORM_TB_MUL(1, 0, 2, an, bo);
+        bn = tb_inflate<1>(xb[3]);
+        STORM_TB_MUL(1, 1, 2, an, bo);
+        ao[0] = tb_inflate<2>(xa[0]);
+        STORM_TB_MUL(1, 0, 3, an, bn);
+        bo = tb_inflate<2>(xb[0]);
+        STORM_TB_MUL(1, 1, 3, an, bn);
+        ao[1] = tb_inflate<2>(xa[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 2
+        issue_piece(dma_stage, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 0, ao, bo);
+        bn = tb_inflate<2>(xb[1]);
+        STORM_TB_MUL(2, 1, 0, ao, bo);
+        STORM_TB_MUL(2, 0, 1, ao, bn);
+        bo = tb_inflate<2>(xb[2]);
+        STORM_TB_MUL(2, 1, 1, ao, bn);
+        STORM_TB_MUL(2, 0, 2, ao, bo);
+        bn = tb_inflate<2>(xb[3]);
+        STORM_TB_MUL(2, 1, 2, ao, bo);
+        an[0] = tb_inflate<3>(xa[0]);
+        STORM_TB_MUL(2, 0, 3, ao, bn);
+        bo = tb_inflate<3>(xb[0]);
+        STORM_TB_MUL(2, 1, 3, ao, bn);
+        an[1] = tb_inflate<3>(xa[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 0, class 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 0, an, bo);
+        bn = tb_inflate<3>(xb[1]);
+        STORM_TB_MUL(3, 1, 0, an, bo);
+        STORM_TB_MUL(3, 0, 1, an, bn);
+        bo = tb_inflate<3>(xb[2]);
+        STORM_TB_MUL(3, 1, 1, an, bn);
+        STORM_TB_MUL(3, 0, 2, an, bo);
+        bn = tb_inflate<3>(xb[3]);
+        STORM_TB_MUL(3, 1, 2, an, bo);
+        ao[0] = tb_inflate<0>(ya[0]);
+        STORM_TB_MUL(3, 0, 3, an, bn);
+        bo = tb_inflate<0>(yb[0]);
+        STORM_TB_MUL(3, 1, 3, an, bn);
+        ao[1] = tb_inflate<0>(ya[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 0
+        issue_piece(dma_stage, 2);
+        STORM_TB_FETCH(xa[0], a0n, 0);
+        STORM_TB_FETCH(xa[1], a0n, 1);
+        STORM_TB_FETCH(xb[0], b0n, 0);
+        STORM_TB_FETCH(xb[1], b0n, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(0, 0, 0, ao, bo);
+        bn = tb_inflate<0>(yb[1]);
+        STORM_TB_MUL(0, 1, 0, ao, bo);
+        STORM_TB_MUL(0, 0, 1, ao, bn);
+        bo = tb_inflate<0>(yb[2]);
+        STORM_TB_MUL(0, 1, 1, ao, bn);
+        STORM_TB_MUL(0, 0, 2, ao, bo);
+        bn = tb_inflate<0>(yb[3]);
+        STORM_TB_MUL(0, 1, 2, ao, bo);
+        an[0] = tb_inflate<1>(ya[0]);
+        STORM_TB_MUL(0, 0, 3, ao, bn);
+        bo = tb_inflate<1>(yb[0]);
+        STORM_TB_MUL(0, 1, 3, ao, bn);
+        an[1] = tb_inflate<1>(ya[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 1
+        STORM_TB_FETCH(xb[2], b0n, 2);
+        STORM_TB_FETCH(xb[3], b0n, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(1, 0, 0, an, bo);
+        bn = tb_inflate<1>(yb[1]);
+        STORM_TB_MUL(1, 1, 0, an, bo);
+        STORM_TB_MUL(1, 0, 1, an, bn);
+        bo = tb_inflate<1>(yb[2]);
+        STORM_TB_MUL(1, 1, 1, an, bn);
+        STORM_TB_MUL(1, 0, 2, an, bo);
+        bn = tb_inflate<1>(yb[3]);
+        STORM_TB_MUL(1, 1, 2, an, bo);
+        ao[0] = tb_inflate<2>(ya[0]);
+        STORM_TB_MUL(1, 0, 3, an, bn);
+        bo = tb_inflate<2>(yb[0]);
+        STORM_TB_MUL(1, 1, 3, an, bn);
+        ao[1] = tb_inflate<2>(ya[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 2
+        issue_piece(dma_stage, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(2, 0, 0, ao, bo);
+        bn = tb_inflate<2>(yb[1]);
+        STORM_TB_MUL(2, 1, 0, ao, bo);
+        STORM_TB_MUL(2, 0, 1, ao, bn);
+        bo = tb_inflate<2>(yb[2]);
+        STORM_TB_MUL(2, 1, 1, ao, bn);
+        STORM_TB_MUL(2, 0, 2, ao, bo);
+        bn = tb_inflate<2>(yb[3]);
+        STORM_TB_MUL(2, 1, 2, ao, bo);
+        an[0] = tb_inflate<3>(ya[0]);
+        STORM_TB_MUL(2, 0, 3, ao, bn);
+        bo = tb_inflate<3>(yb[0]);
+        STORM_TB_MUL(2, 1, 3, ao, bn);
+        an[1] = tb_inflate<3>(ya[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // k-group 1, class 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        STORM_TB_MUL(3, 0, 0, an, bo);
+        bn = tb_inflate<3>(yb[1]);
+        STORM_TB_MUL(3, 1, 0, an, bo);
+        STORM_TB_MUL(3, 0, 1, an, bn);
+        bo = tb_inflate<3>(yb[2]);
+        STORM_TB_MUL(3, 1, 1, an, bn);
+        STORM_TB_MUL(3, 0, 2, an, bo);
+        bn = tb_inflate<3>(yb[3]);
+        STORM_TB_MUL(3, 1, 2, an, bo);
+        ao[0] = tb_inflate<0>(xa[0]);
+        STORM_TB_MUL(3, 0, 3, an, bn);
+        bo = tb_inflate<0>(xb[0]);
+        STORM_TB_MUL(3, 1, 3, an, bn);
+        ao[1] = tb_inflate<0>(xa[1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef STORM_TB_MUL
+#undef STORM_TB_FETCH
+
+    const bool rect = j_count != 0;
+    {
+        const uint32_t col0 = b_row0 - j_base;
+        const bool interior =
+            item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
+            (rect ? (b_row0 >= j_base && col0 + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
+            (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
+        if (interior) {
+            __builtin_amdgcn_s_barrier();  // every wave has left the ring
+            tb_store_interior<2>(acc, &lds[0][0] + wave * 16384u,
+                                 &out[(uint64_t)(a_row0 + wa * 64u - i_lo) * ld + col0 + wb * 128u], ld, lane,
+                                 row_counts, a_row0 + wa * 64u, b_row0 + wb * 128u, and_weight);
+            return;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const uint32_t j = b_row0 + wb * 128u + (uint32_t)n * 32u + (lane & 31u);
+        const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
+        const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t i = a_row0 + wa * 64u + (uint32_t)m * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) +
+                                   4u * (lane >> 5);
+                if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
+                    const uint32_t c = (uint32_t)acc[m][n][r];
+                    uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
+                    if (item_idx < split_from) {
+                        *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
+                    } else {
+                        const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
+                        atomicAdd(dst, row_counts ? once - and_weight * c : c);
+                    }
+                }
+            }
+    }
+}
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
@@ -1818,7 +2641,9 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
     const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
     const bool rect = j_count != 0;
     if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_cols)) return;
-    for (uint32_t r = 0; r < (uint32_t)kTile; ++r) {
+    // blockIdx.y: band of 16 rows (one workgroup per tile took 16 us for the 92 windows of the
+    // headline call: a serial walk down 256 rows)
+    for (uint32_t r = blockIdx.y * 16u; r < blockIdx.y * 16u + 16u; ++r) {
         const uint32_t i = (uint32_t)it.I * kTile + r;
         if (i >= i_lo && i < n_rows && (rect || i < j)) out[(uint64_t)(i - i_lo) * ld + (j - j_base)] = 0;
     }
@@ -1851,13 +2676,32 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
         parts = std::max(parts, (total_stages + kMaxExactStages - 1) / kMaxExactStages);
     }
     const size_t n_full = parts > 1 ? tiles.size() - leftover : tiles.size();
+    // The table of the previous call is still on the device when this call asks for the same tiles
+    // cut the same way (a repeated call, the bands of one output): no upload, and no host wait in
+    // front of the kernels. The key lives in items_key, which the summing tile kernel's own table
+    // (another key layout) overwrites.
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
+    for (const auto& t : tiles) mix(((uint64_t)t.first << 16) | t.second);
+    mix(tiles.size());
+    const uint64_t key[4] = {h, 0x4d504c414e000000ull ^ total_stages,
+                             ((uint64_t)(n_full + (tiles.size() - n_full) * parts) << 32) | (uint64_t)n_full,
+                             ((uint64_t)parts << 32) | (uint64_t)(parts > 1 ? leftover : 0)};
+    if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) {
+        plan->n_items = (uint32_t)(key[2] >> 32);
+        plan->n_full = (uint32_t)n_full;
+        plan->parts = parts;
+        plan->leftover = parts > 1 ? (uint32_t)leftover : 0;
+        return STORM_HIP_OK;
+    }
     std::vector<MfmaItem> items;
     for (size_t t = 0; t < n_full; ++t) items.push_back({tiles[t].first, tiles[t].second, 0, total_stages});
     for (size_t t = n_full; t < tiles.size(); ++t)
         for (uint32_t p = 0; p < parts; ++p) {
-            // cuts on even stages: the 16x16 kernel's stage is two of these (128 bytes of a row)
-            const uint32_t s0 = (uint32_t)((uint64_t)(total_stages / 2) * p / parts) * 2u;
-            const uint32_t s1 = (uint32_t)((uint64_t)(total_stages / 2) * (p + 1) / parts) * 2u;
+            // cuts on multiples of 4 stages: the 16x16 kernel's stage is two of these (128 bytes of
+            // an FP4 row), the bit-operand kernel's four (512 bits)
+            const uint32_t s0 = (uint32_t)((uint64_t)(total_stages / 4) * p / parts) * 4u;
+            const uint32_t s1 = (uint32_t)((uint64_t)(total_stages / 4) * (p + 1) / parts) * 4u;
             items.push_back({tiles[t].first, tiles[t].second, s0, s1 - s0});
         }
     // the context's item buffer (shared with the tile kernel's sum mode, whose cached table is
@@ -1875,6 +2719,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
     STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, items.data(), items.size() * sizeof(MfmaItem),
                                  hipMemcpyHostToDevice, ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` is pageable and leaves scope
+    memcpy(ctx->items_key, key, sizeof(key));
     plan->n_items = (uint32_t)items.size();
     plan->n_full = (uint32_t)n_full;
     plan->parts = parts;
@@ -1890,14 +2735,22 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
 static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64_t pitch,
                             uint32_t* d_out, uint64_t ld, uint32_t n_rows, const uint32_t* d_counts,
                             uint32_t and_weight, uint32_t j_base, uint32_t j_count, uint32_t i_lo = 0,
-                            uint32_t n_cols = 0, bool sync = true) {
+                            uint32_t n_cols = 0, bool sync = true, const TileOperands* bits = nullptr) {
     if (n_cols == 0) n_cols = n_rows;
-    memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
+    if (!bits) memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
     if (plan.parts > 1)
-        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.leftover), dim3(256), 0, ctx->stream, d_items,
+        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.leftover, kTile / 16), dim3(256), 0, ctx->stream, d_items,
                            plan.n_full, plan.parts, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
-    if (ctx->k2_tile_shape == 16)
+    if (bits && ctx->k2_tile_shape == 2)
+        hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
+                           *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+    else if (bits)
+        hipLaunchKernelGGL(tilebits_kernel, dim3(plan.n_items), dim3(kTbThreads), 0, ctx->stream,
+                           *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+    else if (ctx->k2_tile_shape == 16)
         hipLaunchKernelGGL(tile16_fp4_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            ctx->d_x4, pitch, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base,
                            j_count, plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
@@ -1950,15 +2803,17 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     if (m->n_rows < 2) return STORM_HIP_OK;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
-    const uint64_t pitch = shadow_pitch(ctx, row_bytes, false);
-    const size_t x4_bytes = (size_t)n_rows4 * pitch;
+    // bit-operand kernel: the operands are the matrix rows themselves (no shadow, no expansion)
+    const bool bits = ctx->k2_tile_shape <= 2;
+    const uint64_t pitch = bits ? m->stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
+    const size_t x4_bytes = bits ? 0 : (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
         set_error("pairw_matrix: too many row blocks");
         return STORM_HIP_EINVAL;
     }
-    if (pitch * (uint64_t)kTile > (1ull << 32)) {  // rows of 2^25 bits and more
-        set_error("pairw_matrix: rows of %llu nibble bytes exceed the tile kernel's 32-bit DMA offsets",
-                  (unsigned long long)row_bytes);
+    if (pitch * (uint64_t)kTile >= (1ull << 32)) {  // FP4 shadow: rows of 2^25 bits; bit operands: 2^27
+        set_error("pairw_matrix: rows of %llu operand bytes exceed the tile kernel's 32-bit DMA offsets",
+                  (unsigned long long)pitch);
         return STORM_HIP_EINVAL;
     }
     if (x4_bytes > ctx->x4_capacity) {
@@ -1988,14 +2843,18 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, m, d_counts);
     }
     if (rc == STORM_HIP_OK) {
-        const dim3 grid = expand_grid(n_rows4, m->stride_words);
-        hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
-                           m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
-                           reinterpret_cast<uint4*>(ctx->d_x4), kExpandAll, 2u, pitch / 16);
+        const TileOperands ops = {reinterpret_cast<const uint8_t*>(m->d), nullptr, pitch, 0xffffffffu,
+                                  (uint32_t)std::min<uint64_t>(m->n_rows_pad, 0xffffffffu), 0u};
+        if (!bits) {
+            const dim3 grid = expand_grid(n_rows4, m->stride_words);
+            hipLaunchKernelGGL(expand_fp4_kernel, grid, dim3(256), 0, ctx->stream, m->d,
+                               m->stride_words, std::min<uint64_t>(m->n_rows_pad, n_rows4), n_rows4,
+                               reinterpret_cast<uint4*>(ctx->d_x4), kExpandAll, 2u, pitch / 16);
+        }
         // rows [band_row0, band_end) are written; the columns run over the whole matrix
         rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)band_end, d_counts,
                               op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u, (uint32_t)band_row0,
-                              (uint32_t)m->n_rows, sync);
+                              (uint32_t)m->n_rows, sync, bits ? &ops : nullptr);
     }
     if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
     return rc;
@@ -2008,19 +2867,20 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
-    const uint64_t pitch = shadow_pitch(ctx, row_bytes, false);
+    const bool bits = ctx->k2_tile_shape <= 2 && b->stride_words == stride_words;
+    const uint64_t pitch = bits ? stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const uint64_t rows_a = (a->n_rows + kTile - 1) / kTile * kTile;
     const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;
     if ((rows_a + rows_b) / kTile >= 65535) {
         set_error("square_matrix: too many row blocks");
         return STORM_HIP_EINVAL;
     }
-    if (pitch * (uint64_t)kTile > (1ull << 32)) {
-        set_error("square_matrix: rows of %llu nibble bytes exceed the tile kernel's 32-bit DMA offsets",
-                  (unsigned long long)row_bytes);
+    if (pitch * (uint64_t)kTile >= (1ull << 32)) {
+        set_error("square_matrix: rows of %llu operand bytes exceed the tile kernel's 32-bit DMA offsets",
+                  (unsigned long long)pitch);
         return STORM_HIP_EINVAL;
     }
-    const size_t x4_bytes = (size_t)(rows_a + rows_b) * pitch;
+    const size_t x4_bytes = bits ? 0 : (size_t)(rows_a + rows_b) * pitch;
     if (x4_bytes > ctx->x4_capacity) {
         if (ctx->d_x4) STORM_HIP_TRY(hipFree(ctx->d_x4));
         ctx->d_x4 = nullptr;
@@ -2045,7 +2905,11 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
         if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
     }
     if (rc == STORM_HIP_OK) {
-        for (int side = 0; side < 2; ++side) {
+        const TileOperands ops = {reinterpret_cast<const uint8_t*>(a->d),
+                                  reinterpret_cast<const uint8_t*>(b->d), pitch, (uint32_t)rows_a,
+                                  (uint32_t)std::min<uint64_t>(a->n_rows_pad, rows_a),
+                                  (uint32_t)std::min<uint64_t>(b->n_rows_pad, rows_b)};
+        for (int side = 0; side < 2 && !bits; ++side) {
             const storm_hip_matrix_s* m = side ? b : a;
             const uint64_t rows_dst = side ? rows_b : rows_a;
             const dim3 grid = expand_grid(rows_dst, stride_words);
@@ -2055,7 +2919,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                                kExpandAll, 2u, pitch / 16);
         }
         rc = run_matrix_tiles(ctx, plan, pitch, d_out, ld, (uint32_t)a->n_rows, d_counts,
-                              op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows);
+                              op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a, (uint32_t)b->n_rows,
+                              0u, 0u, true, bits ? &ops : nullptr);
     }
     if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
     return rc;
