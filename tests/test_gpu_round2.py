@@ -400,3 +400,62 @@ def test_list_probe_kernel_for_columns_of_short_lists(hip_ctx, orc, M, N, d):
         assert got[0] == want
     assert s.pairw_intersect_cardinality() == got[0]
     s.free()
+
+
+@pytest.mark.parametrize("M,N,d", [(9000, 1100, 4000), (4096, 1024, 700), (70000, 777, 30000), (512, 1301, 200)])
+def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d):
+    """Option k2_tile_shape: the bit-operand kernels (2 = two waves per SIMD, the default; 1 = one wave per
+    SIMD: rows DMA'd as bits, inflated to FP4 in registers, per-class block scales) and the FP4-shadow
+    kernels (16, 32) write the same triangle, for every op. Shapes with interior tiles (stored through
+    the LDS, 16 bytes per lane) and with none, row counts that are and are not multiples of 4 (the
+    host entry point's ld = N decides whether the wide stores may be used), rows shorter than one stage."""
+    import torch
+    mat = synth.dense_matrix_c(M, N, d, seed=M + N)
+    m = hip_ctx.matrix_from_host(mat)
+    want = {"and": np.triu(orc.tile_counts(mat, 0, N, 0, N), k=1)}
+    for code, name in ((1, "or"), (2, "xor")):
+        want[name] = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, code), k=1)
+    try:
+        for shape in (2, 1, 16, 32):
+            hip_ctx.set_option("k2_tile_shape", shape)
+            for name in ("and", "or", "xor"):
+                assert np.array_equal(m.pairw_matrix(name), want[name]), (shape, name)
+            # device output with a padded, 16-byte aligned leading dimension (interior tiles take the wide
+            # stores) and with an odd one (they must not)
+            for ld in ((N + 3) // 4 * 4 + 8, N + 1):
+                out = torch.full((N, ld), 0xABCD, dtype=torch.int32, device="cuda:0")
+                m.pairw_matrix_device(out.data_ptr(), ld, "and")
+                got = out.cpu().numpy().astype(np.uint32)
+                assert np.array_equal(np.triu(got[:, :N], k=1), want["and"]), (shape, ld)
+                # nothing outside the strict upper triangle is touched
+                assert np.all(got[:, :N][np.tril_indices(N)] == 0xABCD) and np.all(got[:, N:] == 0xABCD), (shape, ld)
+            # a band that starts and ends inside row blocks
+            r0, nb = 130, min(N - 130, 600)
+            band = torch.zeros((nb, N), dtype=torch.int32, device="cuda:0")
+            m.pairw_matrix_band_device(band.data_ptr(), N, r0, nb, "xor")
+            assert np.array_equal(band.cpu().numpy().astype(np.uint32), want["xor"][r0:r0 + nb]), shape
+    finally:
+        hip_ctx.set_option("k2_tile_shape", 2)
+        m.close()
+
+
+def test_rectangle_output_on_bit_operands(hip_ctx, orc):
+    """storm_hip_square_matrix with the bit-operand kernels: A and B are separate allocations behind
+    one virtual row space; blocks of A and of B that are full, partial and (B shorter than a block)
+    nearly empty."""
+    M = 20000
+    mat = synth.dense_matrix_c(M, 1500, 7000, seed=77)
+    for na, nbr in ((900, 600), (256, 1024), (37, 1463)):
+        a, b = mat[:na], mat[na:na + nbr]
+        ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
+        want = orc.tile_counts(mat, 0, na, na, na + nbr)
+        try:
+            for shape in (2, 1, 16):
+                hip_ctx.set_option("k2_tile_shape", shape)
+                assert np.array_equal(ma.square_matrix(mb, "and"), want), (na, nbr, shape)
+            want_x = orc.tile_counts_op(mat, 0, na, na, na + nbr, 2)
+            assert np.array_equal(ma.square_matrix(mb, "xor"), want_x), (na, nbr)
+        finally:
+            hip_ctx.set_option("k2_tile_shape", 2)
+            ma.close()
+            mb.close()
