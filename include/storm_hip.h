@@ -184,6 +184,8 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *        "k2_pitch_pad" (-1 = auto): extra bytes per shadow row; "k2_lds_pad": cap workgroups per CU;
  *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k;
  *        "k2_shape" (16): MFMA form of the default strips, 16 = 16x16x128, 32 = 32x32x64;
+ *        "k2_tile_shape" (2): materialised-output kernel: 2 / 1 = bit operands inflated to FP4 in
+ *        registers (two / one wave per SIMD; no FP4 shadow), 16 / 32 = the FP4-shadow kernels;
  *        "k2_shadow_budget_mb" (98304): when the FP4 shadow (4 x the bits) of a matrix would exceed
  *        this many MiB the pass runs k-chunk by k-chunk over a compact shadow of one chunk
  *        (HBM-tiled: bounded footprint for any M x N; 0 = never chunk)
