@@ -32,6 +32,8 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <type_traits>
+#include <utility>
 
 namespace storm {
 
@@ -1668,11 +1670,35 @@ __global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
     }
 }
 
-// The same with TWO waves per SIMD (option k2_tile_shape = 2): 8 waves, wave w owns A rows
-// 64 (w % 4) .. + 63 against B rows 128 (w / 4) .. + 127 = 2 x 4 blocks of 32 x 32 (128 accumulator
-// registers); 3.75 inflation ops per MFMA instead of 2.5, but a wave's DMA issue and waits overlap
-// with its SIMD partner's MFMAs. Waves 4-7 issue their four DMA pieces one class phase later than
-// waves 0-3.
+// ------------------------------------------------------------------------------------------
+// The same with TWO waves per SIMD (default, option k2_tile_shape = 2): 8 waves, wave (wa, wb) owns A rows
+// 64 wa .. + 63 (2 blocks of 32) against the B blocks 64 n + 32 wb .. + 31, n = 0..3 (interleaved between
+// the two B halves): 128 accumulator registers, 3.75 inflation ops per MFMA instead of 2.5, but a wave's
+// DMA issue and waits overlap with its SIMD partner's MFMAs (3 % faster than one wave per SIMD).
+// A wave multiplies only the blocks it needs, a contiguous range [n_lo, n_hi):
+//   * columns beyond the output (the ragged last row block: 16 of 256 rows at N = 10000, 40 of the 820
+//     tiles) drop out through n_hi;
+//   * on a diagonal tile, blocks wholly below the diagonal drop out through n_lo = wa; the A quarters are
+//     dealt so that SIMD partners hold wa and 3 - wa (5 of 8 blocks per SIMD instead of 8).
+// The loop body is instantiated for 1..4 blocks (tb_static_for: indices are compile-time constants, the
+// accumulators stay in registers); every instantiation issues the same DMA pieces and barriers, so the
+// waves of one workgroup may run different ones. The host orders diagonal and ragged tiles last and cuts
+// the tiles beyond the last full round of workgroups into k-parts of equal COST (plan_matrix_tiles).
+// ------------------------------------------------------------------------------------------
+template <class F, int... I>
+__device__ __forceinline__ void tb_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void tb_static_for(F&& f) {
+    tb_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int OFF>
+__device__ __forceinline__ void tb_fetch(v4i& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
+}
+
 __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
     TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
     uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
@@ -1682,13 +1708,15 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wa = wave & 3u, wb = wave >> 2;
+    const uint32_t wb = wave >> 2;
+    const uint32_t wa = wb ? 3u - (wave & 3u) : (wave & 3u);  // SIMD partners: wa and 3 - wa
     const uint32_t item_idx = blockIdx.x;
     const MfmaItem it = items[item_idx];
     const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
     const uint32_t S = it.n_stages / 4u;
     const uint32_t kbyte0 = it.stage0 * 16u;
     const uint32_t pitch = (uint32_t)ops.pitch;
+    const bool rect = j_count != 0;
 
     auto window = [&](uint32_t v0, const uint8_t*& base, uint32_t& bytes) {
         const bool second = v0 >= ops.split;
@@ -1703,9 +1731,15 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
     window(a_row0, a_base, a_bytes);
     window(b_row0, b_base, b_bytes);
 
-    // piece p of a stage: instruction w + 8 (p % 2) of the A image (p < 2) or of the B image
+    // blocks of B this wave multiplies: [n_lo, n_hi)
+    const uint32_t col_limit = rect ? j_base + j_count : n_cols;
+    const uint32_t vc = col_limit > b_row0 ? min(col_limit - b_row0, (uint32_t)kTile) : 0u;
+    const uint32_t n_hi = vc > 32u * wb ? min((vc - 32u * wb + 63u) / 64u, 4u) : 0u;
+    const uint32_t n_lo = (!rect && a_row0 == b_row0) ? min(wa, n_hi) : 0u;
+    const uint32_t nb = n_hi - n_lo;
+
     const uint32_t voff0 = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
-    auto issue_piece = [&](uint32_t s, uint32_t p) {
+    auto issue_piece = [&](uint32_t s, uint32_t p) __attribute__((always_inline)) {
         const uint32_t koff = kbyte0 + s * kTbRowBytes;
         const bool second = p >= 2u;
         const uint32_t bytes = s < S ? (second ? b_bytes : a_bytes) : 0u;
@@ -1714,258 +1748,186 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
         uint8_t* dst = lds[s % kTbRing] + (second ? kTbImageBytes : 0) + (wave + 8u * (p & 1u)) * 1024u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst, 16, (int)(voff0 + (p & 1u) * 128u * pitch), 0, 0, 0);
     };
-    auto issue = [&](uint32_t s) {
-#pragma unroll
-        for (uint32_t p = 0; p < 4; ++p) issue_piece(s, p);
-    };
-
-    v16f acc[2][4];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = v16f{};
 
     const uint32_t lds_base =
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
     const uint32_t slot = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
     const uint32_t a_frag0 = lds_base + (wa * 64u + (lane & 31u)) * kTbRowBytes + slot * 16u;
     const uint32_t a_frag1 = lds_base + (wa * 64u + (lane & 31u)) * kTbRowBytes + (slot ^ 2u) * 16u;
-    const uint32_t b_delta = kTbImageBytes + wb * 128u * kTbRowBytes - wa * 64u * kTbRowBytes;
+    const uint32_t b_delta = kTbImageBytes + (64u * n_lo + 32u * wb) * kTbRowBytes - wa * 64u * kTbRowBytes;
 
-    issue(0);
-    issue(1);
-    issue(2);
-
-#define STORM_TB_FETCH(dst, addr, n) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
-#define STORM_TB_MUL(C, m, n, av, bv)                                                               \
-    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
-        v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
-        acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
-
-    v4i xa[2], xb[4], ya[2], yb[4];
-    v4i ao[2], an[2], bo, bn = {};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-        const uint32_t b0 = a_frag0 + b_delta;
-        STORM_TB_FETCH(xa[0], a_frag0, 0);
-        STORM_TB_FETCH(xa[1], a_frag0, 1);
-        STORM_TB_FETCH(xb[0], b0, 0);
-        STORM_TB_FETCH(xb[1], b0, 1);
-        STORM_TB_FETCH(xb[2], b0, 2);
-        STORM_TB_FETCH(xb[3], b0, 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        ao[0] = tb_inflate<0>(xa[0]);
-        ao[1] = tb_inflate<0>(xa[1]);
-        bo = tb_inflate<0>(xb[0]);
-    }
-    for (uint32_t s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const uint32_t cur = (s % kTbRing) * kTbStageBytes;
-        const uint32_t nxs = ((s + 1 < S ? s + 1 : s) % kTbRing) * kTbStageBytes;
-        const uint32_t a1 = a_frag1 + cur, b1 = a1 + b_delta;
-        const uint32_t a0n = a_frag0 + nxs, b0n = a0n + b_delta;
-        const uint32_t dma_stage = s + kTbRing - 1;
-        // k-group 0, class 0
-        issue_piece(dma_stage, 0);
-        STORM_TB_FETCH(ya[0], a1, 0);
-        STORM_TB_FETCH(ya[1], a1, 1);
-        STORM_TB_FETCH(yb[0], b1, 0);
-        STORM_TB_FETCH(yb[1], b1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 0, ao, bo);
-        bn = tb_inflate<0>(xb[1]);
-        STORM_TB_MUL(0, 1, 0, ao, bo);
-        STORM_TB_MUL(0, 0, 1, ao, bn);
-        bo = tb_inflate<0>(xb[2]);
-        STORM_TB_MUL(0, 1, 1, ao, bn);
-        STORM_TB_MUL(0, 0, 2, ao, bo);
-        bn = tb_inflate<0>(xb[3]);
-        STORM_TB_MUL(0, 1, 2, ao, bo);
-        an[0] = tb_inflate<1>(xa[0]);
-        STORM_TB_MUL(0, 0, 3, ao, bn);
-        bo = tb_inflate<1>(xb[0]);
-        STORM_TB_MUL(0, 1, 3, ao, bn);
-        an[1] = tb_inflate<1>(xa[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 1
-        STORM_TB_FETCH(yb[2], b1, 2);
-        STORM_TB_FETCH(yb[3], b1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 0, an, bo);
-        bn = tb_inflate<1>(xb[1]);
-        STORM_TB_MUL(1, 1, 0, an, bo);
-        STORM_TB_MUL(1, 0, 1, an, bn);
-        bo = tb_inflate<1>(xb[2]);
-        STORM_TB_MUL(1, 1, 1, an, bn);
-        STORM_TB_MUL(1, 0, 2, an, bo);
-        bn = tb_inflate<1>(xb[3]);
-        STORM_TB_MUL(1, 1, 2, an, bo);
-        ao[0] = tb_inflate<2>(xa[0]);
-        STORM_TB_MUL(1, 0, 3, an, bn);
-        bo = tb_inflate<2>(xb[0]);
-        STORM_TB_MUL(1, 1, 3, an, bn);
-        ao[1] = tb_inflate<2>(xa[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 2
-        issue_piece(dma_stage, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 0, ao, bo);
-        bn = tb_inflate<2>(xb[1]);
-        STORM_TB_MUL(2, 1, 0, ao, bo);
-        STORM_TB_MUL(2, 0, 1, ao, bn);
-        bo = tb_inflate<2>(xb[2]);
-        STORM_TB_MUL(2, 1, 1, ao, bn);
-        STORM_TB_MUL(2, 0, 2, ao, bo);
-        bn = tb_inflate<2>(xb[3]);
-        STORM_TB_MUL(2, 1, 2, ao, bo);
-        an[0] = tb_inflate<3>(xa[0]);
-        STORM_TB_MUL(2, 0, 3, ao, bn);
-        bo = tb_inflate<3>(xb[0]);
-        STORM_TB_MUL(2, 1, 3, ao, bn);
-        an[1] = tb_inflate<3>(xa[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 3
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 0, an, bo);
-        bn = tb_inflate<3>(xb[1]);
-        STORM_TB_MUL(3, 1, 0, an, bo);
-        STORM_TB_MUL(3, 0, 1, an, bn);
-        bo = tb_inflate<3>(xb[2]);
-        STORM_TB_MUL(3, 1, 1, an, bn);
-        STORM_TB_MUL(3, 0, 2, an, bo);
-        bn = tb_inflate<3>(xb[3]);
-        STORM_TB_MUL(3, 1, 2, an, bo);
-        ao[0] = tb_inflate<0>(ya[0]);
-        STORM_TB_MUL(3, 0, 3, an, bn);
-        bo = tb_inflate<0>(yb[0]);
-        STORM_TB_MUL(3, 1, 3, an, bn);
-        ao[1] = tb_inflate<0>(ya[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 0
-        issue_piece(dma_stage, 2);
-        STORM_TB_FETCH(xa[0], a0n, 0);
-        STORM_TB_FETCH(xa[1], a0n, 1);
-        STORM_TB_FETCH(xb[0], b0n, 0);
-        STORM_TB_FETCH(xb[1], b0n, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 0, ao, bo);
-        bn = tb_inflate<0>(yb[1]);
-        STORM_TB_MUL(0, 1, 0, ao, bo);
-        STORM_TB_MUL(0, 0, 1, ao, bn);
-        bo = tb_inflate<0>(yb[2]);
-        STORM_TB_MUL(0, 1, 1, ao, bn);
-        STORM_TB_MUL(0, 0, 2, ao, bo);
-        bn = tb_inflate<0>(yb[3]);
-        STORM_TB_MUL(0, 1, 2, ao, bo);
-        an[0] = tb_inflate<1>(ya[0]);
-        STORM_TB_MUL(0, 0, 3, ao, bn);
-        bo = tb_inflate<1>(yb[0]);
-        STORM_TB_MUL(0, 1, 3, ao, bn);
-        an[1] = tb_inflate<1>(ya[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 1
-        STORM_TB_FETCH(xb[2], b0n, 2);
-        STORM_TB_FETCH(xb[3], b0n, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 0, an, bo);
-        bn = tb_inflate<1>(yb[1]);
-        STORM_TB_MUL(1, 1, 0, an, bo);
-        STORM_TB_MUL(1, 0, 1, an, bn);
-        bo = tb_inflate<1>(yb[2]);
-        STORM_TB_MUL(1, 1, 1, an, bn);
-        STORM_TB_MUL(1, 0, 2, an, bo);
-        bn = tb_inflate<1>(yb[3]);
-        STORM_TB_MUL(1, 1, 2, an, bo);
-        ao[0] = tb_inflate<2>(ya[0]);
-        STORM_TB_MUL(1, 0, 3, an, bn);
-        bo = tb_inflate<2>(yb[0]);
-        STORM_TB_MUL(1, 1, 3, an, bn);
-        ao[1] = tb_inflate<2>(ya[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 2
-        issue_piece(dma_stage, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 0, ao, bo);
-        bn = tb_inflate<2>(yb[1]);
-        STORM_TB_MUL(2, 1, 0, ao, bo);
-        STORM_TB_MUL(2, 0, 1, ao, bn);
-        bo = tb_inflate<2>(yb[2]);
-        STORM_TB_MUL(2, 1, 1, ao, bn);
-        STORM_TB_MUL(2, 0, 2, ao, bo);
-        bn = tb_inflate<2>(yb[3]);
-        STORM_TB_MUL(2, 1, 2, ao, bo);
-        an[0] = tb_inflate<3>(ya[0]);
-        STORM_TB_MUL(2, 0, 3, ao, bn);
-        bo = tb_inflate<3>(yb[0]);
-        STORM_TB_MUL(2, 1, 3, ao, bn);
-        an[1] = tb_inflate<3>(ya[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 3
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 0, an, bo);
-        bn = tb_inflate<3>(yb[1]);
-        STORM_TB_MUL(3, 1, 0, an, bo);
-        STORM_TB_MUL(3, 0, 1, an, bn);
-        bo = tb_inflate<3>(yb[2]);
-        STORM_TB_MUL(3, 1, 1, an, bn);
-        STORM_TB_MUL(3, 0, 2, an, bo);
-        bn = tb_inflate<3>(yb[3]);
-        STORM_TB_MUL(3, 1, 2, an, bo);
-        ao[0] = tb_inflate<0>(xa[0]);
-        STORM_TB_MUL(3, 0, 3, an, bn);
-        bo = tb_inflate<0>(xb[0]);
-        STORM_TB_MUL(3, 1, 3, an, bn);
-        ao[1] = tb_inflate<0>(xa[1]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#undef STORM_TB_MUL
-#undef STORM_TB_FETCH
-
-    const bool rect = j_count != 0;
-    {
-        const uint32_t col0 = b_row0 - j_base;
-        const bool interior =
-            item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
-            (rect ? (b_row0 >= j_base && col0 + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
-            (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
-        if (interior) {
-            __builtin_amdgcn_s_barrier();  // every wave has left the ring
-            tb_store_interior<2>(acc, &lds[0][0] + wave * 16384u,
-                                 &out[(uint64_t)(a_row0 + wa * 64u - i_lo) * ld + col0 + wb * 128u], ld, lane,
-                                 row_counts, a_row0 + wa * 64u, b_row0 + wb * 128u, and_weight);
-            return;
-        }
-    }
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const uint32_t j = b_row0 + wb * 128u + (uint32_t)n * 32u + (lane & 31u);
-        const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
-        const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
+    for (uint32_t s = 0; s < 3; ++s)
+#pragma unroll
+        for (uint32_t p = 0; p < 4; ++p) issue_piece(s, p);
+
+    const bool interior =
+        item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
+        (rect ? (b_row0 >= j_base && b_row0 - j_base + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
+        (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
+
+
+    auto run = [&](auto nbc) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nbc)::value;
+        v16f acc[2][NB];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t i = a_row0 + wa * 64u + (uint32_t)m * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) +
-                                   4u * (lane >> 5);
-                if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
-                    const uint32_t c = (uint32_t)acc[m][n][r];
-                    uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
-                    if (item_idx < split_from) {
-                        *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
-                    } else {
-                        const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
-                        atomicAdd(dst, row_counts ? once - and_weight * c : c);
+            for (int n = 0; n < NB; ++n) acc[m][n] = v16f{};
+        v4i ba[2][2], bb[2][NB];   // [k-group parity][block]: bits of the k-group in use / of the next one
+        v4i aop[2][2], bop[2];     // inflated A blocks per class-phase parity, inflated B block per block parity
+        bop[1] = v4i{};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const uint32_t b0 = a_frag0 + b_delta;
+            tb_fetch<0>(ba[0][0], a_frag0);
+            tb_fetch<32 * kTbRowBytes>(ba[0][1], a_frag0);
+            tb_static_for<NB>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = decltype(nc)::value;
+                tb_fetch<n * 64 * kTbRowBytes>(bb[0][n], b0);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            aop[0][0] = tb_inflate<0>(ba[0][0]);
+            aop[0][1] = tb_inflate<0>(ba[0][1]);
+            bop[0] = tb_inflate<0>(bb[0][0]);
+        }
+        for (uint32_t s = 0; s < S; ++s) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const uint32_t cur = (s % kTbRing) * kTbStageBytes;
+            const uint32_t nxs = ((s + 1 < S ? s + 1 : s) % kTbRing) * kTbStageBytes;
+            const uint32_t a1 = a_frag1 + cur, b1 = a1 + b_delta;
+            const uint32_t a0n = a_frag0 + nxs, b0n = a0n + b_delta;
+            const uint32_t dma_stage = s + kTbRing - 1;
+            tb_static_for<8>([&](auto pc) __attribute__((always_inline)) {
+                constexpr int p = decltype(pc)::value;
+                constexpr int kg = p / 4, c = p % 4, cn = (c + 1) % 4;
+                constexpr int src = c < 3 ? kg : 1 - kg;  // bits the next phase's operands come from
+                if constexpr (p % 2 == 0) issue_piece(dma_stage, p / 2);
+                const uint32_t an = kg == 0 ? a1 : a0n, bn = kg == 0 ? b1 : b0n;
+                if constexpr (c == 0) {
+                    tb_fetch<0>(ba[1 - kg][0], an);
+                    tb_fetch<32 * kTbRowBytes>(ba[1 - kg][1], an);
+                    tb_fetch<0>(bb[1 - kg][0], bn);
+                    if constexpr (NB > 1) tb_fetch<64 * kTbRowBytes>(bb[1 - kg][1], bn);
+                }
+                if constexpr (c == 1) {
+                    if constexpr (NB > 2) tb_fetch<2 * 64 * kTbRowBytes>(bb[1 - kg][2], bn);
+                    if constexpr (NB > 3) tb_fetch<3 * 64 * kTbRowBytes>(bb[1 - kg][3], bn);
+                }
+                if constexpr (c == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                tb_static_for<NB>([&](auto bc) __attribute__((always_inline)) {
+                    constexpr int b = decltype(bc)::value;
+                    constexpr int g = p * NB + b;  // blocks since the top of the stage: parity of the B operand
+                    acc[0][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        v8i{aop[p & 1][0].x, aop[p & 1][0].y, aop[p & 1][0].z, aop[p & 1][0].w, 0, 0, 0, 0},
+                        v8i{bop[g & 1].x, bop[g & 1].y, bop[g & 1].z, bop[g & 1].w, 0, 0, 0, 0}, acc[0][b], 4, 4, 0,
+                        tb_scale<c>(), 0, tb_scale<c>());
+                    v4i nextb;
+                    if constexpr (b + 1 < NB) nextb = tb_inflate<c>(bb[kg][b + 1]);
+                    else nextb = tb_inflate<cn>(bb[src][0]);
+                    acc[1][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                        v8i{aop[p & 1][1].x, aop[p & 1][1].y, aop[p & 1][1].z, aop[p & 1][1].w, 0, 0, 0, 0},
+                        v8i{bop[g & 1].x, bop[g & 1].y, bop[g & 1].z, bop[g & 1].w, 0, 0, 0, 0}, acc[1][b], 4, 4, 0,
+                        tb_scale<c>(), 0, tb_scale<c>());
+                    bop[(g + 1) & 1] = nextb;
+                    // the next phase's A operands: in the last two blocks (one block: both here)
+                    if constexpr (NB == 1) {
+                        aop[(p + 1) & 1][0] = tb_inflate<cn>(ba[src][0]);
+                        aop[(p + 1) & 1][1] = tb_inflate<cn>(ba[src][1]);
+                    } else if constexpr (b >= NB - 2) {
+                        aop[(p + 1) & 1][b - (NB - 2)] = tb_inflate<cn>(ba[src][b - (NB - 2)]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the empty pieces of the tail, too
+
+        // ---- epilogue: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a 32 x 32 block
+        if constexpr (NB == 4) {
+            if (interior) {  // every wave of an interior tile runs this instantiation
+                __builtin_amdgcn_s_barrier();  // every wave has left the ring
+                uint8_t* mine = &lds[0][0] + wave * 16384u;
+                uint32_t* w32 = reinterpret_cast<uint32_t*>(mine);
+                const uint4* r128 = reinterpret_cast<const uint4*>(mine);
+                const uint32_t i0 = a_row0 + wa * 64u, j0 = b_row0 + 32u * wb;
+                uint32_t* out_tile = &out[(uint64_t)(i0 - i_lo) * ld + (j0 - j_base)];
+                uint32_t nj[4] = {0u, 0u, 0u, 0u};
+                if (row_counts) {
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) nj[n] = row_counts[j0 + (uint32_t)n * 64u + (lane & 31u)];
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t il = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
+                        const uint32_t ni = row_counts ? row_counts[i0 + (uint32_t)m * 32u + il] : 0u;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const uint32_t c = (uint32_t)acc[m][n][r];
+                            w32[il * 128u + (uint32_t)n * 32u + (lane & 31u)] = row_counts ? ni + nj[n] - and_weight * c : c;
+                        }
+                    }
+                    // lane piece p = lane & 31: columns 4 p .. 4 p + 3 of the wave's 128 = block p / 8
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t row = (uint32_t)q * 2u + (lane >> 5);
+                        const uint32_t pc = lane & 31u;
+                        const uint4 v = r128[row * 32u + pc];
+                        *reinterpret_cast<uint4*>(
+                            &out_tile[(uint64_t)((uint32_t)m * 32u + row) * ld + 64u * (pc >> 3) + 4u * (pc & 7u)]) = v;
                     }
                 }
+                return;
             }
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const uint32_t j = b_row0 + 64u * (n_lo + (uint32_t)n) + 32u * wb + (lane & 31u);
+            const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
+            const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t i = a_row0 + wa * 64u + (uint32_t)m * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) +
+                                       4u * (lane >> 5);
+                    if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
+                        const uint32_t c = (uint32_t)acc[m][n][r];
+                        uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
+                        if (item_idx < split_from) {
+                            *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
+                        } else {
+                            const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
+                            atomicAdd(dst, row_counts ? once - and_weight * c : c);
+                        }
+                    }
+                }
+        }
+    };
+
+    switch (nb) {
+        case 4: run(std::integral_constant<int, 4>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        default:  // nothing to multiply: this wave's share of the DMA and the barriers only
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            for (uint32_t s = 0; s < S; ++s) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (uint32_t p = 0; p < 4; ++p) issue_piece(s + kTbRing - 1, p);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            break;
     }
 }
 
@@ -2630,14 +2592,15 @@ static int ensure_counts_scratch(storm_hip_ctx_t* ctx, size_t n, uint32_t** out)
 }
 
 // Clears the output window of the tiles whose k range is split over several items (same write
-// predicate as pairw_fp4_kernel<., true>). One workgroup per tile, thread = column.
+// predicate as pairw_fp4_kernel<., true>). Grid (k-part item, band of 16 rows), thread = column.
 __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restrict__ items,
-                                                         uint32_t first, uint32_t parts,
+                                                         uint32_t first,
                                                          uint32_t* __restrict__ out, uint64_t ld,
                                                          uint32_t n_rows, uint32_t j_base,
                                                          uint32_t j_count, uint32_t i_lo,
                                                          uint32_t n_cols) {
-    const MfmaItem it = items[first + blockIdx.x * parts];
+    const MfmaItem it = items[first + blockIdx.x];
+    if (it.stage0 != 0) return;  // one window per tile: its first k-part clears it
     const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
     const bool rect = j_count != 0;
     if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_cols)) return;
@@ -2649,33 +2612,54 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
     }
 }
 
-// Runs the tile kernel in write mode over `tiles` (shadow already expanded). The kernel holds one
-// workgroup per CU, so n tiles take ceil(n / CUs) rounds and a nearly empty last round costs a
-// whole one (820 tiles on 256 CUs at the headline shape: 3.2 -> 4). The tiles of the last round
-// are therefore cut along k into as many parts as fill the CUs; the parts add into a cleared
-// window.
 struct MatrixPlan {  // item table of one matrix-output launch, already in ctx->d_items
-    uint32_t n_items = 0, n_full = 0, parts = 1, leftover = 0;
+    uint32_t n_items = 0;  // workgroups to launch
+    uint32_t n_full = 0;   // items [0, n_full) are whole tiles; the rest are k-parts that add into a cleared window
 };
 
-// Builds and uploads the item table (before the caller launches the expansion, so that the one
-// host wait for the pageable upload does not sit between the kernels).
+// Builds and uploads the item table (before the caller launches anything else, so that the one
+// host wait for the pageable upload does not sit between the kernels). `cost` (optional, one per
+// tile, 1 = a full tile): the tiles beyond the last full round of workgroups are cut along k into
+// parts of about equal cost, as many as fill the CUs — a short tile (diagonal or ragged under
+// tilebits8_kernel) into fewer parts than a full one.
 static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<uint16_t, uint16_t>>& tiles,
-                             uint32_t total_stages, MatrixPlan* plan) {
+                             uint32_t total_stages, MatrixPlan* plan, const std::vector<float>* cost = nullptr) {
     const size_t slots = (size_t)std::max(1, ctx->n_cus);
-    size_t leftover = tiles.size() % slots;
-    uint32_t parts = 1;
-    if (leftover > 0 && ctx->k2_matrix_split)
-        parts = (uint32_t)std::max<size_t>(1, std::min<size_t>(slots / leftover, total_stages / 32));
+    size_t leftover = ctx->k2_matrix_split ? tiles.size() % slots : 0;
     // f32 accumulators hold exact integers below 2^24: an item may span at most kMaxExactStages
     // stages (128 bits each). Rows of 2^24 bits and more are therefore cut along k for EVERY tile;
     // the parts add into the cleared window like the parts of the last round do.
     constexpr uint32_t kMaxExactStages = (1u << 24) / 128u - 1u;
+    uint32_t min_parts = 1;
     if (total_stages > kMaxExactStages) {
         leftover = tiles.size();
-        parts = std::max(parts, (total_stages + kMaxExactStages - 1) / kMaxExactStages);
+        min_parts = (total_stages + kMaxExactStages - 1) / kMaxExactStages;
     }
-    const size_t n_full = parts > 1 ? tiles.size() - leftover : tiles.size();
+    const size_t n_full = tiles.size() - leftover;
+    const uint32_t max_parts = std::max(min_parts, total_stages / 32);
+    auto cost_of = [&](size_t t) { return cost ? std::max(0.05f, (*cost)[t]) : 1.0f; };
+    double left_cost = 0;
+    for (size_t t = n_full; t < tiles.size(); ++t) left_cost += cost_of(t);
+    const double per_part = left_cost / (double)slots;  // what one CU should get of the last round
+    std::vector<uint32_t> parts_of(leftover, 1);
+    size_t n_parts = 0;
+    for (size_t t = n_full; t < tiles.size(); ++t) {
+        const double want = per_part > 0 ? cost_of(t) / per_part : 1.0;
+        n_parts += parts_of[t - n_full] = std::min(max_parts, std::max(min_parts, (uint32_t)want));
+    }
+    // rounding down leaves CUs without a part: give them to the tiles whose parts are longest (never
+    // more parts than CUs — a 257th item would wait for a whole part)
+    while (min_parts == 1 && n_parts < slots && leftover > 0) {
+        size_t best = leftover;
+        double longest = 0;
+        for (size_t i = 0; i < leftover; ++i) {
+            const double len = cost_of(n_full + i) / parts_of[i];
+            if (parts_of[i] < max_parts && len > longest) longest = len, best = i;
+        }
+        if (best == leftover) break;
+        ++parts_of[best];
+        ++n_parts;
+    }
     // The table of the previous call is still on the device when this call asks for the same tiles
     // cut the same way (a repeated call, the bands of one output): no upload, and no host wait in
     // front of the kernels. The key lives in items_key, which the summing tile kernel's own table
@@ -2684,26 +2668,29 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
     auto mix = [&h](uint64_t v) { h = (h ^ v) * 0x100000001b3ull; };
     for (const auto& t : tiles) mix(((uint64_t)t.first << 16) | t.second);
     mix(tiles.size());
-    const uint64_t key[4] = {h, 0x4d504c414e000000ull ^ total_stages,
-                             ((uint64_t)(n_full + (tiles.size() - n_full) * parts) << 32) | (uint64_t)n_full,
-                             ((uint64_t)parts << 32) | (uint64_t)(parts > 1 ? leftover : 0)};
-    if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) {
-        plan->n_items = (uint32_t)(key[2] >> 32);
-        plan->n_full = (uint32_t)n_full;
-        plan->parts = parts;
-        plan->leftover = parts > 1 ? (uint32_t)leftover : 0;
-        return STORM_HIP_OK;
+    size_t n_items = n_full;
+    for (uint32_t p : parts_of) {
+        mix(p);
+        n_items += p;
     }
+    const uint64_t key[4] = {h, 0x4d504c414e000000ull ^ total_stages, ((uint64_t)n_items << 32) | (uint64_t)n_full,
+                             (uint64_t)leftover};
+    plan->n_items = (uint32_t)n_items;
+    plan->n_full = (uint32_t)n_full;
+    if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
     std::vector<MfmaItem> items;
+    items.reserve(n_items);
     for (size_t t = 0; t < n_full; ++t) items.push_back({tiles[t].first, tiles[t].second, 0, total_stages});
-    for (size_t t = n_full; t < tiles.size(); ++t)
+    for (size_t t = n_full; t < tiles.size(); ++t) {
+        const uint32_t parts = parts_of[t - n_full];
         for (uint32_t p = 0; p < parts; ++p) {
             // cuts on multiples of 4 stages: the 16x16 kernel's stage is two of these (128 bytes of
-            // an FP4 row), the bit-operand kernel's four (512 bits)
+            // an FP4 row), the bit-operand kernels' four (512 bits)
             const uint32_t s0 = (uint32_t)((uint64_t)(total_stages / 4) * p / parts) * 4u;
             const uint32_t s1 = (uint32_t)((uint64_t)(total_stages / 4) * (p + 1) / parts) * 4u;
             items.push_back({tiles[t].first, tiles[t].second, s0, s1 - s0});
         }
+    }
     // the context's item buffer (shared with the tile kernel's sum mode, whose cached table is
     // dropped here); hipMalloc / hipFree per call would cost more than the kernel's tail
     if (items.size() > ctx->items_capacity) {
@@ -2720,10 +2707,6 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
                                  hipMemcpyHostToDevice, ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` is pageable and leaves scope
     memcpy(ctx->items_key, key, sizeof(key));
-    plan->n_items = (uint32_t)items.size();
-    plan->n_full = (uint32_t)n_full;
-    plan->parts = parts;
-    plan->leftover = parts > 1 ? (uint32_t)leftover : 0;
     return STORM_HIP_OK;
 }
 
@@ -2739,26 +2722,26 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     if (n_cols == 0) n_cols = n_rows;
     if (!bits) memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
-    if (plan.parts > 1)
-        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.leftover, kTile / 16), dim3(256), 0, ctx->stream, d_items,
-                           plan.n_full, plan.parts, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
+    if (plan.n_full < plan.n_items)
+        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
+                           ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
     if (bits && ctx->k2_tile_shape == 2)
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols);
     else if (bits)
         hipLaunchKernelGGL(tilebits_kernel, dim3(plan.n_items), dim3(kTbThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols);
     else if (ctx->k2_tile_shape == 16)
         hipLaunchKernelGGL(tile16_fp4_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            ctx->d_x4, pitch, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base,
-                           j_count, plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+                           j_count, plan.n_full, i_lo, n_cols);
     else
         hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3(plan.n_items), dim3(kMfmaThreads), 0,
                            ctx->stream, ctx->d_x4, pitch, d_items, ctx->d_slots, d_out, ld, n_rows,
                            d_counts, and_weight, j_base, j_count,
-                           plan.parts > 1 ? plan.n_full : 0xffffffffu, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols);
     if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
     if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
     return STORM_HIP_OK;
@@ -2833,11 +2816,30 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // where run_matrix_tiles may cut them along k
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
     const uint32_t t_lo = (uint32_t)(band_row0 / kTile), t_hi = (uint32_t)((band_end + kTile - 1) / kTile);
-    xcd_grouped_tiles(t_lo, t_hi, 0, nT, true, tiles);
-    for (uint32_t i = t_lo; i < t_hi; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
+    // ... and last of all the tiles of a ragged last row block (few valid columns): with
+    // tilebits8_kernel both kinds are short items, and the k-split of the last round then works on
+    // the shortest ones
+    const bool ragged = m->n_rows % kTile != 0 && m->n_rows % kTile <= 192 && nT > 1;
+    const uint32_t nT_full = ragged ? nT - 1 : nT;
+    xcd_grouped_tiles(t_lo, std::min(t_hi, nT_full), 0, nT_full, true, tiles);
+    for (uint32_t i = t_lo; i < std::min(t_hi, nT_full); ++i) tiles.emplace_back((uint16_t)i, (uint16_t)i);
+    if (ragged)
+        for (uint32_t i = t_lo; i < t_hi; ++i) tiles.emplace_back((uint16_t)i, (uint16_t)(nT - 1));
     uint32_t* d_counts = nullptr;
     MatrixPlan plan;
-    int rc = plan_matrix_tiles(ctx, tiles, total_stages, &plan);
+    // what a tile costs next to a full one under tilebits8_kernel: a diagonal tile multiplies 5 of its
+    // 8 block pairs per SIMD; a ragged one ceil(columns / 64) of 4 blocks per wave, but not below the
+    // inflation work of its A operands (measured: 0.3)
+    std::vector<float> cost;
+    if (ctx->k2_tile_shape == 2) {
+        const float ragged_cost = std::max(0.3f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
+        for (const auto& t : tiles) {
+            float c = t.first == t.second ? 0.625f : 1.0f;
+            if (ragged && t.second == nT - 1) c *= ragged_cost;
+            cost.push_back(c);
+        }
+    }
+    int rc = plan_matrix_tiles(ctx, tiles, total_stages, &plan, cost.empty() ? nullptr : &cost);
     if (rc == STORM_HIP_OK && op != STORM_HIP_OP_AND) {
         rc = ensure_counts_scratch(ctx, m->n_rows, &d_counts);
         if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, m, d_counts);

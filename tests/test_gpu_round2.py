@@ -402,13 +402,16 @@ def test_list_probe_kernel_for_columns_of_short_lists(hip_ctx, orc, M, N, d):
     s.free()
 
 
-@pytest.mark.parametrize("M,N,d", [(9000, 1100, 4000), (4096, 1024, 700), (70000, 777, 30000), (512, 1301, 200)])
+@pytest.mark.parametrize("M,N,d", [(9000, 1100, 4000), (4096, 1024, 700), (70000, 777, 30000), (512, 1301, 200),
+                                   (3000, 662, 1000), (2048, 968, 600)])
 def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d):
     """Option k2_tile_shape: the bit-operand kernels (2 = two waves per SIMD, the default; 1 = one wave per
     SIMD: rows DMA'd as bits, inflated to FP4 in registers, per-class block scales) and the FP4-shadow
     kernels (16, 32) write the same triangle, for every op. Shapes with interior tiles (stored through
     the LDS, 16 bytes per lane) and with none, row counts that are and are not multiples of 4 (the
-    host entry point's ld = N decides whether the wide stores may be used), rows shorter than one stage."""
+    host entry point's ld = N decides whether the wide stores may be used), rows shorter than one stage,
+    and ragged last row blocks of 9 / 21 / 76 / 150 / 200 rows: the default kernel multiplies 0..4 column
+    blocks per wave there (every instantiation of its loop body), and 4 - wa on diagonal tiles."""
     import torch
     mat = synth.dense_matrix_c(M, N, d, seed=M + N)
     m = hip_ctx.matrix_from_host(mat)
