@@ -186,6 +186,8 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *        "k2_shape" (16): MFMA form of the default strips, 16 = 16x16x128, 32 = 32x32x64;
  *        "k2_tile_shape" (2): materialised-output kernel: 2 / 1 = bit operands inflated to FP4 in
  *        registers (two / one wave per SIMD; no FP4 shadow), 16 / 32 = the FP4-shadow kernels;
+ *        "k2_tile_cost_diag" (63), "k2_tile_cost_ragged" (30): percent of a full tile's time the
+ *        planner assumes for diagonal / ragged-column tiles when it cuts the last round into k-parts;
  *        "k2_shadow_budget_mb" (98304): when the FP4 shadow (4 x the bits) of a matrix would exceed
  *        this many MiB the pass runs k-chunk by k-chunk over a compact shadow of one chunk
  *        (HBM-tiled: bounded footprint for any M x N; 0 = never chunk)

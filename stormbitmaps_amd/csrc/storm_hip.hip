@@ -642,6 +642,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_tile_shape = (int)value;
+    } else if (!strcmp(key, "k2_tile_cost_diag") || !strcmp(key, "k2_tile_cost_ragged")) {
+        if (value < 5 || value > 100) {
+            set_error("%s is a percentage of a full tile's time, 5..100", key);
+            return STORM_HIP_EINVAL;
+        }
+        (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");

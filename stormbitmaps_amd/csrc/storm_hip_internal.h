@@ -111,6 +111,7 @@ struct storm_hip_ctx_s {
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
     int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
+    int k2_tile_cost_diag = 63, k2_tile_cost_ragged = 30;  // percent of a full tile (tilebits8_kernel): what the planner assumes when it cuts the last round
     int k2_shape = 16;      // K2s: MFMA shape of the default strip kernel: 16 = 16x16x128 (default), 32 = 32x32x64
     int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)
     uint32_t strip_queue_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};

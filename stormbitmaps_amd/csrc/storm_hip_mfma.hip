@@ -2832,9 +2832,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // inflation work of its A operands (measured: 0.3)
     std::vector<float> cost;
     if (ctx->k2_tile_shape == 2) {
-        const float ragged_cost = std::max(0.3f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
+        const float ragged_cost =
+            std::max(ctx->k2_tile_cost_ragged / 100.0f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
         for (const auto& t : tiles) {
-            float c = t.first == t.second ? 0.625f : 1.0f;
+            float c = t.first == t.second ? ctx->k2_tile_cost_diag / 100.0f : 1.0f;
             if (ragged && t.second == nT - 1) c *= ragged_cost;
             cost.push_back(c);
         }
