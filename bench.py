@@ -202,16 +202,15 @@ def main():
     fence()
     # dominant kernel alone: the library brackets it with HIP events on the launch stream
     ctx.set_option("time_kernels", 1)
-    # kernel-only duration: HIP events on the launch stream, per step
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    # The timed region carries exactly the contract's instrumentation: the library's two HIP events
+    # around the dominant kernel on the launch stream (roofline.achieved). An event record costs the
+    # stream ~4 us (measured: 8.7 us per step for a second pair around the whole pass), so the
+    # per-pass durations are taken in a separate, untimed loop below.
     t0 = time.perf_counter()
     host_us = []
-    for a, b in ev:
+    for _ in range(args.steps):
         th = time.perf_counter()
-        a.record(stream)
         k = launch_pass()
-        b.record(stream)
         reduce_total(k)
         state["n"] += 1
         host_us.append((time.perf_counter() - th) * 1e6)
@@ -223,10 +222,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total = last_total()
-    per_step_pass_ms = [a.elapsed_time(b) for a, b in ev]
-    launch_ms = sum(per_step_pass_ms) / len(ev)   # expand + dominant kernel + fold
     dom_sum_ms, dom_n = ctx.kernel_time()
     ctx.set_option("time_kernels", 0)
+    # untimed diagnostic: expand + dominant kernel + fold of single passes, bracketed by stream events
+    # (same collective count on every rank: min(steps, 24) more steps)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(min(args.steps, 24))]
+    for a, b in ev:
+        a.record(stream)
+        k = launch_pass()
+        b.record(stream)
+        reduce_total(k)
+        state["n"] += 1
+    fence()
+    per_step_pass_ms = [a.elapsed_time(b) for a, b in ev]
+    launch_ms = sum(per_step_pass_ms) / len(ev)
     kernel_ms = dom_sum_ms / dom_n if dom_n else launch_ms
 
     # N > 1 diagnostics (outside the timed region): the 8-byte all-reduce alone, and every rank's
@@ -315,7 +325,7 @@ def main():
                     "frac_whole_pass": alg_flop_launch / (step_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS,
                     "kernel": ("storm::strip16_fp4_kernel<4>" if ctx.get_option("k2_shape") == 16 else
                                "storm::strip_fp4_kernel") if used >= 4 else "storm::pairw_fp4_kernel",
-                    "kernel_ms": kernel_ms, "launch_ms": launch_ms,
+                    "kernel_ms": kernel_ms, "pass_ms_untimed": launch_ms,
                     "algorithmic_flop_per_launch": alg_flop_launch,
                     "measured_fp4_mfma_peak_frac": (pairs * W / world / (kernel_ms * 1e-3)) / FP4_MEASURED_WORDPAIRS,
                     "hbm_algorithmic_gb_s": hbm_gbs, "hbm_algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
@@ -326,7 +336,7 @@ def main():
             roof = {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": f"storm::pairw_dense_kernel<{used}>", "kernel_ms": kernel_ms,
-                    "launch_ms": launch_ms,
+                    "pass_ms_untimed": launch_ms,
                     "algorithmic_bytes_per_launch": alg_bytes_launch,
                     "valu_popcount_frac": (info["word_pairs_executed"] / (kernel_ms * 1e-3)) / VALU_PEAK_WORDPAIRS,
                     "note": "algorithmic bytes use the reference's no-reuse accounting (16 B per word pair, "
@@ -351,7 +361,7 @@ def main():
             "total": total, "verified_against_column_identity": ok,
             "roofline": roof,
         }
-        out["pass_ms_first_steps"] = [round(x, 4) for x in per_step_pass_ms[:24]]  # rank 0: ramp after the fence?
+        out["pass_ms_untimed_passes"] = [round(x, 4) for x in per_step_pass_ms[:24]]  # rank 0, after the timed steps
         out["host_enqueue_us_first_steps"] = [round(x, 1) for x in host_us[:24]]
         if per_rank is not None:
             out["per_rank"] = per_rank
