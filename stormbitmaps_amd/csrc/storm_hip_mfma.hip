@@ -1845,6 +1845,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
+            // the operands of the next stage's first phase are final here: keep them in their registers
+            // across the back edge (hipcc otherwise re-inflates all 12 dwords at the top of every stage)
+            asm volatile("" : "+v"(aop[0][0]), "+v"(aop[0][1]), "+v"(bop[0]));
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the empty pieces of the tail, too
 
