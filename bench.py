@@ -206,10 +206,15 @@ def main():
     # around the dominant kernel on the launch stream (roofline.achieved). An event record costs the
     # stream ~4 us (measured: 8.7 us per step for a second pair around the whole pass), so the
     # per-pass durations are taken in a separate, untimed loop below.
+    # At N > 1 a rank's pass is 1/N as long and the two event records (~8 us) are not: there the kernel is
+    # bracketed on every 4th step only (still live, still inside the timed region; `kernel_ms_samples`).
+    sample_every = 1 if world == 1 else 4
     t0 = time.perf_counter()
     host_us = []
-    for _ in range(args.steps):
+    for i in range(args.steps):
         th = time.perf_counter()
+        if sample_every > 1 and i % sample_every < 2:
+            ctx.set_option("time_kernels", 1 if i % sample_every == 0 else 0)
         k = launch_pass()
         reduce_total(k)
         state["n"] += 1
@@ -325,7 +330,7 @@ def main():
                     "frac_whole_pass": alg_flop_launch / (step_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS,
                     "kernel": ("storm::strip16_fp4_kernel<4>" if ctx.get_option("k2_shape") == 16 else
                                "storm::strip_fp4_kernel") if used >= 4 else "storm::pairw_fp4_kernel",
-                    "kernel_ms": kernel_ms, "pass_ms_untimed": launch_ms,
+                    "kernel_ms": kernel_ms, "kernel_ms_samples": dom_n, "pass_ms_untimed": launch_ms,
                     "algorithmic_flop_per_launch": alg_flop_launch,
                     "measured_fp4_mfma_peak_frac": (pairs * W / world / (kernel_ms * 1e-3)) / FP4_MEASURED_WORDPAIRS,
                     "hbm_algorithmic_gb_s": hbm_gbs, "hbm_algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
