@@ -184,6 +184,9 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *        "k2_pitch_pad" (-1 = auto): extra bytes per shadow row; "k2_lds_pad": cap workgroups per CU;
  *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k;
  *        "k2_shape" (16): MFMA form of the default strips, 16 = 16x16x128, 32 = 32x32x64;
+ *        "k2_strip_operands" (4): operands of the strips: 4 = FP4 shadow (expansion pass + strips), 1 = the
+ *        bit matrix itself, inflated to FP4 in registers (no shadow; 6 % slower at the headline shape; set it
+ *        before storm_hip_matrix_create so that the row pitch is padded for it);
  *        "k2_tile_shape" (2): materialised-output kernel: 2 / 1 = bit operands inflated to FP4 in
  *        registers (two / one wave per SIMD; no FP4 shadow), 16 / 32 = the FP4-shadow kernels;
  *        "k2_tile_cost_diag" (63), "k2_tile_cost_ragged" (30): percent of a full tile's time the

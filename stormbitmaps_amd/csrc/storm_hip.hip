@@ -648,6 +648,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
+    } else if (!strcmp(key, "k2_strip_operands")) {
+        if (value != 1 && value != 4) {
+            set_error("k2_strip_operands must be 1 (bit operands) or 4 (FP4 shadow)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_strip_operands = (int)value;
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
@@ -726,6 +732,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
     if (!strcmp(key, "k2_shape")) return ctx->k2_shape;
+    if (!strcmp(key, "k2_strip_operands")) return ctx->k2_strip_operands;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
 #ifdef STORM_HIP_PROBES
@@ -806,9 +813,14 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     m->n_rows = n_rows;
     m->n_words = n_words;
     m->generation = next_matrix_generation();
-    m->n_rows_pad = std::max<uint64_t>(kABlockRows,
-                                       (n_rows + kABlockRows - 1) / kABlockRows * kABlockRows);
+    m->n_rows_pad = std::max<uint64_t>(kRowPad, (n_rows + kRowPad - 1) / kRowPad * kRowPad);
     m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
+    // Bit-operand strips (option k2_strip_operands = 1 at creation) read 64-byte pieces of 64+ consecutive
+    // rows straight from this buffer: rows whose byte length is a multiple of 1 KiB would put the rows of a
+    // k-slice into a handful of L2 sets and memory channels, so one more chunk of zero words per row breaks
+    // the pattern (same finding as shadow_pitch, storm_hip_mfma.hip). The FP4 paths copy the rows into
+    // their own padded shadow and keep the dense pitch.
+    if (ctx->k2_strip_operands == 1 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);
@@ -840,7 +852,7 @@ int storm_hip_matrix_resize(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t row_bytes = m->stride_words * sizeof(uint64_t);
     if (n_rows > m->n_rows_pad) {
-        const uint64_t want = (n_rows + kABlockRows - 1) / kABlockRows * kABlockRows;
+        const uint64_t want = (n_rows + kRowPad - 1) / kRowPad * kRowPad;
         const uint64_t new_pad = std::max<uint64_t>(want, 2 * m->n_rows_pad);
         uint64_t* nd = nullptr;
         if (hipMalloc(reinterpret_cast<void**>(&nd), new_pad * row_bytes) != hipSuccess) {

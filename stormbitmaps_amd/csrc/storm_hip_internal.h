@@ -54,6 +54,7 @@ constexpr int kThreads = kLanes * kWaves;            // 256
 constexpr int kChunkWords = 64;                      // k-chunk: one 64-bit word per lane
 constexpr int kRowsPerWave = 32;                     // A rows held in VGPRs by one wave
 constexpr int kABlockRows = kWaves * kRowsPerWave;   // 128 A rows per workgroup
+constexpr int kRowPad = 256;                         // allocated rows: a multiple of this, zero beyond n_rows (a strip's A tile)
 constexpr int kStageRows = 32;                       // B rows per LDS stage
 constexpr int kSlots = 4096;  // partial-sum slots (uint64 each)
 constexpr int kSlotsExtra = 8;  // words behind the slots: work-queue heads, zeroed by the fold
@@ -110,6 +111,7 @@ struct storm_hip_ctx_s {
     int k2_max_run = 128;   // K2s: B stages per strip item
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
     int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
+    int k2_strip_operands = 4;  // strips: 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel, default); 1 = bit operands inflated in registers (stripbits_kernel, no shadow; 6 % slower at the headline shape)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
     int k2_tile_cost_diag = 63, k2_tile_cost_ragged = 30;  // percent of a full tile (tilebits8_kernel): what the planner assumes when it cuts the last round
     int k2_shape = 16;      // K2s: MFMA shape of the default strip kernel: 16 = 16x16x128 (default), 32 = 32x32x64

@@ -1317,14 +1317,16 @@ __global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
     issue(1);
     issue(2);
 
+    // ("+v", here and in tb_fetch: the bit words keep their registers — see stripbits_kernel for what an LDS
+    //  return into the registers of a just-issued MFMA's operand does)
 #define STORM_TB_FETCH(dst, addr, n) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
 #define STORM_TB_MUL(C, m, n, av, bv)                                                               \
     acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
         v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
         acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
 
-    v4i xa[4], xb[4], ya[4], yb[4];  // bits of the k-group in use / of the next one (x: even groups)
+    v4i xa[4] = {}, xb[4] = {}, ya[4] = {}, yb[4] = {};  // bits of the k-group in use / of the next one (x: even groups)
     v4i ao[4], an[4], bo, bn = {};   // inflated A blocks of the running / next class phase, B block
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1696,7 +1698,7 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
 
 template <int OFF>
 __device__ __forceinline__ void tb_fetch(v4i& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(OFF));
 }
 
 __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
@@ -1774,7 +1776,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n) acc[m][n] = v16f{};
-        v4i ba[2][2], bb[2][NB];   // [k-group parity][block]: bits of the k-group in use / of the next one
+        v4i ba[2][2] = {}, bb[2][NB] = {};  // [k-group parity][block]: bits of the k-group in use / of the next one
         v4i aop[2][2], bop[2];     // inflated A blocks per class-phase parity, inflated B block per block parity
         bop[1] = v4i{};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
@@ -1932,6 +1934,237 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             break;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2sb: the strips on BIT operands (option k2_strip_operands = 1; the default stays the FP4 shadow).
+//
+// Same work items, ring protocol and accumulator handling as strip_fp4_kernel, but the rows travel as
+// bits and are inflated to FP4 in registers (the output kernels' operand trick, tilebits_kernel above):
+// no FP4 shadow (4 x the matrix), no expansion pass (8 % of a headline pass) and a quarter of the
+// L2 -> LDS DMA. Measured at the headline shape, same box, interleaved (profiles/r02_p_strip_operands.txt):
+// 0.857 ms per launch against 0.737 for strip16_fp4_kernel — the pass is 6 % SLOWER (0.865 against
+// 0.815 ms) although it has nothing to expand: B is streamed, so every wave inflates every B operand it
+// multiplies (2.5 ops per MFMA), the 64 stationary A registers leave 3 waves per SIMD instead of 4, and
+// real rows (39 % of the bits set, all four classes busy) hold this body at 2.09 GHz against the FP4
+// strips' 2.30 (matrix pipe 86 % busy). tools/ubench_shape had promised 8.8 PFLOP/s at 2.29 GHz while it
+// fed the NIBBLE image as bits (10 % density, one class of four non-zero); with real densities it says
+// 8.3 at 2.17 GHz against 8.1-8.2 for the FP4-fed stage. Kept for matrices whose FP4 shadow does not fit.
+//   k-slice   : 512 bits (StripItem.ks counts 64-byte pieces of the bit rows).
+//   A operand : this wave's 64 rows x 512 bits, inflated ONCE per item into all four classes:
+//               2 row blocks x 2 k-groups x 4 classes x 4 VGPRs = 64 VGPRs.
+//   B operand : stage = 64 rows x 64 B of bits = 4 KiB, ONE LDS-DMA piece per wave, ring of 4 (16 KiB);
+//               per stage 4 ds_read_b128 (2 blocks of 32 rows x 2 k-groups), each inflated into the four
+//               classes (20 ops) behind the MFMAs it feeds: 32 MFMAs of 32 cycles and 80 inflation ops per
+//               stage and wave.
+//   registers : the two bit words live in FIXED registers ("+v" on the reads). With plain outputs hipcc
+//               gave a read the registers that had just died — the inflated operand of MFMAs issued a
+//               moment before — and with three waves per SIMD an MFMA can still be queued behind its
+//               partners' when the LDS data lands: wrong totals, different from run to run, only with
+//               several workgroups per CU (one per CU: never). The hardware does not order an LDS return
+//               behind the operand read of an MFMA that was issued earlier.
+//   exactness : an accumulator gains at most 512 per stage, runs are capped at 4096 stages: < 2^24.
+// storm_hip_matrix_create keeps rows up to a multiple of 256 zero, so every row an item touches exists;
+// with this option set it also pads the row pitch off multiples of 1 KiB (L2 sets).
+// ------------------------------------------------------------------------------------------
+constexpr int kSbRowBytes = 64;                                  // 512 bits of k
+constexpr int kSbStageBytes = kStripBRows * kSbRowBytes;         // 4 KiB
+constexpr int kSbRing = 4;
+
+__global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
+    const uint8_t* __restrict__ X, uint64_t pitch64, const StripItem* __restrict__ items,
+    unsigned long long* __restrict__ slots) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSbRing * kSbStageBytes];
+    auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
+    const uint32_t item_idx = blockIdx.x;
+    const StripItem it = items[item_idx];
+    const uint32_t pitch = (uint32_t)pitch64;
+    const uint8_t* Xk = X + (uint64_t)it.ks * kSbRowBytes;  // the item's k-slice of row 0
+    constexpr uint32_t kATile = (uint32_t)kStripATile;
+    const uint32_t D = it.diag ? kATile / (uint32_t)kStripBRows : 0u;
+    const uint32_t T = D + (it.j1 - it.j0);
+
+    // B stage = 4 LDS-DMA pieces of 16 rows x 64 B, one per wave. Lane L fills row L / 4 of the piece,
+    // physical slot L % 4 = logical slot (L % 4) ^ ((L / 16) % 4)  (image: slot s of row r at s ^ ((r / 4) % 4))
+    const uint32_t goff = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
+    auto issue = [&](uint32_t t) {
+        const uint32_t blk = t < D ? it.a_row0 / (uint32_t)kStripBRows + t : it.j1 - 1u - (t - D);
+        const uint8_t* base = Xk + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[t % kSbRing] + wave * 1024u), 16, (int)goff, 0,
+                                                 0, 0);
+    };
+
+    // A bits first (older in the VMEM queue than the DMAs)
+    v4i abits[2][2];  // [k-group][row block]
+    {
+        const uint8_t* ap = Xk + (uint64_t)(it.a_row0 + wm * 64u + (lane & 31u)) * pitch64 + (lane >> 5) * 16u;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                abits[g][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 32u * pitch64 + g * 32);
+    }
+#pragma unroll
+    for (uint32_t t = 0; t < kSbRing - 1; ++t)
+        if (t < T) issue(t);
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
+
+    // fragment (block n, k-group g): row 32 n + (lane & 31), logical slot 2 g + (lane >> 5)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    const uint32_t slot0 = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
+    const uint32_t baddr0 = lds_base + (lane & 31u) * kSbRowBytes + slot0 * 16u;
+    const uint32_t baddr1 = lds_base + (lane & 31u) * kSbRowBytes + (slot0 ^ 2u) * 16u;
+
+    // the A operands, all four classes (retires the A loads: older than the DMAs, the ring stays in flight)
+    v4i a[2][4][2];  // [k-group][class][row block]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a[g][0][m] = tb_inflate<0>(abits[g][m]);
+            a[g][1][m] = tb_inflate<1>(abits[g][m]);
+            a[g][2][m] = tb_inflate<2>(abits[g][m]);
+            a[g][3][m] = tb_inflate<3>(abits[g][m]);
+        }
+
+    // retire(t, ahead): this wave's piece of stage t has landed — `ahead` younger pieces (one per stage)
+    // may stay in flight while that many stages exist beyond t, else everything is drained — and the
+    // barrier makes every wave's piece visible and says that every wave is done with the stages before.
+    auto retire = [&](uint32_t t, uint32_t ahead) {
+        if (ahead == 2u && t + 2u < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (ahead == 1u && t + 1u < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // ("+v": the word registers stay w0 / w1 for the whole item. With a plain output hipcc gave the read
+    //  whatever registers had just died — those of the inflated operand of MFMAs issued a moment before —
+    //  and the LDS data could land before a queued MFMA had read them: wrong totals, only with several
+    //  workgroups per CU, different from run to run.)
+#define STORM_SB_FETCH(dst, t, n, g) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+#define STORM_SB_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
+    acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
+        v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                          \
+        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>()); \
+    acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
+        v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                          \
+        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>()); \
+    enxt = NEXT;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0)
+#define STORM_SB_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+    // One stage. On entry w0 holds the bits of (block 0, k-group 0) of stage `tc` and e0 their class 0; on
+    // exit the same of stage `tn` (the look-ahead: the next stage, or a re-read that is never consumed).
+    // Word order: (n, g) = (0,0) (1,0) (0,1) (1,1) in w0, w1, w0, w1; every word is fetched while the one
+    // before it runs its first three classes.
+#define STORM_SB_STAGE(tc, tn)                                      \
+    STORM_SB_FETCH(w1, tc, 1, 0);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_SB_STEP(0, 0, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_SB_STEP(0, 0, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_SB_STEP(0, 0, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_SB_WAIT();                                                \
+    STORM_SB_STEP(0, 0, 3, e0, e0, tb_inflate<0>(w1));              \
+    STORM_SB_FETCH(w0, tc, 0, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_SB_STEP(1, 0, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_SB_STEP(1, 0, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_SB_STEP(1, 0, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_SB_WAIT();                                                \
+    STORM_SB_STEP(1, 0, 3, e0, e0, tb_inflate<0>(w0));              \
+    STORM_SB_FETCH(w1, tc, 1, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_SB_STEP(0, 1, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_SB_STEP(0, 1, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_SB_STEP(0, 1, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_SB_WAIT();                                                \
+    STORM_SB_STEP(0, 1, 3, e0, e0, tb_inflate<0>(w1));              \
+    STORM_SB_FETCH(w0, tn, 0, 0);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_SB_STEP(1, 1, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_SB_STEP(1, 1, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_SB_STEP(1, 1, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_SB_WAIT();                                                \
+    STORM_SB_STEP(1, 1, 3, e0, e0, tb_inflate<0>(w0))
+
+    v4i w0 = {}, w1 = {}, e0 = {};  // one inflated operand: the next one is computed behind the step's second MFMA
+    uint32_t t = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    // ---- the A tile's own 4 blocks (strict upper triangle), not pipelined across stages: wave wm skips
+    //      the blocks before its own rows, masks its own 64 x 64 block, takes the later ones whole
+#pragma unroll 1
+    for (; t < D; ++t) {
+        retire(t, 2u);
+        if (t + kSbRing - 1 < T) issue(t + kSbRing - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= wm) {
+            STORM_SB_FETCH(w0, t, 0, 0);
+            STORM_SB_WAIT();
+            e0 = tb_inflate<0>(w0);
+            STORM_SB_STAGE(t, t);
+            STORM_SB_WAIT();  // the look-ahead read
+            if (t == wm) {
+                // the accumulators have seen nothing but this stage: clear the pairs with i >= j in place
+                // (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+                acc[1][0] = v16f{};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const bool keep = row < (lane & 31u);
+                    acc[0][0][r] = keep ? acc[0][0][r] : 0.0f;
+                    acc[1][1][r] = keep ? acc[1][1][r] : 0.0f;
+                }
+            }
+        }
+    }
+    // ---- later blocks: stage t + 1 is retired at the top of iteration t, so that its first word can be
+    //      fetched while stage t still multiplies; the refill of the ring follows the barrier
+    if (t < T) {
+        retire(t, 2u);
+        STORM_SB_FETCH(w0, t, 0, 0);
+        STORM_SB_WAIT();
+        e0 = tb_inflate<0>(w0);
+        for (; t < T; ++t) {
+            if (t + 1 < T) retire(t + 1, 1u);
+            else __builtin_amdgcn_s_barrier();
+            if (t + kSbRing - 1 < T) issue(t + kSbRing - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t tn = t + 1 < T ? t + 1 : t;
+            STORM_SB_STAGE(t, tn);
+        }
+        STORM_SB_WAIT();
+    }
+#undef STORM_SB_STAGE
+#undef STORM_SB_WAIT
+#undef STORM_SB_STEP
+#undef STORM_SB_FETCH
+
+    uint64_t mine = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {  // one 32 x 64 strip at a time stays below 2^32
+        uint32_t part = 0;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += (uint32_t)acc[m][n][r];
+        mine += part;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (lane == 0 && mine != 0)
+        atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)], (unsigned long long)mine);
 }
 
 void release_mfma_state(storm_hip_ctx_t* ctx) {
@@ -2932,9 +3165,47 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     return rc;
 }
 
+// The default pass: strips on bit operands over the matrix itself (no shadow, nothing to expand).
+static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
+                             uint32_t shard_count, uint64_t* d_total) {
+    const uint64_t pitch = m->stride_words * 8;
+    const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
+    if (n_rows4 > m->n_rows_pad || pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
+        set_error("K2sb: matrix of %llu rows (%llu allocated) x %llu bytes per row is outside the bit-operand strips' reach",
+                  (unsigned long long)m->n_rows, (unsigned long long)m->n_rows_pad, (unsigned long long)pitch);
+        return STORM_HIP_EINVAL;
+    }
+    std::vector<RowRange> ranges;
+    if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
+    // k-slices of 512 bits that hold data (the zero padding of the rows is never multiplied)
+    const uint32_t n_kslices = (m->n_words + 7u) / 8u;
+    ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
+    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
+        return rc;
+    const uint32_t n_strip = ctx->n_strip_items;
+    if (n_strip > 0) {
+        kernel_time_mark(ctx);
+        hipLaunchKernelGGL(stripbits_kernel, dim3(n_strip), dim3(kStripThreads), 0, ctx->stream,
+                           reinterpret_cast<const uint8_t*>(m->d), pitch,
+                           static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
+        kernel_time_mark(ctx);
+        STORM_HIP_TRY(hipGetLastError());
+    }
+    ctx->last_info[0] = n_strip;
+    ctx->last_info[1] = ctx->k2_stages_per_item;
+    ctx->last_info[2] = 1;
+    ctx->last_info[3] = 0;
+    return launch_fold_slots(ctx, d_total);
+}
+
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
+    // (a matrix created before the option was set may lack the zero rows up to a multiple of 256)
+    if (strip_mode == 1 && ctx->k2_strip_operands == 1 && !ctx->k2_persistent && ctx->k2_debug == 0 &&
+        (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad)
+        return launch_pairw_bits(ctx, m, shard_rank, shard_count, d_total);
     const uint64_t tile = strip_mode == 2 ? 512 : kStripATile;
     const uint64_t n_rows4 = (m->n_rows + tile - 1) / tile * tile;
     std::vector<RowRange> ranges;

@@ -462,3 +462,33 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
             hip_ctx.set_option("k2_tile_shape", 2)
             ma.close()
             mb.close()
+
+
+def test_strips_on_bit_operands(hip_ctx, orc):
+    """Option k2_strip_operands = 1: the strips read the bit matrix itself (512-bit k-slices, rows
+    inflated to FP4 in registers, no shadow). Matrices created under the option (row pitch padded off
+    multiples of 1 KiB) and before it (dense pitch); against the oracle where the CPU can afford it,
+    against the column identity and the FP4 strips otherwise; shards; ragged rows around the waves' own
+    diagonal blocks. The larger shapes put several workgroups on every CU: that is where an LDS read that
+    lands in the registers of a just-issued MFMA's operand gave totals that changed from run to run."""
+    try:
+        for M, N, d, check_oracle in ((4096, 256, 2048, True), (1000, 131, 300, True), (65536, 513, 9000, True),
+                                      (300, 65, 100, True), (20000, 1029, 7000, True), (65536, 2000, 32768, False),
+                                      (70000, 777, 30000, False), (32768, 2000, 16000, False)):
+            for created_under in (1, 4):
+                hip_ctx.set_option("k2_strip_operands", created_under)
+                m = hip_ctx.matrix(N, (M + 63) // 64)
+                m.fill_synthetic(M, d, seed=N)
+                assert (m.stride_words * 8) % 1024 != 0 or created_under == 4
+                want = m.column_identity()
+                if check_oracle and created_under == 1:
+                    assert want == orc.wrapper_diag_blocked(m.download(), 31)
+                for operands in (1, 4):
+                    hip_ctx.set_option("k2_strip_operands", operands)
+                    got = [m.pairw() for _ in range(4 if operands == 1 else 1)]
+                    assert got == [want] * len(got), (M, N, d, created_under, operands, got, want)
+                    assert sum(m.pairw(r, 3) for r in range(3)) == want, (M, N, d, created_under, operands)
+                m.close()
+    finally:
+        hip_ctx.set_option("k2_strip_operands", 4)
+    assert hip_ctx.get_option("k2_strip_operands") == 4

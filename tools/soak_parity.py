@@ -41,6 +41,7 @@ def main():
                 "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
                 "k2_shape": int(rng.choice([16, 16, 32])),
                 "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32])),
+                "k2_strip_operands": int(rng.choice([4, 4, 1])),
                 "k2_shadow_budget_mb": int(rng.choice([98304, 98304, 1, 8])),
                 "sparse_probe": int(rng.choice([-1, -1, 0, 1]))}
         for k, v in opts.items():
@@ -112,7 +113,7 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 4,
                          "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
         n_cases += 1
