@@ -211,7 +211,8 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
  * expansion or the final fold), for roofline accounting: with option "time_kernels" = 1 every
  * pairwise launch brackets that kernel with HIP events on the launch stream. This call waits for
  * the stream, returns the summed duration and the number of launches since the last call, and
- * starts a new series. */
+ * starts a new series. "time_kernels" = 0 pauses the bracketing and keeps the series, 2 resumes it
+ * (1 starts a new one): bench.py brackets every 4th step at N > 1. */
 int storm_hip_kernel_time(storm_hip_ctx_t* ctx, double* sum_ms, uint64_t* launches);
 /* work decomposition of the last dense launch: out[0]=work items, [1]=k-chunks per item,
  * [2]=word-pairs executed incl. zero padding (popcount kernel) / k-chunks of the pass (matrix-core

@@ -708,8 +708,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
     } else if (!strcmp(key, "time_kernels")) {
+        // 1: start a new series of bracketed launches; 0: pause (the series is kept for
+        // storm_hip_kernel_time); 2: resume it (bench.py brackets every 4th step at N > 1)
         ctx->time_kernels = value != 0;
-        ctx->kernel_events_used = 0;
+        if (value == 1) ctx->kernel_events_used = 0;
     } else if (!strcmp(key, "chunks_per_item")) {
         if (value < 0 || value > 4096) {
             set_error("chunks_per_item out of range");

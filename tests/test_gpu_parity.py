@@ -446,7 +446,7 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", str(ranks), "--backend", "gloo", "--all-on-device0", "--steps", "3", "--warmup", "1",
+           "--gpus", str(ranks), "--backend", "gloo", "--all-on-device0", "--steps", "5", "--warmup", "1",
            "--rows", "3000", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -460,6 +460,8 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     assert [r["rank"] for r in out["per_rank"]] == list(range(ranks))
     assert all(r["kernel_ms"] > 0 and r["work_items"] > 0 for r in out["per_rank"])
     assert 0 < out["roofline"]["frac_whole_pass"] <= out["roofline"]["frac"] * 1.05
+    # at N > 1 the dominant kernel is bracketed on every 4th timed step: steps 0 (.. 4, 8) of the 5
+    assert out["roofline"]["kernel_ms_samples"] == 2
 
 
 def test_benchmark_cli_rows_agree_with_golden_totals():
