@@ -156,6 +156,8 @@ struct STORM_contiguous_s {
     void* hip_matrix;        /* storm_hip_matrix_t*: device mirror of `data`        */
     uint64_t hip_rows_synced;
     uint64_t hip_rows_capacity;
+    STORM_t* hip_lists;      /* the same rows as a STORM_t while EVERY row is below scalar_cutoff:   */
+    uint32_t hip_lists_off;  /* such a container goes through the list-probe kernel (see storm_host.c) */
 };
 
 /* per-block API (reference storm.h:203-212, storm.c:372-380, :398-656) */

@@ -492,3 +492,49 @@ def test_strips_on_bit_operands(hip_ctx, orc):
     finally:
         hip_ctx.set_option("k2_strip_operands", 4)
     assert hip_ctx.get_option("k2_strip_operands") == 4
+
+
+def test_sparse_contiguous_containers_take_the_list_path(lib, orc):
+    """A STORM_contiguous_t whose rows are ALL below scalar_cutoff (the reference's list regime,
+    storm.c:1151-1162) is mirrored into a private STORM_t and totalled by the list-probe kernel; the first
+    row at or above the cutoff ends that for good, STORM_contig_clear starts over, an in-place edit
+    (STORM_contig_hip_invalidate) ends it too. Every state against the oracle's container; the timing
+    line pins that the list path is the one that ran (an order of magnitude at 20 positions per row)."""
+    import time
+    M, N = 131072, 6000
+    rows = synth.positions(M, N + 2, 20, seed=5)           # 20 draws per row, cutoff 200
+    dense_row = synth.positions(M, 1, 3000, seed=6)[0]     # >= cutoff
+    c, oc = sb.StormContig(M), orc.contig(M, ())
+    for r in rows[:N]:
+        c.add(r)
+        oc.add(r)
+    want = oc.pairw()
+    assert c.pairw_intersect_cardinality() == want == c.pairw_intersect_cardinality_blocked(31)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        assert c.pairw_intersect_cardinality() == want
+    t_lists = (time.perf_counter() - t0) / 5
+    # a dense row: back to the dense mirror, which was kept up to date all along
+    c.add(dense_row)
+    oc.add(dense_row)
+    want2 = oc.pairw()
+    assert c.pairw_intersect_cardinality() == want2
+    c.add(rows[N])        # sparse rows after it do not bring the list path back
+    oc.add(rows[N])
+    want3 = oc.pairw()
+    assert c.pairw_intersect_cardinality() == want3
+    t0 = time.perf_counter()
+    for _ in range(5):
+        assert c.pairw_intersect_cardinality() == want3
+    t_dense = (time.perf_counter() - t0) / 5
+    assert t_lists * 3 < t_dense, (t_lists, t_dense)
+    # clear: a fresh start
+    c.clear()
+    oc2 = orc.contig(M, ())
+    for r in rows[:500]:
+        c.add(r)
+        oc2.add(r)
+    assert c.pairw_intersect_cardinality() == oc2.pairw()
+    c.hip_invalidate()
+    assert c.pairw_intersect_cardinality() == oc2.pairw()
+    assert np.array_equal(c.pairw_matrix("and"), np.triu(orc.tile_counts(oc2.dense(), 0, 500, 0, 500), k=1))
