@@ -429,7 +429,7 @@ static void contig_drop_device(STORM_contiguous_t* h) {
  * costs work proportional to the listed positions (list-probe kernel K4) instead of a dense pass over
  * N x M bits — at M = 65536, N = 10000: 0.18 ms at 65 positions per row, 0.08 ms at 5, against 0.83 ms.
  * The first row at or above the cutoff, a failed allocation or STORM_contig_hip_invalidate ends it for
- * this container (until STORM_contig_clear); the dense mirror is kept up to date either way.
+ * this container (until STORM_contig_clear); the dense mirror is then brought up to date on demand.
  * STORM_HIP_CONTIG_LISTS=0 in the environment turns it off. */
 static void contig_lists_end(STORM_contiguous_t* h) {
     if (h->hip_lists) STORM_free(h->hip_lists);
@@ -624,6 +624,10 @@ static void contig_stream_rows(STORM_contiguous_t* h) {
         g_stream_state = (e && e[0] == '0') ? -1 : 1;
     }
     if (g_stream_state < 0) return;
+    /* a container that is all lists so far needs no dense mirror (N x M bits over PCIe for a handful of
+     * positions per row): contig_mirror() uploads whatever is missing the day a dense row or the per-pair
+     * matrix asks for it */
+    if (h->hip_lists && !h->hip_lists_off) return;
     g_quiet_ctx = 1;
     const int rc = contig_upload_rows(h, h->n_data);
     g_quiet_ctx = 0;

@@ -514,7 +514,7 @@ def test_sparse_contiguous_containers_take_the_list_path(lib, orc):
     for _ in range(5):
         assert c.pairw_intersect_cardinality() == want
     t_lists = (time.perf_counter() - t0) / 5
-    # a dense row: back to the dense mirror, which was kept up to date all along
+    # a dense row: back to the dense mirror (filled in on demand: nothing was streamed while all rows were lists)
     c.add(dense_row)
     oc.add(dense_row)
     want2 = oc.pairw()
