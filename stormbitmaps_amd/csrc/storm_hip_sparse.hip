@@ -35,7 +35,8 @@ struct storm_hip_sparse_s {
     std::vector<uint8_t> col_probe;  // per entry of `cols`: 1 = has probe data
     std::vector<uint32_t> col_avg_len;  // per entry of `cols`: mean list length (probe columns)
     uint32_t* d_probe_elems = nullptr;  // (row in column) << 16 | position in block, column by column, row order
-    struct ProbeItemHost { uint32_t a_begin, a_end, b_begin, b_end, a0, col; };
+    uint16_t* d_probe_pos16 = nullptr;  // the positions alone, same indexing
+    struct ProbeItemHost { uint32_t a_begin, a_end, n_begin, n_end, b_begin, b_end, a0, col; };
     std::vector<ProbeItemHost> probe_items;  // all eligible columns; filtered per launch
     void* d_probe_items = nullptr;
     size_t probe_items_capacity = 0;
@@ -99,26 +100,33 @@ __global__ __launch_bounds__(kThreads) void place_bitmaps_u16_kernel(
 // through the kind dispatch :618-656). The dense path multiplies 8 KiB per present block whatever
 // its density; here the work is proportional to the listed positions.
 //   data  : per column the lists of its rows, concatenated in row order, one uint32 per listed
-//           position: (row in column) << 16 | position in block;
-//   item  : 16 consecutive A rows of a column x a chunk of the elements of the LATER rows;
+//           position: (row in column) << 16 | position in block — and the positions alone as uint16;
+//   item  : 16 consecutive A rows of a column x (first item of the group: the later rows inside the
+//           group, as tagged elements, +) a chunk of the positions of the rows BEHIND the group;
 //   LDS   : the 16 A rows as a TRANSPOSED bitmap — T[position] = 16-bit mask of the A rows that have
 //           that position set (65536 x 16 bit = 128 KiB) — zeroed and scattered per item;
 //   stream: every element of the later rows is ONE LDS read: popcount(T[pos] & rows_before(j)) is that
-//           element's contribution against all 16 A rows at once; 16-byte coalesced loads of the
-//           element array (an XCD's L2 holds a column's few MB), 1024 threads per workgroup.
+//           element's contribution against all 16 A rows at once (rows behind the group: no mask, no
+//           tag); 16-byte coalesced loads (8 positions), an XCD's L2 holds a column's few MB, 1024
+//           threads per workgroup.
 // Pairs i < j: B rows inside the A group mask off the A rows that are not before them.
 // ------------------------------------------------------------------------------------------
 struct ProbeItem {
     uint32_t a_begin, a_end;  // elements of the A rows [a0, a0 + 16)
-    uint32_t b_begin, b_end;  // chunk of the elements of rows > a0
+    uint32_t n_begin, n_end;  // "near" elements: the later rows INSIDE the A group (row-tagged, masked); first chunk only
+    uint32_t b_begin, b_end;  // chunk of the elements of the rows behind the group (positions only)
     uint32_t a0;              // first A row (row index within the column)
 };
 constexpr int kProbeThreads = 1024;
 constexpr uint32_t kProbeChunk = 1u << 17;  // elements per item
 
+// [r2] The rows behind the A group need no row tag (every A row is before them): they stream as
+// uint16 POSITIONS, half the bytes of the tagged elements — the kernel was bound by re-reading the
+// column's elements from L2 once per A group (5 GB per column of 2 M elements at N = 10000).
 __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
-    const uint32_t* __restrict__ elems, const ProbeItem* __restrict__ items, uint32_t item_stride,
-    uint32_t item_first, unsigned long long* __restrict__ slots) {
+    const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
+    const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
+    unsigned long long* __restrict__ slots) {
     __shared__ __attribute__((aligned(16))) uint32_t T[32768];  // two 16-bit masks per word
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
@@ -131,23 +139,26 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
         atomicOr(&T[pos >> 1], 1u << (r + 16u * (pos & 1u)));
     }
     __syncthreads();
+    const uint16_t* T16 = reinterpret_cast<const uint16_t*>(T);  // T16[pos] = mask of the A rows holding pos
     uint32_t count = 0;
-    auto visit = [&](uint32_t v) {
-        const uint32_t pos = v & 0xffffu, jr = (v >> 16) - it.a0;  // >= 1
-        const uint32_t mask = jr >= 16u ? 0xffffu : (1u << jr) - 1u;
-        count += __popc((T[pos >> 1] >> (16u * (pos & 1u))) & mask);
-    };
-    // head up to a 16-byte boundary, body in uint4, tail
-    uint32_t e = it.b_begin;
-    const uint32_t head_end = min(it.b_end, (it.b_begin + 3u) & ~3u);
-    if (e + tid < head_end) visit(elems[e + tid]);
-    e = head_end;
-    const uint32_t body_end = e + ((it.b_end - e) & ~3u);
-    for (uint32_t q = e + tid * 4u; q < body_end; q += kProbeThreads * 4u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&elems[q]);
-        visit(v.x); visit(v.y); visit(v.z); visit(v.w);
+    // near: B rows inside the A group mask off the A rows that are not before them
+    for (uint32_t e = it.n_begin + tid; e < it.n_end; e += kProbeThreads) {
+        const uint32_t v = elems[e];
+        const uint32_t jr = (v >> 16) - it.a0;  // 1..15
+        count += __popc((uint32_t)T16[v & 0xffffu] & ((1u << jr) - 1u));
     }
-    if (body_end + tid < it.b_end) visit(elems[body_end + tid]);
+    // far: head up to a 16-byte boundary, body 8 positions per load, tail
+    auto visit2 = [&](uint32_t w) { count += __popc((uint32_t)T16[w & 0xffffu]) + __popc((uint32_t)T16[w >> 16]); };
+    uint32_t e = it.b_begin;
+    const uint32_t head_end = min(it.b_end, (it.b_begin + 7u) & ~7u);
+    if (e + tid < head_end) count += __popc((uint32_t)T16[pos16[e + tid]]);
+    e = head_end;
+    const uint32_t body_end = e + ((it.b_end - e) & ~7u);
+    for (uint32_t q = e + tid * 8u; q < body_end; q += kProbeThreads * 8u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&pos16[q]);
+        visit2(v.x); visit2(v.y); visit2(v.z); visit2(v.w);
+    }
+    if (body_end + tid < it.b_end) count += __popc((uint32_t)T16[pos16[body_end + tid]]);
     uint64_t mine = count;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
@@ -312,14 +323,14 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 col_elems[c] <= n_c * kProbeMaxAvgLen && total + col_elems[c] < (1ull << 32) - 8) {
                 s->col_probe[entry] = 1;
                 s->col_avg_len[entry] = (uint32_t)(col_elems[c] / n_c);
-                total = (total + 3) & ~3ull;  // columns start on 16-byte boundaries
+                total = (total + 7) & ~7ull;  // columns start on 16-byte boundaries of the uint16 position array
                 elem_base[c] = total;
                 total += col_elems[c];
             }
             ++entry;
         }
         if (total > 0) {
-            probe_elems.assign((size_t)total + 4, 0);
+            probe_elems.assign((size_t)total + 8, 0);
             std::vector<uint64_t> cursor(elem_base);
             std::vector<uint64_t> next(start);
             // per probe column: element offset of every row (rows are visited in order)
@@ -349,9 +360,16 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 for (uint32_t a0 = 0; a0 + 1 < n_c; a0 += 16) {
                     const uint32_t a1 = std::min(a0 + 16u, n_c);
                     if (rs[a1] == rs[a0]) continue;  // no listed position in the A rows
-                    for (uint32_t b0 = rs[a0 + 1]; b0 < rs[n_c]; b0 += kProbeChunk)
-                        s->probe_items.push_back({rs[a0], rs[a1], b0, std::min(rs[n_c], b0 + kProbeChunk),
-                                                  a0, (uint32_t)e});
+                    // first item of the group: the later rows inside it (tagged elements) + the first chunk
+                    // of the rows behind it; further chunks of those follow as items of their own
+                    bool first = true;
+                    for (uint32_t b0 = rs[a1]; first || b0 < rs[n_c]; b0 += kProbeChunk) {
+                        const uint32_t b1 = std::min(rs[n_c], b0 + kProbeChunk);
+                        const uint32_t n0 = first ? rs[a0 + 1] : 0u, n1 = first ? rs[a1] : 0u;
+                        if (n1 > n0 || b1 > b0)
+                            s->probe_items.push_back({rs[a0], rs[a1], n0, n1, std::min(b0, b1), b1, a0, (uint32_t)e});
+                        first = false;
+                    }
                 }
             }
         }
@@ -376,9 +394,13 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             rc = STORM_HIP_EHIP;
             break;
         }
-        if (!probe_elems.empty() &&
-            (rc = upload(&s->d_probe_elems, probe_elems.data(), probe_elems.size(), ctx->stream)))
-            break;
+        if (!probe_elems.empty()) {
+            if ((rc = upload(&s->d_probe_elems, probe_elems.data(), probe_elems.size(), ctx->stream))) break;
+            std::vector<uint16_t> pos16(probe_elems.size());
+            for (size_t i = 0; i < probe_elems.size(); ++i) pos16[i] = (uint16_t)probe_elems[i];
+            if ((rc = upload(&s->d_probe_pos16, pos16.data(), pos16.size(), ctx->stream))) break;
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = STORM_HIP_EHIP; break; }  // pos16 leaves scope
+        }
         // the list pool (or the whole serialized stream) goes up once
         if (!list_row.empty() || (bitmaps_in_stream && !dense_row.empty()))
             if ((rc = upload(&d_lists, list_pool, (size_t)list_pool_len, ctx->stream))) break;
@@ -540,6 +562,7 @@ void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
     if (s->d_pool) (void)hipFree(s->d_pool);
     if (s->d_segs) (void)hipFree(s->d_segs);
     if (s->d_probe_elems) (void)hipFree(s->d_probe_elems);
+    if (s->d_probe_pos16) (void)hipFree(s->d_probe_pos16);
     if (s->d_probe_items) (void)hipFree(s->d_probe_items);
     delete s;
 }
@@ -590,14 +613,14 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     ctx->variant_used = variant;
     if (variant >= 3) {
         // K4: columns of short lists go to the probe kernel ("sparse_probe": -1 = when the mean list
-        // has at most 400 positions — measured at c4 (profiles/r02_j_sparse_probe.jsonl): 31x faster
-        // than the dense path at 13 positions per list, 7.5x at 65, 1.2x at 393, 0.67x at 655 —,
+        // has at most 560 positions — measured at c4 (profiles/r02_q_sparse_probe.jsonl): 46x faster
+        // than the dense path at 13 positions per list, 12x at 65, 1.9x at 393, 1.0x at 655 —,
         // 1 = every eligible column, 0 = never); what it counts lands in the same slots the strips'
         // fold sums up
         std::vector<uint8_t> use_probe(s->cols.size(), 0);
         if (ctx->sparse_probe != 0 && s->d_probe_elems)
             for (size_t e = 0; e < s->cols.size(); ++e)
-                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 400u);
+                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 560u);
         {
             uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
             for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;
@@ -606,7 +629,8 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                 uint32_t cols_used = 0;
                 for (size_t e = 0; e < use_probe.size(); ++e) cols_used += use_probe[e];
                 for (const auto& pi : s->probe_items)
-                    if (use_probe[pi.col]) mine.push_back({pi.a_begin, pi.a_end, pi.b_begin, pi.b_end, pi.a0});
+                    if (use_probe[pi.col])
+                        mine.push_back({pi.a_begin, pi.a_end, pi.n_begin, pi.n_end, pi.b_begin, pi.b_end, pi.a0});
                 if (mine.size() > s->probe_items_capacity) {
                     if (s->d_probe_items) STORM_HIP_TRY(hipFree(s->d_probe_items));
                     s->d_probe_items = nullptr;
@@ -629,7 +653,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         }
         if (s->n_probe_launch > 0) {
             hipLaunchKernelGGL(probe_lists_kernel, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
-                               s->d_probe_elems, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
+                               s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
                                shard_rank, ctx->d_slots);
             STORM_HIP_TRY(hipGetLastError());
         }

@@ -427,7 +427,7 @@ static void contig_drop_device(STORM_contiguous_t* h) {
 /* A container whose rows are ALL below scalar_cutoff (the regime in which the reference diverts to its
  * list variants, storm.c:1151-1162) is mirrored row by row into a private STORM_t: its all-pairs total then
  * costs work proportional to the listed positions (list-probe kernel K4) instead of a dense pass over
- * N x M bits — at M = 65536, N = 10000: 0.18 ms at 65 positions per row, 0.08 ms at 5, against 0.83 ms.
+ * N x M bits — at M = 65536, N = 10000: 0.125 ms at 65 positions per row, 0.066 ms at 5, against 0.82 ms.
  * The first row at or above the cutoff, a failed allocation or STORM_contig_hip_invalidate ends it for
  * this container (until STORM_contig_clear); the dense mirror is then brought up to date on demand.
  * STORM_HIP_CONTIG_LISTS=0 in the environment turns it off. */
