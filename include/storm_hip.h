@@ -174,7 +174,7 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *                  storm_hip_matrix_device_ptr. storm.h handles use it.
  *   key "time_kernels": see storm_hip_kernel_time
  *   key "sparse_probe": sparse container, block columns whose blocks are all lists: -1 = auto (the
- *                  list-probe kernel K4 when the mean list has <= 560 positions, else the dense path),
+ *                  list-probe kernel K4 when the mean list has <= 1000 positions, else the dense path),
  *                  0 = never, 1 = every eligible column
  *   key "seg_rows": K1 B rows per work item (default 256)
  *   key "chunks_per_item": K1 k-chunks (64 words each) per work item, 0 = auto

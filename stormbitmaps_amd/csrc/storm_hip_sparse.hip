@@ -118,7 +118,9 @@ struct ProbeItem {
     uint32_t a0;              // first A row (row index within the column)
 };
 constexpr int kProbeThreads = 1024;
-constexpr uint32_t kProbeChunk = 1u << 17;  // elements per item
+// Positions per item: every item zeroes and scatters its 128 KiB table first (~1200 cycles; 128 lookups
+// per thread at 2^17 positions cost about as much), so chunks grow with the work — about 1024 items over
+// all probe columns, between 2^17 and 2^21 positions each.
 
 // [r2] The rows behind the A group need no row tag (every A row is before them): they stream as
 // uint16 POSITIONS, half the bytes of the tagged elements — the kernel was bound by re-reading the
@@ -347,6 +349,24 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 for (uint32_t k = 0; k < block_n[b]; ++k)
                     probe_elems[(size_t)cursor[c]++] = ((uint32_t)local << 16) | l[k];
             }
+            // chunk size from the far work of all probe columns (rows are visited in order: a group's far
+            // positions are the column's elements behind its last row)
+            uint64_t far_work = 0;
+            for (size_t e = 0; e < s->cols.size(); ++e) {
+                if (!s->col_probe[e] || row_start[e].empty()) continue;
+                const std::vector<uint32_t>& rs = row_start[e];
+                const uint32_t n_c = (uint32_t)rs.size();
+                uint64_t cnt = 0;
+                for (uint32_t c = 0; c <= max_id; ++c)
+                    if (col_entry[c] == (int64_t)e) { cnt = col_elems[c]; break; }
+                const uint64_t end = rs[0] + cnt;
+                for (uint32_t a0 = 0; a0 + 1 < n_c; a0 += 16) {
+                    const uint32_t a1 = std::min(a0 + 16u, n_c);
+                    far_work += end - (a1 < n_c ? rs[a1] : end);
+                }
+            }
+            const uint32_t kProbeChunk =
+                (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 17, far_work / 1024)) & ~7u;
             for (size_t e = 0; e < s->cols.size(); ++e) {
                 if (!s->col_probe[e]) continue;
                 std::vector<uint32_t>& rs = row_start[e];
@@ -613,14 +633,14 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     ctx->variant_used = variant;
     if (variant >= 3) {
         // K4: columns of short lists go to the probe kernel ("sparse_probe": -1 = when the mean list
-        // has at most 560 positions — measured at c4 (profiles/r02_q_sparse_probe.jsonl): 46x faster
-        // than the dense path at 13 positions per list, 12x at 65, 1.9x at 393, 1.0x at 655 —,
+        // has at most 1000 positions — measured at c4 (profiles/r02_q_sparse_probe.jsonl): 47x faster
+        // than the dense path at 13 positions per list, 15x at 65, 3.0x at 393, 1.7x at 655, 1.1x at 1012 —,
         // 1 = every eligible column, 0 = never); what it counts lands in the same slots the strips'
         // fold sums up
         std::vector<uint8_t> use_probe(s->cols.size(), 0);
         if (ctx->sparse_probe != 0 && s->d_probe_elems)
             for (size_t e = 0; e < s->cols.size(); ++e)
-                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 560u);
+                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 1000u);
         {
             uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
             for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;

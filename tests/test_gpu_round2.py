@@ -385,7 +385,7 @@ def test_list_probe_kernel_for_columns_of_short_lists(hip_ctx, orc, M, N, d):
             assert lib.storm_hip_pairw_sparse(ctx._h, h, 0, 1, C.byref(out)) == 0, lib.storm_hip_last_error()
             got[probe] = out.value
             used = ctx.last_launch_info()["segments"]            # out[3]: columns the probe kernel counted
-            auto = d * 65536 // M <= 560                         # mean list length per block vs the auto rule
+            auto = d * 65536 // M <= 1000                         # mean list length per block vs the auto rule
             assert (used > 0) == (probe == 1 or (probe == -1 and auto)), (probe, used)
             parts = []
             for r in range(3):
