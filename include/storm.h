@@ -129,6 +129,8 @@ struct STORM_s {
     uint32_t hip_dirty;
     uint32_t hip_generation; /* device configuration the arena was built for */
     uint64_t hip_fingerprint; /* rows / blocks / set-bit counts the arena was built from */
+    uint32_t hip_private;     /* a container the library keeps for itself (the list mirror of a
+                                 STORM_contiguous_t): nobody edits its members, no fingerprint per call */
 };
 
 /* one row of the dense container (reference storm.h:181-186) */
