@@ -1317,16 +1317,16 @@ __global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
     issue(1);
     issue(2);
 
-    // ("+v", here and in tb_fetch: the bit words keep their registers — see stripbits_kernel for what an LDS
-    //  return into the registers of a just-issued MFMA's operand does)
+    // (every look-ahead read of these kernels feeds a loop-carried value, alive to the wait behind the loop:
+    //  no read's output is dead in hipcc's eyes while it is still in flight — see STORM_SB_KEEP below)
 #define STORM_TB_FETCH(dst, addr, n) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
 #define STORM_TB_MUL(C, m, n, av, bv)                                                               \
     acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
         v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
         acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
 
-    v4i xa[4] = {}, xb[4] = {}, ya[4] = {}, yb[4] = {};  // bits of the k-group in use / of the next one (x: even groups)
+    v4i xa[4], xb[4], ya[4], yb[4];  // bits of the k-group in use / of the next one (x: even groups)
     v4i ao[4], an[4], bo, bn = {};   // inflated A blocks of the running / next class phase, B block
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1698,7 +1698,7 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
 
 template <int OFF>
 __device__ __forceinline__ void tb_fetch(v4i& dst, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF));
 }
 
 __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
@@ -1776,7 +1776,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < NB; ++n) acc[m][n] = v16f{};
-        v4i ba[2][2] = {}, bb[2][NB] = {};  // [k-group parity][block]: bits of the k-group in use / of the next one
+        v4i ba[2][2], bb[2][NB];   // [k-group parity][block]: bits of the k-group in use / of the next one
         v4i aop[2][2], bop[2];     // inflated A blocks per class-phase parity, inflated B block per block parity
         bop[1] = v4i{};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
@@ -1957,12 +1957,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
 //               per stage 4 ds_read_b128 (2 blocks of 32 rows x 2 k-groups), each inflated into the four
 //               classes (20 ops) behind the MFMAs it feeds: 32 MFMAs of 32 cycles and 80 inflation ops per
 //               stage and wave.
-//   registers : the two bit words live in FIXED registers ("+v" on the reads). With plain outputs hipcc
-//               gave a read the registers that had just died — the inflated operand of MFMAs issued a
-//               moment before — and with three waves per SIMD an MFMA can still be queued behind its
-//               partners' when the LDS data lands: wrong totals, different from run to run, only with
-//               several workgroups per CU (one per CU: never). The hardware does not order an LDS return
-//               behind the operand read of an MFMA that was issued earlier.
+//   asm reads : every fetched word is kept alive up to the wait that covers it (STORM_SB_KEEP; see there).
 //   exactness : an accumulator gains at most 512 per stage, runs are capped at 4096 stages: < 2^24.
 // storm_hip_matrix_create keeps rows up to a multiple of 256 zero, so every row an item touches exists;
 // with this option set it also pads the row pitch off multiples of 1 KiB (L2 sets).
@@ -2049,12 +2044,15 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
         __builtin_amdgcn_s_barrier();
     };
 
-    // ("+v": the word registers stay w0 / w1 for the whole item. With a plain output hipcc gave the read
-    //  whatever registers had just died — those of the inflated operand of MFMAs issued a moment before —
-    //  and the LDS data could land before a queued MFMA had read them: wrong totals, only with several
-    //  workgroups per CU, different from run to run.)
+    // An inline-asm read completes long after hipcc thinks it has: a fetched word must stay LIVE (in hipcc's
+    // eyes) until the wait that covers it. The first version's diagonal phase ended every stage with the same
+    // look-ahead read as the main loop but never used its result; hipcc gave the dead output's registers to
+    // the next inflated operand, the LDS data landed on top of it some 100 cycles later, and the totals came
+    // out different from run to run — only with several workgroups per CU, where the LDS answers late enough
+    // (tools/mfma_war_probe: the hardware itself never lets an LDS return overtake an MFMA's operand read).
+    // STORM_SB_KEEP marks the words as used behind the wait.
 #define STORM_SB_FETCH(dst, t, n, g) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
 #define STORM_SB_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
     acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
         v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                          \
@@ -2065,6 +2063,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
     enxt = NEXT;                                                                                          \
     __builtin_amdgcn_sched_barrier(0)
 #define STORM_SB_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STORM_SB_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
     // One stage. On entry w0 holds the bits of (block 0, k-group 0) of stage `tc` and e0 their class 0; on
     // exit the same of stage `tn` (the look-ahead: the next stage, or a re-read that is never consumed).
     // Word order: (n, g) = (0,0) (1,0) (0,1) (1,1) in w0, w1, w0, w1; every word is fetched while the one
@@ -2114,7 +2113,8 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
             STORM_SB_WAIT();
             e0 = tb_inflate<0>(w0);
             STORM_SB_STAGE(t, t);
-            STORM_SB_WAIT();  // the look-ahead read
+            STORM_SB_WAIT();  // the look-ahead read, not consumed in this phase ...
+            STORM_SB_KEEP();  // ... but alive until it has landed
             if (t == wm) {
                 // the accumulators have seen nothing but this stage: clear the pairs with i >= j in place
                 // (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
@@ -2145,8 +2145,10 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
             STORM_SB_STAGE(t, tn);
         }
         STORM_SB_WAIT();
+        STORM_SB_KEEP();
     }
 #undef STORM_SB_STAGE
+#undef STORM_SB_KEEP
 #undef STORM_SB_WAIT
 #undef STORM_SB_STEP
 #undef STORM_SB_FETCH
