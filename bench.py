@@ -56,7 +56,55 @@ def cpu_baseline(head_rows_fn, n_words, budget_s=12.0):
             "leaf": orc.leaf_name(kind), "seconds": round(secs, 3),
             "sample": f"first {n} rows of the benchmark matrix ({n * (n - 1) // 2} pairs), "
                       f"orc_wrapper_diag_blocked bsize={bsize}",
-            "host_cpus": os.cpu_count(), "sample_total": total}
+            "host_cpus": os.cpu_count(), "sample_total": total, "sample_rows": n}
+
+
+def mat_head_total(ctx, mat, n, n_words):
+    """GPU all-pairs total over the first n rows of the benchmark matrix (device-to-device copy of
+    the head rows into a second matrix): what a CPU sample smaller than the matrix is compared with."""
+    head = ctx.matrix(n, n_words)
+    try:
+        head.import_device(mat.device_ptr(), n, mat.stride_words())
+        return head.pairw()
+    finally:
+        head.close()
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:   # fixed ports collide with concurrent runs and TIME_WAIT
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def launch_ranks(args, real_stdout):
+    """`python3 bench.py --gpus N` without RANK in the environment: run
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`
+    as a child (never os.exec*), one rank per GPU, rendezvous on 127.0.0.1 at a free port. Rank 0's
+    JSON line is the child's whole stdout; it is passed on unchanged. Returns the exit code."""
+    import subprocess
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        # a profiler's preloaded library has initialised the GPU in THIS process already
+        print("bench.py: refusing to start ranks from a profiled process; profile at --gpus 1 or put "
+              "torch.distributed.run outside the profiler", file=sys.stderr)
+        return 2
+    port = args.master_port or free_port()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting", args.gpus, "ranks:", " ".join(cmd), file=sys.stderr)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, cwd=ROOT)
+    out, _ = child.communicate()
+    lines = [l for l in out.decode(errors="replace").splitlines() if l.lstrip().startswith("{")]
+    rc = child.returncode
+    if lines:
+        os.write(real_stdout, (lines[-1] + "\n").encode())
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 1
+    return rc
 
 
 def main():
@@ -82,7 +130,16 @@ def main():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal)")
     ap.add_argument("--all-on-device0", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port when bench.py starts its own ranks (0 = a free one)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # Called bare (`python3 bench.py --gpus N`), not under a launcher: start the N ranks as CHILD
+        # processes — decided here, before torch is imported or anything touches a GPU (a process
+        # that has initialised HIP must never be replaced or forked) — and relay the job's single
+        # JSON line and exit code.
+        sys.exit(launch_ranks(args, real_stdout))
 
     import torch
     import torch.distributed as dist
@@ -261,9 +318,17 @@ def main():
                             device=dev if args.backend != "gloo" else "cpu")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
+        # which physical GPU every rank drove (ordinal + PCI address), through the collective itself:
+        # "the communicator saw N ranks on N different GPUs" is then checkable from the one line
+        import ctypes
+        pci = ctypes.create_string_buffer(32)
+        sb.load().storm_hip_device_pci_bus_id(local_rank, pci, 32)
+        ident = [None] * world
+        dist.all_gather_object(ident, {"device": local_rank, "pci_bus_id": pci.value.decode(),
+                                       "pid": os.getpid()})
         per_rank = [{"rank": r, "kernel_ms": round(float(g[0]), 4), "pass_ms": round(float(g[1]), 4),
                      "wall_ms_per_step": round(float(g[2]), 4), "allreduce_us": round(float(g[3]), 1),
-                     "work_items": int(g[4])} for r, g in enumerate(gathered)]
+                     "work_items": int(g[4]), **ident[r]} for r, g in enumerate(gathered)]
 
     # Secondary figure, never `value`: the same pass when the FP4 re-encoding of the (unchanged)
     # matrix is kept in HBM between calls (library option keep_shadow, what the storm.h handles
@@ -370,6 +435,9 @@ def main():
         out["host_enqueue_us_first_steps"] = [round(x, 1) for x in host_us[:24]]
         if per_rank is not None:
             out["per_rank"] = per_rank
+            out["rccl_ranks"] = dist.get_world_size()     # ranks the process group (backend below) holds
+            out["collective_backend"] = dist.get_backend()
+            out["distinct_gpus"] = len({r["pci_bus_id"] for r in per_rank})
             out["slowest_rank_kernel_ms"] = max(r["kernel_ms"] for r in per_rank)
         if shadow_resident is not None:
             shadow_resident["value"] = words / (shadow_resident["ms_per_step"] * 1e-3)
@@ -377,7 +445,17 @@ def main():
                                        "(option keep_shadow); informational, `value` always re-expands")
             out["shadow_resident"] = shadow_resident
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lambda n: mat.download(0, min(n, N)), W)
+            base = cpu_baseline(lambda n: mat.download(0, min(n, N)), W)
+            out["cpu_baseline"] = base
+            # the checker's word on what was timed: when the CPU sample was the whole matrix its
+            # pair-by-pair total must be the GPU's (a smaller sample is checked on its own rows)
+            n_cpu = base.pop("sample_rows")
+            want = total if n_cpu == N else mat_head_total(ctx, mat, n_cpu, W)
+            base["sample_total_matches_gpu"] = (base["sample_total"] == want)
+            if not base["sample_total_matches_gpu"]:
+                print(f"VERIFICATION FAILED: CPU oracle total over the first {n_cpu} rows "
+                      f"{base['sample_total']} != GPU {want}", file=sys.stderr)
+                ok = False
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
         if not ok:
             print(f"VERIFICATION FAILED: total {total} != column identity {identity}", file=sys.stderr)

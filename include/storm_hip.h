@@ -42,6 +42,8 @@ const char* storm_hip_last_error(void);
 int storm_hip_device_count(void);
 /* arch string of `device` ("gfx950:sramecc+:xnack-") into buf */
 int storm_hip_device_arch(int device, char* buf, size_t buflen);
+/* PCI address of `device` ("0000:75:00.0") into buf: which physical GPU a rank drives */
+int storm_hip_device_pci_bus_id(int device, char* buf, size_t buflen);
 
 /* ---- context: device, stream, reusable workspace ---- */
 int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out);

@@ -24,6 +24,7 @@ SIGNATURES = {
     "storm_hip_last_error": (cp, []),
     "storm_hip_device_count": (C.c_int, []),
     "storm_hip_device_arch": (C.c_int, [C.c_int, cp, sz]),
+    "storm_hip_device_pci_bus_id": (C.c_int, [C.c_int, cp, sz]),
     "storm_hip_ctx_create": (C.c_int, [C.c_int, vp, P(vp)]),
     "storm_hip_ctx_set_stream": (C.c_int, [vp, vp]),
     "storm_hip_ctx_synchronize": (C.c_int, [vp]),

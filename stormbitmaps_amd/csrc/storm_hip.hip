@@ -511,6 +511,12 @@ int storm_hip_device_arch(int device, char* buf, size_t buflen) {
     return STORM_HIP_OK;
 }
 
+int storm_hip_device_pci_bus_id(int device, char* buf, size_t buflen) {
+    if (!buf || buflen < 13) return STORM_HIP_EINVAL;
+    STORM_HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buflen, device));
+    return STORM_HIP_OK;
+}
+
 int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
     if (!out) {
         set_error("storm_hip_ctx_create: NULL out");

@@ -27,12 +27,27 @@ def rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def free_port() -> int:
+    """A TCP port nobody listens on right now (fixed ports collide with concurrent jobs on one
+    host and with sockets still in TIME_WAIT)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def init_process_group(backend: str):
     import torch.distributed as dist
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         rank, world, _ = rank_world()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            # Only a 1-process group can pick its own port (nobody else has to find it); a
+            # launcher (torch.distributed.run, bench.py's own) always exports one for world > 1.
+            if world > 1:
+                raise RuntimeError("MASTER_PORT is not set: start the ranks with torch.distributed.run "
+                                   "or `python bench.py --gpus N`, which pick a free rendezvous port")
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return dist
 

@@ -440,20 +440,22 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import socket
-    with socket.socket() as sock:   # a free port: fixed ones collide with concurrent runs / TIME_WAIT
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+    # the bare form, as the driver calls it: bench.py starts its own ranks (child
+    # torch.distributed.run on a free port) and relays the job's one JSON line
+    cmd = [sys.executable, os.path.join(root, "bench.py"),
            "--gpus", str(ranks), "--backend", "gloo", "--all-on-device0", "--steps", "5", "--warmup", "1",
            "--rows", "3000", "--no-cpu-baseline"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["verified_against_column_identity"] is True
+    assert out["rccl_ranks"] == ranks and out["collective_backend"] == "gloo"
+    assert out["distinct_gpus"] == 1 and all(r["device"] == 0 and r["pci_bus_id"] for r in out["per_rank"])
+    assert len({r["pid"] for r in out["per_rank"]}) == ranks
     assert out["config"]["kernel_variant"] == 4
     assert out["shadow_resident"]["total_matches"] is True
     # the per-rank diagnostics a scaling run is read by
@@ -462,6 +464,31 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     assert 0 < out["roofline"]["frac_whole_pass"] <= out["roofline"]["frac"] * 1.05
     # at N > 1 the dominant kernel is bracketed on every 4th timed step: steps 0 (.. 4, 8) of the 5
     assert out["roofline"]["kernel_ms_samples"] == 2
+
+
+def test_bench_over_rccl_when_the_box_has_two_gpus():
+    """The first multi-GPU box must carry a rank > 0 over RCCL inside the suite, not only in the
+    driver's scaling run: `python bench.py --gpus 2` (bare; bench.py starts the ranks), backend
+    nccl = RCCL over xGMI, one GPU per rank. Skipped on 1-GPU boxes (RCCL refuses two ranks on
+    one device)."""
+    import subprocess
+    import sys
+    n_dev = sb.load().storm_hip_device_count()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU visible: RCCL needs one GPU per rank")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "nccl"
+    assert out["distinct_gpus"] == 2 and [r["device"] for r in out["per_rank"]] == [0, 1]
+    assert out["verified_against_column_identity"] is True
+    assert out["total"] == 507277197315          # c2: the CPU oracle's pair-by-pair sum (BENCH_r02.json cpu_baseline.sample_total)
 
 
 def test_benchmark_cli_rows_agree_with_golden_totals():
