@@ -64,7 +64,7 @@ def mat_head_total(ctx, mat, n, n_words):
     the head rows into a second matrix): what a CPU sample smaller than the matrix is compared with."""
     head = ctx.matrix(n, n_words)
     try:
-        head.import_device(mat.device_ptr(), n, mat.stride_words())
+        head.import_device(mat.device_ptr, n, mat.stride_words)
         return head.pairw()
     finally:
         head.close()

@@ -655,11 +655,23 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_strip_operands")) {
-        if (value != 1 && value != 4) {
-            set_error("k2_strip_operands must be 1 (bit operands) or 4 (FP4 shadow)");
+        if (value != 1 && value != 2 && value != 4) {
+            set_error("k2_strip_operands must be 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup) or 4 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_strip_operands = (int)value;
+    } else if (!strcmp(key, "k2_stream_groups_per_cu")) {
+        if (value < 0 || value > 3) {
+            set_error("k2_stream_groups_per_cu must be 0 (auto) .. 3");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_stream_groups_per_cu = (int)value;
+    } else if (!strcmp(key, "k2_stream_min_piece") || !strcmp(key, "k2_stream_min_run")) {
+        if (value < 1 || value > 4096) {
+            set_error("%s must be 1..4096 stages", key);
+            return STORM_HIP_EINVAL;
+        }
+        (key[14] == 'p' ? ctx->k2_stream_min_piece : ctx->k2_stream_min_run) = (int)value;
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
@@ -783,10 +795,11 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
     const uint64_t n = std::min<uint64_t>(capacity_items, ctx->trace_items);
     // per item: 4 trace words, then the item record {a_row0, diag, j0, j1} widened to 64 bit
     std::vector<uint64_t> raw(n * 4);
-    std::vector<uint32_t> items(n * 5);
+    std::vector<uint32_t> items(n * 5, 0);
     STORM_HIP_TRY(hipMemcpy(raw.data(), ctx->d_trace, n * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    STORM_HIP_TRY(hipMemcpy(items.data(), ctx->d_strip_items, n * 5 * sizeof(uint32_t),
-                            hipMemcpyDeviceToHost));
+    if (!ctx->trace_is_stream)  // (bitstream_kernel traces workgroups, which have no item record)
+        STORM_HIP_TRY(hipMemcpy(items.data(), ctx->d_strip_items, n * 5 * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost));
     for (uint64_t i = 0; i < n; ++i) {
         for (int k = 0; k < 4; ++k) out[i * 8 + k] = raw[i * 4 + k];
         out[i * 8 + 4] = items[i * 5 + 0];
@@ -828,7 +841,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     // k-slice into a handful of L2 sets and memory channels, so one more chunk of zero words per row breaks
     // the pattern (same finding as shadow_pitch, storm_hip_mfma.hip). The FP4 paths copy the rows into
     // their own padded shadow and keep the dense pitch.
-    if (ctx->k2_strip_operands == 1 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
+    if ((ctx->k2_strip_operands == 1 || ctx->k2_strip_operands == 2) && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

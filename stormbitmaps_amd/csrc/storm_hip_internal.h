@@ -140,6 +140,18 @@ struct storm_hip_ctx_s {
     unsigned long long* d_trace = nullptr;  // k2_ring = 18: per-item schedule trace of the strip kernel
     size_t trace_capacity = 0;
     uint32_t trace_items = 0;
+    // K2q (bitstream_kernel): segment table + per-workgroup bounds of the last geometry
+    void* d_bitsegs = nullptr;
+    size_t bitsegs_capacity = 0;
+    void* d_bitfirst = nullptr;
+    size_t bitfirst_capacity = 0;
+    uint64_t bit_key[4] = {0, 0, 0, 0};
+    uint32_t n_bit_groups = 0, n_bit_segs = 0, bit_max_stages = 0;
+    uint64_t bit_stages = 0;
+    int k2_stream_groups_per_cu = 0;  // K2q: workgroups per CU (0 = by the length of the stream: 1, 2 or 3)
+    int k2_stream_min_piece = 8;      // K2q: stages a workgroup should at least have before a CU's share is cut further
+    int k2_stream_min_run = 2;        // K2q: a cut leaves at least this many later blocks on either side
+    bool trace_is_stream = false;     // d_trace holds per-workgroup words of bitstream_kernel (no strip items)
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };
 

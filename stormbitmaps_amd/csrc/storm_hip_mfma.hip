@@ -2169,6 +2169,311 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
         atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)], (unsigned long long)mine);
 }
 
+// ------------------------------------------------------------------------------------------
+// K2q: bit-operand strips as ONE stream of stages per workgroup (option k2_strip_operands = 2; the
+// default for matrices up to a few thousand rows).
+//
+// What the strips cost at N = 1024 ... 4096 is not their stage loop but everything around it
+// (tools/strip_trace.py, profiles/r03_a_*): three launches, an expansion that writes 4 x the matrix
+// only to have it read back once, a first touch of that shadow by every workgroup at the same moment
+// (4.6 us at N = 1024), a diagonal phase that is not pipelined, work items of 4 ... 32 stages dealt to
+// slots that all start and all finish together, and a fold. This kernel removes them:
+//   * bits in, total out, ONE launch: operands inflated in registers (stripbits_kernel's stage body),
+//     partial sums folded by the last workgroup to arrive (a ticket), slots and ticket left zeroed;
+//   * the work is a STREAM of stages cut into equal shares on the host (build_bitstream): a workgroup
+//     walks a list of segments {A tile, k-slice, the tile's own four 64-row blocks, a run of later
+//     blocks} with the LDS ring running across segment boundaries; the accumulators are never flushed;
+//   * every A tile meets the SAME number of later blocks: the tile pairs are dealt CYCLICALLY (tile I
+//     takes the (T - 1) / 2 tiles behind it, wrapping around; popcount(a & b) is symmetric), so the
+//     segments of one matrix are all the same length and shares of equal length are shares of equal
+//     work;
+//   * the A rows come through the ring too: a tile's own four blocks are the first four stages of
+//     its segment, and wave w takes its operand (block w, rotated per segment so that the SIMDs share
+//     the diagonal work) out of stage w before it multiplies it — no global loads into registers, no
+//     second kind of memory traffic to count in vmcnt. A segment that continues a cut one brings the
+//     four blocks in without multiplying them;
+//   * no masking of the wave's own 64 x 64 block: it is multiplied whole at HALF weight (the block
+//     scale of the B operand one lower) and sums to U + D / 2, where U is its strict upper triangle and
+//     D the set bits of the wave's rows in this k-slice; D is counted with v_bcnt when the rows are
+//     taken and subtracted at the end. Every accumulator stays a multiple of 1/2 below 2^23: exact.
+// Stage, ring, swizzle and operand registers are stripbits_kernel's. Reference loop being replaced:
+// storm.c:1199-1238 (blocked upper triangle), whose order of pairs the cyclic deal does not keep —
+// the total does not depend on it.
+// ------------------------------------------------------------------------------------------
+struct BitSeg {
+    uint32_t a_blk;     // first 64-row block of the A tile (4 blocks; absolute block index)
+    uint32_t ks;        // k-slice: 64 bytes of every bit row
+    uint32_t b_first;   // first later block, relative to range_b0, cyclic over range_nb
+    uint32_t n_b;       // later blocks = stages behind the tile's own four
+    uint32_t range_b0;  // first block of the all-pairs problem (row range) the tile belongs to
+    uint32_t range_nb;  // blocks of that problem: the cyclic order wraps here
+    uint32_t flags;     // bit 0: the tile's own four stages are multiplied (else they only bring A in); bits 8-9: rotation
+    uint32_t pad;
+};
+constexpr uint32_t kBsDiag = 1u;
+constexpr int kBsFoldSlots = 64;             // partial sums of this kernel: slots[0 .. 64)
+constexpr int kBsTicket = kSlots + 6;        // arrival counter (behind the strip queue heads; zero between passes)
+constexpr uint32_t kBsMaxStages = 8192;      // per workgroup: accumulators stay below 2^22 (in halves: 2^23)
+
+template <bool kTrace>
+__global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
+    const uint8_t* __restrict__ X, uint64_t pitch64, const BitSeg* __restrict__ segs,
+    const uint32_t* __restrict__ first, unsigned long long* __restrict__ slots,
+    unsigned long long* __restrict__ out, unsigned long long* __restrict__ trace) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSbRing * kSbStageBytes];
+    auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
+
+    unsigned long long t_start = 0, t_ready = 0;
+    if (kTrace) t_start = __builtin_amdgcn_s_memrealtime();
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t pitch = (uint32_t)pitch64;
+    const uint32_t s_begin = first[blockIdx.x], s_end = first[blockIdx.x + 1];
+
+    // B stage = 4 LDS-DMA pieces of 16 rows x 64 B, one per wave (stripbits_kernel's image:
+    // slot s of row r at s ^ ((r / 4) % 4))
+    const uint32_t goff = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
+    const uint32_t slot0 = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
+    const uint32_t baddr0 = lds_base + (lane & 31u) * kSbRowBytes + slot0 * 16u;
+    const uint32_t baddr1 = lds_base + (lane & 31u) * kSbRowBytes + (slot0 ^ 2u) * 16u;
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
+    v4i a[2][4][2];  // [k-group][class][row block]: the wave's 64 A rows x 512 bits, all four classes
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[g][c][m] = v4i{};
+    uint32_t dbits = 0;  // set bits of the rows this lane took as A in multiplied diagonal stages
+
+    // ---- the stream: two cursors over the segment list, `issue` three stages ahead of `consume`
+    BitSeg ri = {}, rn = {}, rc = {};
+    uint32_t si = s_begin;  // segment of the issue cursor
+    uint32_t ii = 0;        // its stage in that segment
+    uint32_t issued = 0;    // stages handed to the DMA so far
+    bool more = s_begin < s_end;
+    if (more) {
+        ri = segs[s_begin];
+        rn = segs[min(s_begin + 1u, s_end - 1u)];
+        rc = ri;
+    }
+    auto issue_next = [&]() {
+        uint32_t rel = ri.b_first + (ii - 4u);
+        rel = rel >= ri.range_nb ? rel - ri.range_nb : rel;
+        const uint32_t blk = ii < 4u ? ri.a_blk + ii : ri.range_b0 + rel;
+        const uint8_t* base = X + (uint64_t)ri.ks * kSbRowBytes + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[issued % kSbRing] + wave * 1024u), 16,
+                                                 (int)goff, 0, 0, 0);
+        ++issued;
+        ++ii;
+        if (ii == 4u + ri.n_b) {
+            ii = 0;
+            ++si;
+            if (si < s_end) {
+                ri = rn;
+                rn = segs[min(si + 1u, s_end - 1u)];
+            } else {
+                more = false;
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kSbRing - 1; ++k)
+        if (more) issue_next();
+
+#define STORM_BS_FETCH(dst, t, n, g) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+#define STORM_BS_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
+    acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
+        v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                          \
+        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]);    \
+    acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
+        v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                          \
+        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]);    \
+    enxt = NEXT;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0)
+#define STORM_BS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STORM_BS_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
+    // One stage (stripbits_kernel's): on entry w0 holds the bits of (block 0, k-group 0) of stage `tc` and
+    // e0 their class 0; on exit the same of stage `tn`.
+#define STORM_BS_STAGE(tc, tn)                                      \
+    STORM_BS_FETCH(w1, tc, 1, 0);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(0, 0, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_BS_STEP(0, 0, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_BS_STEP(0, 0, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(0, 0, 3, e0, e0, tb_inflate<0>(w1));              \
+    STORM_BS_FETCH(w0, tc, 0, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(1, 0, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_BS_STEP(1, 0, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_BS_STEP(1, 0, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(1, 0, 3, e0, e0, tb_inflate<0>(w0));              \
+    STORM_BS_FETCH(w1, tc, 1, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(0, 1, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_BS_STEP(0, 1, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_BS_STEP(0, 1, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(0, 1, 3, e0, e0, tb_inflate<0>(w1));              \
+    STORM_BS_FETCH(w0, tn, 0, 0);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(1, 1, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_BS_STEP(1, 1, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_BS_STEP(1, 1, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(1, 1, 3, e0, e0, tb_inflate<0>(w0))
+
+    v4i w0 = {}, w1 = {}, e0 = {};
+    int sb[4] = {tb_scale<0>(), tb_scale<1>(), tb_scale<2>(), tb_scale<3>()};  // B-side block scales of the stage
+    uint32_t ci = 0;  // stage of the consume cursor in its segment rc
+    uint32_t t = 0;   // stages consumed
+    if (issued > 0) {
+        // stage 0 has landed (the younger pieces may stay in flight)
+        if (issued >= 3u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (issued == 2u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        STORM_BS_FETCH(w0, 0u, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        e0 = tb_inflate<0>(w0);
+    }
+    if (kTrace) t_ready = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    while (t < issued) {
+        // top of stage t: stage t + 1 has landed and every wave is done with stage t - 1, whose slot the
+        // next piece takes (invariant: issued == min(stages of this workgroup, t + 3))
+        const bool has_next = issued > t + 1u;
+        if (has_next) {
+            if (issued >= t + 3u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (more) issue_next();
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t tn = has_next ? t + 1u : t;
+        // what this wave does with the stage
+        const uint32_t wm = (wave + (rc.flags >> 8)) & 3u;  // its A rows are block wm of the tile
+        const bool own = ci == wm;
+        const bool diag = (rc.flags & kBsDiag) != 0u;
+        const bool mul = ci >= 4u || (diag && ci >= wm);
+        if (own) {
+            // the wave's A rows are this stage's rows: all four words, every class
+            v4i x1, x2, x3;
+            STORM_BS_FETCH(x1, t, 1, 0);
+            STORM_BS_FETCH(x2, t, 0, 1);
+            STORM_BS_FETCH(x3, t, 1, 1);
+            // (the wait DEFINES the words it covers: hipcc moves code that only depends on an asm's outputs
+            //  across basic blocks, past a bare s_waitcnt — sched_barrier pins the order inside one block only)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x1), "+v"(x2), "+v"(x3)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            a[0][0][0] = tb_inflate<0>(w0); a[0][1][0] = tb_inflate<1>(w0);
+            a[0][2][0] = tb_inflate<2>(w0); a[0][3][0] = tb_inflate<3>(w0);
+            a[0][0][1] = tb_inflate<0>(x1); a[0][1][1] = tb_inflate<1>(x1);
+            a[0][2][1] = tb_inflate<2>(x1); a[0][3][1] = tb_inflate<3>(x1);
+            a[1][0][0] = tb_inflate<0>(x2); a[1][1][0] = tb_inflate<1>(x2);
+            a[1][2][0] = tb_inflate<2>(x2); a[1][3][0] = tb_inflate<3>(x2);
+            a[1][0][1] = tb_inflate<0>(x3); a[1][1][1] = tb_inflate<1>(x3);
+            a[1][2][1] = tb_inflate<2>(x3); a[1][3][1] = tb_inflate<3>(x3);
+            if (diag) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dbits += __builtin_popcount((uint32_t)w0[k]) + __builtin_popcount((uint32_t)x1[k]) +
+                             __builtin_popcount((uint32_t)x2[k]) + __builtin_popcount((uint32_t)x3[k]);
+            }
+        }
+        if (mul) {
+            const int half = (own && ci < 4u) ? 1 : 0;  // the wave's own block: half weight
+            sb[0] = tb_scale<0>() - half;
+            sb[1] = tb_scale<1>() - half;
+            sb[2] = tb_scale<2>() - half;
+            sb[3] = tb_scale<3>() - half;
+            __builtin_amdgcn_sched_barrier(0);
+            STORM_BS_STAGE(t, tn);
+            STORM_BS_WAIT();
+            STORM_BS_KEEP();
+        } else {
+            // nothing to multiply: only the look-ahead word of the next stage (the first version wrote
+            // `e0 = inflate(w0)` behind a bare wait shared with the other branch; hipcc hoisted it into this
+            // block, in front of the wait, and the waves that skip stages multiplied stale words)
+            STORM_BS_FETCH(w0, tn, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            e0 = tb_inflate<0>(w0);
+        }
+        ++t;
+        ++ci;
+        if (ci == 4u + rc.n_b) {
+            ci = 0;
+            rc = ri;  // the issue cursor is three stages ahead: inside the segment `consume` now enters
+        }
+    }
+#undef STORM_BS_STAGE
+#undef STORM_BS_KEEP
+#undef STORM_BS_WAIT
+#undef STORM_BS_STEP
+#undef STORM_BS_FETCH
+
+    // ---- the wave's total: accumulators in halves (exact), minus the diagonal's set bits, halved
+    long long mine2 = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        uint32_t part = 0;  // 32 values below 2^23 each
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += (uint32_t)(acc[m][n][r] * 2.0f);
+        mine2 += part;
+    }
+    mine2 -= (long long)dbits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine2 += __shfl_down(mine2, o, 64);
+    // the four waves through the (drained) ring, one atomic per workgroup, then the ticket
+    __builtin_amdgcn_s_barrier();
+    long long* wsum = reinterpret_cast<long long*>(lds_raw);
+    if (lane == 0) wsum[wave] = mine2;
+    __syncthreads();
+    if (tid == 0) {
+        const long long tot2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tot2 != 0) atomicAdd(&slots[blockIdx.x & (kBsFoldSlots - 1)], (unsigned long long)(tot2 / 2));
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(&slots[kBsTicket], 1ull);
+        wsum[4] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+        if (kTrace) {
+            trace[blockIdx.x * 4ull + 0] = t_start;
+            trace[blockIdx.x * 4ull + 1] = __builtin_amdgcn_s_memrealtime();
+            trace[blockIdx.x * 4ull + 2] = ((t_ready - t_start) & 0xffffffffull) | ((unsigned long long)t << 32);
+            trace[blockIdx.x * 4ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) |
+                                           ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 32);
+        }
+    }
+    __syncthreads();
+    if (wsum[4] != 0 && wave == 0) {
+        // last workgroup to arrive: every other one's sum is in the slots (its atomic add is ordered
+        // before its ticket). Fold, hand over the total, leave slots and ticket zero for the next pass.
+        __threadfence();
+        unsigned long long v = __hip_atomic_exchange(&slots[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) {
+            out[0] = v;
+            __hip_atomic_store(&slots[kBsTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
@@ -2176,6 +2481,11 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_band) (void)hipFree(ctx->d_band);
+    if (ctx->d_bitsegs) (void)hipFree(ctx->d_bitsegs);
+    if (ctx->d_bitfirst) (void)hipFree(ctx->d_bitfirst);
+    ctx->d_bitsegs = ctx->d_bitfirst = nullptr;
+    ctx->bitsegs_capacity = ctx->bitfirst_capacity = 0;
+    memset(ctx->bit_key, 0, sizeof(ctx->bit_key));
     ctx->d_band = nullptr;
     ctx->band_capacity = 0;
     ctx->d_counts = nullptr;
@@ -2629,6 +2939,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                         ctx->trace_capacity = need;
                     }
                     ctx->trace_items = n_strip;
+                    ctx->trace_is_stream = false;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8, 2, true>), pgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace, queues, heads);
                     break;
@@ -2685,6 +2996,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                         ctx->trace_capacity = need;
                     }
                     ctx->trace_items = n_strip;
+                    ctx->trace_is_stream = false;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace);
                     break;
@@ -3167,6 +3479,229 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     return rc;
 }
 
+// ---- K2q work decomposition: the stage stream of bitstream_kernel, cut into equal shares ----
+// Pure host computation (no device). `groups` workgroups; workgroup w walks segs[first[w] .. first[w+1]).
+struct BitstreamPlan {
+    std::vector<BitSeg> segs;
+    std::vector<uint32_t> first;
+    uint32_t groups = 0;
+    uint64_t stages = 0;      // multiplied + operand-only stages of this shard, after cutting
+    uint32_t max_stages = 0;  // longest workgroup
+};
+struct BitstreamShaping {
+    int groups_per_cu = 0;  // 0 = by the length of the stream: 1, 2 or 3
+    int min_piece = 8;      // stages a workgroup should have at least before a CU's share is cut further
+    int min_run = 2;        // a cut leaves at least this many later blocks on either side of it
+};
+
+static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRange>& ranges,
+                            uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
+                            uint32_t n_cus, BitstreamPlan& plan) {
+    // natural segments, k-slice major: every A tile of every range with the later tiles dealt cyclically
+    struct Nat {
+        BitSeg s;
+        uint64_t start;  // position of its first stage in the stream
+    };
+    std::vector<Nat> nat;
+    uint64_t L = 0;
+    for (uint32_t ks = 0; ks < n_kslices; ++ks)
+        for (const RowRange& rg : ranges) {
+            if (rg.r1 < rg.r0 + 2) continue;
+            const uint32_t b0 = (uint32_t)(rg.r0 / kStripBRows);
+            const uint32_t nb = (uint32_t)((rg.r1 - rg.r0 + kStripBRows - 1) / kStripBRows);
+            const uint32_t nT = (nb + 3u) / 4u;
+            auto blocks_of = [&](uint32_t J) { return std::min(4u, nb - 4u * J); };
+            for (uint32_t I = 0; I < nT; ++I) {
+                // tile I takes the (nT - 1) / 2 tiles behind it (cyclically); with an even number of
+                // tiles the opposite one goes to the lower tile on even k-slices, to the upper on odd ones
+                uint32_t take = (nT - 1u) / 2u;
+                if (nT > 1u && nT % 2u == 0u && ((I < nT / 2u) == ((ks & 1u) == 0u))) ++take;
+                uint32_t n_b = 0;
+                for (uint32_t d = 1; d <= take; ++d) n_b += blocks_of((I + d) % nT);
+                BitSeg s = {};
+                s.a_blk = b0 + 4u * I;
+                s.ks = ks;
+                s.b_first = (I + 1u == nT) ? 0u : 4u * (I + 1u);
+                s.n_b = n_b;
+                s.range_b0 = b0;
+                s.range_nb = nb;
+                s.flags = kBsDiag | (((I + ks) & 3u) << 8);
+                nat.push_back({s, L});
+                L += 4u + n_b;
+            }
+        }
+    plan.segs.clear();
+    plan.first.clear();
+    plan.stages = 0;
+    plan.max_stages = 0;
+    // this shard's part of the stream (contiguous: a shard touches a contiguous range of k-slices)
+    const uint64_t lo = L * shard_rank / shard_count, hi = L * (shard_rank + 1ull) / shard_count;
+    const uint64_t Ls = hi - lo;
+    // workgroups: as many per CU as the share of a CU is worth cutting, and never a workgroup
+    // beyond the accumulators' exact range
+    uint32_t per_cu = (uint32_t)sh.groups_per_cu;
+    if (per_cu == 0) {
+        const uint64_t share = Ls / std::max(1u, n_cus);
+        per_cu = share >= 3ull * (uint64_t)sh.min_piece ? 3u : share >= 2ull * (uint64_t)sh.min_piece ? 2u : 1u;
+    }
+    uint64_t G = (uint64_t)n_cus * per_cu;
+    G = std::max<uint64_t>(G, (Ls + kBsMaxStages / 2 - 1) / (kBsMaxStages / 2));
+    G = std::max<uint64_t>(1, std::min<uint64_t>(G, std::max<uint64_t>(1, Ls / 4)));
+    if (Ls == 0) G = 0;
+    plan.groups = (uint32_t)G;
+    if (G == 0) {
+        plan.first.push_back(0);
+        return;
+    }
+    // cut positions, snapped: never inside a tile's own four stages, never leaving a stub of a run
+    auto seg_at = [&](uint64_t p) {  // natural segment holding stream position p (< L)
+        size_t a = 0, b = nat.size();
+        while (b - a > 1) {
+            const size_t m = (a + b) / 2;
+            if (nat[m].start <= p) a = m; else b = m;
+        }
+        return a;
+    };
+    std::vector<uint64_t> cut(G + 1);
+    for (uint64_t k = 0; k <= G; ++k) {
+        uint64_t c = lo + Ls * k / G;
+        if (c < L) {
+            const Nat& n = nat[seg_at(c)];
+            const uint64_t off = c - n.start, len = 4ull + n.s.n_b;
+            if (off > 0 && off < 4ull + (uint64_t)sh.min_run) c = n.start;
+            else if (off > 0 && len - off < (uint64_t)sh.min_run) c = n.start + len;
+        }
+        cut[k] = c;
+    }
+    for (uint64_t k = 1; k <= G; ++k) cut[k] = std::max(cut[k], cut[k - 1]);
+    // piece p of the stream goes to workgroup w with p = (w % 8) * (G / 8) + w / 8: block w runs on XCD
+    // w % 8 (observed; speed only), so an XCD's workgroups hold one contiguous eighth of the stream
+    auto piece_of = [&](uint64_t w) { return G % 8 == 0 ? (w % 8) * (G / 8) + w / 8 : w; };
+    for (uint64_t w = 0; w < G; ++w) {
+        const uint64_t p = piece_of(w);
+        plan.first.push_back((uint32_t)plan.segs.size());
+        uint64_t c0 = cut[p], c1 = cut[p + 1];
+        uint32_t mine = 0;
+        while (c0 < c1) {
+            const Nat& n = nat[seg_at(c0)];
+            const uint64_t len = 4ull + n.s.n_b, off = c0 - n.start;
+            const uint64_t end = std::min(c1, n.start + len);
+            BitSeg s = n.s;
+            if (off == 0) {
+                s.n_b = (uint32_t)(end - n.start - 4ull);
+            } else {  // continues a cut segment: its four blocks only bring the A rows in
+                const uint32_t skip = (uint32_t)(off - 4ull);
+                s.flags &= ~kBsDiag;
+                s.b_first = (n.s.b_first + skip) % n.s.range_nb;
+                s.n_b = (uint32_t)(end - c0);
+            }
+            plan.segs.push_back(s);
+            mine += 4u + s.n_b;
+            c0 = end;
+        }
+        plan.stages += mine;
+        plan.max_stages = std::max(plan.max_stages, mine);
+    }
+    plan.first.push_back((uint32_t)plan.segs.size());
+}
+
+static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges, uint32_t n_kslices,
+                            uint32_t shard_rank, uint32_t shard_count) {
+    const uint64_t key[4] = {ranges_hash(ranges), n_kslices, ((uint64_t)shard_rank << 32) | shard_count,
+                             ((uint64_t)(ctx->k2_stream_groups_per_cu & 0xff) << 32) |
+                                 ((uint64_t)(ctx->k2_stream_min_piece & 0xffff) << 16) |
+                                 (uint64_t)(ctx->k2_stream_min_run & 0xffff)};
+    if (ctx->d_bitsegs && !memcmp(key, ctx->bit_key, sizeof(key))) return STORM_HIP_OK;
+    BitstreamShaping sh;
+    sh.groups_per_cu = ctx->k2_stream_groups_per_cu;
+    sh.min_piece = std::max(1, ctx->k2_stream_min_piece);
+    sh.min_run = std::max(1, ctx->k2_stream_min_run);
+    BitstreamPlan plan;
+    build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), plan);
+    if (plan.max_stages > kBsMaxStages) {
+        set_error("K2q: a workgroup of %u stages exceeds the exact range of its accumulators", plan.max_stages);
+        return STORM_HIP_EINVAL;
+    }
+    const size_t seg_bytes = std::max<size_t>(plan.segs.size(), 1) * sizeof(BitSeg);
+    const size_t first_bytes = plan.first.size() * sizeof(uint32_t);
+    if (seg_bytes > ctx->bitsegs_capacity) {
+        if (ctx->d_bitsegs) STORM_HIP_TRY(hipFree(ctx->d_bitsegs));
+        ctx->d_bitsegs = nullptr;
+        ctx->bitsegs_capacity = 0;
+        STORM_HIP_TRY(hipMalloc(&ctx->d_bitsegs, seg_bytes));
+        ctx->bitsegs_capacity = seg_bytes;
+    }
+    if (first_bytes > ctx->bitfirst_capacity) {
+        if (ctx->d_bitfirst) STORM_HIP_TRY(hipFree(ctx->d_bitfirst));
+        ctx->d_bitfirst = nullptr;
+        ctx->bitfirst_capacity = 0;
+        STORM_HIP_TRY(hipMalloc(&ctx->d_bitfirst, first_bytes));
+        ctx->bitfirst_capacity = first_bytes;
+    }
+    if (!plan.segs.empty())
+        STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitsegs, plan.segs.data(), plan.segs.size() * sizeof(BitSeg),
+                                     hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitfirst, plan.first.data(), first_bytes, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_bit_groups = plan.groups;
+    ctx->bit_stages = plan.stages;
+    ctx->bit_max_stages = plan.max_stages;
+    ctx->n_bit_segs = (uint32_t)plan.segs.size();
+    memcpy(ctx->bit_key, key, sizeof(key));
+    return STORM_HIP_OK;
+}
+
+// One launch: the all-pairs total of every row range of a bit matrix (pitch in bytes, rows up to the
+// next multiple of 256 behind every range readable and zero) into *d_total.
+int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pitch,
+                           const std::vector<RowRange>& ranges, uint32_t n_kslices, uint32_t shard_rank,
+                           uint32_t shard_count, uint64_t* d_total) {
+    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || pitch % 16 != 0) {
+        set_error("K2q: rows of %llu bytes are outside the bit-operand stream's 32-bit DMA offsets",
+                  (unsigned long long)pitch);
+        return STORM_HIP_EINVAL;
+    }
+    if (int rc = ensure_bitstream(ctx, ranges, n_kslices, shard_rank, shard_count)) return rc;
+    ctx->n_items = 0;
+    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    ctx->last_info[0] = ctx->n_bit_groups;
+    ctx->last_info[1] = ctx->bit_max_stages;
+    ctx->last_info[2] = 1;
+    ctx->last_info[3] = ctx->n_bit_segs;
+    if (ctx->n_bit_groups == 0) {
+        STORM_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
+        return STORM_HIP_OK;
+    }
+    kernel_time_mark(ctx);
+    const dim3 grid(ctx->n_bit_groups), block(kStripThreads);
+#ifdef STORM_HIP_PROBES
+    if (ctx->k2_ring == 18) {  // schedule trace (results stay correct)
+        const size_t need = (size_t)ctx->n_bit_groups * 4 * sizeof(unsigned long long);
+        if (need > ctx->trace_capacity) {
+            if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
+            ctx->d_trace = nullptr;
+            ctx->trace_capacity = 0;
+            STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace), need));
+            ctx->trace_capacity = need;
+        }
+        ctx->trace_items = ctx->n_bit_groups;
+        ctx->trace_is_stream = true;
+        hipLaunchKernelGGL(bitstream_kernel<true>, grid, block, 0, ctx->stream,
+                           reinterpret_cast<const uint8_t*>(X), pitch, static_cast<const BitSeg*>(ctx->d_bitsegs),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst), ctx->d_slots,
+                           reinterpret_cast<unsigned long long*>(d_total), ctx->d_trace);
+    } else
+#endif
+        hipLaunchKernelGGL(bitstream_kernel<false>, grid, block, 0, ctx->stream,
+                           reinterpret_cast<const uint8_t*>(X), pitch, static_cast<const BitSeg*>(ctx->d_bitsegs),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst), ctx->d_slots,
+                           reinterpret_cast<unsigned long long*>(d_total), (unsigned long long*)nullptr);
+    kernel_time_mark(ctx);
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+
 // The default pass: strips on bit operands over the matrix itself (no shadow, nothing to expand).
 static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                              uint32_t shard_count, uint64_t* d_total) {
@@ -3181,6 +3716,8 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     // k-slices of 512 bits that hold data (the zero padding of the rows is never multiplied)
     const uint32_t n_kslices = (m->n_words + 7u) / 8u;
+    if (ctx->k2_strip_operands == 2)
+        return launch_pairw_bitstream(ctx, m->d, pitch, ranges, n_kslices, shard_rank, shard_count, d_total);
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
@@ -3205,7 +3742,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
     // (a matrix created before the option was set may lack the zero rows up to a multiple of 256)
-    if (strip_mode == 1 && ctx->k2_strip_operands == 1 && !ctx->k2_persistent && ctx->k2_debug == 0 &&
+    if (strip_mode == 1 && (ctx->k2_strip_operands == 1 || ctx->k2_strip_operands == 2) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad)
         return launch_pairw_bits(ctx, m, shard_rank, shard_count, d_total);
     const uint64_t tile = strip_mode == 2 ? 512 : kStripATile;
