@@ -236,6 +236,21 @@ int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
                          uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
                          uint64_t* n_items);
 
+/* The same for the one-launch stage stream on bit operands (K2q, the default for matrices of up to 8192
+ * rows on one device): the segments shard `shard_rank` of `shard_count` walks on a device of
+ * `n_cus` compute units, workgroup by workgroup, as 8 uint32 per segment:
+ *   {workgroup, a_blk, ks, b_first, n_b, range_nb, diag, stages}
+ *   = A tile = the 64-row blocks [a_blk, a_blk + 4) x k-slice ks (bits [512 ks, 512 ks + 512) of every row);
+ *     diag ? the pairs inside the tile (strictly above the diagonal) : nothing; then the n_b later blocks
+ *     (b_first + i) % range_nb, i < n_b, whole: the pairs (row of the tile, row of the block).
+ * Tile pairs are dealt cyclically (tile I takes the (T - 1) / 2 tiles behind it, wrapping around; with an
+ * even number of tiles the opposite one goes to the lower tile on even k-slices and to the upper on odd ones),
+ * so the segments of all shards cover every unordered row pair x k-slice exactly once. Shards the reference
+ * loop storm.c:1199-1238 into contiguous parts of the k-slice-major stage stream. Host only. */
+int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,
+                          uint32_t n_cus, uint32_t* out, uint64_t capacity_segments, uint64_t* n_segments,
+                          uint32_t* n_workgroups);
+
 /* ---- sparse (STORM_t) arena: flattened rows -> blocks (storm.h:157-178) --------------
  * Host-side flat description of all rows' 65536-bit blocks:
  *   row_block_offset[n_rows+1]   CSR over blocks

@@ -57,6 +57,7 @@ SIGNATURES = {
     "storm_hip_pairw_matrix_band_begin": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
     "storm_hip_pairw_matrix_band_end": (C.c_int, [vp]),
     "storm_hip_strip_plan": (C.c_int, [u64, u32, u32, u32, vp, u64, vp]),
+    "storm_hip_stream_plan": (C.c_int, [u64, u32, u32, u32, u32, vp, u64, vp, vp]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),

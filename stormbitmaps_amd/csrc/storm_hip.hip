@@ -655,14 +655,20 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_strip_operands")) {
-        if (value != 1 && value != 2 && value != 4) {
-            set_error("k2_strip_operands must be 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup) or 4 (FP4 shadow)");
+        if (value != 0 && value != 1 && value != 2 && value != 4) {
+            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup) or 4 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_strip_operands = (int)value;
+    } else if (!strcmp(key, "k2_stream_max_rows")) {
+        if (value < 0 || value > (1ll << 31)) {
+            set_error("k2_stream_max_rows must be 0 .. 2^31");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_stream_max_rows = (int)value;
     } else if (!strcmp(key, "k2_stream_groups_per_cu")) {
-        if (value < 0 || value > 3) {
-            set_error("k2_stream_groups_per_cu must be 0 (auto) .. 3");
+        if (value < 0 || value > 255) {
+            set_error("k2_stream_groups_per_cu must be 0 (auto) .. 255");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_stream_groups_per_cu = (int)value;
@@ -753,6 +759,8 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;
     if (!strcmp(key, "k2_shape")) return ctx->k2_shape;
     if (!strcmp(key, "k2_strip_operands")) return ctx->k2_strip_operands;
+    if (!strcmp(key, "k2_operands_used")) return ctx->k2_operands_used;
+    if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
 #ifdef STORM_HIP_PROBES
@@ -793,6 +801,10 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const uint64_t n = std::min<uint64_t>(capacity_items, ctx->trace_items);
+    if (ctx->trace_is_stream) {  // bitstream_kernel: 8 words per workgroup, as they are
+        STORM_HIP_TRY(hipMemcpy(out, ctx->d_trace, n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        return STORM_HIP_OK;
+    }
     // per item: 4 trace words, then the item record {a_row0, diag, j0, j1} widened to 64 bit
     std::vector<uint64_t> raw(n * 4);
     std::vector<uint32_t> items(n * 5, 0);
@@ -841,7 +853,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     // k-slice into a handful of L2 sets and memory channels, so one more chunk of zero words per row breaks
     // the pattern (same finding as shadow_pitch, storm_hip_mfma.hip). The FP4 paths copy the rows into
     // their own padded shadow and keep the dense pitch.
-    if ((ctx->k2_strip_operands == 1 || ctx->k2_strip_operands == 2) && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
+    if (ctx->k2_strip_operands == 1 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

@@ -111,7 +111,9 @@ struct storm_hip_ctx_s {
     int k2_max_run = 128;   // K2s: B stages per strip item
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
     int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
-    int k2_strip_operands = 4;  // strips: 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel, default); 1 = bit operands inflated in registers (stripbits_kernel, no shadow; 6 % slower at the headline shape)
+    int k2_strip_operands = 0;  // strips: 0 = by size (K2q up to k2_stream_max_rows rows on one device, the FP4 shadow beyond); 2 = bit operands, one stage stream per workgroup, one launch (bitstream_kernel, K2q); 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel); 1 = bit operands, one item per workgroup (stripbits_kernel)
+    int k2_stream_max_rows = 8192;  // auto: matrices up to this many rows take K2q
+    int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
     int k2_tile_cost_diag = 63, k2_tile_cost_ragged = 30;  // percent of a full tile (tilebits8_kernel): what the planner assumes when it cuts the last round
     int k2_shape = 16;      // K2s: MFMA shape of the default strip kernel: 16 = 16x16x128 (default), 32 = 32x32x64
@@ -149,7 +151,7 @@ struct storm_hip_ctx_s {
     uint32_t n_bit_groups = 0, n_bit_segs = 0, bit_max_stages = 0;
     uint64_t bit_stages = 0;
     int k2_stream_groups_per_cu = 0;  // K2q: workgroups per CU (0 = by the length of the stream: 1, 2 or 3)
-    int k2_stream_min_piece = 8;      // K2q: stages a workgroup should at least have before a CU's share is cut further
+    int k2_stream_min_piece = 6;      // K2q: stages a workgroup should at least have before a CU's share is cut further
     int k2_stream_min_run = 2;        // K2q: a cut leaves at least this many later blocks on either side
     bool trace_is_stream = false;     // d_trace holds per-workgroup words of bitstream_kernel (no strip items)
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping

@@ -2224,6 +2224,8 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
 
     unsigned long long t_start = 0, t_ready = 0;
+    unsigned long long c_wait = 0, c_issue = 0, c_body = 0, c_mark = 0;  // shader clocks of wave 0 (trace build)
+    uint32_t n_mul = 0;
     if (kTrace) t_start = __builtin_amdgcn_s_memrealtime();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -2264,43 +2266,67 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
         rn = segs[min(s_begin + 1u, s_end - 1u)];
         rc = ri;
     }
-    auto issue_next = [&]() {
-        uint32_t rel = ri.b_first + (ii - 4u);
-        rel = rel >= ri.range_nb ? rel - ri.range_nb : rel;
-        const uint32_t blk = ii < 4u ? ri.a_blk + ii : ri.range_b0 + rel;
-        const uint8_t* base = X + (uint64_t)ri.ks * kSbRowBytes + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[issued % kSbRing] + wave * 1024u), 16,
-                                                 (int)goff, 0, 0, 0);
-        ++issued;
-        ++ii;
-        if (ii == 4u + ri.n_b) {
-            ii = 0;
-            ++si;
-            if (si < s_end) {
-                ri = rn;
-                rn = segs[min(si + 1u, s_end - 1u)];
-            } else {
-                more = false;
+    // A wave alone on its SIMD issues one instruction every four cycles, so every instruction between the
+    // barrier and the first MFMA of a stage costs the matrix pipe four cycles (the first version computed the
+    // next piece's address there: 265 of a lone wave's 1760 cycles per stage, tools/stream_trace.py). Behind
+    // the barrier there is only the DMA instruction (fire); the address of the piece after it and the cursor's
+    // step (prep) follow the stage's last MFMA, while the pipe drains.
+    uint64_t nbase = 0;   // the next piece to hand over ...
+    bool nvalid = false;  // ... if there is one
+    auto prep = [&]() {
+        nvalid = more;
+        if (more) {
+            uint32_t rel = ri.b_first + (ii - 4u);
+            rel = rel >= ri.range_nb ? rel - ri.range_nb : rel;
+            const uint32_t blk = ii < 4u ? ri.a_blk + ii : ri.range_b0 + rel;
+            nbase = (uint64_t)(uintptr_t)X + (uint64_t)ri.ks * kSbRowBytes + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
+            ++ii;
+            if (ii == 4u + ri.n_b) {
+                ii = 0;
+                ++si;
+                if (si < s_end) {
+                    ri = rn;
+                    rn = segs[min(si + 1u, s_end - 1u)];
+                } else {
+                    more = false;
+                }
             }
         }
     };
+    auto fire = [&]() {
+        if (nvalid) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<uint8_t*>((uintptr_t)nbase), 0, -1, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[issued % kSbRing] + wave * 1024u), 16,
+                                                     (int)goff, 0, 0, 0);
+            ++issued;
+        }
+    };
+    prep();
 #pragma unroll
-    for (int k = 0; k < kSbRing - 1; ++k)
-        if (more) issue_next();
+    for (int k = 0; k < kSbRing - 1; ++k) {
+        fire();
+        prep();
+    }
 
 #define STORM_BS_FETCH(dst, t, n, g) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+    // one class of one B word against both A row blocks; the next operand is inflated BETWEEN the two MFMAs
+    // (in the shadow of the first: the second cannot start before the first has left the pipe's front anyway)
 #define STORM_BS_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
-    acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
-        v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                          \
-        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]);    \
-    acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
-        v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                          \
-        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]);    \
-    enxt = NEXT;                                                                                          \
-    __builtin_amdgcn_sched_barrier(0)
+    {                                                                                                     \
+        acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
+            v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                      \
+            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const v4i en_ = NEXT;                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
+            v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                      \
+            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
+        enxt = en_;                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
 #define STORM_BS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
 #define STORM_BS_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
     // One stage (stripbits_kernel's): on entry w0 holds the bits of (block 0, k-group 0) of stage `tc` and
@@ -2338,6 +2364,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     v4i w0 = {}, w1 = {}, e0 = {};
     int sb[4] = {tb_scale<0>(), tb_scale<1>(), tb_scale<2>(), tb_scale<3>()};  // B-side block scales of the stage
     uint32_t ci = 0;  // stage of the consume cursor in its segment rc
+    uint32_t sc = s_begin;
     uint32_t t = 0;   // stages consumed
     if (issued > 0) {
         // stage 0 has landed (the younger pieces may stay in flight)
@@ -2356,12 +2383,19 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
         // top of stage t: stage t + 1 has landed and every wave is done with stage t - 1, whose slot the
         // next piece takes (invariant: issued == min(stages of this workgroup, t + 3))
         const bool has_next = issued > t + 1u;
+        if (kTrace) c_mark = __builtin_readcyclecounter();
         if (has_next) {
             if (issued >= t + 3u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (more) issue_next();
+        if (kTrace) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            c_wait += now - c_mark;
+            c_mark = now;
+        }
+        fire();
+        prep();
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t tn = has_next ? t + 1u : t;
         // what this wave does with the stage
@@ -2369,6 +2403,11 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
         const bool own = ci == wm;
         const bool diag = (rc.flags & kBsDiag) != 0u;
         const bool mul = ci >= 4u || (diag && ci >= wm);
+        if (kTrace) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            c_issue += now - c_mark;
+            c_mark = now;
+        }
         if (own) {
             // the wave's A rows are this stage's rows: all four words, every class
             v4i x1, x2, x3;
@@ -2413,11 +2452,19 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
             __builtin_amdgcn_sched_barrier(0);
             e0 = tb_inflate<0>(w0);
         }
+        if (kTrace) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            c_body += now - c_mark;
+            c_mark = now;
+            n_mul += mul ? 1u : 0u;
+        }
+        if (kTrace) c_issue += __builtin_readcyclecounter() - c_mark;
         ++t;
         ++ci;
         if (ci == 4u + rc.n_b) {
             ci = 0;
-            rc = ri;  // the issue cursor is three stages ahead: inside the segment `consume` now enters
+            ++sc;
+            rc = segs[min(sc, s_end - 1u)];
         }
     }
 #undef STORM_BS_STAGE
@@ -2452,11 +2499,15 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
         const unsigned long long arrived = atomicAdd(&slots[kBsTicket], 1ull);
         wsum[4] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
         if (kTrace) {
-            trace[blockIdx.x * 4ull + 0] = t_start;
-            trace[blockIdx.x * 4ull + 1] = __builtin_amdgcn_s_memrealtime();
-            trace[blockIdx.x * 4ull + 2] = ((t_ready - t_start) & 0xffffffffull) | ((unsigned long long)t << 32);
-            trace[blockIdx.x * 4ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) |
+            trace[blockIdx.x * 8ull + 0] = t_start;
+            trace[blockIdx.x * 8ull + 1] = __builtin_amdgcn_s_memrealtime();
+            trace[blockIdx.x * 8ull + 2] = ((t_ready - t_start) & 0xffffffffull) | ((unsigned long long)t << 32);
+            trace[blockIdx.x * 8ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) |
                                            ((unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) << 32);
+            trace[blockIdx.x * 8ull + 4] = c_wait;
+            trace[blockIdx.x * 8ull + 5] = c_issue;
+            trace[blockIdx.x * 8ull + 6] = c_body;
+            trace[blockIdx.x * 8ull + 7] = n_mul;
         }
     }
     __syncthreads();
@@ -2940,6 +2991,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     }
                     ctx->trace_items = n_strip;
                     ctx->trace_is_stream = false;
+                    ctx->trace_is_stream = false;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8, 2, true>), pgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace, queues, heads);
                     break;
@@ -2996,6 +3048,7 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                         ctx->trace_capacity = need;
                     }
                     ctx->trace_items = n_strip;
+                    ctx->trace_is_stream = false;
                     ctx->trace_is_stream = false;
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 8>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace);
@@ -3490,8 +3543,9 @@ struct BitstreamPlan {
 };
 struct BitstreamShaping {
     int groups_per_cu = 0;  // 0 = by the length of the stream: 1, 2 or 3
-    int min_piece = 8;      // stages a workgroup should have at least before a CU's share is cut further
+    int min_piece = 6;      // stages a workgroup should have at least before a CU's share is cut further
     int min_run = 2;        // a cut leaves at least this many later blocks on either side of it
+    int long_piece = 80;    // stages per workgroup once the stream is longer than the chip's slots x this
 };
 
 static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRange>& ranges,
@@ -3545,6 +3599,20 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
         per_cu = share >= 3ull * (uint64_t)sh.min_piece ? 3u : share >= 2ull * (uint64_t)sh.min_piece ? 2u : 1u;
     }
     uint64_t G = (uint64_t)n_cus * per_cu;
+    // A long stream is cut into MORE shares than the chip holds workgroups (three per CU): the waves of a SIMD
+    // do not advance evenly (its arbiter prefers the oldest), so equal shares end at very different times and
+    // the last ones run alone, at a lone wave's 60 % of the pipe; with shares of ~80 stages a CU that finishes
+    // one early simply gets the next (headline shape: 883 us with 768 shares, 821 with 6144; N = 6144: 341 ->
+    // 317; from ~30 stages down the four stages that bring a continued segment's A rows in cost more than the
+    // tail does: N = 2048 is fastest with 768). Never a share beyond the accumulators' exact range.
+    // Whole rounds of the chip's slots only: 870 shares on 768 slots leave a fourth share to 102 CUs (N = 4096:
+    // 185 us against 152 with 768 or 1536).
+    if (sh.groups_per_cu == 0 && per_cu == 3u) {
+        const uint64_t slots = (uint64_t)n_cus * 3u;
+        const uint64_t rounds = (Ls + slots * (uint64_t)std::max(1, sh.long_piece) / 2) /
+                                (slots * (uint64_t)std::max(1, sh.long_piece));
+        G = slots * std::max<uint64_t>(1, rounds);
+    }
     G = std::max<uint64_t>(G, (Ls + kBsMaxStages / 2 - 1) / (kBsMaxStages / 2));
     G = std::max<uint64_t>(1, std::min<uint64_t>(G, std::max<uint64_t>(1, Ls / 4)));
     if (Ls == 0) G = 0;
@@ -3677,7 +3745,7 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
     const dim3 grid(ctx->n_bit_groups), block(kStripThreads);
 #ifdef STORM_HIP_PROBES
     if (ctx->k2_ring == 18) {  // schedule trace (results stay correct)
-        const size_t need = (size_t)ctx->n_bit_groups * 4 * sizeof(unsigned long long);
+        const size_t need = (size_t)ctx->n_bit_groups * 8 * sizeof(unsigned long long);
         if (need > ctx->trace_capacity) {
             if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
             ctx->d_trace = nullptr;
@@ -3686,6 +3754,7 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
             ctx->trace_capacity = need;
         }
         ctx->trace_items = ctx->n_bit_groups;
+        ctx->trace_is_stream = true;
         ctx->trace_is_stream = true;
         hipLaunchKernelGGL(bitstream_kernel<true>, grid, block, 0, ctx->stream,
                            reinterpret_cast<const uint8_t*>(X), pitch, static_cast<const BitSeg*>(ctx->d_bitsegs),
@@ -3704,7 +3773,7 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
 
 // The default pass: strips on bit operands over the matrix itself (no shadow, nothing to expand).
 static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
-                             uint32_t shard_count, uint64_t* d_total) {
+                             uint32_t shard_count, int operands, uint64_t* d_total) {
     const uint64_t pitch = m->stride_words * 8;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     if (n_rows4 > m->n_rows_pad || pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
@@ -3716,7 +3785,7 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     if (m->n_rows > 1) ranges.push_back({0, m->n_rows});
     // k-slices of 512 bits that hold data (the zero padding of the rows is never multiplied)
     const uint32_t n_kslices = (m->n_words + 7u) / 8u;
-    if (ctx->k2_strip_operands == 2)
+    if (operands == 2)
         return launch_pairw_bitstream(ctx, m->d, pitch, ranges, n_kslices, shard_rank, shard_count, d_total);
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
@@ -3742,9 +3811,25 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
     // (a matrix created before the option was set may lack the zero rows up to a multiple of 256)
-    if (strip_mode == 1 && (ctx->k2_strip_operands == 1 || ctx->k2_strip_operands == 2) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
-        (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad)
-        return launch_pairw_bits(ctx, m, shard_rank, shard_count, d_total);
+    // Which strips (option k2_strip_operands; 0 = by measurement, same box, M = 65536, tools/midsize_pass.py):
+    // the one-launch stream on bit operands (K2q) is ahead up to N ~ 9000 — 12.6 us against 20.7 at N = 512,
+    // 20.1 / 33.8 at 1024, 46.8 / 60.5 at 2048, 161 / 174 at 4096, 581 / 594 at 8192 — where the FP4 strips'
+    // faster stage loop has made up for their expansion pass and two extra launches (872 / 848 at N = 10000).
+    // A shard of a multi-GPU pass stays on the FP4 strips (whole k-slices per shard make its expansion cheap:
+    // 0.120 against 0.122 ms for an eighth of the headline matrix), and with them on the planner's ownership.
+    int operands = ctx->k2_strip_operands;
+    if (operands == 0)
+        operands = (shard_count == 1 && m->n_rows <= (uint64_t)ctx->k2_stream_max_rows && ctx->k2_ring == kStripRingDefault &&
+                    ctx->k2_shape == 16 && ctx->k2_lds_pad == 0)
+                       ? 2 : 4;
+    if (strip_mode == 1 && (operands == 1 || operands == 2) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
+        (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
+        m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))
+    {
+        ctx->k2_operands_used = operands;
+        return launch_pairw_bits(ctx, m, shard_rank, shard_count, operands, d_total);
+    }
+    ctx->k2_operands_used = 4;
     const uint64_t tile = strip_mode == 2 ? 512 : kStripATile;
     const uint64_t n_rows4 = (m->n_rows + tile - 1) / tile * tile;
     std::vector<RowRange> ranges;
@@ -3786,6 +3871,44 @@ extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t 
             }
     } catch (const std::exception& e) {
         set_error("strip_plan: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+    return STORM_HIP_OK;
+}
+
+extern "C" int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,
+                                     uint32_t n_cus, uint32_t* out, uint64_t capacity_segments,
+                                     uint64_t* n_segments, uint32_t* n_workgroups) {
+    using namespace storm;
+    if (!n_segments || shard_count == 0 || shard_rank >= shard_count || n_words == 0 || n_cus == 0) {
+        set_error("stream_plan: bad arguments");
+        return STORM_HIP_EINVAL;
+    }
+    try {
+        std::vector<RowRange> ranges;
+        if (n_rows > 1) ranges.push_back({0, n_rows});
+        BitstreamPlan plan;
+        build_bitstream(BitstreamShaping{}, ranges, (n_words + 7u) / 8u, shard_rank, shard_count, n_cus, plan);
+        *n_segments = plan.segs.size();
+        if (n_workgroups) *n_workgroups = plan.groups;
+        if (out) {
+            uint32_t wg = 0;
+            for (uint64_t i = 0; i < std::min<uint64_t>(capacity_segments, plan.segs.size()); ++i) {
+                while (wg + 1 < plan.first.size() && plan.first[wg + 1] <= i) ++wg;
+                const BitSeg& sg = plan.segs[i];
+                uint32_t* o = out + i * 8;
+                o[0] = wg;
+                o[1] = sg.a_blk;
+                o[2] = sg.ks;
+                o[3] = sg.b_first;
+                o[4] = sg.n_b;
+                o[5] = sg.range_nb;
+                o[6] = sg.flags & kBsDiag;
+                o[7] = 4u + sg.n_b;
+            }
+        }
+    } catch (const std::exception& e) {
+        set_error("stream_plan: %s", e.what());
         return STORM_HIP_ENOMEM;
     }
     return STORM_HIP_OK;

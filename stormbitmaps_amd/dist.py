@@ -72,6 +72,26 @@ def strip_plan(n_rows: int, n_words: int, rank: int, world: int):
     return out
 
 
+def stream_plan(n_rows: int, n_words: int, rank: int = 0, world: int = 1, n_cus: int = 256):
+    """The segments rank `rank` of `world` walks on the one-launch stage stream (K2q, matrices of up to 8192
+    rows), as an [n, 8] uint32 array of {workgroup, a_blk, ks, b_first, n_b, range_nb, diag, stages} (see
+    storm_hip_stream_plan in include/storm_hip.h), and the number of workgroups. Host-only."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    lib = _lib.load()
+    n, g = C.c_uint64(0), C.c_uint32(0)
+    _lib.check(lib.storm_hip_stream_plan(n_rows, n_words, rank, world, n_cus, None, 0, C.byref(n), C.byref(g)),
+               "storm_hip_stream_plan")
+    out = np.zeros((int(n.value), 8), dtype=np.uint32)
+    if n.value:
+        _lib.check(lib.storm_hip_stream_plan(n_rows, n_words, rank, world, n_cus, out.ctypes.data_as(C.c_void_p),
+                                             n.value, C.byref(n), C.byref(g)), "storm_hip_stream_plan")
+    return out, int(g.value)
+
+
 def allreduce_total(partial: int, device=None) -> int:
     """Sum the per-rank partial totals. Totals are < 2^63 for every supported shape
     (N^2/2 * M < 2^63), so the int64 transport is exact."""

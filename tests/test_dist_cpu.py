@@ -129,3 +129,64 @@ def test_two_rank_gloo_allreduce_equals_single_rank(orc, n_bits):
         assert p.exitcode == 0
     assert res[0][1] == res[1][1] == want
     assert res[0][2] + res[1][2] == want and res[0][2] != want
+
+
+# ---- the one-launch stage stream on bit operands (K2q): matrices of up to 8192 rows on one device ----
+def _stream_cover(n_rows, n_words, world, n_cus):
+    """cover[ks][p, q] (p <= q, 64-row blocks) = how often the segments of all ranks' workgroups multiply
+    the unordered block pair {p, q} in k-slice ks (512 bits); stages per workgroup of every rank."""
+    nb = (n_rows + 63) // 64
+    ks_n = (n_words + 7) // 8
+    cover = np.zeros((ks_n, nb + 4, nb + 4), dtype=np.int32)
+    loads = []
+    for r in range(world):
+        segs, groups = sdist.stream_plan(n_rows, n_words, r, world, n_cus)
+        per_wg = np.zeros(max(groups, 1), dtype=np.int64)
+        for wg, a_blk, ks, b_first, n_b, range_nb, diag, stages in segs.tolist():
+            assert range_nb == nb and stages == 4 + n_b and wg < groups
+            per_wg[wg] += stages
+            tile = [a_blk + i for i in range(4)]
+            if diag:
+                for i, p in enumerate(tile):          # wave i: its own block (half weight twice = once) ...
+                    cover[ks, p, p] += 1
+                    for q in tile[i + 1:]:            # ... and the tile's later blocks
+                        cover[ks, p, q] += 1
+            for i in range(n_b):
+                q = (b_first + i) % range_nb
+                for p in tile:
+                    cover[ks, min(p, q), max(p, q)] += 1
+        loads.append(per_wg)
+    return cover, loads
+
+
+@pytest.mark.parametrize("n_rows,n_words,worlds,n_cus", [
+    (65, 10, (1, 2), 256),          # two blocks, one tile, a ragged second k-slice
+    (700, 32, (1, 2, 3, 8), 256),   # 3 tiles (odd): every tile takes one tile behind it
+    (1024, 128, (1, 3), 256),       # 4 tiles (even): the opposite tile alternates with the k-slice
+    (1100, 20, (1, 2, 5), 4),       # 5 tiles, last one ragged; a 4-CU device cuts segments in the middle
+    (2048, 64, (1, 8), 16),         # 8 tiles, many cuts: continued segments bring A in without multiplying
+    (2300, 8, (1, 3), 2),           # ONE k-slice
+])
+def test_stream_plans_of_all_ranks_cover_every_block_pair_exactly_once(n_rows, n_words, worlds, n_cus):
+    nb = (n_rows + 63) // 64
+    for world in worlds:
+        cover, loads = _stream_cover(n_rows, n_words, world, n_cus)
+        want = np.triu(np.ones((nb, nb), np.int32))              # every unordered pair incl. a block with itself
+        for ks in range(cover.shape[0]):
+            assert np.array_equal(cover[ks][:nb, :nb], want), (world, ks)
+            # blocks beyond the matrix (the zero rows up to the tile's 256) may be touched by a tile, never twice
+            assert cover[ks].max() <= 1
+        # the ranks' shares are contiguous parts of one stream: equal to within the snapping of a cut
+        totals = [int(l.sum()) for l in loads]
+        assert max(totals) - min(totals) <= 4 * 64 + 16, totals
+
+
+def test_stream_plan_shares_are_even_at_the_sizes_the_bench_reports():
+    """N = 1024 ... 8192 at M = 65536 on 256 CUs: whole rounds of the chip's 768 workgroup slots (or 256 / 512
+    for short streams), every workgroup within a few stages of the mean."""
+    for n_rows in (512, 1024, 2048, 4096, 8192):
+        segs, groups = sdist.stream_plan(n_rows, 1024, 0, 1, 256)
+        assert groups % 256 == 0 and groups >= 256
+        per_wg = np.bincount(segs[:, 0], weights=segs[:, 7], minlength=groups)
+        assert per_wg.min() > 0
+        assert per_wg.max() <= per_wg.mean() * 1.3 + 6, (n_rows, groups, per_wg.min(), per_wg.mean(), per_wg.max())

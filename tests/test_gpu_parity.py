@@ -774,9 +774,16 @@ def test_rows_beyond_the_dma_offsets_are_multiplied_in_k_chunks(hip_ctx, orc):
     mat[:, -1] &= np.uint64((1 << (M % 64)) - 1) if M % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
     m = hip_ctx.matrix_from_host(mat)
     want = orc.wrapper_diag(mat)
+    # default path: three rows take the one-launch stream on bit operands, whose DMA reaches rows of 2^29 bits
     assert m.pairw() == want
-    assert hip_ctx.get_option("variant_used") == 4
-    assert hip_ctx.last_launch_info()["word_pairs_executed"] >= 2      # out[2]: k-chunks of the pass
+    assert hip_ctx.get_option("variant_used") == 4 and hip_ctx.get_option("k2_operands_used") == 2
+    hip_ctx.set_option("k2_strip_operands", 4)     # the FP4 strips: k-chunked
+    try:
+        assert m.pairw() == want
+        assert hip_ctx.get_option("k2_operands_used") == 4
+        assert hip_ctx.last_launch_info()["word_pairs_executed"] >= 2      # out[2]: k-chunks of the pass
+    finally:
+        hip_ctx.set_option("k2_strip_operands", 0)
     try:
         hip_ctx.set_option("variant", 2)
         assert m.pairw() == want

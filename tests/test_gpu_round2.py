@@ -196,6 +196,10 @@ def test_hbm_tiled_passes_under_a_shadow_budget(hip_ctx, orc):
             m = hip_ctx.matrix(N, (M + 63) // 64)
             m.fill_synthetic(M, d, seed=N)
             want = m.column_identity()
+            # (matrices of this size take the one-launch stream on bit operands by default, which has no
+            #  shadow to bound: same total; the budget is a property of the FP4 strips, pinned here)
+            assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 2
+            hip_ctx.set_option("k2_strip_operands", 4)
             hip_ctx.set_option("k2_shadow_budget_mb", 0)
             assert m.pairw() == want and hip_ctx.last_launch_info()["word_pairs_executed"] == 1
             if N < 2000:
@@ -218,8 +222,10 @@ def test_hbm_tiled_passes_under_a_shadow_budget(hip_ctx, orc):
                     hip_ctx.set_option("k2_persistent", 0)
                     assert m.pairw() == want, (M, N, mb, shape)
                 hip_ctx.set_option("k2_shape", 16)
+            hip_ctx.set_option("k2_strip_operands", 0)
             m.close()
     finally:
+        hip_ctx.set_option("k2_strip_operands", 0)
         hip_ctx.set_option("k2_shadow_budget_mb", 96 * 1024)
         hip_ctx.set_option("keep_shadow", 0)
         hip_ctx.set_option("k2_shape", 16)
@@ -465,8 +471,8 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
 
 
 def test_strips_on_bit_operands(hip_ctx, orc):
-    """Option k2_strip_operands = 1: the strips read the bit matrix itself (512-bit k-slices, rows
-    inflated to FP4 in registers, no shadow). Matrices created under the option (row pitch padded off
+    """Options k2_strip_operands = 1 and 2: the strips read the bit matrix itself (512-bit k-slices, rows
+    inflated to FP4 in registers, no shadow; 2 = one stage stream per workgroup, one launch). Matrices created under the option (row pitch padded off
     multiples of 1 KiB) and before it (dense pitch); against the oracle where the CPU can afford it,
     against the column identity and the FP4 strips otherwise; shards; ragged rows around the waves' own
     diagonal blocks. The larger shapes put several workgroups on every CU: that is where an LDS read that
@@ -483,15 +489,15 @@ def test_strips_on_bit_operands(hip_ctx, orc):
                 want = m.column_identity()
                 if check_oracle and created_under == 1:
                     assert want == orc.wrapper_diag_blocked(m.download(), 31)
-                for operands in (1, 4):
+                for operands in (1, 2, 4):
                     hip_ctx.set_option("k2_strip_operands", operands)
-                    got = [m.pairw() for _ in range(4 if operands == 1 else 1)]
+                    got = [m.pairw() for _ in range(4 if operands != 4 else 1)]
                     assert got == [want] * len(got), (M, N, d, created_under, operands, got, want)
                     assert sum(m.pairw(r, 3) for r in range(3)) == want, (M, N, d, created_under, operands)
                 m.close()
     finally:
-        hip_ctx.set_option("k2_strip_operands", 4)
-    assert hip_ctx.get_option("k2_strip_operands") == 4
+        hip_ctx.set_option("k2_strip_operands", 0)
+    assert hip_ctx.get_option("k2_strip_operands") == 0
 
 
 def test_sparse_contiguous_containers_take_the_list_path(lib, orc):

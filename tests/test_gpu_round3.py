@@ -1,0 +1,119 @@
+"""Round-3 GPU parity tests: the one-launch stage stream on bit operands (K2q, bitstream_kernel) that
+matrices of up to 8192 rows take by default — against the CPU oracle where the CPU can afford it, the
+column identity and the FP4 strips otherwise. Everything goes through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import stormbitmaps_amd as sb
+from stormbitmaps_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_ctx():
+    ctx = sb.HipContext(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from tests._orc import Oracle
+    return Oracle()
+
+
+def _reset(ctx):
+    for k, v in (("k2_strip_operands", 0), ("k2_stream_groups_per_cu", 0), ("k2_stream_min_piece", 6),
+                 ("k2_stream_min_run", 2), ("k2_stream_max_rows", 8192)):
+        ctx.set_option(k, v)
+
+
+def test_stream_kernel_is_the_default_up_to_8192_rows_and_matches_the_oracle(hip_ctx, orc):
+    """Default path by size: K2q up to k2_stream_max_rows rows on one device, the FP4 strips beyond and for
+    every shard of a multi-device pass. Shapes around every edge of the decomposition: one block, one tile,
+    2 / 3 / 4 / 5 tiles (the cyclic deal of tile pairs has an odd and an even form), ragged last blocks and
+    tiles, one k-slice, a ragged last k-slice, rows of zero."""
+    shapes = ((64, 2), (100, 3), (4096, 63), (4096, 64), (640, 65), (4096, 200), (4096, 256), (1000, 257),
+              (8192, 511), (4160, 513), (9000, 700), (30000, 1000), (4096, 1100), (12345, 1500))
+    try:
+        for M, N in shapes:
+            for d in (M // 2, max(1, M // 50)):
+                mat = synth.dense_matrix_c(M, N, d, seed=N + M)
+                mat[N // 2] = 0                                   # an empty row in the middle
+                want = orc.wrapper_diag_blocked(mat, 31)
+                m = hip_ctx.matrix_from_host(mat)
+                got = [m.pairw() for _ in range(3)]               # (run-to-run: the race a skipped wait gives)
+                assert got == [want] * 3, (M, N, d, got, want)
+                assert hip_ctx.get_option("k2_operands_used") == 2 and hip_ctx.get_option("variant_used") == 4
+                assert m.column_identity() == want
+                # a shard of a multi-device pass stays on the FP4 strips; the stream can be sharded too
+                assert sum(m.pairw(r, 3) for r in range(3)) == want
+                assert hip_ctx.get_option("k2_operands_used") == 4
+                hip_ctx.set_option("k2_strip_operands", 2)
+                for world in (2, 5):
+                    assert sum(m.pairw(r, world) for r in range(world)) == want, (M, N, d, world)
+                hip_ctx.set_option("k2_strip_operands", 0)
+                m.close()
+        # beyond the threshold: FP4 strips; the threshold is an option
+        m = hip_ctx.matrix(8300, 64)
+        m.fill_synthetic(4096, 1500, seed=3)
+        want = m.column_identity()
+        assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 4
+        hip_ctx.set_option("k2_stream_max_rows", 10000)
+        assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 2
+        m.close()
+    finally:
+        _reset(hip_ctx)
+
+
+@pytest.mark.parametrize("per_cu,min_piece,min_run", [(0, 6, 2), (1, 1, 1), (2, 40, 9), (3, 6, 2), (7, 6, 1), (16, 1, 3)])
+def test_stream_shaping_options_do_not_change_the_total(hip_ctx, per_cu, min_piece, min_run):
+    """How the stage stream is cut into workgroups (shares per CU, shortest share, shortest run beside a cut,
+    more shares than slots) is tuning: every setting gives the same total. Shapes of 2..40 tiles, sizes at
+    which segments are cut in the middle and continued by another workgroup."""
+    try:
+        hip_ctx.set_option("k2_strip_operands", 2)
+        hip_ctx.set_option("k2_stream_groups_per_cu", per_cu)
+        hip_ctx.set_option("k2_stream_min_piece", min_piece)
+        hip_ctx.set_option("k2_stream_min_run", min_run)
+        for M, N in ((65536, 1024), (20000, 2300), (9999, 777), (65536, 300), (2048, 5000), (512, 10000)):
+            m = hip_ctx.matrix(N, (M + 63) // 64)
+            m.fill_synthetic(M, M // 3, seed=5)
+            want = m.column_identity()
+            assert m.pairw() == want, (M, N, per_cu, min_piece, min_run)
+            assert sum(m.pairw(r, 3) for r in range(3)) == want
+            m.close()
+    finally:
+        _reset(hip_ctx)
+
+
+def test_stream_kernel_through_the_storm_h_containers(orc):
+    """STORM_contiguous_t (storm.h) containers of mid-size take K2q on the way through
+    STORM_contig_pairw_intersect_cardinality[_blocked]: same totals as the oracle's blocked loop
+    (storm.c:1175-1241) and as the raw-buffer wrappers."""
+    M, N, d = 65536, 1200, 20000
+    mat = synth.dense_matrix_c(M, N, d, seed=77)
+    want = orc.wrapper_diag_blocked(mat, 31)
+    c = sb.StormContig(M)
+    for r in synth.positions_from_dense(mat):
+        c.add(r)
+    assert c.pairw_intersect_cardinality_blocked(31) == want
+    assert c.pairw_intersect_cardinality() == want
+    assert sb.wrapper_diag_blocked(mat, 31) == want
+    c.free()
+
+
+def test_stream_kernel_at_full_mid_sizes_against_the_column_identity(hip_ctx):
+    """The sizes tools/midsize_pass.py reports (M = 65536, dense): totals against the size-independent
+    identity sum_c C(n_c, 2), repeated (the last workgroup to arrive folds the partial sums and leaves
+    slots and ticket zeroed for the next pass)."""
+    for N in (512, 1024, 2048, 4096, 8192):
+        m = hip_ctx.matrix(N, 1024)
+        m.fill_synthetic(65536, 32768, seed=42)
+        want = m.column_identity()
+        assert [m.pairw() for _ in range(5)] == [want] * 5, N
+        assert hip_ctx.get_option("k2_operands_used") == 2
+        m.close()

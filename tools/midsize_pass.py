@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1024)
     ap.add_argument("--bits", type=int, default=65536)
     ap.add_argument("--passes", type=int, default=200)
+    ap.add_argument("--warm-ms", type=float, default=40.0)
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     import torch
@@ -29,9 +30,12 @@ def main():
     m = ctx.matrix(args.rows, W)
     m.fill_synthetic(args.bits, args.bits // 2, seed=42)
     want = m.column_identity()
-    for _ in range(50):
-        m.pairw_launch(t.data_ptr(), 0, 1)
-    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()   # clock ramp: ~30 ms of back-to-back passes (profiles/r02_k_bench_nccl_ramp.txt)
+    while time.perf_counter() - t0 < args.warm_ms * 1e-3:
+        for _ in range(50):
+            m.pairw_launch(t.data_ptr(), 0, 1)
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(stream)
     for _ in range(args.passes):

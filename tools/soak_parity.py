@@ -41,7 +41,10 @@ def main():
                 "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
                 "k2_shape": int(rng.choice([16, 16, 32])),
                 "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32])),
-                "k2_strip_operands": int(rng.choice([4, 4, 1])),
+                "k2_strip_operands": int(rng.choice([0, 0, 4, 1, 2])),
+                "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
+                "k2_stream_min_piece": int(rng.choice([6, 6, 1, 30])),
+                "k2_stream_min_run": int(rng.choice([2, 2, 1, 9])),
                 "k2_shadow_budget_mb": int(rng.choice([98304, 98304, 1, 8])),
                 "sparse_probe": int(rng.choice([-1, -1, 0, 1]))}
         for k, v in opts.items():
@@ -113,7 +116,8 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 4,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
+                         "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
         n_cases += 1
