@@ -26,8 +26,11 @@
 using namespace storm;
 
 struct storm_hip_sparse_s {
-    uint64_t* d_pool = nullptr;      // pool rows: [n_pool_rows + kABlockRows][1024] words
-    uint64_t n_pool_rows = 0;
+    uint64_t* d_pool = nullptr;      // pool rows: [pool_rows_ready + 512][1024] words
+    uint64_t n_pool_rows = 0;        // rows of the whole layout: columns the list-probe kernel cannot take first, ...
+    uint64_t pool_rows_ready = 0;    // ... and only those exist until a dense pass over a probe column is asked for
+    struct ProbeRegion { uint32_t e_begin, e_end, pool_row0, octant; };
+    std::vector<ProbeRegion> probe_regions;  // (column, octant) element ranges: how ensure_full_pool expands the lists
     std::vector<RowRange> cols;      // pool-row range [r0, r1) of each non-empty column; every r0
                                      // is a multiple of 512 and the gap up to it is zero rows
     uint64_t census[4] = {0, 0, 0, 0};
@@ -95,77 +98,113 @@ __global__ __launch_bounds__(kThreads) void place_bitmaps_u16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K4 — list probe kernel for block columns whose blocks are all short sorted lists (the reference's
-// "extremely fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached
-// through the kind dispatch :618-656). The dense path multiplies 8 KiB per present block whatever
-// its density; here the work is proportional to the listed positions.
-//   data  : per column the lists of its rows, concatenated in row order, one uint32 per listed
-//           position: (row in column) << 16 | position in block — and the positions alone as uint16;
-//   item  : 16 consecutive A rows of a column x (first item of the group: the later rows inside the
-//           group, as tagged elements, +) a chunk of the positions of the rows BEHIND the group;
-//   LDS   : the 16 A rows as a TRANSPOSED bitmap — T[position] = 16-bit mask of the A rows that have
-//           that position set (65536 x 16 bit = 128 KiB) — zeroed and scattered per item;
-//   stream: every element of the later rows is ONE LDS read: popcount(T[pos] & rows_before(j)) is that
-//           element's contribution against all 16 A rows at once (rows behind the group: no mask, no
-//           tag); 16-byte coalesced loads (8 positions), an XCD's L2 holds a column's few MB, 1024
-//           threads per workgroup.
-// Pairs i < j: B rows inside the A group mask off the A rows that are not before them.
+// K4 — list probe kernel for block columns whose blocks are all sorted lists (the reference's "extremely
+// fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached through the kind
+// dispatch :618-656). The dense path multiplies 8 KiB per present block whatever its density; here the work
+// is proportional to the listed positions.
+//   data  : per column AND per OCTANT of the block (8192 positions), the listed positions of its rows in row
+//           order: one uint32 per position, (row in column) << 16 | position in octant — and the positions
+//           alone as uint16;
+//   item  : 128 consecutive A rows of a column x one octant x (first item of the group: the A rows' own
+//           elements, each against the rows before it, +) a chunk of the positions of the rows BEHIND the group;
+//   LDS   : the 128 A rows as a TRANSPOSED bitmap — T[position] = 128-bit mask of the A rows that have that
+//           position set (8192 x 16 B = 128 KiB) — zeroed and scattered per item;
+//   stream: every element of the later rows is ONE 16-byte LDS read: popcount(T[pos] & rows_before(j)) is its
+//           contribution against all 128 A rows at once (rows behind the group: no mask, no tag); 16-byte
+//           coalesced loads (8 positions); 1024 threads per workgroup.
+// [r3] Round 2's table held 16 rows x 65536 positions (one 2-byte read per element and 16 rows): it sat at
+// ~7 lookups per clock and CU, an eighth of what the LDS moves, and re-read a column's elements from L2 once
+// per 16 rows. Eight times the rows per lookup and per pass over the elements moved the crossover with the
+// dense path from ~1000 listed positions per block to beyond the longest list a block can hold (4095).
+// Pairs i < j: an A row's own elements mask off the A rows that are not before it.
 // ------------------------------------------------------------------------------------------
 struct ProbeItem {
-    uint32_t a_begin, a_end;  // elements of the A rows [a0, a0 + 16)
-    uint32_t n_begin, n_end;  // "near" elements: the later rows INSIDE the A group (row-tagged, masked); first chunk only
+    uint32_t a_begin, a_end;  // elements of the A rows [a0, a0 + 128) in this octant
+    uint32_t n_begin, n_end;  // "near" elements: the A rows' own (row-tagged, masked); first chunk only
     uint32_t b_begin, b_end;  // chunk of the elements of the rows behind the group (positions only)
     uint32_t a0;              // first A row (row index within the column)
 };
 constexpr int kProbeThreads = 1024;
-// Positions per item: every item zeroes and scatters its 128 KiB table first (~1200 cycles; 128 lookups
-// per thread at 2^17 positions cost about as much), so chunks grow with the work — about 1024 items over
-// all probe columns, between 2^17 and 2^21 positions each.
+// (256 rows x 4096 positions — half the passes over the elements, two 16-byte reads per lookup — is slower:
+//  4.57 against 3.67 ms at c4's 20971 draws; the LDS reads are the larger half of the time)
+constexpr uint32_t kProbeRows = 128;        // A rows per item
+constexpr uint32_t kProbeWords = kProbeRows / 32u;
+constexpr uint32_t kProbeOctBits = 13;      // positions per table: 2^13 of the block's 2^16 (table = 2^13 x 16 B)
+constexpr uint32_t kProbeOctants = 1u << (16 - kProbeOctBits);
 
-// [r2] The rows behind the A group need no row tag (every A row is before them): they stream as
-// uint16 POSITIONS, half the bytes of the tagged elements — the kernel was bound by re-reading the
-// column's elements from L2 once per A group (5 GB per column of 2 M elements at N = 10000).
 __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
     unsigned long long* __restrict__ slots) {
-    __shared__ __attribute__((aligned(16))) uint32_t T[32768];  // two 16-bit masks per word
+    __shared__ __attribute__((aligned(16))) uint32_t T[(1u << kProbeOctBits) * kProbeWords];  // kProbeRows bits per position
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t w = tid * 4u; w < 32768u; w += kProbeThreads * 4u)
+    for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) * kProbeWords; w += kProbeThreads * 4u)
         *reinterpret_cast<uint4*>(&T[w]) = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
+    constexpr uint32_t kPosMask = (1u << kProbeOctBits) - 1u;
     for (uint32_t e = it.a_begin + tid; e < it.a_end; e += kProbeThreads) {
         const uint32_t v = elems[e];
-        const uint32_t pos = v & 0xffffu, r = (v >> 16) - it.a0;  // r in 0..15
-        atomicOr(&T[pos >> 1], 1u << (r + 16u * (pos & 1u)));
+        const uint32_t pos = v & kPosMask, r = (v >> 16) - it.a0;  // r in 0 .. kProbeRows - 1
+        atomicOr(&T[pos * kProbeWords + (r >> 5)], 1u << (r & 31u));
     }
     __syncthreads();
-    const uint16_t* T16 = reinterpret_cast<const uint16_t*>(T);  // T16[pos] = mask of the A rows holding pos
+    const uint4* T4 = reinterpret_cast<const uint4*>(T);
     uint32_t count = 0;
-    // near: B rows inside the A group mask off the A rows that are not before them
+    // near: an A row's own elements against the A rows before it
     for (uint32_t e = it.n_begin + tid; e < it.n_end; e += kProbeThreads) {
         const uint32_t v = elems[e];
-        const uint32_t jr = (v >> 16) - it.a0;  // 1..15
-        count += __popc((uint32_t)T16[v & 0xffffu] & ((1u << jr) - 1u));
+        const uint32_t jr = (v >> 16) - it.a0;
+        auto below = [&](uint32_t w) {  // mask of the rows < jr inside word w
+            const uint32_t lo = 32u * w;
+            return jr >= lo + 32u ? 0xffffffffu : jr <= lo ? 0u : (1u << (jr - lo)) - 1u;
+        };
+#pragma unroll
+        for (uint32_t q = 0; q < kProbeWords / 4u; ++q) {
+            const uint4 m = T4[(v & kPosMask) * (kProbeWords / 4u) + q];
+            count += __popc(m.x & below(4u * q)) + __popc(m.y & below(4u * q + 1u)) +
+                     __popc(m.z & below(4u * q + 2u)) + __popc(m.w & below(4u * q + 3u));
+        }
     }
     // far: head up to a 16-byte boundary, body 8 positions per load, tail
-    auto visit2 = [&](uint32_t w) { count += __popc((uint32_t)T16[w & 0xffffu]) + __popc((uint32_t)T16[w >> 16]); };
+    auto visit = [&](uint32_t p) {
+#pragma unroll
+        for (uint32_t q = 0; q < kProbeWords / 4u; ++q) {
+            const uint4 m = T4[(p & kPosMask) * (kProbeWords / 4u) + q];
+            count += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
+        }
+    };
     uint32_t e = it.b_begin;
     const uint32_t head_end = min(it.b_end, (it.b_begin + 7u) & ~7u);
-    if (e + tid < head_end) count += __popc((uint32_t)T16[pos16[e + tid]]);
+    if (e + tid < head_end) visit(pos16[e + tid]);
     e = head_end;
     const uint32_t body_end = e + ((it.b_end - e) & ~7u);
     for (uint32_t q = e + tid * 8u; q < body_end; q += kProbeThreads * 8u) {
         const uint4 v = *reinterpret_cast<const uint4*>(&pos16[q]);
-        visit2(v.x); visit2(v.y); visit2(v.z); visit2(v.w);
+        visit(v.x); visit(v.x >> 16); visit(v.y); visit(v.y >> 16);
+        visit(v.z); visit(v.z >> 16); visit(v.w); visit(v.w >> 16);
     }
-    if (body_end + tid < it.b_end) count += __popc((uint32_t)T16[pos16[body_end + tid]]);
+    if (body_end + tid < it.b_end) visit(pos16[body_end + tid]);
     uint64_t mine = count;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
     if ((tid & 63u) == 0 && mine != 0)
         atomicAdd(&slots[(blockIdx.x * 16u + (tid >> 6)) & (kSlots - 1)], (unsigned long long)mine);
+}
+
+// Pool rows of a probe column from its probe elements (ensure_full_pool): one workgroup per (column, octant)
+// region {first element, end, first pool row of the column, octant}
+__global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __restrict__ pool,
+                                                                const uint32_t* __restrict__ elems,
+                                                                const uint32_t* __restrict__ regions) {
+    const uint32_t e0 = regions[blockIdx.x * 4u + 0], e1 = regions[blockIdx.x * 4u + 1];
+    const uint32_t row0 = regions[blockIdx.x * 4u + 2], oct = regions[blockIdx.x * 4u + 3];
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += kThreads) {
+        const uint32_t v = elems[e];
+        const uint32_t pos = (oct << kProbeOctBits) | (v & ((1u << kProbeOctBits) - 1u));
+        unsigned long long* row = reinterpret_cast<unsigned long long*>(pool + (uint64_t)(row0 + (v >> 16)) * kBlockWords);
+        atomicOr(&row[pos >> 6], 1ull << (pos & 63u));
+    }
 }
 
 template <typename T>
@@ -262,20 +301,44 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     }
     storm_hip_sparse_t* s = new (std::nothrow) storm_hip_sparse_t();
     if (!s) return STORM_HIP_ENOMEM;
+    // Which columns the list-probe kernel (K4) can take: all blocks lists, 2 .. 65535 rows, element offsets
+    // within 32 bits (8 octants x up to 7 elements of alignment each). Their pool rows come LAST in the
+    // layout and are not materialised at all unless a dense pass over them is asked for (sparse_probe = 0,
+    // the popcount variants): a column of short lists costs its listed positions, not 8 KiB per block.
+    std::vector<uint64_t> col_elems((size_t)max_id + 2, 0);
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (block_kind[b] == 0) col_elems[block_id[b]] += block_n[b];
+    std::vector<uint8_t> probe_c((size_t)max_id + 2, 0);
+    {
+        uint64_t total = 0;
+        for (uint32_t c = 0; c <= max_id; ++c) {
+            const uint64_t n_c = per_col[c];
+            if (n_c >= 2 && n_list_col[c] == n_c && n_c <= 65535 && col_elems[c] > 0 &&
+                total + col_elems[c] + 64 < (1ull << 32) - 8) {
+                probe_c[c] = 1;
+                total += col_elems[c] + 64;
+            }
+        }
+    }
     std::vector<uint64_t> start((size_t)max_id + 2, 0);
     uint64_t run = 0;
-    for (uint32_t c = 0; c <= max_id; ++c) {
-        start[c] = run;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (uint32_t c = 0; c <= max_id; ++c)
+            if (per_col[c] && probe_c[c] == pass) {
+                start[c] = run;
+                run = (run + per_col[c] + 511) / 512 * 512;  // next column starts on a 512-row A tile
+            }
+        if (pass == 0) s->pool_rows_ready = run;
+    }
+    for (uint32_t c = 0; c <= max_id; ++c)
         if (per_col[c]) {
-            s->cols.push_back({run, run + per_col[c]});
+            s->cols.push_back({start[c], start[c] + per_col[c]});
             const uint64_t nl = n_list_col[c], nb = per_col[c] - nl;
             s->census[0] += nl * (nl - (nl != 0)) / 2;
             s->census[1] += nl * nb;
             s->census[2] += nb * (nb - (nb != 0)) / 2;
             s->census[3] += 1;
-            run = (run + per_col[c] + 511) / 512 * 512;  // next column starts on a 512-row A tile
         }
-    }
     s->n_pool_rows = run;
     if (s->n_pool_rows >= (1ull << 32) - 512) {
         set_error("sparse_create: block pool too large");
@@ -291,7 +354,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         for (uint64_t b = 0; b < n_blocks; ++b) {
             const uint32_t pr = (uint32_t)next[block_id[b]]++;
             if (block_kind[b] == 0) {
-                if (block_n[b]) {
+                if (block_n[b] && pr < s->pool_rows_ready) {
                     list_row.push_back(pr);
                     list_off.push_back(block_data_offset[b]);
                     list_len.push_back(block_n[b]);
@@ -303,16 +366,11 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
     }
 
-    // ---- probe data (K4): columns whose blocks are all lists, at most 65535 rows, mean list length
-    //      <= kProbeMaxAvgLen (beyond that the dense path is faster anyway: DESIGN.md §4)
+    // ---- probe data (K4): columns whose blocks are all lists and that have at most 65535 rows. Per column
+    //      and octant (8192 positions of the block) the listed positions in row order.
     std::vector<uint32_t> probe_elems;
     {
-        constexpr uint64_t kProbeMaxAvgLen = 1024;
-        std::vector<uint64_t> col_elems((size_t)max_id + 2, 0);
-        for (uint64_t b = 0; b < n_blocks; ++b)
-            if (block_kind[b] == 0) col_elems[block_id[b]] += block_n[b];
         std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
-        std::vector<uint64_t> elem_base((size_t)max_id + 2, 0);
         s->col_probe.assign(s->cols.size(), 0);
         s->col_avg_len.assign(s->cols.size(), 0);
         uint64_t total = 0;
@@ -320,78 +378,102 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         for (uint32_t c = 0; c <= max_id; ++c) {
             if (!per_col[c]) continue;
             col_entry[c] = (int64_t)entry;
-            const uint64_t n_c = per_col[c];
-            if (n_list_col[c] == n_c && n_c >= 2 && n_c <= 65535 && col_elems[c] > 0 &&
-                col_elems[c] <= n_c * kProbeMaxAvgLen && total + col_elems[c] < (1ull << 32) - 8) {
+            if (probe_c[c]) {
                 s->col_probe[entry] = 1;
-                s->col_avg_len[entry] = (uint32_t)(col_elems[c] / n_c);
-                total = (total + 7) & ~7ull;  // columns start on 16-byte boundaries of the uint16 position array
-                elem_base[c] = total;
-                total += col_elems[c];
+                s->col_avg_len[entry] = (uint32_t)(col_elems[c] / per_col[c]);
+                total += col_elems[c] + 64;
             }
             ++entry;
         }
         if (total > 0) {
-            probe_elems.assign((size_t)total + 8, 0);
-            std::vector<uint64_t> cursor(elem_base);
+            // count per (probe column, octant), then lay the octants out one after the other, each on a
+            // 16-byte boundary of the uint16 position array
+            const size_t n_e = s->cols.size();
+            std::vector<uint64_t> oct_count(n_e * kProbeOctants, 0), oct_base(n_e * kProbeOctants, 0);
+            for (uint64_t b = 0; b < n_blocks; ++b) {
+                const int64_t e = col_entry[block_id[b]];
+                if (e < 0 || !s->col_probe[(size_t)e] || block_kind[b] != 0) continue;
+                const uint16_t* l = list_pool + block_data_offset[b];
+                for (uint32_t k = 0; k < block_n[b]; ++k) oct_count[(size_t)e * kProbeOctants + (l[k] >> kProbeOctBits)]++;
+            }
+            uint64_t at = 0;
+            for (size_t i = 0; i < oct_count.size(); ++i) {
+                at = (at + 7) & ~7ull;
+                oct_base[i] = at;
+                at += oct_count[i];
+            }
+            probe_elems.assign((size_t)at + 8, 0);
+            for (size_t i = 0; i < oct_count.size(); ++i)
+                if (oct_count[i])
+                    s->probe_regions.push_back({(uint32_t)oct_base[i], (uint32_t)(oct_base[i] + oct_count[i]),
+                                                (uint32_t)s->cols[i / kProbeOctants].r0, (uint32_t)(i % kProbeOctants)});
+            // rows are visited in order: element offset of every row, per octant
+            std::vector<uint64_t> cursor(oct_base);
             std::vector<uint64_t> next(start);
-            // per probe column: element offset of every row (rows are visited in order)
-            std::vector<std::vector<uint32_t>> row_start(s->cols.size());
-            for (size_t e = 0; e < s->cols.size(); ++e)
-                if (s->col_probe[e]) row_start[e].reserve((size_t)(s->cols[e].r1 - s->cols[e].r0) + 1);
+            std::vector<std::vector<uint32_t>> row_start(n_e * kProbeOctants);
+            for (size_t e = 0; e < n_e; ++e)
+                if (s->col_probe[e])
+                    for (uint32_t o = 0; o < kProbeOctants; ++o)
+                        row_start[e * kProbeOctants + o].reserve((size_t)(s->cols[e].r1 - s->cols[e].r0) + 1);
             for (uint64_t b = 0; b < n_blocks; ++b) {
                 const uint32_t c = block_id[b];
                 const uint64_t local = next[c]++ - start[c];
                 const int64_t e = col_entry[c];
                 if (e < 0 || !s->col_probe[(size_t)e]) continue;
-                row_start[(size_t)e].push_back((uint32_t)cursor[c]);
+                for (uint32_t o = 0; o < kProbeOctants; ++o)
+                    row_start[(size_t)e * kProbeOctants + o].push_back((uint32_t)cursor[(size_t)e * kProbeOctants + o]);
                 const uint16_t* l = list_pool + block_data_offset[b];
-                for (uint32_t k = 0; k < block_n[b]; ++k)
-                    probe_elems[(size_t)cursor[c]++] = ((uint32_t)local << 16) | l[k];
+                for (uint32_t k = 0; k < block_n[b]; ++k) {
+                    const size_t i = (size_t)e * kProbeOctants + (l[k] >> kProbeOctBits);
+                    probe_elems[(size_t)cursor[i]++] = ((uint32_t)local << 16) | (l[k] & ((1u << kProbeOctBits) - 1u));
+                }
             }
-            // chunk size from the far work of all probe columns (rows are visited in order: a group's far
-            // positions are the column's elements behind its last row)
+            // far work of all groups -> positions per item: about 4096 items over all probe columns, between
+            // 2^15 and 2^21 positions each (an item zeroes and scatters its 128 KiB table first)
             uint64_t far_work = 0;
-            for (size_t e = 0; e < s->cols.size(); ++e) {
-                if (!s->col_probe[e] || row_start[e].empty()) continue;
-                const std::vector<uint32_t>& rs = row_start[e];
+            for (size_t i = 0; i < row_start.size(); ++i) {
+                const std::vector<uint32_t>& rs = row_start[i];
+                if (rs.empty()) continue;
                 const uint32_t n_c = (uint32_t)rs.size();
-                uint64_t cnt = 0;
-                for (uint32_t c = 0; c <= max_id; ++c)
-                    if (col_entry[c] == (int64_t)e) { cnt = col_elems[c]; break; }
-                const uint64_t end = rs[0] + cnt;
-                for (uint32_t a0 = 0; a0 + 1 < n_c; a0 += 16) {
-                    const uint32_t a1 = std::min(a0 + 16u, n_c);
+                const uint64_t end = oct_base[i] + oct_count[i];
+                for (uint32_t a0 = 0; a0 < n_c; a0 += kProbeRows) {
+                    const uint32_t a1 = std::min(a0 + kProbeRows, n_c);
                     far_work += end - (a1 < n_c ? rs[a1] : end);
                 }
             }
             const uint32_t kProbeChunk =
-                (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 17, far_work / 1024)) & ~7u;
-            for (size_t e = 0; e < s->cols.size(); ++e) {
-                if (!s->col_probe[e]) continue;
-                std::vector<uint32_t>& rs = row_start[e];
+                (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 15, far_work / 4096)) & ~7u;
+            for (size_t i = 0; i < row_start.size(); ++i) {
+                std::vector<uint32_t>& rs = row_start[i];
+                if (rs.empty()) continue;
                 const uint32_t n_c = (uint32_t)rs.size();
-                rs.push_back(n_c ? rs[0] + 0u : 0u);  // placeholder, fixed below
-                // end offset of the column = start of its first row + its element count
-                uint64_t cnt = 0;
-                for (uint32_t c = 0; c <= max_id; ++c)
-                    if (col_entry[c] == (int64_t)e) { cnt = col_elems[c]; break; }
-                rs[n_c] = rs[0] + (uint32_t)cnt;
-                for (uint32_t a0 = 0; a0 + 1 < n_c; a0 += 16) {
-                    const uint32_t a1 = std::min(a0 + 16u, n_c);
-                    if (rs[a1] == rs[a0]) continue;  // no listed position in the A rows
-                    // first item of the group: the later rows inside it (tagged elements) + the first chunk
-                    // of the rows behind it; further chunks of those follow as items of their own
+                rs.push_back((uint32_t)(oct_base[i] + oct_count[i]));  // end of the octant
+                const uint32_t e = (uint32_t)(i / kProbeOctants);
+                for (uint32_t a0 = 0; a0 < n_c; a0 += kProbeRows) {
+                    const uint32_t a1 = std::min(a0 + kProbeRows, n_c);
+                    if (rs[a1] == rs[a0]) continue;  // no listed position of the A rows in this octant
+                    // first item of the group: the A rows' own elements against the rows before them + the
+                    // first chunk of the rows behind the group; further chunks follow as items of their own
                     bool first = true;
-                    for (uint32_t b0 = rs[a1]; first || b0 < rs[n_c]; b0 += kProbeChunk) {
-                        const uint32_t b1 = std::min(rs[n_c], b0 + kProbeChunk);
-                        const uint32_t n0 = first ? rs[a0 + 1] : 0u, n1 = first ? rs[a1] : 0u;
-                        if (n1 > n0 || b1 > b0)
-                            s->probe_items.push_back({rs[a0], rs[a1], n0, n1, std::min(b0, b1), b1, a0, (uint32_t)e});
+                    for (uint64_t b0 = rs[a1]; first || b0 < rs[n_c]; b0 += kProbeChunk) {
+                        const uint32_t b1 = (uint32_t)std::min<uint64_t>(rs[n_c], b0 + kProbeChunk);
+                        const uint32_t n0 = first ? rs[a0] : 0u, n1 = first ? rs[a1] : 0u;
+                        if (n1 > n0 || b1 > (uint32_t)b0)
+                            s->probe_items.push_back({rs[a0], rs[a1], n0, n1, std::min((uint32_t)b0, b1), b1, a0, e});
                         first = false;
                     }
                 }
             }
+            // longest first: the launch ends on small items. (Dealing the groups of one (column, octant) to one
+            // XCD, neighbours at the same time, so that they share their stream through its L2 — at the denser
+            // loads the kernel fetches 17 GB per launch from HBM, L2 hit rate 9 %, profiles/r03_b_* — was measured
+            // and is slower: 4.42 against 3.67 ms at c4's 20971 draws; an XCD then works through one pair at a
+            // time and idles at every pair's tail.)
+            std::stable_sort(s->probe_items.begin(), s->probe_items.end(),
+                             [](const storm_hip_sparse_s::ProbeItemHost& x, const storm_hip_sparse_s::ProbeItemHost& y) {
+                                 return (uint64_t)(x.b_end - x.b_begin) + (x.n_end - x.n_begin) >
+                                        (uint64_t)(y.b_end - y.b_begin) + (y.n_end - y.n_begin);
+                             });
         }
     }
 
@@ -403,7 +485,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     uint64_t* h_stage = nullptr;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
-        const size_t pool_bytes = (s->n_pool_rows + 512) * kBlockWords * sizeof(uint64_t);
+        const size_t pool_bytes = (s->pool_rows_ready + 512) * kBlockWords * sizeof(uint64_t);
         if (hipMalloc(reinterpret_cast<void**>(&s->d_pool), pool_bytes) != hipSuccess) {
             set_error("sparse_create: hipMalloc of %zu bytes for the block pool failed",
                       pool_bytes);
@@ -495,6 +577,48 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         return rc;
     }
     *out = s;
+    return STORM_HIP_OK;
+}
+
+// The pool rows of the probe columns too (a dense pass over them was asked for): a larger pool, the rows that
+// exist copied over, the lists of the probe columns expanded from their probe elements.
+static int ensure_full_pool(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
+    if (s->pool_rows_ready >= s->n_pool_rows) return STORM_HIP_OK;
+    const size_t old_bytes = (size_t)s->pool_rows_ready * kBlockWords * sizeof(uint64_t);
+    const size_t new_bytes = (size_t)(s->n_pool_rows + 512) * kBlockWords * sizeof(uint64_t);
+    uint64_t* np = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&np), new_bytes) != hipSuccess) {
+        set_error("sparse: hipMalloc of %zu bytes for the pool rows of the list columns failed", new_bytes);
+        return STORM_HIP_ENOMEM;
+    }
+    uint32_t* d_regions = nullptr;
+    int rc = STORM_HIP_OK;
+    do {
+        if (hipMemsetAsync(reinterpret_cast<uint8_t*>(np) + old_bytes, 0, new_bytes - old_bytes, ctx->stream) != hipSuccess ||
+            (old_bytes && hipMemcpyAsync(np, s->d_pool, old_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)) {
+            rc = STORM_HIP_EHIP;
+            break;
+        }
+        if (!s->probe_regions.empty()) {
+            static_assert(sizeof(storm_hip_sparse_s::ProbeRegion) == 16, "four uint32 per region");
+            if ((rc = upload(&d_regions, reinterpret_cast<const uint32_t*>(s->probe_regions.data()),
+                             s->probe_regions.size() * 4, ctx->stream)))
+                break;
+            hipLaunchKernelGGL(expand_probe_kernel, dim3((uint32_t)s->probe_regions.size()), dim3(kThreads), 0,
+                               ctx->stream, np, s->d_probe_elems, d_regions);
+            if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = STORM_HIP_EHIP;
+    } while (0);
+    (void)hipFree(d_regions);
+    if (rc != STORM_HIP_OK) {
+        (void)hipFree(np);
+        if (rc == STORM_HIP_EHIP) set_error("sparse: building the pool rows of the list columns failed");
+        return rc;
+    }
+    (void)hipFree(s->d_pool);
+    s->d_pool = np;
+    s->pool_rows_ready = s->n_pool_rows;
     return STORM_HIP_OK;
 }
 
@@ -640,7 +764,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         std::vector<uint8_t> use_probe(s->cols.size(), 0);
         if (ctx->sparse_probe != 0 && s->d_probe_elems)
             for (size_t e = 0; e < s->cols.size(); ++e)
-                use_probe[e] = s->col_probe[e] && (ctx->sparse_probe > 0 || s->col_avg_len[e] <= 1000u);
+                use_probe[e] = s->col_probe[e];
         {
             uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
             for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;
@@ -678,16 +802,25 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             STORM_HIP_TRY(hipGetLastError());
         }
         std::vector<RowRange> ranges;
+        uint64_t rows_needed = 0;
         for (size_t e = 0; e < s->cols.size(); ++e)
-            if (!use_probe[e] && s->cols[e].r1 - s->cols[e].r0 > 1) ranges.push_back(s->cols[e]);
-        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->n_pool_rows + 512,
-                                              std::max<uint64_t>(s->n_pool_rows, 512), ranges,
+            if (!use_probe[e] && s->cols[e].r1 - s->cols[e].r0 > 1) {
+                ranges.push_back(s->cols[e]);
+                rows_needed = std::max(rows_needed, s->cols[e].r1);
+            }
+        if (rows_needed > s->pool_rows_ready)
+            if (int rc = ensure_full_pool(ctx, s)) return rc;
+        // (only the rows the dense pass multiplies are expanded: the probe columns lie behind them)
+        const uint64_t rows_dst = (rows_needed + 511) / 512 * 512;
+        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->pool_rows_ready + 512,
+                                              std::max<uint64_t>(rows_dst, 512), ranges,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
             return rc;
         ctx->last_info[3] = s->n_probe_cols_launch;  // block columns counted by the list-probe kernel
         return STORM_HIP_OK;
     }
+    if (int rc = ensure_full_pool(ctx, s)) return rc;  // the popcount kernel walks every column's pool rows
     const uint32_t seg_len = (uint32_t)ctx->seg_rows;
     if (!s->d_segs || s->seg_rank != shard_rank || s->seg_count != shard_count ||
         s->seg_len != seg_len) {

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Roofline summary of the list-probe kernel (K4) from the outputs of tools/profile_sparse.sh.
+
+Unit of work: one streamed position = one 2-byte read from L2 (the element arrays stay in the XCD's L2) + one
+16-byte LDS lookup (128 A rows at once) + 4 popcounts. Roofs per MI355X_MICROARCH.md: LDS 128 B/clk/CU =
+8 lookups/clk/CU x 256 CUs; clock taken as 2.4 GHz (spec peak). Algorithmic lookups for the synthetic c4
+container: per block column E = N x u listed positions (u = 65536 (1 - exp(-d / 65536)) unique positions per
+block of d = load / 8 draws), N / 128 groups of A rows, every group meets the positions of the rows behind it
+(far) and its own rows' positions (near)."""
+import csv
+import glob
+import json
+import math
+import os
+import sys
+
+N, BLOCKS, ROWS_PER_ITEM = 10000, 8, 128
+LDS_LOOKUPS_PER_CLK_CU, CUS, CLK = 8, 256, 2.4e9
+
+
+def counters(path):
+    acc = {}
+    for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "probe_lists_kernel" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def kernel_us(path):
+    for f in glob.glob(path + "/**/*kernel_stats.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "probe_lists_kernel" in r["Name"]:
+                return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    return None, 0
+
+
+def main():
+    out = sys.argv[1]
+    wall = {}
+    for l in open(os.path.join(out, "wall.jsonl")):
+        if l.startswith("{"):
+            d = json.loads(l)
+            wall[d["load"]] = d
+    print("load  mean_len  dense_ms  probe_ms  | kernel_us  lookups      lookups/s   frac of LDS roof | L2 hit  "
+          "L2 req B/launch  alg B/launch  HBM fetch B | LDS insts  bank-conflict/active  wait_lds/wave")
+    roof = LDS_LOOKUPS_PER_CLK_CU * CUS * CLK
+    for load in sorted(wall):
+        d = load / BLOCKS
+        u = 65536.0 * (1.0 - math.exp(-d / 65536.0))
+        e_col = N * u
+        groups = (N + ROWS_PER_ITEM - 1) // ROWS_PER_ITEM
+        far = sum(e_col * max(0, N - (g + 1) * ROWS_PER_ITEM) / N for g in range(groups))
+        lookups = BLOCKS * (far + e_col)
+        us, calls = kernel_us(os.path.join(out, f"trace_{load}"))
+        w = wall[load]
+        line = f"{load:6d} {u:8.0f} {w['dense_ms']:9.3f} {w['probe_ms']:9.3f}  |"
+        if us:
+            rate = lookups / (us * 1e-6)
+            line += f" {us:9.1f}  {lookups:11.3e}  {rate:10.3e}  {rate / roof:8.3f}        |"
+            sq = counters(os.path.join(out, f"sq_{load}"))
+            tcc = counters(os.path.join(out, f"tcc_{load}"))
+            fetch = counters(os.path.join(out, f"fetch_{load}"))
+            if tcc:
+                hit, miss, req = tcc.get("TCC_HIT_sum", 0), tcc.get("TCC_MISS_sum", 0), tcc.get("TCC_REQ_sum", 0)
+                line += f" {hit / max(hit + miss, 1):6.3f}  {req * 128:14.3e}  {BLOCKS * far * 2:11.3e}"
+            if fetch:
+                line += f"  {fetch.get('FETCH_SIZE', 0) * 1024 * 2:10.3e} |"   # KiB units; x2 on gfx950 (16 B/lane streams)
+            if sq:
+                line += (f" {sq.get('SQ_INSTS_LDS', 0):9.3e}  {sq.get('SQ_LDS_BANK_CONFLICT', 0) / max(sq.get('SQ_LDS_IDX_ACTIVE', 1), 1):8.3f}"
+                         f"  {sq.get('SQ_WAIT_INST_LDS', 0) / max(sq.get('SQ_WAVE_CYCLES', 1), 1):8.3f}")
+        print(line)
+    print(f"# LDS roof: {LDS_LOOKUPS_PER_CLK_CU} sixteen-byte lookups/clk/CU x {CUS} CUs x {CLK / 1e9} GHz = {roof:.3e} lookups/s")
+
+
+if __name__ == "__main__":
+    main()
