@@ -162,7 +162,11 @@ namespace storm {
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total);
 struct RowRange {
-    uint64_t r0, r1;  // rows [r0, r1) form one all-pairs problem; r0 is a multiple of the A tile (256; 512 for wide strips)
+    uint64_t r0, r1;     // rows [r0, r1) form one all-pairs problem; r0 is a multiple of the A tile (256; 512 for wide strips)
+    uint64_t a_end = 0;  // 0: the whole triangle. Otherwise only the pairs with the EARLIER row below a_end (a
+                         // multiple of the A tile from r0, or >= r1): the rows [r0, a_end) among themselves and
+                         // against everything behind them — a block column's bitmap rows, with its list rows,
+                         // which the list-probe kernel pairs with each other, behind them
 };
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,

@@ -2559,6 +2559,7 @@ static uint64_t ranges_hash(const std::vector<RowRange>& ranges) {
     for (const RowRange& r : ranges) {
         h = (h ^ r.r0) * 1099511628211ull;
         h = (h ^ r.r1) * 1099511628211ull;
+        h = (h ^ r.a_end) * 1099511628211ull;
     }
     return h;
 }
@@ -2577,9 +2578,11 @@ static int ensure_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& range
     for (const RowRange& rg : ranges) {
         const uint32_t b0 = (uint32_t)(rg.r0 / kTile);
         const uint32_t nT = (uint32_t)((rg.r1 - rg.r0 + kTile - 1) / kTile);
-        for (uint32_t gi = 0; gi < nT; gi += 4)
+        // (a_end: only the tile rows below it)
+        const uint32_t nTa = rg.a_end ? (uint32_t)std::min<uint64_t>(nT, (std::min(rg.a_end, rg.r1) - rg.r0 + kTile - 1) / kTile) : nT;
+        for (uint32_t gi = 0; gi < nTa; gi += 4)
             for (uint32_t gj = gi / 8 * 8; gj < nT; gj += 8)
-                for (uint32_t i = gi; i < std::min(gi + 4, nT); ++i)
+                for (uint32_t i = gi; i < std::min(gi + 4, nTa); ++i)
                     for (uint32_t j = std::max(gj, i); j < std::min(gj + 8, nT); ++j)
                         if (!diag_only || i == j)
                             tiles.emplace_back((uint16_t)(b0 + i), (uint16_t)(b0 + j));
@@ -2690,7 +2693,8 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
         for (const RowRange& rg : ranges) {
             // A tiles of a_tile rows from the start of the range (the rows between r1 and
             // the end of its last A tile are zero: the caller pads ranges accordingly)
-            const uint32_t nA = (uint32_t)((rg.r1 - rg.r0 + a_tile - 1) / a_tile);
+            const uint64_t a_rows = (rg.a_end ? std::min(rg.a_end, rg.r1) : rg.r1) - rg.r0;  // A tiles only below a_end
+            const uint32_t nA = (uint32_t)((a_rows + a_tile - 1) / a_tile);
             const uint32_t jend = (uint32_t)((rg.r1 + kStripBRows - 1) / kStripBRows);  // absolute
             for (uint32_t i = 0; i < nA; ++i) {
                 const uint32_t a_row0 = (uint32_t)rg.r0 + i * a_tile;

@@ -35,7 +35,9 @@ struct storm_hip_sparse_s {
                                      // is a multiple of 512 and the gap up to it is zero rows
     uint64_t census[4] = {0, 0, 0, 0};
     // list-probe path (K4): columns whose blocks are all short lists
-    std::vector<uint8_t> col_probe;  // per entry of `cols`: 1 = has probe data
+    std::vector<uint64_t> col_list0; // per entry of `cols`: first pool row of the column's LIST blocks (its bitmap
+                                     // blocks come first, the lists on the next multiple of 512 rows)
+    std::vector<uint8_t> col_probe;  // per entry of `cols`: 1 = has probe data (its list blocks among themselves)
     std::vector<uint32_t> col_avg_len;  // per entry of `cols`: mean list length (probe columns)
     uint32_t* d_probe_elems = nullptr;  // (row in column) << 16 | position in block, column by column, row order
     uint16_t* d_probe_pos16 = nullptr;  // the positions alone, same indexing
@@ -312,27 +314,36 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     {
         uint64_t total = 0;
         for (uint32_t c = 0; c <= max_id; ++c) {
-            const uint64_t n_c = per_col[c];
-            if (n_c >= 2 && n_list_col[c] == n_c && n_c <= 65535 && col_elems[c] > 0 &&
-                total + col_elems[c] + 64 < (1ull << 32) - 8) {
+            const uint64_t n_l = n_list_col[c];
+            if (n_l >= 2 && n_l <= 65535 && col_elems[c] > 0 && total + col_elems[c] + 64 < (1ull << 32) - 8) {
                 probe_c[c] = 1;
                 total += col_elems[c] + 64;
             }
         }
     }
-    std::vector<uint64_t> start((size_t)max_id + 2, 0);
+    // Layout of a column: its bitmap blocks, then — on the next multiple of 512 rows — its list blocks (the kind
+    // dispatch of storm.c:618-656, once per block: list x list pairs go to the probe kernel, every pair with a
+    // bitmap block to the matrix cores, which then need the bitmap rows alone as A rows). Columns made of lists
+    // only come last: they need no pool rows at all.
+    std::vector<uint64_t> start((size_t)max_id + 2, 0), list0((size_t)max_id + 2, 0), col_end((size_t)max_id + 2, 0);
     uint64_t run = 0;
     for (int pass = 0; pass < 2; ++pass) {
-        for (uint32_t c = 0; c <= max_id; ++c)
-            if (per_col[c] && probe_c[c] == pass) {
+        for (uint32_t c = 0; c <= max_id; ++c) {
+            const bool lists_only = probe_c[c] && n_list_col[c] == per_col[c];
+            if (per_col[c] && (int)lists_only == pass) {
+                const uint64_t n_b = per_col[c] - n_list_col[c];
                 start[c] = run;
-                run = (run + per_col[c] + 511) / 512 * 512;  // next column starts on a 512-row A tile
+                list0[c] = n_b && n_list_col[c] ? (run + n_b + 511) / 512 * 512 : run + n_b;
+                col_end[c] = list0[c] + n_list_col[c];
+                run = (col_end[c] + 511) / 512 * 512;  // next column starts on a 512-row A tile
             }
+        }
         if (pass == 0) s->pool_rows_ready = run;
     }
     for (uint32_t c = 0; c <= max_id; ++c)
         if (per_col[c]) {
-            s->cols.push_back({start[c], start[c] + per_col[c]});
+            s->cols.push_back({start[c], col_end[c]});
+            s->col_list0.push_back(list0[c]);
             const uint64_t nl = n_list_col[c], nb = per_col[c] - nl;
             s->census[0] += nl * (nl - (nl != 0)) / 2;
             s->census[1] += nl * nb;
@@ -350,9 +361,9 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     std::vector<uint32_t> list_row, dense_row, list_len;
     std::vector<uint64_t> list_off, dense_src;
     {
-        std::vector<uint64_t> next(start);
+        std::vector<uint64_t> next_bitmap(start), next_list(list0);
         for (uint64_t b = 0; b < n_blocks; ++b) {
-            const uint32_t pr = (uint32_t)next[block_id[b]]++;
+            const uint32_t pr = (uint32_t)(block_kind[b] == 0 ? next_list[block_id[b]]++ : next_bitmap[block_id[b]]++);
             if (block_kind[b] == 0) {
                 if (block_n[b] && pr < s->pool_rows_ready) {
                     list_row.push_back(pr);
@@ -380,7 +391,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             col_entry[c] = (int64_t)entry;
             if (probe_c[c]) {
                 s->col_probe[entry] = 1;
-                s->col_avg_len[entry] = (uint32_t)(col_elems[c] / per_col[c]);
+                s->col_avg_len[entry] = (uint32_t)(col_elems[c] / n_list_col[c]);
                 total += col_elems[c] + 64;
             }
             ++entry;
@@ -406,18 +417,19 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             for (size_t i = 0; i < oct_count.size(); ++i)
                 if (oct_count[i])
                     s->probe_regions.push_back({(uint32_t)oct_base[i], (uint32_t)(oct_base[i] + oct_count[i]),
-                                                (uint32_t)s->cols[i / kProbeOctants].r0, (uint32_t)(i % kProbeOctants)});
+                                                (uint32_t)s->col_list0[i / kProbeOctants], (uint32_t)(i % kProbeOctants)});
             // rows are visited in order: element offset of every row, per octant
             std::vector<uint64_t> cursor(oct_base);
-            std::vector<uint64_t> next(start);
+            std::vector<uint64_t> next((size_t)max_id + 2, 0);  // list blocks of the column seen so far
             std::vector<std::vector<uint32_t>> row_start(n_e * kProbeOctants);
             for (size_t e = 0; e < n_e; ++e)
                 if (s->col_probe[e])
                     for (uint32_t o = 0; o < kProbeOctants; ++o)
-                        row_start[e * kProbeOctants + o].reserve((size_t)(s->cols[e].r1 - s->cols[e].r0) + 1);
+                        row_start[e * kProbeOctants + o].reserve((size_t)(s->cols[e].r1 - s->col_list0[e]) + 1);
             for (uint64_t b = 0; b < n_blocks; ++b) {
                 const uint32_t c = block_id[b];
-                const uint64_t local = next[c]++ - start[c];
+                if (block_kind[b] != 0) continue;
+                const uint64_t local = next[c]++;
                 const int64_t e = col_entry[c];
                 if (e < 0 || !s->col_probe[(size_t)e]) continue;
                 for (uint32_t o = 0; o < kProbeOctants; ++o)
@@ -803,11 +815,19 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         }
         std::vector<RowRange> ranges;
         uint64_t rows_needed = 0;
-        for (size_t e = 0; e < s->cols.size(); ++e)
-            if (!use_probe[e] && s->cols[e].r1 - s->cols[e].r0 > 1) {
-                ranges.push_back(s->cols[e]);
-                rows_needed = std::max(rows_needed, s->cols[e].r1);
+        for (size_t e = 0; e < s->cols.size(); ++e) {
+            RowRange rg = s->cols[e];
+            if (use_probe[e]) {
+                // the list blocks pair with each other in the probe kernel: the matrix cores take the pairs with a
+                // bitmap block — the column's bitmap rows as A rows, against each other and the lists behind them
+                if (s->col_list0[e] == rg.r0) continue;  // no bitmap block
+                rg.a_end = s->col_list0[e];
             }
+            if (rg.r1 - rg.r0 > 1) {
+                ranges.push_back(rg);
+                rows_needed = std::max(rows_needed, rg.r1);
+            }
+        }
         if (rows_needed > s->pool_rows_ready)
             if (int rc = ensure_full_pool(ctx, s)) return rc;
         // (only the rows the dense pass multiplies are expanded: the probe columns lie behind them)

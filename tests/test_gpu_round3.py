@@ -117,3 +117,47 @@ def test_stream_kernel_at_full_mid_sizes_against_the_column_identity(hip_ctx):
         assert [m.pairw() for _ in range(5)] == [want] * 5, N
         assert hip_ctx.get_option("k2_operands_used") == 2
         m.close()
+
+
+def test_block_columns_of_mixed_kinds_split_per_block(orc):
+    """The reference dispatches per BLOCK PAIR on the kinds of the two blocks (storm.c:618-656). Here a block
+    column's list blocks pair with each other in the list-probe kernel, and every pair with a bitmap block goes
+    to the matrix cores (the column's bitmap rows as A rows, with the lists behind them): mostly short lists
+    with a few bitmap blocks among them no longer cost a dense pass over the whole column. Rows of three
+    densities in every order, several block columns, against the oracle's STORM_t restatement (intended
+    semantics, defect D1 not reproduced) and the dense-everything setting."""
+    import ctypes as C
+    lib = sb.load()
+    M = 3 * 65536 + 1000
+    rng = np.random.default_rng(11)
+    for n_rows, kinds in ((300, (40, 5000, 30000)), (700, (3, 3, 20000, 200)), (130, (30000, 2)), (513, (1, 60000, 700))):
+        rows = []
+        for r in range(n_rows):
+            d = kinds[int(rng.integers(0, len(kinds)))]
+            rows.append(np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32))
+        rows[n_rows // 3] = np.zeros(0, dtype=np.uint32)     # an empty row
+        s = sb.Storm()
+        for r in rows:
+            s.add(r)
+        want = orc.storm(rows).pairw_blocked(0)
+        got = s.pairw_intersect_cardinality_blocked(0)
+        assert got == want, (n_rows, kinds, got, want)
+        data = s.serialize()
+        ctx = sb.HipContext(0)
+        h = C.c_void_p()
+        assert lib.storm_hip_sparse_create_serialized(ctx._h, data.ctypes.data_as(C.c_void_p), data.size, C.byref(h)) == 0
+        out = C.c_uint64()
+        for probe in (-1, 0, 1):
+            ctx.set_option("sparse_probe", probe)
+            for world in (1, 3):
+                tot = 0
+                for r in range(world):
+                    assert lib.storm_hip_pairw_sparse(ctx._h, h, r, world, C.byref(out)) == 0
+                    tot += out.value
+                assert tot == want, (n_rows, kinds, probe, world, tot, want)
+        census = (C.c_uint64 * 4)()
+        assert lib.storm_hip_sparse_last_census(ctx._h, C.byref(census)) == 0
+        assert census[1] > 0            # list x bitmap block pairs exist: the columns are mixed
+        lib.storm_hip_sparse_destroy(ctx._h, h)
+        ctx.close()
+        s.free()
