@@ -264,6 +264,14 @@ int STORM_hip_invalidate(STORM_t* bitmap);
 int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
 const char* STORM_hip_error(void);
+/* Threading. Like the reference (no locks anywhere in storm.c), a HANDLE is not thread-safe: one thread at a
+ * time per STORM_t / STORM_contiguous_t. The process-wide device state behind the handles (contexts, the
+ * device selection above) is set up on first use and by the two setters: call those while no other thread is
+ * inside the library. The raw-buffer wrappers (STORM_wrapper_*) share one cached device matrix per GPU and
+ * take a lock: concurrent calls are safe and run one after the other.
+ * STORM_hip_shutdown(): releases the wrappers' cached device matrices and every device context (handles that
+ * still hold device copies re-create them on their next all-pairs call). Returns 0. */
+int STORM_hip_shutdown(void);
 
 #ifdef __cplusplus
 }

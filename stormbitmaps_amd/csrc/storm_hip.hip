@@ -583,6 +583,7 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+    if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
     for (hipEvent_t ev : ctx->kernel_events) (void)hipEventDestroy(ev);
@@ -1166,6 +1167,18 @@ int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stri
     return STORM_HIP_OK;
 }
 
+// The context's result word to the host, through a pinned word (a pageable destination makes the runtime stage
+// the 8 bytes and costs a call ~10 us more; with G devices driven from one process that is G times).
+int fetch_result_word(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    if (!ctx->h_scalar &&
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalar), 64, hipHostMallocDefault) != hipSuccess)
+        ctx->h_scalar = nullptr;
+    unsigned long long* dst = ctx->h_scalar ? ctx->h_scalar : reinterpret_cast<unsigned long long*>(h_total);
+    STORM_HIP_TRY(hipMemcpyAsync(dst, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_scalar) *h_total = *ctx->h_scalar;
+    return STORM_HIP_OK;
+}
 }  // namespace storm
 
 extern "C" {
@@ -1217,10 +1230,7 @@ int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return STORM_HIP_OK;
+    return fetch_result_word(ctx, h_total);
 }
 
 int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,

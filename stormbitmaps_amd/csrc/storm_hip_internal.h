@@ -80,6 +80,7 @@ struct storm_hip_ctx_s {
     // workspace
     unsigned long long* d_slots = nullptr;   // kSlots partial sums
     unsigned long long* d_scalar = nullptr;  // one uint64 result
+    unsigned long long* h_scalar = nullptr;  // pinned host word the result is read back through
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
     size_t segs_capacity = 0;
     // cache key of d_segs
@@ -182,6 +183,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                          const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld);
 int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_counts);
 void release_mfma_state(storm_hip_ctx_t* ctx);
+// ctx->d_scalar -> *h_total through the context's pinned word; synchronises the stream (storm_hip.hip)
+int fetch_result_word(storm_hip_ctx_t* ctx, uint64_t* h_total);
 // folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
 // record the next event of the "time_kernels" series on the launch stream (no-op when off)

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <memory>
 
 using namespace storm;
 
@@ -301,7 +302,14 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         per_col[block_id[b]]++;
         if (block_kind[b] == 0) n_list_col[block_id[b]]++;
     }
-    storm_hip_sparse_t* s = new (std::nothrow) storm_hip_sparse_t();
+    // owned here until it is handed to the caller: a std::vector below may throw (guarded() turns that into
+    // ENOMEM) and every early return must release the arena and its device buffers
+    struct ArenaDeleter {
+        storm_hip_ctx_t* ctx;
+        void operator()(storm_hip_sparse_t* a) const { storm_hip_sparse_destroy(ctx, a); }
+    };
+    std::unique_ptr<storm_hip_sparse_t, ArenaDeleter> owner(new (std::nothrow) storm_hip_sparse_t(), ArenaDeleter{ctx});
+    storm_hip_sparse_t* s = owner.get();
     if (!s) return STORM_HIP_ENOMEM;
     // Which columns the list-probe kernel (K4) can take: all blocks lists, 2 .. 65535 rows, element offsets
     // within 32 bits (8 octants x up to 7 elements of alignment each). Their pool rows come LAST in the
@@ -353,7 +361,6 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     s->n_pool_rows = run;
     if (s->n_pool_rows >= (1ull << 32) - 512) {
         set_error("sparse_create: block pool too large");
-        delete s;
         return STORM_HIP_EINVAL;
     }
 
@@ -584,11 +591,8 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     (void)hipFree(d_lrow); (void)hipFree(d_loff); (void)hipFree(d_llen); (void)hipFree(d_lists);
     (void)hipFree(d_stage); (void)hipFree(d_drow);
     free(h_stage);
-    if (rc != STORM_HIP_OK) {
-        storm_hip_sparse_destroy(ctx, s);
-        return rc;
-    }
-    *out = s;
+    if (rc != STORM_HIP_OK) return rc;
+    *out = owner.release();
     return STORM_HIP_OK;
 }
 
@@ -668,6 +672,9 @@ int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, ui
         const char* bad = "sparse_create_serialized: truncated or malformed stream";
         if (n_bytes < 8 || (n_bytes & 1) || u32_at(4) != kSerialMagic) { set_error("%s", bad); return STORM_HIP_EINVAL; }
         const uint64_t n_rows = u32_at(0);
+        // (same validity rules as STORM_deserialize, storm_host.c) a row costs at least its 12 header bytes:
+        // the row count is bounded by the stream before it sizes anything
+        if (n_rows > (n_bytes - 8) / 12) { set_error("%s", bad); return STORM_HIP_EINVAL; }
         std::vector<uint64_t> row_off(n_rows + 1, 0), offs;
         std::vector<uint32_t> ids, lens;
         std::vector<uint8_t> kinds;
@@ -677,17 +684,28 @@ int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, ui
             const uint32_t nb = u32_at(at);
             at += 12;
             if (at + 4ull * nb > n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
-            at += 4ull * nb;  // block_ids[] (repeated in the block headers)
+            const uint64_t ids_at = at;  // block_ids[] (repeated in the block headers)
+            at += 4ull * nb;
             for (uint32_t b = 0; b < nb; ++b) {
                 if (at + 16 > n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
-                const uint32_t n_bitmap = u32_at(at) & 0x3fffffffu;
+                const uint32_t n_bitmap = u32_at(at), n_bits_set = u32_at(at + 4);
                 const uint32_t w2 = u32_at(at + 8), id = u32_at(at + 12);
                 const uint32_t n_scalar = w2 & 0x7fffffffu, has_list = w2 >> 31;
                 at += 16;
                 const uint64_t words = 8ull * n_bitmap, list = has_list ? 2ull * n_scalar : 0;
-                if ((n_bitmap != 0 && n_bitmap != kBlockWords) || at + words + list > n_bytes) {
+                if ((n_bitmap != 0 && n_bitmap != kBlockWords) || n_scalar > 65536u ||
+                    id != u32_at(ids_at + 4ull * b) || (b && id <= u32_at(ids_at + 4ull * (b - 1))) ||
+                    at + words + list > n_bytes || (!n_bitmap && has_list && n_bits_set != n_scalar)) {
                     set_error("%s", bad);
                     return STORM_HIP_EINVAL;
+                }
+                if (!n_bitmap && has_list) {  // a list is strictly ascending: the probe kernel counts every element
+                    const uint8_t* l = p + at + words;
+                    uint16_t prev = 0, cur = 0;
+                    for (uint32_t k = 0; k < n_scalar; ++k, prev = cur) {
+                        memcpy(&cur, l + 2ull * k, 2);
+                        if (k && cur <= prev) { set_error("%s", bad); return STORM_HIP_EINVAL; }
+                    }
                 }
                 ids.push_back(id);
                 if (n_bitmap) {  // bitmap kind (storm.c:745-749: a block is one kind or the other)
@@ -729,10 +747,7 @@ int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return STORM_HIP_OK;
+    return fetch_result_word(ctx, h_total);
 }
 
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* cs,

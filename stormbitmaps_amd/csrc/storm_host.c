@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 #include "storm.h"
+#include <pthread.h>
+
 #include "storm_hip.h"
 
 #define BLOCK_BITS ((uint32_t)STORM_DEFAULT_BLOCK_SIZE)
@@ -48,8 +50,11 @@ static void device_error(const char* where) {
     fprintf(stderr, "[storm_hip] %s: %s\n", where, storm_hip_last_error());
 }
 
+static void wrapper_states_release(void);
+
 int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     if (n_devices < 1 || n_devices > MAX_DEVICES || !device_ids) return -1;
+    wrapper_states_release(); /* their matrices live on the contexts that go away here */
     for (int d = 0; d < MAX_DEVICES; ++d) {
         if (g_ctx[d]) storm_hip_ctx_destroy(g_ctx[d]);
         g_ctx[d] = NULL;
@@ -112,6 +117,111 @@ static storm_hip_ctx_t* device_ctx(int slot) {
         }
     }
     return g_ctx[slot];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One worker thread per configured device beyond the first (created on the first multi-device call, parked
+ * on a condition variable): a pass over G devices is G launches + G result reads, and issued one after the
+ * other from the caller's thread they cost the host more than a 1/8 shard of the headline pass takes the GPUs
+ * (a shard: ~118 us; eight launch + read-back rounds in a row: ~300 us). The caller's thread drives slot 0.
+ * ---------------------------------------------------------------------------------------- */
+typedef int (*slot_fn)(int slot, int phase, void* arg); /* phase 0: launch, 1: fetch the result */
+static struct {
+    pthread_t th[MAX_DEVICES];
+    int started[MAX_DEVICES];
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+    uint64_t generation;
+    int pending, n_slots;
+    slot_fn fn;
+    void* arg;
+    int rc[MAX_DEVICES];
+    char err[MAX_DEVICES][256];
+} g_pool = {.mu = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER};
+
+static void* pool_main(void* p) {
+    const int slot = (int)(intptr_t)p;
+    uint64_t seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&g_pool.mu);
+        while (g_pool.generation == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+        seen = g_pool.generation;
+        const slot_fn fn = g_pool.fn;
+        void* const arg = g_pool.arg;
+        const int mine = slot < g_pool.n_slots;
+        pthread_mutex_unlock(&g_pool.mu);
+        if (!mine) continue;
+        int rc = fn(slot, 0, arg);
+        if (!rc) rc = fn(slot, 1, arg);
+        if (rc) snprintf(g_pool.err[slot], sizeof(g_pool.err[slot]), "%s", storm_hip_last_error());
+        pthread_mutex_lock(&g_pool.mu);
+        g_pool.rc[slot] = rc;
+        if (--g_pool.pending == 0) pthread_cond_signal(&g_pool.done);
+        pthread_mutex_unlock(&g_pool.mu);
+    }
+    return NULL;
+}
+
+/* Threads only pay when the slots are different GPUs: the HIP runtime serialises calls to ONE device, and the
+ * same ordinal configured several times (a rehearsal on one card) is faster driven from one thread (measured,
+ * tools/bench_inprocess.py: 246 against 324 us per call for 8 contexts on one MI355X).
+ * STORM_HIP_HOST_THREADS=0 / 1 overrides. */
+static int use_host_threads(void) {
+    const char* e = getenv("STORM_HIP_HOST_THREADS");
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    for (int a = 0; a < g_n_devices; ++a)
+        for (int b = a + 1; b < g_n_devices; ++b)
+            if (g_device_ids[a] == g_device_ids[b]) return 0;
+    return 1;
+}
+
+/* fn(slot, launch) then fn(slot, fetch) on every configured device; 0 if all returned 0 */
+static int run_on_devices(slot_fn fn, void* arg, const char* what) {
+    const int n = g_n_devices;
+    int rc0 = 0, threads = n > 1 && use_host_threads();
+    for (int d = 1; threads && d < n; ++d)
+        if (!g_pool.started[d]) {
+            if (pthread_create(&g_pool.th[d], NULL, pool_main, (void*)(intptr_t)d) != 0) {
+                threads = 0;
+            } else {
+                pthread_detach(g_pool.th[d]);
+                g_pool.started[d] = 1;
+            }
+        }
+    if (!threads) { /* one thread: every device launched before the first result is waited for */
+        int launched = 0;
+        for (int k = 0; k < n && !rc0; ++k) {
+            rc0 = fn(k, 0, arg);
+            if (!rc0) launched = k + 1;
+        }
+        for (int k = 0; k < launched; ++k) {
+            const int r = fn(k, 1, arg);
+            if (r && !rc0) rc0 = r;
+        }
+        if (rc0) device_error(what);
+        return rc0;
+    }
+    pthread_mutex_lock(&g_pool.mu);
+    g_pool.fn = fn;
+    g_pool.arg = arg;
+    g_pool.n_slots = n;
+    g_pool.pending = n - 1;
+    ++g_pool.generation;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.mu);
+    rc0 = fn(0, 0, arg);
+    if (!rc0) rc0 = fn(0, 1, arg);
+    if (rc0) device_error(what);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.pending > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    for (int d = 1; d < n; ++d)
+        if (g_pool.rc[d]) {
+            g_host_error[0] = '\0';
+            fprintf(stderr, "[storm_hip] %s (device slot %d): %s\n", what, d, g_pool.err[d]);
+            if (!rc0) rc0 = g_pool.rc[d];
+        }
+    return rc0;
 }
 
 /* a STORM_compute_func is only an identity token on the device path (libalgebra.h) */
@@ -229,25 +339,27 @@ static void dense_state_release(dense_state_t* st) {
     }
 }
 
-/* all configured devices work concurrently on disjoint shards; the host adds the partials */
-static uint64_t dense_state_pairw(dense_state_t* st) {
+/* all configured devices work concurrently on disjoint shards (one host thread each); the host adds the partials */
+typedef struct {
+    dense_state_t* st;
+    uint64_t part[MAX_DEVICES];
+} dense_job_t;
+
+static int dense_job(int d, int phase, void* arg) {
+    dense_job_t* j = (dense_job_t*)arg;
     const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
-    for (int d = 0; d < g_n_devices; ++d) {
-        const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
-        if (storm_hip_pairw_dense_begin(g_ctx[d], st->m[d], rank, world) != STORM_HIP_OK) {
-            device_error("storm_hip_pairw_dense_begin");
-            return ALL_PAIRS_FAILED;
-        }
-    }
+    const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+    return phase == 0 ? storm_hip_pairw_dense_begin(g_ctx[d], j->st->m[d], rank, world)
+                      : storm_hip_pairw_dense_end(g_ctx[d], &j->part[d]);
+}
+
+static uint64_t dense_state_pairw(dense_state_t* st) {
+    dense_job_t j;
+    j.st = st;
+    memset(j.part, 0, sizeof(j.part));
+    if (run_on_devices(dense_job, &j, "all-pairs pass (dense)")) return ALL_PAIRS_FAILED;
     uint64_t total = 0;
-    for (int d = 0; d < g_n_devices; ++d) {
-        uint64_t part = 0;
-        if (storm_hip_pairw_dense_end(g_ctx[d], &part) != STORM_HIP_OK) {
-            device_error("storm_hip_pairw_dense_end");
-            return ALL_PAIRS_FAILED;
-        }
-        total += part;
-    }
+    for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
     return total;
 }
 
@@ -256,6 +368,9 @@ static uint64_t dense_state_pairw(dense_state_t* st) {
  * (a hipMalloc + zero fill + hipFree of the matrix per call cost more than the copy at small sizes). */
 static dense_state_t g_wrapper_state;
 static uint32_t g_wrapper_words = 0;
+static pthread_mutex_t g_wrapper_mu = PTHREAD_MUTEX_INITIALIZER; /* the wrappers' cached matrices */
+
+static uint64_t raw_pairw_locked(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints);
 
 static uint64_t raw_pairw(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints) {
     if (n_vectors < 2 || n_ints == 0) return 0;
@@ -263,6 +378,13 @@ static uint64_t raw_pairw(uint32_t n_vectors, const uint64_t* vals, uint32_t n_i
         host_error("all-pairs wrapper: NULL buffer");
         return ALL_PAIRS_FAILED;
     }
+    pthread_mutex_lock(&g_wrapper_mu);
+    const uint64_t total = raw_pairw_locked(n_vectors, vals, n_ints);
+    pthread_mutex_unlock(&g_wrapper_mu);
+    return total;
+}
+
+static uint64_t raw_pairw_locked(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints) {
     configure_from_env();
     dense_state_t* st = &g_wrapper_state;
     if (st->config_generation != g_config_generation || g_wrapper_words != n_ints) {
@@ -366,7 +488,42 @@ uint64_t STORM_wrapper_diag_list_blocked(const uint32_t n_vectors,
                                    f, fl, cutoff);
 }
 
-/* reference storm.c:153-171 (rectangle; device 0 only) */
+/* reference storm.c:153-171 (rectangle A x B^T; the reference never resets its second offset, :164-168 — the
+ * intended sum over all (row of A, row of B) is computed). The rows of A are dealt to the configured devices in
+ * equal parts, B goes to every one of them; the device matrices are kept between calls like the other
+ * wrappers' (resized and re-uploaded: the caller's buffers are new every time). */
+static dense_state_t g_square_a, g_square_b;
+static uint32_t g_square_words = 0;
+
+typedef struct {
+    const uint64_t *vals1, *vals2;
+    uint32_t n1, n2, n_ints;
+    uint64_t part[MAX_DEVICES];
+} square_job_t;
+
+static void square_rows(const square_job_t* j, int d, uint32_t* r0, uint32_t* r1) {
+    *r0 = (uint32_t)((uint64_t)j->n1 * (uint32_t)d / (uint32_t)g_n_devices);
+    *r1 = (uint32_t)((uint64_t)j->n1 * ((uint32_t)d + 1u) / (uint32_t)g_n_devices);
+}
+
+static int square_job(int d, int phase, void* arg) {
+    square_job_t* j = (square_job_t*)arg;
+    uint32_t r0, r1;
+    square_rows(j, d, &r0, &r1);
+    if (phase == 1 || r1 == r0) return STORM_HIP_OK;
+    storm_hip_ctx_t* ctx = g_ctx[d];
+    int rc;
+    if (!g_square_a.m[d] && (rc = storm_hip_matrix_create(ctx, r1 - r0, j->n_ints, &g_square_a.m[d]))) return rc;
+    if (!g_square_b.m[d] && (rc = storm_hip_matrix_create(ctx, j->n2, j->n_ints, &g_square_b.m[d]))) return rc;
+    if ((rc = storm_hip_matrix_resize(ctx, g_square_a.m[d], r1 - r0)) ||
+        (rc = storm_hip_matrix_resize(ctx, g_square_b.m[d], j->n2)) ||
+        (rc = storm_hip_matrix_upload(ctx, g_square_a.m[d], 0, r1 - r0, j->vals1 + (uint64_t)r0 * j->n_ints, j->n_ints)) ||
+        (rc = storm_hip_matrix_upload(ctx, g_square_b.m[d], 0, j->n2, j->vals2, j->n_ints)))
+        return rc;
+    /* (synchronous: the product's own launch + read-back; the devices overlap through their host threads) */
+    return storm_hip_square_dense(ctx, g_square_a.m[d], g_square_b.m[d], &j->part[d]);
+}
+
 uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_RESTRICT vals1,
                               const uint32_t n_vectors2, const uint64_t* STORM_RESTRICT vals2,
                               const uint32_t n_ints, const STORM_compute_func f) {
@@ -379,23 +536,54 @@ uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_R
         host_error("STORM_wrapper_square: NULL buffer");
         return ALL_PAIRS_FAILED;
     }
-    storm_hip_ctx_t* ctx = device_ctx(0);
-    if (!ctx) return ALL_PAIRS_FAILED;
-    storm_hip_matrix_t *a = NULL, *b = NULL;
-    uint64_t total = ALL_PAIRS_FAILED;
-    if (storm_hip_matrix_create(ctx, n_vectors1, n_ints, &a) == STORM_HIP_OK &&
-        storm_hip_matrix_create(ctx, n_vectors2, n_ints, &b) == STORM_HIP_OK &&
-        storm_hip_matrix_upload(ctx, a, 0, n_vectors1, vals1, n_ints) == STORM_HIP_OK &&
-        storm_hip_matrix_upload(ctx, b, 0, n_vectors2, vals2, n_ints) == STORM_HIP_OK &&
-        storm_hip_square_dense(ctx, a, b, &total) == STORM_HIP_OK) {
-        /* total set */
-    } else {
-        device_error("STORM_wrapper_square");
-        total = ALL_PAIRS_FAILED;
+    pthread_mutex_lock(&g_wrapper_mu);
+    configure_from_env();
+    if (g_square_a.config_generation != g_config_generation || g_square_words != n_ints) {
+        dense_state_release(&g_square_a);
+        dense_state_release(&g_square_b);
+        g_square_a.config_generation = g_square_b.config_generation = g_config_generation;
+        g_square_words = n_ints;
     }
-    storm_hip_matrix_destroy(ctx, a);
-    storm_hip_matrix_destroy(ctx, b);
+    for (int d = 0; d < g_n_devices; ++d)
+        if (!device_ctx(d)) {
+            pthread_mutex_unlock(&g_wrapper_mu);
+            return ALL_PAIRS_FAILED;
+        }
+    square_job_t j;
+    memset(&j, 0, sizeof(j));
+    j.vals1 = vals1;
+    j.vals2 = vals2;
+    j.n1 = n_vectors1;
+    j.n2 = n_vectors2;
+    j.n_ints = n_ints;
+    uint64_t total = 0;
+    if (run_on_devices(square_job, &j, "STORM_wrapper_square")) {
+        dense_state_release(&g_square_a);
+        dense_state_release(&g_square_b);
+        total = ALL_PAIRS_FAILED;
+    } else {
+        for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
+    }
+    pthread_mutex_unlock(&g_wrapper_mu);
     return total;
+}
+
+static void wrapper_states_release(void) {
+    pthread_mutex_lock(&g_wrapper_mu);
+    dense_state_release(&g_wrapper_state);
+    dense_state_release(&g_square_a);
+    dense_state_release(&g_square_b);
+    pthread_mutex_unlock(&g_wrapper_mu);
+}
+
+int STORM_hip_shutdown(void) {
+    wrapper_states_release();
+    for (int d = 0; d < MAX_DEVICES; ++d) {
+        if (g_ctx[d]) storm_hip_ctx_destroy(g_ctx[d]);
+        g_ctx[d] = NULL;
+    }
+    ++g_config_generation; /* device copies cached in handles are rebuilt on their next use */
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -611,19 +799,23 @@ static int contig_upload_rows(STORM_contiguous_t* h, uint64_t upto) {
     return 0;
 }
 
-/* Streaming: STORM_contig_add sends every finished batch of CONTIG_STREAM_ROWS rows to the device
- * while the host builds the next ones (PCIe beside the host's bit setting), so that the first
- * all-pairs call only has the last partial batch left to copy. Best effort: without a usable
- * device the adds still succeed and the failure surfaces at the all-pairs call, as before.
- * STORM_HIP_STREAM_ROWS=0 in the environment turns it off. */
-static int g_stream_state = 0; /* 0 unknown, 1 on, -1 off (no device, or disabled) */
+/* Streaming: STORM_contig_add sends every finished batch of CONTIG_STREAM_ROWS rows to the device mirror
+ * (a synchronous copy from the container's pageable rows: the cost of the upload moves from the first
+ * all-pairs call into the adds, it does not overlap the host's bit setting), so that the first all-pairs
+ * call only has the last partial batch left to copy. A container builder must not be the thing that
+ * initialises the GPU in a process (callers build containers and then fork or start workers; a launcher has
+ * to run before any HIP call): batches are streamed only once the process already holds a device context —
+ * i.e. after its first all-pairs call — or when STORM_HIP_STREAM_ROWS=1 asks for it; =0 turns it off.
+ * Best effort: a failure here surfaces at the all-pairs call, as before. */
+static int g_stream_state = 0; /* 0 unknown, 1 forced on, 2 on once a context exists, -1 off */
 
 static void contig_stream_rows(STORM_contiguous_t* h) {
     if (g_stream_state == 0) {
         const char* e = getenv("STORM_HIP_STREAM_ROWS");
-        g_stream_state = (e && e[0] == '0') ? -1 : 1;
+        g_stream_state = (e && e[0] == '0') ? -1 : (e && e[0] == '1') ? 1 : 2;
     }
     if (g_stream_state < 0) return;
+    if (g_stream_state == 2 && !g_ctx[0]) return;
     /* a container that is all lists so far needs no dense mirror (N x M bits over PCIe for a handful of
      * positions per row): contig_mirror() uploads whatever is missing the day a dense row or the per-pair
      * matrix asks for it */
@@ -654,8 +846,17 @@ static dense_state_t* contig_mirror(STORM_contiguous_t* h) {
 /* the device mirror is rebuilt whenever rows were added since the last all-pairs call */
 static uint64_t contig_pairw_device(STORM_contiguous_t* h) {
     if (h->n_data < 2) return 0;
-    if (h->hip_lists && !h->hip_lists_off && h->hip_lists->n_conts == h->n_data)
-        return STORM_pairw_intersect_cardinality(h->hip_lists);
+    if (h->hip_lists && !h->hip_lists_off && h->hip_lists->n_conts == h->n_data) {
+        /* The list mirror pays while every block column can go to the probe kernel (at most 65535 rows per
+         * column: its work is then the listed positions, and lists-only columns hold no 8 KiB pool rows).
+         * Beyond that, or when the mirror's arena or its pass fails, the container goes back to its dense
+         * mirror for good — N x M bits, which is what the caller allocated anyway. */
+        if (h->n_data <= 65535) {
+            const uint64_t total = STORM_pairw_intersect_cardinality(h->hip_lists);
+            if (total != ALL_PAIRS_FAILED) return total;
+        }
+        contig_lists_end(h);
+    }
     dense_state_t* st = contig_mirror(h);
     return st ? dense_state_pairw(st) : ALL_PAIRS_FAILED;
 }
@@ -1120,6 +1321,9 @@ STORM_t* STORM_deserialize(const void* buf, uint64_t n_bytes) {
     const uint8_t* p = (const uint8_t*)buf;
     if (!p || n_bytes < 8 || get_u32(p + 4) != STORM_SERIAL_MAGIC) return NULL;
     const uint32_t n_rows = get_u32(p);
+    /* a row costs at least its 12 header bytes: a header claiming more rows than the stream can hold must
+     * not size an allocation (a 16-byte stream once asked calloc for 2^32 row records) */
+    if ((uint64_t)n_rows > (n_bytes - 8) / 12) return NULL;
     STORM_t* h = STORM_new();
     if (!h) return NULL;
     uint64_t at = 8;
@@ -1149,6 +1353,7 @@ STORM_t* STORM_deserialize(const void* buf, uint64_t n_bytes) {
             if (at + 16 > n_bytes) { ok = 0; break; }
             const uint32_t n_bitmap = get_u32(p + at), w2 = get_u32(p + at + 8);
             const uint32_t n_scalar = w2 & 0x7fffffffu, has_list = w2 >> 31;
+            if (n_scalar > BLOCK_BITS) { ok = 0; break; }
             blk->n_bits_set = get_u32(p + at + 4);
             blk->id = get_u32(p + at + 12);
             at += 16;
@@ -1170,6 +1375,13 @@ STORM_t* STORM_deserialize(const void* buf, uint64_t n_bytes) {
                 memcpy(blk->scalar, p + at, (size_t)n_scalar * 2);
                 blk->n_scalar = n_scalar;
                 at += (uint64_t)n_scalar * 2;
+                /* a list is strictly ascending (sorted, duplicate-free: storm.h:227) — the probe kernel counts
+                 * every listed element, the dense path ORs bits: a duplicate would make the total depend on
+                 * the path — and, for a list-kind block, holds exactly the block's set bits */
+                for (uint32_t k = 1; k < n_scalar; ++k)
+                    if (blk->scalar[k] <= blk->scalar[k - 1]) { ok = 0; break; }
+                if (!n_bitmap && blk->n_bits_set != n_scalar) ok = 0;
+                if (!ok) break;
             }
             r->n_bitmaps = b + 1;
         }
@@ -1303,7 +1515,20 @@ static int storm_build_arena(STORM_t* h) {
     return rc;
 }
 
-/* all configured devices work concurrently on disjoint shards; the host adds the partials */
+/* all configured devices work concurrently on disjoint shards (one host thread each); the host adds the partials */
+typedef struct {
+    sparse_state_t* st;
+    uint64_t part[MAX_DEVICES];
+} sparse_job_t;
+
+static int sparse_job(int d, int phase, void* arg) {
+    sparse_job_t* j = (sparse_job_t*)arg;
+    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
+    const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+    return phase == 0 ? storm_hip_pairw_sparse_begin(g_ctx[d], j->st->a[d], rank, world)
+                      : storm_hip_pairw_sparse_end(g_ctx[d], &j->part[d]);
+}
+
 static uint64_t storm_pairw_device(STORM_t* h) {
     if (h->n_conts < 2) return 0;
     configure_from_env();
@@ -1312,24 +1537,12 @@ static uint64_t storm_pairw_device(STORM_t* h) {
         storm_drop_device(h);
         if (storm_build_arena(h)) return ALL_PAIRS_FAILED;
     }
-    sparse_state_t* st = (sparse_state_t*)h->hip_arena;
-    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
-    for (int d = 0; d < g_n_devices; ++d) {
-        const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
-        if (storm_hip_pairw_sparse_begin(g_ctx[d], st->a[d], rank, world) != STORM_HIP_OK) {
-            device_error("storm_hip_pairw_sparse_begin");
-            return ALL_PAIRS_FAILED;
-        }
-    }
+    sparse_job_t j;
+    j.st = (sparse_state_t*)h->hip_arena;
+    memset(j.part, 0, sizeof(j.part));
+    if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return ALL_PAIRS_FAILED;
     uint64_t total = 0;
-    for (int d = 0; d < g_n_devices; ++d) {
-        uint64_t part = 0;
-        if (storm_hip_pairw_sparse_end(g_ctx[d], &part) != STORM_HIP_OK) {
-            device_error("storm_hip_pairw_sparse_end");
-            return ALL_PAIRS_FAILED;
-        }
-        total += part;
-    }
+    for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
     return total;
 }
 

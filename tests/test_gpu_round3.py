@@ -161,3 +161,35 @@ def test_block_columns_of_mixed_kinds_split_per_block(orc):
         lib.storm_hip_sparse_destroy(ctx._h, h)
         ctx.close()
         s.free()
+
+
+def test_serialized_walker_applies_the_host_parser_s_rules():
+    """storm_hip_sparse_create_serialized walks the headers of a serialized STORM_t itself: a stream that
+    STORM_deserialize refuses (more rows than bytes, an unsorted or duplicated list, a set-bit count or block
+    id that contradicts the header) is refused here too, before anything is allocated for it."""
+    import ctypes as C
+    import struct
+    lib = sb.load()
+    ctx = sb.HipContext(0)
+    rows = [np.array([5, 9, 70000, 70001], dtype=np.uint32), np.array([1, 2, 3], dtype=np.uint32)]
+    s = sb.Storm()
+    for r in rows:
+        s.add(r)
+    data = s.serialize()
+    s.free()
+    at = 8 + 12 + 8 + 16
+    unsorted = data.copy(); unsorted[at:at + 4] = np.frombuffer(struct.pack("<HH", 9, 5), dtype=np.uint8)
+    duplicate = data.copy(); duplicate[at:at + 4] = np.frombuffer(struct.pack("<HH", 5, 5), dtype=np.uint8)
+    wrong_count = data.copy(); wrong_count[8 + 12 + 8 + 4] = 7
+    wrong_id = data.copy(); wrong_id[8 + 12 + 8 + 12] = 3
+    huge = np.frombuffer(struct.pack("<IIII", 0xFFFFFFFF, 0x314D5453, 0, 0), dtype=np.uint8).copy()
+    h = C.c_void_p()
+    assert lib.storm_hip_sparse_create_serialized(ctx._h, data.ctypes.data_as(C.c_void_p), data.size, C.byref(h)) == 0
+    out = C.c_uint64()
+    assert lib.storm_hip_pairw_sparse(ctx._h, h, 0, 1, C.byref(out)) == 0 and out.value == 0
+    lib.storm_hip_sparse_destroy(ctx._h, h)
+    for bad in (unsorted, duplicate, wrong_count, wrong_id, huge):
+        h = C.c_void_p()
+        assert lib.storm_hip_sparse_create_serialized(ctx._h, bad.ctypes.data_as(C.c_void_p), bad.size, C.byref(h)) != 0
+        assert not h.value
+    ctx.close()

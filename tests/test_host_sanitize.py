@@ -20,7 +20,7 @@ def test_host_containers_under_asan_ubsan(tmp_path):
             os.path.join(ROOT, "tests", "host_sanitize", "driver.c")]
     build = subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined",
                             "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-Wall",
-                            "-I" + os.path.join(ROOT, "include"), *srcs, "-o", str(exe), "-lm"],
+                            "-pthread", "-I" + os.path.join(ROOT, "include"), *srcs, "-o", str(exe), "-lm"],
                            capture_output=True, text=True)
     if build.returncode != 0 and "asan" in build.stderr.lower() and "cannot find" in build.stderr.lower():
         pytest.skip("libasan not installed")

@@ -53,3 +53,31 @@ def test_deserialize_rejects_damaged_streams():
     empty = sb.Storm()
     assert empty.serialize().size == 8 == empty.serialized_size()
     assert sb.Storm.deserialize(empty.serialize()).serialized_size() == 8
+
+
+def test_deserialize_rejects_headers_that_lie():
+    """A stream is bounded by its own length before anything is allocated, and a list must be strictly
+    ascending and as long as the block's set-bit count (the device walker of
+    storm_hip_sparse_create_serialized applies the same rules: tests/test_gpu_round3.py)."""
+    import struct
+    # 16 bytes claiming 2^32 - 1 rows: rejected without sizing an allocation by it
+    huge = np.frombuffer(struct.pack("<IIII", 0xFFFFFFFF, 0x314D5453, 0, 0), dtype=np.uint8)
+    with pytest.raises(ValueError):
+        sb.Storm.deserialize(huge)
+    rows = [np.array([5, 9, 70000, 70001], dtype=np.uint32), np.array([1, 2, 3], dtype=np.uint32)]
+    s = sb.Storm()
+    for r in rows:
+        s.add(r)
+    data = s.serialize()
+    s.free()
+    assert sb.Storm.deserialize(data).serialized_size() == data.size
+    # row 0: header 12 + 2 ids (8) + block header 16 + list [5, 9] -> swap the two list entries
+    at = 8 + 12 + 8 + 16
+    assert struct.unpack_from("<HH", data.tobytes(), at) == (5, 9)
+    unsorted = data.copy(); unsorted[at:at + 4] = np.frombuffer(struct.pack("<HH", 9, 5), dtype=np.uint8)
+    duplicate = data.copy(); duplicate[at:at + 4] = np.frombuffer(struct.pack("<HH", 5, 5), dtype=np.uint8)
+    wrong_count = data.copy(); wrong_count[8 + 12 + 8 + 4] = 7          # n_bits_set of the first block
+    wrong_id = data.copy(); wrong_id[8 + 12 + 8 + 12] = 3               # block id != block_ids[0]
+    for bad in (unsorted, duplicate, wrong_count, wrong_id):
+        with pytest.raises(ValueError):
+            sb.Storm.deserialize(bad)
