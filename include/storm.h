@@ -264,6 +264,16 @@ int STORM_hip_invalidate(STORM_t* bitmap);
 int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
 const char* STORM_hip_error(void);
+/* Multi-PROCESS runs, one process per GPU: every process sets its shard (STORM_hip_set_shard) and joins one
+ * RCCL communicator; from then on every all-pairs entry point above returns the SUM over all processes (the
+ * shard partials all-reduced over xGMI: ncclAllReduce of one uint64), so host code written for the reference
+ * needs nothing else. Rank 0 obtains the 128-byte id and hands it to the other processes (pipe, file, MPI);
+ * STORM_hip_comm_init is collective — every process calls it, after it was forked / started and before its
+ * first all-pairs call. Return 0, or -1 with the reason in STORM_hip_error().
+ * (tools/storm_benchmark.cpp --ranks N: fork before any HIP call, id through a pipe.) */
+int STORM_hip_comm_unique_id(uint8_t id[128]);
+int STORM_hip_comm_init(const uint8_t id[128]);
+int STORM_hip_comm_finalize(void);
 /* Threading. Like the reference (no locks anywhere in storm.c), a HANDLE is not thread-safe: one thread at a
  * time per STORM_t / STORM_contiguous_t. The process-wide device state behind the handles (contexts, the
  * device selection above) is set up on first use and by the two setters: call those while no other thread is

@@ -251,6 +251,29 @@ int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank
                           uint32_t n_cus, uint32_t* out, uint64_t capacity_segments, uint64_t* n_segments,
                           uint32_t* n_workgroups);
 
+/* ---- the 8-byte exchange of a multi-process run (one process per GPU), over RCCL / xGMI ----------------
+ * Every rank computes its shard's partial (storm_hip_pairw_dense(..., shard_rank, shard_count), or a storm.h
+ * handle after STORM_hip_set_shard) and the partials are summed: ncclAllReduce(count 1, ncclUint64, ncclSum)
+ * — SURVEY §5; the reference is single-process and has no counterpart. librccl.so is loaded on first use
+ * (dlopen; STORM_HIP_RCCL names another build), single-GPU users need none.
+ *   rank 0: storm_hip_comm_unique_id(id); hand the 128 bytes to the other ranks (pipe, file, MPI, ...);
+ *   every rank, AFTER forking / starting its own process and BEFORE the first collective:
+ *     storm_hip_comm_init_rank(ctx, id, rank, world, &comm)      (collective: all ranks call it)
+ *   per all-pairs call: storm_hip_comm_allreduce_u64(ctx, comm, &value)   value := sum over ranks, or
+ *     storm_hip_pairw_dense_begin(...) + storm_hip_comm_allreduce_result(ctx, comm, &total): the shard's
+ *     partial is reduced where the pass left it (the context's result word), one host wait for both.
+ * tools/storm_benchmark.cpp --ranks N is a complete example (fork before any HIP call, id through a pipe). */
+#define STORM_HIP_COMM_ID_BYTES 128
+typedef struct storm_hip_comm_s storm_hip_comm_t;
+int storm_hip_comm_unique_id(uint8_t id[STORM_HIP_COMM_ID_BYTES]);
+int storm_hip_comm_init_rank(storm_hip_ctx_t* ctx, const uint8_t id[STORM_HIP_COMM_ID_BYTES], uint32_t rank,
+                             uint32_t world, storm_hip_comm_t** out);
+int storm_hip_comm_allreduce_u64(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* value);
+int storm_hip_comm_allreduce_result(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* total);
+uint32_t storm_hip_comm_rank(const storm_hip_comm_t* comm);
+uint32_t storm_hip_comm_world(const storm_hip_comm_t* comm);
+void storm_hip_comm_destroy(storm_hip_comm_t* comm);
+
 /* ---- sparse (STORM_t) arena: flattened rows -> blocks (storm.h:157-178) --------------
  * Host-side flat description of all rows' 65536-bit blocks:
  *   row_block_offset[n_rows+1]   CSR over blocks

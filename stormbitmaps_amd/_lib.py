@@ -66,6 +66,13 @@ SIGNATURES = {
     "storm_hip_ctx_set_option": (C.c_int, [vp, cp, i64]),
     "storm_hip_ctx_get_option": (i64, [vp, cp]),
     "storm_hip_last_launch_info": (C.c_int, [vp, P(u64 * 4)]),
+    "storm_hip_comm_unique_id": (C.c_int, [vp]),
+    "storm_hip_comm_init_rank": (C.c_int, [vp, vp, u32, u32, P(vp)]),
+    "storm_hip_comm_allreduce_u64": (C.c_int, [vp, vp, P(u64)]),
+    "storm_hip_comm_allreduce_result": (C.c_int, [vp, vp, P(u64)]),
+    "storm_hip_comm_rank": (u32, [vp]),
+    "storm_hip_comm_world": (u32, [vp]),
+    "storm_hip_comm_destroy": (None, [vp]),
     "storm_hip_sparse_create": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, vp, u64, vp, u64,
                                           P(vp)]),
     "storm_hip_sparse_destroy": (None, [vp, vp]),
@@ -119,6 +126,9 @@ SIGNATURES = {
     "STORM_hip_set_shard": (C.c_int, [u32, u32]),
     "STORM_hip_error": (cp, []),
     "STORM_hip_shutdown": (C.c_int, []),
+    "STORM_hip_comm_unique_id": (C.c_int, [vp]),
+    "STORM_hip_comm_init": (C.c_int, [vp]),
+    "STORM_hip_comm_finalize": (C.c_int, []),
 }
 
 _lib = None

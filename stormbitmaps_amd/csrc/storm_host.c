@@ -51,6 +51,16 @@ static void device_error(const char* where) {
 }
 
 static void wrapper_states_release(void);
+static storm_hip_comm_t* g_comm = NULL; /* multi-process runs: the partials of the ranks are all-reduced */
+
+int STORM_hip_comm_unique_id(uint8_t id[128]) {
+    if (storm_hip_comm_unique_id(id) != STORM_HIP_OK) {
+        g_host_error[0] = '\0';
+        fprintf(stderr, "[storm_hip] STORM_hip_comm_unique_id: %s\n", storm_hip_last_error());
+        return -1;
+    }
+    return 0;
+}
 
 int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     if (n_devices < 1 || n_devices > MAX_DEVICES || !device_ids) return -1;
@@ -224,6 +234,38 @@ static int run_on_devices(slot_fn fn, void* arg, const char* what) {
     return rc0;
 }
 
+int STORM_hip_comm_init(const uint8_t id[128]) {
+    if (!id) return -1;
+    if (g_comm) {
+        host_error("STORM_hip_comm_init: a communicator is already attached (STORM_hip_comm_finalize first)");
+        return -1;
+    }
+    storm_hip_ctx_t* ctx = device_ctx(0);
+    if (!ctx || storm_hip_comm_init_rank(ctx, id, g_shard_rank, g_shard_count, &g_comm) != STORM_HIP_OK) {
+        device_error("STORM_hip_comm_init");
+        g_comm = NULL;
+        return -1;
+    }
+    return 0;
+}
+
+int STORM_hip_comm_finalize(void) {
+    if (g_comm) storm_hip_comm_destroy(g_comm);
+    g_comm = NULL;
+    return 0;
+}
+
+/* the total an entry point returns: this process's partial, summed over the ranks when a communicator is attached */
+static uint64_t across_ranks(uint64_t partial) {
+    if (!g_comm || partial == ALL_PAIRS_FAILED) return partial;
+    uint64_t v = partial;
+    if (storm_hip_comm_allreduce_u64(g_ctx[0], g_comm, &v) != STORM_HIP_OK) {
+        device_error("all-reduce of the shard totals");
+        return ALL_PAIRS_FAILED;
+    }
+    return v;
+}
+
 /* a STORM_compute_func is only an identity token on the device path (libalgebra.h) */
 static int leaf_is_ours(STORM_compute_func f) {
     return f == NULL || f == STORM_intersect_count_scalar;
@@ -360,7 +402,7 @@ static uint64_t dense_state_pairw(dense_state_t* st) {
     if (run_on_devices(dense_job, &j, "all-pairs pass (dense)")) return ALL_PAIRS_FAILED;
     uint64_t total = 0;
     for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
-    return total;
+    return across_ranks(total);
 }
 
 /* The raw-buffer wrappers (STORM_wrapper_*) get the caller's matrix anew on every call; what can be
@@ -577,6 +619,7 @@ static void wrapper_states_release(void) {
 }
 
 int STORM_hip_shutdown(void) {
+    (void)STORM_hip_comm_finalize();
     wrapper_states_release();
     for (int d = 0; d < MAX_DEVICES; ++d) {
         if (g_ctx[d]) storm_hip_ctx_destroy(g_ctx[d]);
@@ -1425,7 +1468,7 @@ uint64_t STORM_serialized_pairw_intersect_cardinality(const void* buf, uint64_t 
     }
     for (int d = 0; d < MAX_DEVICES; ++d)
         if (arena[d]) storm_hip_sparse_destroy(g_ctx[d], arena[d]);
-    return ok ? total : ALL_PAIRS_FAILED;
+    return ok ? across_ranks(total) : ALL_PAIRS_FAILED;
 }
 
 /* Fingerprint of what the device arena was built from: rows, blocks per row, and per block its
@@ -1543,7 +1586,7 @@ static uint64_t storm_pairw_device(STORM_t* h) {
     if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return ALL_PAIRS_FAILED;
     uint64_t total = 0;
     for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
-    return total;
+    return across_ranks(total);
 }
 
 /* Extensions (storm.h): forget the device copy of a handle whose public members were edited

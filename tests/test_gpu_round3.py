@@ -193,3 +193,51 @@ def test_serialized_walker_applies_the_host_parser_s_rules():
         assert lib.storm_hip_sparse_create_serialized(ctx._h, bad.ctypes.data_as(C.c_void_p), bad.size, C.byref(h)) != 0
         assert not h.value
     ctx.close()
+
+
+def _golden_total(M, N, d):
+    import json
+    import os
+    root = os.path.dirname(os.path.abspath(__file__))
+    for c in json.load(open(os.path.join(root, "golden", "synth_totals.json")))["dense"]:
+        if (c["M"], c["N"], c["draws"]) == (M, N, d):
+            return c["total"]
+    raise KeyError((M, N, d))
+
+
+def _benchmark_rows(args, timeout=600):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "stormbitmaps_amd", "storm_benchmark")
+    res = subprocess.run([exe, *args], capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    # (RCCL prints a version banner on stdout when a communicator is created: keep the result rows)
+    return [l.split("\t") for l in res.stdout.strip().splitlines()
+            if l.count("\t") >= 15 and not l.startswith(("Samples", "#"))]
+
+
+def test_native_rccl_reduce_for_c_callers_with_one_rank():
+    """The C-side exchange (include/storm_hip.h storm_hip_comm_*, storm.h STORM_hip_comm_*): librccl is
+    dlopen'ed, a communicator of ONE rank is created and the storm.h entry points return the all-reduced
+    total — through tools/storm_benchmark.cpp --ranks 1, which forks its rank before any HIP call and hands
+    the id over a pipe, exactly as it does for N ranks. Totals against the committed oracle vectors."""
+    rows = _benchmark_rows(["4096", "256", "2048,40", "--ranks", "1", "--reps", "1"])
+    assert rows and all(int(r[-5]) == 1 for r in rows)          # GPUs column
+    for load in (2048, 40):
+        totals = {int(r[2]) for r in rows if int(r[1]) == load}
+        assert totals == {_golden_total(4096, 256, load)}, (load, totals)
+
+
+def test_native_rccl_reduce_over_two_gpus_when_the_box_has_them():
+    """Two processes, one GPU each, shard partials all-reduced over RCCL by the C library itself
+    (ncclAllReduce, count 1, ncclUint64, ncclSum). Skipped on 1-GPU boxes: RCCL refuses two ranks on one
+    device."""
+    n_dev = sb.load().storm_hip_device_count()
+    if n_dev < 2:
+        pytest.skip(f"{n_dev} GPU visible: RCCL needs one GPU per rank")
+    rows = _benchmark_rows(["65536", "700", "32768,262", "--ranks", "2", "--reps", "2"])
+    assert rows and all(int(r[-5]) == 2 for r in rows)
+    for load in (32768, 262):
+        totals = {int(r[2]) for r in rows if int(r[1]) == load}
+        assert totals == {_golden_total(65536, 700, load)}, (load, totals)

@@ -2,7 +2,11 @@
 //
 // Counterpart of benchmark.cpp (intersect_test :644-1059, benchmark_large :505-642, main
 // :1085-1125), written from scratch against include/storm.h + libstorm_hip.so:
-//     storm_benchmark <M> <N> [load1,load2,...] [--gpus G] [--seed S] [--reps R]
+//     storm_benchmark <M> <N> [load1,load2,...] [--gpus G | --ranks R] [--seed S] [--reps R]
+// --gpus G : one process drives G GPUs (STORM_hip_set_devices; partials added on the host).
+// --ranks R: R processes, one per GPU — forked HERE, before anything touches HIP — each computes its shard
+//            (STORM_hip_set_shard) and the storm.h entry points return the RCCL all-reduced total
+//            (STORM_hip_comm_init; the id travels from rank 0 through a pipe). Rank 0 prints the rows.
 // Same positional arguments (samples first, benchmark.cpp:1067), same default loads and
 // zero/duplicate rules (:695, :715-730), same routing (M < 256000 -> both containers, else
 // STORM_t only, :1117-1121; STORM_t rows only when M >= 65536, :832), same optimal block size
@@ -25,6 +29,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "storm.h"
 #include "storm_hip.h"
@@ -91,15 +98,16 @@ int main(int argc, char** argv) {
         fprintf(stderr,
                 "\nAbout:   Computes sum(popcnt(A & B)) for the all-vs-all comparison of N integer\n"
                 "         lists bounded by [0, M) on the MI355X.\n"
-                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G] [--seed S] [--reps R] [--describe]\n\n");
+                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G | --ranks R] [--seed S] [--reps R] [--describe]\n\n");
         return EXIT_FAILURE;
     }
     int64_t n_samples = 0, n_vals = 10000;  // one-argument form uses N = 10000 (benchmark.cpp:1102)
     std::vector<uint32_t> loads;
-    int gpus = 1, reps = 3, positional = 0;
+    int gpus = 1, reps = 3, positional = 0, ranks = 0;
     uint64_t seed = 42;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--describe")) { describe_columns(); return EXIT_SUCCESS; }
@@ -117,12 +125,60 @@ int main(int argc, char** argv) {
     const bool large = n_samples >= 256000;  // benchmark.cpp:1117-1121
     if (loads.empty()) loads = default_loads(M);
 
-    const int visible = storm_hip_device_count();
-    if (visible < 1) { fprintf(stderr, "no HIP device visible (no CPU fallback)\n"); return EXIT_FAILURE; }
-    if (gpus > visible) { fprintf(stderr, "--gpus %d but only %d device(s) visible; using %d\n", gpus, visible, visible); gpus = visible; }
-    std::vector<int> ids(gpus);
-    for (int g = 0; g < gpus; ++g) ids[g] = g;
-    STORM_hip_set_devices(gpus, ids.data());
+    int rank = 0;
+    if (ranks > 0) {
+        // One process per GPU. The fork comes BEFORE any HIP call (a process that has initialised the GPU must
+        // not be forked), so the device count is not looked at here: every child checks its own device.
+        if (ranks > 16) { fprintf(stderr, "--ranks %d: at most 16\n", ranks); return EXIT_FAILURE; }
+        int id_pipe[2];
+        if (pipe(id_pipe) != 0) { perror("pipe"); return EXIT_FAILURE; }
+        std::vector<pid_t> kids;
+        bool child = false;
+        for (int r = 0; r < ranks; ++r) {
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (pid == 0) { rank = r; child = true; break; }
+            kids.push_back(pid);
+        }
+        if (!child) {  // the launcher: no HIP here; wait for the ranks, report the worst exit code
+            close(id_pipe[0]);
+            close(id_pipe[1]);
+            int worst = 0;
+            for (pid_t k : kids) {
+                int st = 0;
+                waitpid(k, &st, 0);
+                const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
+                if (code > worst) worst = code;
+            }
+            return worst;
+        }
+        const int dev = rank;
+        if (storm_hip_device_count() < ranks) {  // every rank sees the same count: all leave before the collective
+            if (rank == 0) fprintf(stderr, "--ranks %d but only %d device(s) visible\n", ranks, storm_hip_device_count());
+            return EXIT_FAILURE;
+        }
+        if (STORM_hip_set_devices(1, &dev) != 0 || STORM_hip_set_shard((uint32_t)rank, (uint32_t)ranks) != 0) return EXIT_FAILURE;
+        uint8_t id[128];
+        if (rank == 0) {
+            if (STORM_hip_comm_unique_id(id) != 0) return EXIT_FAILURE;
+            for (int r = 1; r < ranks; ++r)
+                if (write(id_pipe[1], id, sizeof(id)) != (ssize_t)sizeof(id)) return EXIT_FAILURE;  // 128 B: atomic
+        } else if (read(id_pipe[0], id, sizeof(id)) != (ssize_t)sizeof(id)) {
+            return EXIT_FAILURE;
+        }
+        close(id_pipe[0]);
+        close(id_pipe[1]);
+        if (STORM_hip_comm_init(id) != 0) { fprintf(stderr, "rank %d: %s\n", rank, STORM_hip_error()); return EXIT_FAILURE; }
+        gpus = ranks;  // the rows report the GPUs the job ran on
+        if (rank != 0 && !freopen("/dev/null", "w", stdout)) return EXIT_FAILURE;  // rank 0 prints
+    } else {
+        const int visible = storm_hip_device_count();
+        if (visible < 1) { fprintf(stderr, "no HIP device visible (no CPU fallback)\n"); return EXIT_FAILURE; }
+        if (gpus > visible) { fprintf(stderr, "--gpus %d but only %d device(s) visible; using %d\n", gpus, visible, visible); gpus = visible; }
+        std::vector<int> ids(gpus);
+        for (int g = 0; g < gpus; ++g) ids[g] = g;
+        STORM_hip_set_devices(gpus, ids.data());
+    }
 
     // the reference's header line as it stands (benchmark.cpp:506, :671; it does not match its own rows),
     // then the names of the columns actually printed
@@ -170,5 +226,6 @@ int main(int argc, char** argv) {
     }
     STORM_free(twk2);
     if (twk_cont) STORM_contig_free(twk_cont);
+    if (ranks > 0) STORM_hip_shutdown();  // communicator first, then the contexts
     return EXIT_SUCCESS;
 }
