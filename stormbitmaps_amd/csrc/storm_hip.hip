@@ -597,6 +597,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             set_error("variant must be -1 (auto) or 0..5");
             return STORM_HIP_EINVAL;
         }
+#ifndef STORM_HIP_PROBES
+        if (value == 5) {
+            set_error("variant 5 (wide 32x32x64 strips) is a form of the tools build (`make probes`), not of the shipped library");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->variant = (int)value;
     } else if (!strcmp(key, "sparse_probe")) {
         if (value < -1 || value > 1) {
@@ -648,6 +654,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             set_error("k2_tile_shape must be 1 (bit operands), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
+#ifndef STORM_HIP_PROBES
+        if (value == 1 || value == 16) {
+            set_error("k2_tile_shape = 1 / 16 (tilebits_kernel, tile16_fp4_kernel) is a form of the tools build (`make probes`), not of the shipped library");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->k2_tile_shape = (int)value;
     } else if (!strcmp(key, "k2_tile_cost_diag") || !strcmp(key, "k2_tile_cost_ragged")) {
         if (value < 5 || value > 100) {
@@ -660,6 +672,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup) or 4 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
+#ifndef STORM_HIP_PROBES
+        if (value == 1) {
+            set_error("k2_strip_operands = 1 (stripbits_kernel) is a form of the tools build (`make probes`), not of the shipped library");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->k2_strip_operands = (int)value;
     } else if (!strcmp(key, "k2_stream_max_rows")) {
         if (value < 0 || value > (1ll << 31)) {
@@ -684,6 +702,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
             return STORM_HIP_EINVAL;
         }
+#ifndef STORM_HIP_PROBES
+        if (value == 32) {
+            set_error("k2_shape = 32 (strip_fp4_kernel) is a form of the tools build (`make probes`), not of the shipped library");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->k2_shape = (int)value;
     } else if (!strcmp(key, "keep_shadow")) {
         ctx->keep_shadow = value != 0;
@@ -703,6 +727,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_lds_pad = (int)value;
     } else if (!strcmp(key, "k2_persistent")) {
+#ifndef STORM_HIP_PROBES
+        if (value != 0) {
+            set_error("k2_persistent (strip_fp4_kernel with work queues) is a form of the tools build (`make probes`), not of the shipped library");
+            return STORM_HIP_EINVAL;
+        }
+#endif
         ctx->k2_persistent = value != 0;
     } else if (!strcmp(key, "k2_lpt_rounds")) {
         if (value < 0 || value > 63) {
@@ -764,6 +794,13 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
+    if (!strcmp(key, "probes_build")) {
+#ifdef STORM_HIP_PROBES
+        return 1;
+#else
+        return 0;
+#endif
+    }
 #ifdef STORM_HIP_PROBES
     if (!strcmp(key, "probes_built")) return 1;
 #else

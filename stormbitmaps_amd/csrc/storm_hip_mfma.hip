@@ -386,7 +386,7 @@ constexpr int kStripStageBytes = kStripBRows * kStripRowBytes;  // 8 KiB
 constexpr int kStripWaves = 4;                           // waves per workgroup = A tile / 64 rows
 constexpr int kStripATile = 64 * kStripWaves;            // A rows per workgroup (256; 8 waves / 512 rows measured slower)
 constexpr int kStripThreads = 64 * kStripWaves;
-constexpr int kStripPieces = 8 / kStripWaves;            // LDS-DMA instructions per wave and stage
+[[maybe_unused]] constexpr int kStripPieces = 8 / kStripWaves;            // LDS-DMA instructions per wave and stage
 static_assert(kStripWaves == 4 || kStripWaves == 8, "a B stage is 8 DMA pieces");
 constexpr int kStripRingDefault = 4;
 
@@ -410,8 +410,9 @@ struct StripQueues {
     uint32_t base[8];   // first item of XCD x's list in the item table
     uint32_t count[8];  // its length
 };
-constexpr uint32_t kNoItem = 0xffffffffu;
+[[maybe_unused]] constexpr uint32_t kNoItem = 0xffffffffu;
 
+#ifdef STORM_HIP_PROBES  // 32x32x64 strips (plain, wide, persistent) and their timing probes: the shipped strips are strip16_fp4_kernel
 template <int kStripRing, int kProbe = 0, int kMB = 2, bool kPersist = false>
 __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
@@ -702,6 +703,7 @@ __global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_k
     if constexpr (!kPersist) break;
     }  // items
 }
+#endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
 // K2s16: the same strips on v_mfma_scale_f32_16x16x128_f8f6f4.
@@ -951,10 +953,11 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_fp4_kernel(
 // A(s); everything older — A(s) and the B stages up to s+1 — has landed. The last iterations, where
 // fewer operations are issued, drain with vmcnt(0).
 // ------------------------------------------------------------------------------------------
-constexpr int kT16Ring = 4;
+[[maybe_unused]] constexpr int kT16Ring = 4;
 constexpr int kT16RowBytes = 128;                       // two k-steps of 128 bits
-constexpr int kT16StageBytes = kTile * kT16RowBytes;    // B only: 32 KiB
+[[maybe_unused]] constexpr int kT16StageBytes = kTile * kT16RowBytes;    // B only: 32 KiB
 
+#ifdef STORM_HIP_PROBES  // FP4-shadow output kernel, 45 % slower than tilebits8_kernel; tools build
 __global__ __launch_bounds__(kMfmaThreads, 2) void tile16_fp4_kernel(
     const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
     uint32_t* __restrict__ out, uint64_t ld, uint32_t n_rows, const uint32_t* __restrict__ row_counts,
@@ -1147,6 +1150,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tile16_fp4_kernel(
             }
     }
 }
+#endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
 // K2t-bits: the materialised-output kernel on the BIT matrix itself (default, option k2_tile_shape = 1).
@@ -1181,7 +1185,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tile16_fp4_kernel(
 // Rows beyond the matrix read as zero through the buffer descriptor's range (num_records = valid
 // rows x pitch, rebuilt per stage with the k offset folded into the base).
 // ------------------------------------------------------------------------------------------
-constexpr int kTbThreads = 256;
+[[maybe_unused]] constexpr int kTbThreads = 256;
 constexpr int kTbRing = 4;
 constexpr int kTbRowBytes = 64;                          // 512 bits of k per stage
 constexpr int kTbImageBytes = kTile * kTbRowBytes;       // 16 KiB per operand
@@ -1246,6 +1250,7 @@ __device__ __forceinline__ void tb_store_interior(const v16f (&acc)[MB][4], uint
 }
 
 
+#ifdef STORM_HIP_PROBES  // one wave per SIMD: 3 % slower than tilebits8_kernel; tools build
 __global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
     TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
     uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
@@ -1671,6 +1676,7 @@ __global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
             }
     }
 }
+#endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
 // The same with TWO waves per SIMD (default, option k2_tile_shape = 2): 8 waves, wave (wa, wb) owns A rows
@@ -1966,6 +1972,7 @@ constexpr int kSbRowBytes = 64;                                  // 512 bits of 
 constexpr int kSbStageBytes = kStripBRows * kSbRowBytes;         // 4 KiB
 constexpr int kSbRing = 4;
 
+#ifdef STORM_HIP_PROBES  // superseded by bitstream_kernel (K2q); kept for A/B in the tools build
 __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
     const uint8_t* __restrict__ X, uint64_t pitch64, const StripItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {
@@ -2168,6 +2175,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
     if (lane == 0 && mine != 0)
         atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)], (unsigned long long)mine);
 }
+#endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
 // K2q: bit-operand strips as ONE stream of stages per workgroup (option k2_strip_operands = 2; the
@@ -2973,17 +2981,22 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             //  k-chunked pass launches the strips several times in front of it, so it runs the plain
             //  form — found by the randomised soak, a second chunk saw exhausted queues)
             const bool persist = ctx->k2_persistent && n_chunks == 1;
+#ifdef STORM_HIP_PROBES
             const int sel = strip_mode == 2 ? 100 + ctx->k2_ring
                                             : (persist && ctx->k2_ring == 4) ? 204
                                             : (persist && ctx->k2_ring == 18) ? 218
                                                                               : ctx->k2_ring;
+#else
+            (void)persist; (void)pgrid; (void)heads; (void)queues;
+            const int sel = 4;  // (the shipped library refuses the options that select the other forms)
+#endif
             switch (sel) {  // ring depth: tuning probe
+#ifdef STORM_HIP_PROBES  // 32x32x64 forms, timing probes and the schedule trace: tools build (make probes)
                 case 204:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock,
                                        (size_t)ctx->k2_lds_pad, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots, nullptr, queues, heads);
                     break;
-#ifdef STORM_HIP_PROBES  // timing probes and the schedule trace: tools build (make probes)
                 case 218: {
                     const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
                     if (need > ctx->trace_capacity) {
@@ -3004,12 +3017,10 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                     hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
-#endif
                 case 104:
                     hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
                     break;
-#ifdef STORM_HIP_PROBES
                 case 105:
                     hipLaunchKernelGGL((strip_fp4_kernel<5, 0, 4>), sgrid, sblock, 0, ctx->stream,
                                        ctx->d_x4, pitch, sit, ctx->d_slots);
@@ -3061,12 +3072,14 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
 #endif  // STORM_HIP_PROBES
                 default:
                     // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
-                    if (ctx->k2_shape == 16)
-                        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, sgrid, sblock,
+#ifdef STORM_HIP_PROBES
+                    if (ctx->k2_shape != 16)
+                        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
                                            (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
                                            ctx->d_slots);
                     else
-                        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, sgrid, sblock,
+#endif
+                        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, sgrid, sblock,
                                            (size_t)ctx->k2_lds_pad, ctx->stream, ctx->d_x4, pitch, sit,
                                            ctx->d_slots);
                     break;
@@ -3169,12 +3182,14 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                            kExpandAll, 2u, pitch / 16);
         STORM_HIP_TRY(hipGetLastError());
     }
-    if (ctx->k2_shape == 16)
-        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
+#ifdef STORM_HIP_PROBES
+    if (ctx->k2_shape != 16)
+        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
                            dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
                            static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
     else
-        hipLaunchKernelGGL(strip_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
+#endif
+        hipLaunchKernelGGL(strip16_fp4_kernel<kStripRingDefault>, dim3((uint32_t)items.size()),
                            dim3(kStripThreads), 0, ctx->stream, ctx->d_x4, pitch,
                            static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots);
     STORM_HIP_TRY(hipGetLastError());
@@ -3336,6 +3351,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
+#ifdef STORM_HIP_PROBES
     else if (bits)
         hipLaunchKernelGGL(tilebits_kernel, dim3(plan.n_items), dim3(kTbThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
@@ -3344,6 +3360,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         hipLaunchKernelGGL(tile16_fp4_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            ctx->d_x4, pitch, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base,
                            j_count, plan.n_full, i_lo, n_cols);
+#endif
     else
         hipLaunchKernelGGL((pairw_fp4_kernel<0, true>), dim3(plan.n_items), dim3(kMfmaThreads), 0,
                            ctx->stream, ctx->d_x4, pitch, d_items, ctx->d_slots, d_out, ld, n_rows,
@@ -3795,6 +3812,10 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
         return rc;
+#ifndef STORM_HIP_PROBES
+    set_error("k2_strip_operands = 1 (stripbits_kernel) is in the tools build only (`make probes`)");
+    return STORM_HIP_EINVAL;
+#else
     const uint32_t n_strip = ctx->n_strip_items;
     if (n_strip > 0) {
         kernel_time_mark(ctx);
@@ -3809,6 +3830,7 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     ctx->last_info[2] = 1;
     ctx->last_info[3] = 0;
     return launch_fold_slots(ctx, d_total);
+#endif
 }
 
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,

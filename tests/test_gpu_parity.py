@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import shipped
+
 import stormbitmaps_amd as sb
 from stormbitmaps_amd import synth
 
@@ -89,7 +91,7 @@ def test_dense_golden_vectors(hip_ctx, case):
     mat = synth.dense_matrix_c(case["M"], case["N"], case["draws"], seed=42)
     m = hip_ctx.matrix_from_host(mat)
     try:
-        for variant in (2, 0, 1, 3, 4, 5):  # 3/4 = K2, the FP4 matrix-core paths
+        for variant in shipped(hip_ctx, "variant", (2, 0, 1, 3, 4, 5)):  # 3/4 = K2, the FP4 matrix-core paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == case["total"], f"variant {variant}"
     finally:
@@ -279,7 +281,7 @@ def test_headline_shape_properties(hip_ctx):
     assert total == m.column_identity()                      # sum_c C(n_c, 2)
     assert sum(m.pairw(r, 8) for r in range(8)) == total      # 8-way shard partition
     try:
-        for variant in (0, 3, 4, 5):                             # independent operand paths
+        for variant in shipped(hip_ctx, "variant", (0, 3, 4, 5)):        # independent operand paths
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
@@ -303,7 +305,7 @@ def test_wide_shape_properties(hip_ctx):
     total = m.pairw()
     assert total == m.column_identity()
     try:
-        for variant in (3, 4, 5):
+        for variant in shipped(hip_ctx, "variant", (3, 4, 5)):
             hip_ctx.set_option("variant", variant)
             assert m.pairw() == total, variant
     finally:
@@ -364,7 +366,7 @@ def test_sparse_arena_kernel_variants(lib, hip_ctx, orc):
                                        p(a_lists), a_lists.size, p(a_words), a_words.size, C.byref(h)) == 0, lib.storm_hip_last_error()
     out = C.c_uint64()
     try:
-        for variant in (2, 3, 4, 5, -1):
+        for variant in shipped(hip_ctx, "variant", (2, 3, 4, 5, -1)):
             hip_ctx.set_option("variant", variant)
             assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, 0, 1, C.byref(out)) == 0, lib.storm_hip_last_error()
             assert out.value == want, variant
@@ -526,7 +528,7 @@ def test_repeated_launches_are_stable(hip_ctx):
     m.fill_synthetic(M, d, seed=43)
     want = m.column_identity()
     try:
-        for variant in (5, 4, 3, 2):
+        for variant in shipped(hip_ctx, "variant", (5, 4, 3, 2)):
             hip_ctx.set_option("variant", variant)
             got = {m.pairw() for _ in range(30 if variant != 2 else 5)}
             assert got == {want}, (variant, got, want)
@@ -619,13 +621,14 @@ def test_strip_item_shaping_options(hip_ctx, orc):
     try:
         for pad in (0, 128, 1152, -1):                     # row pitch of the FP4 shadow
             hip_ctx.set_option("k2_pitch_pad", pad)
-            for variant in (3, 4, 5):
+            for variant in shipped(hip_ctx, "variant", (3, 4, 5)):
                 hip_ctx.set_option("variant", variant)
                 assert m.pairw() == want, (pad, variant)
             assert np.array_equal(m.pairw_matrix()[:40, :300],
                                   np.triu(orc.tile_counts(mat, 0, 40, 0, 300), k=1)), pad
         hip_ctx.set_option("variant", 4)
-        for persistent in (0, 1):
+        hip_ctx.set_option("k2_strip_operands", 4)        # the work-list shaping of the FP4 strips
+        for persistent in shipped(hip_ctx, "k2_persistent", (0, 1)):
             for max_run, tail_slices, tail_run in ((4096, 0, 32), (128, 3, 32), (5, 2, 3), (1, 255, 1)):
                 hip_ctx.set_option("k2_persistent", persistent)
                 hip_ctx.set_option("k2_max_run", max_run)
@@ -635,6 +638,7 @@ def test_strip_item_shaping_options(hip_ctx, orc):
                 assert sum(m.pairw(r, 3) for r in range(3)) == want
     finally:
         hip_ctx.set_option("variant", -1)
+        hip_ctx.set_option("k2_strip_operands", 0)
         hip_ctx.set_option("k2_persistent", 0)
         hip_ctx.set_option("k2_max_run", defaults["k2_max_run"])
         hip_ctx.set_option("k2_tail_slices", 3)
@@ -646,6 +650,8 @@ def test_strip_item_shaping_options(hip_ctx, orc):
 def test_persistent_queues_at_headline_shape(hip_ctx):
     """Persistent per-XCD queues at N=10000 x M=65536: repeated launches (the queue heads are
     re-zeroed by the fold kernel) must all reproduce the column identity."""
+    if not shipped(hip_ctx, "k2_persistent", (1,)):
+        pytest.skip("the persistent-queue strips are a form of the tools build (make probes)")
     M, N, d = 65536, 10000, 32768
     m = hip_ctx.matrix(N, M // 64)
     m.fill_synthetic(M, d, seed=44)
@@ -814,7 +820,7 @@ def test_keep_shadow_follows_every_mutation(hip_ctx, orc):
         assert ma.pairw() == orc.wrapper_diag(mixed)
         assert sum(ma.pairw(r, 3) for r in range(3)) == orc.wrapper_diag(mixed)   # shard change
         assert ma.pairw() == orc.wrapper_diag(mixed)
-        for variant in (5, 3, 4):                      # layout change
+        for variant in shipped(hip_ctx, "variant", (5, 3, 4)):    # layout change
             hip_ctx.set_option("variant", variant)
             assert ma.pairw() == orc.wrapper_diag(mixed), variant
         hip_ctx.set_option("variant", -1)

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import shipped
+
 import stormbitmaps_amd as sb
 from stormbitmaps_amd import synth
 
@@ -156,13 +158,15 @@ def test_strip_kernel_mfma_shapes_agree(hip_ctx, orc):
             mat = synth.dense_matrix_c(M, N, d, seed=N)
             want = orc.wrapper_diag_blocked(mat, 31)
             m = hip_ctx.matrix_from_host(mat)
-            for shape in (16, 32):
+            hip_ctx.set_option("k2_strip_operands", 4)     # (these sizes take K2q by default)
+            for shape in shipped(hip_ctx, "k2_shape", (16, 32)):
                 hip_ctx.set_option("k2_shape", shape)
                 assert m.pairw() == want, (M, N, d, shape)
                 assert sum(m.pairw(r, 5) for r in range(5)) == want, (M, N, d, shape)
             m.close()
     finally:
         hip_ctx.set_option("k2_shape", 16)
+        hip_ctx.set_option("k2_strip_operands", 0)
     assert hip_ctx.get_option("k2_shape") == 16
 
 
@@ -215,10 +219,11 @@ def test_hbm_tiled_passes_under_a_shadow_budget(hip_ctx, orc):
                 hip_ctx.set_option("keep_shadow", 0)
                 # the persistent-queue forms (32-row and wide strips) under chunks: their queue heads
                 # are only re-zeroed at the end of a pass (soak seed 397310033 caught a lost chunk)
-                for shape in (32, 16):
+                for shape in shipped(hip_ctx, "k2_shape", (32, 16)):
                     hip_ctx.set_option("k2_shape", shape)
-                    hip_ctx.set_option("k2_persistent", 1)
-                    assert m.pairw() == want and m.pairw() == want, (M, N, mb, shape)
+                    for persistent in shipped(hip_ctx, "k2_persistent", (1,)):
+                        hip_ctx.set_option("k2_persistent", persistent)
+                        assert m.pairw() == want and m.pairw() == want, (M, N, mb, shape)
                     hip_ctx.set_option("k2_persistent", 0)
                     assert m.pairw() == want, (M, N, mb, shape)
                 hip_ctx.set_option("k2_shape", 16)
@@ -425,7 +430,7 @@ def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d
     for code, name in ((1, "or"), (2, "xor")):
         want[name] = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, code), k=1)
     try:
-        for shape in (2, 1, 16, 32):
+        for shape in shipped(hip_ctx, "k2_tile_shape", (2, 1, 16, 32)):
             hip_ctx.set_option("k2_tile_shape", shape)
             for name in ("and", "or", "xor"):
                 assert np.array_equal(m.pairw_matrix(name), want[name]), (shape, name)
@@ -459,7 +464,7 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
         ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
         want = orc.tile_counts(mat, 0, na, na, na + nbr)
         try:
-            for shape in (2, 1, 16):
+            for shape in shipped(hip_ctx, "k2_tile_shape", (2, 1, 16)):
                 hip_ctx.set_option("k2_tile_shape", shape)
                 assert np.array_equal(ma.square_matrix(mb, "and"), want), (na, nbr, shape)
             want_x = orc.tile_counts_op(mat, 0, na, na, na + nbr, 2)
@@ -481,7 +486,7 @@ def test_strips_on_bit_operands(hip_ctx, orc):
         for M, N, d, check_oracle in ((4096, 256, 2048, True), (1000, 131, 300, True), (65536, 513, 9000, True),
                                       (300, 65, 100, True), (20000, 1029, 7000, True), (65536, 2000, 32768, False),
                                       (70000, 777, 30000, False), (32768, 2000, 16000, False)):
-            for created_under in (1, 4):
+            for created_under in shipped(hip_ctx, "k2_strip_operands", (1, 4)):
                 hip_ctx.set_option("k2_strip_operands", created_under)
                 m = hip_ctx.matrix(N, (M + 63) // 64)
                 m.fill_synthetic(M, d, seed=N)
@@ -489,7 +494,7 @@ def test_strips_on_bit_operands(hip_ctx, orc):
                 want = m.column_identity()
                 if check_oracle and created_under == 1:
                     assert want == orc.wrapper_diag_blocked(m.download(), 31)
-                for operands in (1, 2, 4):
+                for operands in shipped(hip_ctx, "k2_strip_operands", (1, 2, 4)):
                     hip_ctx.set_option("k2_strip_operands", operands)
                     got = [m.pairw() for _ in range(4 if operands != 4 else 1)]
                     assert got == [want] * len(got), (M, N, d, created_under, operands, got, want)

@@ -33,15 +33,16 @@ def main():
     while time.time() < t_end and n_cases < args.max_cases:
         kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "sparse"])
         seed = int(rng.integers(1, 1 << 30))
-        opts = {"variant": int(rng.choice([-1, -1, 4, 5, 3, 2])),
+        probes = ctx.get_option("probes_build") == 1   # the alternative kernel forms exist in the tools build only
+        opts = {"variant": int(rng.choice([-1, -1, 4, 5 if probes else 4, 3, 2])),
                 "k2_max_run": int(rng.choice([128, 128, 1, 7, 64, 4096])),
                 "k2_tail_slices": int(rng.choice([3, 0, 1, 8])),
                 "k2_tail_run": int(rng.choice([32, 1, 5, 64])),
-                "k2_persistent": int(rng.choice([0, 0, 1])),
+                "k2_persistent": int(rng.choice([0, 0, 1 if probes else 0])),
                 "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
-                "k2_shape": int(rng.choice([16, 16, 32])),
-                "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32])),
-                "k2_strip_operands": int(rng.choice([0, 0, 4, 1, 2])),
+                "k2_shape": int(rng.choice([16, 16, 32 if probes else 16])),
+                "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32] if probes else [2, 2, 32])),
+                "k2_strip_operands": int(rng.choice([0, 0, 4, 1 if probes else 2, 2])),
                 "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
                 "k2_stream_min_piece": int(rng.choice([6, 6, 1, 30])),
                 "k2_stream_min_run": int(rng.choice([2, 2, 1, 9])),
