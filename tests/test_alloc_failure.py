@@ -62,7 +62,7 @@ def test_every_failing_allocation_of_the_host_side_is_survived(tmp_path):
         objs.append(str(obj))
     build = subprocess.run(common + objs + [os.path.join(ROOT, "tests", "host_sanitize", "device_stub.c"),
                                             os.path.join(ROOT, "tests", "host_sanitize", "alloc_inject.c"),
-                                            "-o", str(exe), "-lm"], capture_output=True, text=True)
+                                            "-o", str(exe), "-lm", "-pthread"], capture_output=True, text=True)
     assert build.returncode == 0, build.stderr
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
