@@ -2226,7 +2226,8 @@ constexpr uint32_t kBsMaxStages = 8192;      // per workgroup: accumulators stay
 template <bool kTrace>
 __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     const uint8_t* __restrict__ X, uint64_t pitch64, const BitSeg* __restrict__ segs,
-    const uint32_t* __restrict__ first, unsigned long long* __restrict__ slots,
+    const uint32_t* __restrict__ first, const uint32_t* __restrict__ bases,
+    const uint32_t* __restrict__ first_stage, unsigned long long* __restrict__ slots,
     unsigned long long* __restrict__ out, unsigned long long* __restrict__ trace) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSbRing * kSbStageBytes];
     auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
@@ -2263,43 +2264,25 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
             for (int m = 0; m < 2; ++m) a[g][c][m] = v4i{};
     uint32_t dbits = 0;  // set bits of the rows this lane took as A in multiplied diagonal stages
 
-    // ---- the stream: two cursors over the segment list, `issue` three stages ahead of `consume`
-    BitSeg ri = {}, rn = {}, rc = {};
-    uint32_t si = s_begin;  // segment of the issue cursor
-    uint32_t ii = 0;        // its stage in that segment
-    uint32_t issued = 0;    // stages handed to the DMA so far
-    bool more = s_begin < s_end;
-    if (more) {
-        ri = segs[s_begin];
-        rn = segs[min(s_begin + 1u, s_end - 1u)];
-        rc = ri;
-    }
-    // A wave alone on its SIMD issues one instruction every four cycles, so every instruction between the
-    // barrier and the first MFMA of a stage costs the matrix pipe four cycles (the first version computed the
-    // next piece's address there: 265 of a lone wave's 1760 cycles per stage, tools/stream_trace.py). Behind
-    // the barrier there is only the DMA instruction (fire); the address of the piece after it and the cursor's
-    // step (prep) follow the stage's last MFMA, while the pipe drains.
-    uint64_t nbase = 0;   // the next piece to hand over ...
-    bool nvalid = false;  // ... if there is one
+    // ---- the stream. The DMA side reads the address of every stage's 64 rows from a table the host wrote
+    // (64-byte units from X; build_bitstream): a wave alone on its SIMD issues one instruction every four cycles,
+    // and the first version's address arithmetic between the barrier and the first MFMA of a stage (the cursor
+    // over the segment records, a 64-bit multiply) cost a lone wave 265 of its 1760 cycles per stage
+    // (tools/stream_trace.py). The consume side walks the segment records (what a stage is to this wave).
+    const uint32_t bs0 = first_stage[blockIdx.x];
+    const uint32_t T = first_stage[blockIdx.x + 1] - bs0;
+    uint32_t issued = 0;     // stages handed to the DMA so far
+    uint32_t prepared = 0;   // stages whose address has been fetched
+    uint32_t off_next = T ? bases[bs0] : 0u;
+    uint64_t nbase = 0;      // the next piece to hand over ...
+    bool nvalid = false;     // ... if there is one
+    BitSeg rc = {};
+    if (s_begin < s_end) rc = segs[s_begin];
     auto prep = [&]() {
-        nvalid = more;
-        if (more) {
-            uint32_t rel = ri.b_first + (ii - 4u);
-            rel = rel >= ri.range_nb ? rel - ri.range_nb : rel;
-            const uint32_t blk = ii < 4u ? ri.a_blk + ii : ri.range_b0 + rel;
-            nbase = (uint64_t)(uintptr_t)X + (uint64_t)ri.ks * kSbRowBytes + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
-            ++ii;
-            if (ii == 4u + ri.n_b) {
-                ii = 0;
-                ++si;
-                if (si < s_end) {
-                    ri = rn;
-                    rn = segs[min(si + 1u, s_end - 1u)];
-                } else {
-                    more = false;
-                }
-            }
-        }
+        nvalid = prepared < T;
+        nbase = (uint64_t)(uintptr_t)X + ((uint64_t)off_next << 6);
+        ++prepared;
+        off_next = bases[bs0 + min(prepared, T ? T - 1u : 0u)];
     };
     auto fire = [&]() {
         if (nvalid) {
@@ -2387,9 +2370,9 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     }
     if (kTrace) t_ready = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
-    while (t < issued) {
+    while (t < T) {
         // top of stage t: stage t + 1 has landed and every wave is done with stage t - 1, whose slot the
-        // next piece takes (invariant: issued == min(stages of this workgroup, t + 3))
+        // next piece takes (invariant: issued == min(T, t + 3))
         const bool has_next = issued > t + 1u;
         if (kTrace) c_mark = __builtin_readcyclecounter();
         if (has_next) {
@@ -3557,6 +3540,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
 // Pure host computation (no device). `groups` workgroups; workgroup w walks segs[first[w] .. first[w+1]).
 struct BitstreamPlan {
     std::vector<BitSeg> segs;
+    std::vector<uint32_t> bases;        // per stage, workgroup by workgroup: where its 64 rows x 64 B start (64-byte units)
+    std::vector<uint32_t> first_stage;  // workgroup w's stages are bases[first_stage[w] .. first_stage[w + 1])
     std::vector<uint32_t> first;
     uint32_t groups = 0;
     uint64_t stages = 0;      // multiplied + operand-only stages of this shard, after cutting
@@ -3571,7 +3556,7 @@ struct BitstreamShaping {
 
 static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRange>& ranges,
                             uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
-                            uint32_t n_cus, BitstreamPlan& plan) {
+                            uint32_t n_cus, uint64_t pitch_bytes, BitstreamPlan& plan) {
     // natural segments, k-slice major: every A tile of every range with the later tiles dealt cyclically
     struct Nat {
         BitSeg s;
@@ -3607,6 +3592,8 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
         }
     plan.segs.clear();
     plan.first.clear();
+    plan.bases.clear();
+    plan.first_stage.clear();
     plan.stages = 0;
     plan.max_stages = 0;
     // this shard's part of the stream (contiguous: a shard touches a contiguous range of k-slices)
@@ -3640,6 +3627,7 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
     plan.groups = (uint32_t)G;
     if (G == 0) {
         plan.first.push_back(0);
+        plan.first_stage.push_back(0);
         return;
     }
     // cut positions, snapped: never inside a tile's own four stages, never leaving a stub of a run
@@ -3692,11 +3680,33 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
         plan.max_stages = std::max(plan.max_stages, mine);
     }
     plan.first.push_back((uint32_t)plan.segs.size());
+    // the DMA's view of the same stream: the start of every stage's 64 rows x 64 B, in 64-byte units from the
+    // matrix ((ks * 64 + blk * 64 * pitch) / 64; the pitch is a multiple of 64 bytes)
+    plan.bases.reserve(plan.stages);
+    for (uint64_t w = 0; w < G; ++w) {
+        plan.first_stage.push_back((uint32_t)plan.bases.size());
+        for (uint32_t si = plan.first[w]; si < plan.first[w + 1]; ++si) {
+            const BitSeg& sg = plan.segs[si];
+            for (uint32_t i = 0; i < 4u + sg.n_b; ++i) {
+                uint32_t blk;
+                if (i < 4u) {
+                    blk = sg.a_blk + i;
+                } else {
+                    uint32_t rel = sg.b_first + (i - 4u);
+                    if (rel >= sg.range_nb) rel -= sg.range_nb;
+                    blk = sg.range_b0 + rel;
+                }
+                plan.bases.push_back((uint32_t)((uint64_t)sg.ks + (uint64_t)blk * pitch_bytes));
+            }
+        }
+    }
+    plan.first_stage.push_back((uint32_t)plan.bases.size());
 }
 
 static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges, uint32_t n_kslices,
-                            uint32_t shard_rank, uint32_t shard_count) {
-    const uint64_t key[4] = {ranges_hash(ranges), n_kslices, ((uint64_t)shard_rank << 32) | shard_count,
+                            uint32_t shard_rank, uint32_t shard_count, uint64_t pitch) {
+    const uint64_t key[4] = {ranges_hash(ranges) ^ (pitch * 0x9e3779b97f4a7c15ull), n_kslices,
+                             ((uint64_t)shard_rank << 32) | shard_count,
                              ((uint64_t)(ctx->k2_stream_groups_per_cu & 0xff) << 32) |
                                  ((uint64_t)(ctx->k2_stream_min_piece & 0xffff) << 16) |
                                  (uint64_t)(ctx->k2_stream_min_run & 0xffff)};
@@ -3706,13 +3716,22 @@ static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& r
     sh.min_piece = std::max(1, ctx->k2_stream_min_piece);
     sh.min_run = std::max(1, ctx->k2_stream_min_run);
     BitstreamPlan plan;
-    build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), plan);
+    build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), pitch, plan);
+    if (plan.bases.size() >= (1ull << 32) ||
+        (!ranges.empty() && ranges.back().r1 * pitch / 64 + n_kslices >= (1ull << 32))) {
+        set_error("K2q: the matrix is beyond the 32-bit stage addresses (64-byte units)");
+        return STORM_HIP_EINVAL;
+    }
     if (plan.max_stages > kBsMaxStages) {
         set_error("K2q: a workgroup of %u stages exceeds the exact range of its accumulators", plan.max_stages);
         return STORM_HIP_EINVAL;
     }
     const size_t seg_bytes = std::max<size_t>(plan.segs.size(), 1) * sizeof(BitSeg);
-    const size_t first_bytes = plan.first.size() * sizeof(uint32_t);
+    // one device buffer: first[G + 1] | first_stage[G + 1] | bases[stages]
+    std::vector<uint32_t> packed(plan.first);
+    packed.insert(packed.end(), plan.first_stage.begin(), plan.first_stage.end());
+    packed.insert(packed.end(), plan.bases.begin(), plan.bases.end());
+    const size_t first_bytes = packed.size() * sizeof(uint32_t);
     if (seg_bytes > ctx->bitsegs_capacity) {
         if (ctx->d_bitsegs) STORM_HIP_TRY(hipFree(ctx->d_bitsegs));
         ctx->d_bitsegs = nullptr;
@@ -3730,7 +3749,7 @@ static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& r
     if (!plan.segs.empty())
         STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitsegs, plan.segs.data(), plan.segs.size() * sizeof(BitSeg),
                                      hipMemcpyHostToDevice, ctx->stream));
-    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitfirst, plan.first.data(), first_bytes, hipMemcpyHostToDevice,
+    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitfirst, packed.data(), first_bytes, hipMemcpyHostToDevice,
                                  ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->n_bit_groups = plan.groups;
@@ -3746,12 +3765,12 @@ static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& r
 int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pitch,
                            const std::vector<RowRange>& ranges, uint32_t n_kslices, uint32_t shard_rank,
                            uint32_t shard_count, uint64_t* d_total) {
-    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || pitch % 16 != 0) {
+    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || pitch % 64 != 0) {
         set_error("K2q: rows of %llu bytes are outside the bit-operand stream's 32-bit DMA offsets",
                   (unsigned long long)pitch);
         return STORM_HIP_EINVAL;
     }
-    if (int rc = ensure_bitstream(ctx, ranges, n_kslices, shard_rank, shard_count)) return rc;
+    if (int rc = ensure_bitstream(ctx, ranges, n_kslices, shard_rank, shard_count, pitch)) return rc;
     ctx->n_items = 0;
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
     ctx->last_info[0] = ctx->n_bit_groups;
@@ -3779,13 +3798,17 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
         ctx->trace_is_stream = true;
         hipLaunchKernelGGL(bitstream_kernel<true>, grid, block, 0, ctx->stream,
                            reinterpret_cast<const uint8_t*>(X), pitch, static_cast<const BitSeg*>(ctx->d_bitsegs),
-                           static_cast<const uint32_t*>(ctx->d_bitfirst), ctx->d_slots,
+                           static_cast<const uint32_t*>(ctx->d_bitfirst),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst) + 2 * ((size_t)ctx->n_bit_groups + 1),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst) + ((size_t)ctx->n_bit_groups + 1), ctx->d_slots,
                            reinterpret_cast<unsigned long long*>(d_total), ctx->d_trace);
     } else
 #endif
         hipLaunchKernelGGL(bitstream_kernel<false>, grid, block, 0, ctx->stream,
                            reinterpret_cast<const uint8_t*>(X), pitch, static_cast<const BitSeg*>(ctx->d_bitsegs),
-                           static_cast<const uint32_t*>(ctx->d_bitfirst), ctx->d_slots,
+                           static_cast<const uint32_t*>(ctx->d_bitfirst),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst) + 2 * ((size_t)ctx->n_bit_groups + 1),
+                           static_cast<const uint32_t*>(ctx->d_bitfirst) + ((size_t)ctx->n_bit_groups + 1), ctx->d_slots,
                            reinterpret_cast<unsigned long long*>(d_total), (unsigned long long*)nullptr);
     kernel_time_mark(ctx);
     STORM_HIP_TRY(hipGetLastError());
@@ -3914,7 +3937,9 @@ extern "C" int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t
         std::vector<RowRange> ranges;
         if (n_rows > 1) ranges.push_back({0, n_rows});
         BitstreamPlan plan;
-        build_bitstream(BitstreamShaping{}, ranges, (n_words + 7u) / 8u, shard_rank, shard_count, n_cus, plan);
+        const uint64_t stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
+        build_bitstream(BitstreamShaping{}, ranges, (n_words + 7u) / 8u, shard_rank, shard_count, n_cus,
+                        stride_words * 8, plan);
         *n_segments = plan.segs.size();
         if (n_workgroups) *n_workgroups = plan.groups;
         if (out) {
