@@ -2222,6 +2222,8 @@ constexpr uint32_t kBsDiag = 1u;
 constexpr int kBsFoldSlots = 64;             // partial sums of this kernel: slots[0 .. 64)
 constexpr int kBsTicket = kSlots + 6;        // arrival counter (behind the strip queue heads; zero between passes)
 constexpr uint32_t kBsMaxStages = 8192;      // per workgroup: accumulators stay below 2^22 (in halves: 2^23)
+constexpr int kBsRing = 8;                   // LDS stages of 4 KiB; ONE barrier serves two stages (four, with a ring
+                                             // of 12: faster at N = 512 only, 12.0 against 12.2 us, slower from 2048 up)
 
 template <bool kTrace>
 __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
@@ -2229,7 +2231,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     const uint32_t* __restrict__ first, const uint32_t* __restrict__ bases,
     const uint32_t* __restrict__ first_stage, unsigned long long* __restrict__ slots,
     unsigned long long* __restrict__ out, unsigned long long* __restrict__ trace) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSbRing * kSbStageBytes];
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kBsRing * kSbStageBytes];
     auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
 
     unsigned long long t_start = 0, t_ready = 0;
@@ -2288,20 +2290,20 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
         if (nvalid) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 reinterpret_cast<uint8_t*>((uintptr_t)nbase), 0, -1, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[issued % kSbRing] + wave * 1024u), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[issued % kBsRing] + wave * 1024u), 16,
                                                      (int)goff, 0, 0, 0);
             ++issued;
         }
     };
     prep();
 #pragma unroll
-    for (int k = 0; k < kSbRing - 1; ++k) {
+    for (int k = 0; k < kBsRing - 2; ++k) {  // stages 0 .. 5: the ring's eight slots minus the pair a barrier frees
         fire();
         prep();
     }
 
 #define STORM_BS_FETCH(dst, t, n, g) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kBsRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
     // one class of one B word against both A row blocks; the next operand is inflated BETWEEN the two MFMAs
     // (in the shadow of the first: the second cannot start before the first has left the pipe's front anyway)
 #define STORM_BS_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
@@ -2358,9 +2360,8 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     uint32_t sc = s_begin;
     uint32_t t = 0;   // stages consumed
     if (issued > 0) {
-        // stage 0 has landed (the younger pieces may stay in flight)
-        if (issued >= 3u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (issued == 2u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        // stage 0 has landed (the younger pieces may stay in flight: the loop's first barrier waits for more)
+        if (issued >= 6u) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         STORM_BS_FETCH(w0, 0u, 0, 0);
@@ -2371,22 +2372,27 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     if (kTrace) t_ready = __builtin_amdgcn_s_memrealtime();
 #pragma unroll 1
     while (t < T) {
-        // top of stage t: stage t + 1 has landed and every wave is done with stage t - 1, whose slot the
-        // next piece takes (invariant: issued == min(T, t + 3))
-        const bool has_next = issued > t + 1u;
+        // ONE barrier serves two stages (a lone wave spends ~230 clocks per barrier: arrival skew of the four
+        // waves + the DMA wait). At the top of an EVEN stage t: stages up to t + 2 have landed (t and t + 1 are
+        // multiplied before the next barrier, and the end of t + 1 already reads the first word of t + 2), every
+        // wave is done with the stages before t, and the two pieces behind the six in flight are handed over
+        // (invariant: issued == min(T, t + 6) at an even t).
+        const bool has_next = t + 1u < T;
         if (kTrace) c_mark = __builtin_readcyclecounter();
-        if (has_next) {
-            if (issued >= t + 3u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((t & 1u) == 0u) {
+            if (issued >= t + 6u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // t + 3 .. t + 5 may fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the stream's last stages
+            __builtin_amdgcn_s_barrier();
+            if (kTrace) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                c_wait += now - c_mark;
+                c_mark = now;
+            }
+            fire();
+            prep();
+            fire();
+            prep();
         }
-        __builtin_amdgcn_s_barrier();
-        if (kTrace) {
-            const unsigned long long now = __builtin_readcyclecounter();
-            c_wait += now - c_mark;
-            c_mark = now;
-        }
-        fire();
-        prep();
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t tn = has_next ? t + 1u : t;
         // what this wave does with the stage
