@@ -697,6 +697,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         (key[14] == 'p' ? ctx->k2_stream_min_piece : ctx->k2_stream_min_run) = (int)value;
+    } else if (!strcmp(key, "k2_stream_w3_1") || !strcmp(key, "k2_stream_w3_2")) {
+        if (value < 10 || value > 1000) {
+            set_error("%s must be 10..1000 percent of the first workgroup's share", key);
+            return STORM_HIP_EINVAL;
+        }
+        (key[13] == '1' ? ctx->k2_stream_w3_1 : ctx->k2_stream_w3_2) = (int)value;
     } else if (!strcmp(key, "k2_shape")) {
         if (value != 16 && value != 32) {
             set_error("k2_shape must be 16 (16x16x128 MFMA) or 32 (32x32x64)");
@@ -792,6 +798,8 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_strip_operands")) return ctx->k2_strip_operands;
     if (!strcmp(key, "k2_operands_used")) return ctx->k2_operands_used;
     if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
+    if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
+    if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
     if (!strcmp(key, "n_cus")) return ctx->n_cus;
     if (!strcmp(key, "probes_build")) {

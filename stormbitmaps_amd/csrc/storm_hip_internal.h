@@ -154,6 +154,9 @@ struct storm_hip_ctx_s {
     int k2_stream_groups_per_cu = 0;  // K2q: workgroups per CU (0 = by the length of the stream: 1, 2 or 3)
     int k2_stream_min_piece = 6;      // K2q: stages a workgroup should at least have before a CU's share is cut further
     int k2_stream_min_run = 2;        // K2q: a cut leaves at least this many later blocks on either side
+    // K2q: length of the shares of the second / third workgroup of a CU in percent of the first one's, when the
+    // stream is one round of 3 workgroups per CU (build_bitstream: the SIMD arbiter serves the oldest wave)
+    int k2_stream_w3_1 = 120, k2_stream_w3_2 = 60;
     bool trace_is_stream = false;     // d_trace holds per-workgroup words of bitstream_kernel (no strip items)
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };

@@ -3558,6 +3558,10 @@ struct BitstreamShaping {
     int min_piece = 6;      // stages a workgroup should have at least before a CU's share is cut further
     int min_run = 2;        // a cut leaves at least this many later blocks on either side of it
     int long_piece = 80;    // stages per workgroup once the stream is longer than the chip's slots x this
+    // one round of 3 workgroups per CU: the later workgroups' shares in percent of the first one's (below) ...
+    int w3_1 = 120, w3_2 = 60;
+    int weighted_min = 16;       // ... from this many stages per share (shorter ones: equal shares)
+    int single_round_max = 220;  // stages per slot up to which the stream is ONE round of weighted shares
 };
 
 static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRange>& ranges,
@@ -3625,7 +3629,9 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
         const uint64_t slots = (uint64_t)n_cus * 3u;
         const uint64_t rounds = (Ls + slots * (uint64_t)std::max(1, sh.long_piece) / 2) /
                                 (slots * (uint64_t)std::max(1, sh.long_piece));
-        G = slots * std::max<uint64_t>(1, rounds);
+        // up to ~220 stages per slot ONE round of weighted shares (below) is faster than the dynamic deal, which
+        // pays four operand-only stages per cut (N = 6144: 308 against 314 us; N = 8192: 545 against 538)
+        G = slots * (Ls <= slots * (uint64_t)sh.single_round_max ? 1ull : std::max<uint64_t>(1, rounds));
     }
     G = std::max<uint64_t>(G, (Ls + kBsMaxStages / 2 - 1) / (kBsMaxStages / 2));
     G = std::max<uint64_t>(1, std::min<uint64_t>(G, std::max<uint64_t>(1, Ls / 4)));
@@ -3645,9 +3651,26 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
         }
         return a;
     };
+    // Shares of ONE round are not equal. The waves of a SIMD do not take turns: its arbiter issues for the oldest
+    // wave that can go, and a wave alone reaches ~60 % of the matrix pipe (one instruction every four cycles). Of
+    // three equal shares per CU the first-dispatched workgroup ends after 0.55 of the kernel, the second at 0.75,
+    // the third runs the last quarter nearly alone (N = 2048: 24 / 33 / 42 us; tools/stream_trace.py, end by
+    // dispatch round; workgroup w is dispatched in round w / n_cus, one per CU per round). Shares in the proportion
+    // 100 : 120 : 60 let the three end closer together: -3 % at N = 2048, -6 % at 3072 ... 4096, -2 % at 6144
+    // against the dynamic deal (profiles/r03_e_stream_weights.txt; the optimum is flat: 100 : 100 : 50 and
+    // 100 : 125 : 65 are within 1 %). Shares shorter than ~16 stages keep equal lengths: start-up and drain
+    // dominate them, and whole segments as shares (no cut, no operand-only stages, but two workgroups per CU) lose
+    // 15 % at N = 1024.
+    std::vector<uint32_t> weight(G, 100u);
+    if (G == (uint64_t)n_cus * 3u && n_cus % 8u == 0u && Ls >= G * (uint64_t)sh.weighted_min) {
+        const uint32_t wr[3] = {100u, (uint32_t)sh.w3_1, (uint32_t)sh.w3_2};
+        for (uint64_t p = 0; p < G; ++p) weight[p] = std::max(1u, wr[(p % (G / 8)) / (n_cus / 8u)]);
+    }
+    std::vector<uint64_t> cum(G + 1, 0);
+    for (uint64_t p = 0; p < G; ++p) cum[p + 1] = cum[p] + weight[p];
     std::vector<uint64_t> cut(G + 1);
     for (uint64_t k = 0; k <= G; ++k) {
-        uint64_t c = lo + Ls * k / G;
+        uint64_t c = lo + (uint64_t)((unsigned __int128)Ls * cum[k] / cum[G]);
         if (c < L) {
             const Nat& n = nat[seg_at(c)];
             const uint64_t off = c - n.start, len = 4ull + n.s.n_b;
@@ -3659,9 +3682,10 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
     for (uint64_t k = 1; k <= G; ++k) cut[k] = std::max(cut[k], cut[k - 1]);
     // piece p of the stream goes to workgroup w with p = (w % 8) * (G / 8) + w / 8: block w runs on XCD
     // w % 8 (observed; speed only), so an XCD's workgroups hold one contiguous eighth of the stream
-    auto piece_of = [&](uint64_t w) { return G % 8 == 0 ? (w % 8) * (G / 8) + w / 8 : w; };
+    std::vector<uint32_t> piece_of(G);
+    for (uint64_t w = 0; w < G; ++w) piece_of[w] = (uint32_t)(G % 8 == 0 ? (w % 8) * (G / 8) + w / 8 : w);
     for (uint64_t w = 0; w < G; ++w) {
-        const uint64_t p = piece_of(w);
+        const uint64_t p = piece_of[w];
         plan.first.push_back((uint32_t)plan.segs.size());
         uint64_t c0 = cut[p], c1 = cut[p + 1];
         uint32_t mine = 0;
@@ -3711,16 +3735,20 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
 
 static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges, uint32_t n_kslices,
                             uint32_t shard_rank, uint32_t shard_count, uint64_t pitch) {
-    const uint64_t key[4] = {ranges_hash(ranges) ^ (pitch * 0x9e3779b97f4a7c15ull), n_kslices,
-                             ((uint64_t)shard_rank << 32) | shard_count,
+    const uint64_t key[4] = {ranges_hash(ranges) ^ (pitch * 0x9e3779b97f4a7c15ull) ^
+                                 ((uint64_t)(ctx->k2_stream_w3_2) * 0xc2b2ae3d27d4eb4full),
+                             n_kslices, ((uint64_t)shard_rank << 32) | shard_count,
                              ((uint64_t)(ctx->k2_stream_groups_per_cu & 0xff) << 32) |
                                  ((uint64_t)(ctx->k2_stream_min_piece & 0xffff) << 16) |
-                                 (uint64_t)(ctx->k2_stream_min_run & 0xffff)};
+                                 (uint64_t)(ctx->k2_stream_min_run & 0xffff) |
+                                 ((uint64_t)(ctx->k2_stream_w3_1 & 0x3ff) << 40)};
     if (ctx->d_bitsegs && !memcmp(key, ctx->bit_key, sizeof(key))) return STORM_HIP_OK;
     BitstreamShaping sh;
     sh.groups_per_cu = ctx->k2_stream_groups_per_cu;
     sh.min_piece = std::max(1, ctx->k2_stream_min_piece);
     sh.min_run = std::max(1, ctx->k2_stream_min_run);
+    sh.w3_1 = ctx->k2_stream_w3_1;
+    sh.w3_2 = ctx->k2_stream_w3_2;
     BitstreamPlan plan;
     build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), pitch, plan);
     if (plan.bases.size() >= (1ull << 32) ||

@@ -181,12 +181,21 @@ def test_stream_plans_of_all_ranks_cover_every_block_pair_exactly_once(n_rows, n
         assert max(totals) - min(totals) <= 4 * 64 + 16, totals
 
 
-def test_stream_plan_shares_are_even_at_the_sizes_the_bench_reports():
-    """N = 1024 ... 8192 at M = 65536 on 256 CUs: whole rounds of the chip's 768 workgroup slots (or 256 / 512
-    for short streams), every workgroup within a few stages of the mean."""
-    for n_rows in (512, 1024, 2048, 4096, 8192):
+def test_stream_plan_shares_at_the_sizes_the_bench_reports():
+    """N = 512 ... 8192 at M = 65536 on 256 CUs: whole rounds of the chip's 768 workgroup slots (or 256 / 512 for
+    short streams). Short shares and the shares of a multi-round deal are equal to within a few stages; ONE round
+    of long shares (from 16 stages) is dealt 100 : 120 : 60 by dispatch round (workgroup w / 256), for the SIMD
+    arbiter's oldest-first issue (build_bitstream)."""
+    for n_rows in (512, 1024, 1536, 2048, 4096, 6144, 8192):
         segs, groups = sdist.stream_plan(n_rows, 1024, 0, 1, 256)
         assert groups % 256 == 0 and groups >= 256
         per_wg = np.bincount(segs[:, 0], weights=segs[:, 7], minlength=groups)
         assert per_wg.min() > 0
-        assert per_wg.max() <= per_wg.mean() * 1.3 + 6, (n_rows, groups, per_wg.min(), per_wg.mean(), per_wg.max())
+        if groups == 768 and per_wg.mean() >= 20:
+            r = [per_wg[k * 256:(k + 1) * 256].mean() for k in range(3)]
+            assert abs(r[1] / r[0] - 1.2) < 0.08 and abs(r[2] / r[0] - 0.6) < 0.08, (n_rows, r)
+            for k in range(3):
+                part = per_wg[k * 256:(k + 1) * 256]
+                assert part.max() <= part.mean() * 1.15 + 6, (n_rows, k, part.min(), part.mean(), part.max())
+        else:
+            assert per_wg.max() <= per_wg.mean() * 1.3 + 6, (n_rows, groups, per_wg.min(), per_wg.mean(), per_wg.max())

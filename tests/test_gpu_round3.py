@@ -27,7 +27,8 @@ def orc():
 
 def _reset(ctx):
     for k, v in (("k2_strip_operands", 0), ("k2_stream_groups_per_cu", 0), ("k2_stream_min_piece", 6),
-                 ("k2_stream_min_run", 2), ("k2_stream_max_rows", 8192)):
+                 ("k2_stream_min_run", 2), ("k2_stream_max_rows", 8192), ("k2_stream_w3_1", 120),
+                 ("k2_stream_w3_2", 60)):
         ctx.set_option(k, v)
 
 
@@ -69,17 +70,22 @@ def test_stream_kernel_is_the_default_up_to_8192_rows_and_matches_the_oracle(hip
         _reset(hip_ctx)
 
 
-@pytest.mark.parametrize("per_cu,min_piece,min_run", [(0, 6, 2), (1, 1, 1), (2, 40, 9), (3, 6, 2), (7, 6, 1), (16, 1, 3)])
-def test_stream_shaping_options_do_not_change_the_total(hip_ctx, per_cu, min_piece, min_run):
+@pytest.mark.parametrize("per_cu,min_piece,min_run,w1,w2",
+                         [(0, 6, 2, 120, 60), (1, 1, 1, 120, 60), (2, 40, 9, 100, 100), (3, 6, 2, 300, 10),
+                          (7, 6, 1, 120, 60), (16, 1, 3, 120, 60), (0, 6, 2, 10, 1000), (3, 1, 1, 1000, 1000)])
+def test_stream_shaping_options_do_not_change_the_total(hip_ctx, per_cu, min_piece, min_run, w1, w2):
     """How the stage stream is cut into workgroups (shares per CU, shortest share, shortest run beside a cut,
-    more shares than slots) is tuning: every setting gives the same total. Shapes of 2..40 tiles, sizes at
+    more shares than slots, the proportion of a CU's three shares) is tuning: every setting gives the same total. Shapes of 2..40 tiles, sizes at
     which segments are cut in the middle and continued by another workgroup."""
     try:
         hip_ctx.set_option("k2_strip_operands", 2)
         hip_ctx.set_option("k2_stream_groups_per_cu", per_cu)
         hip_ctx.set_option("k2_stream_min_piece", min_piece)
         hip_ctx.set_option("k2_stream_min_run", min_run)
-        for M, N in ((65536, 1024), (20000, 2300), (9999, 777), (65536, 300), (2048, 5000), (512, 10000)):
+        hip_ctx.set_option("k2_stream_w3_1", w1)
+        hip_ctx.set_option("k2_stream_w3_2", w2)
+        for M, N in ((65536, 1024), (20000, 2300), (9999, 777), (65536, 300), (2048, 5000), (512, 10000),
+                     (65536, 2048)):
             m = hip_ctx.matrix(N, (M + 63) // 64)
             m.fill_synthetic(M, M // 3, seed=5)
             want = m.column_identity()

@@ -46,6 +46,8 @@ def main():
                 "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
                 "k2_stream_min_piece": int(rng.choice([6, 6, 1, 30])),
                 "k2_stream_min_run": int(rng.choice([2, 2, 1, 9])),
+                "k2_stream_w3_1": int(rng.choice([120, 120, 100, 300])),
+                "k2_stream_w3_2": int(rng.choice([60, 60, 100, 15])),
                 "k2_shadow_budget_mb": int(rng.choice([98304, 98304, 1, 8])),
                 "sparse_probe": int(rng.choice([-1, -1, 0, 1]))}
         for k, v in opts.items():
@@ -119,7 +121,7 @@ def main():
             for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
                          "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
-                         "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
+                         "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
         n_cases += 1
         kinds[kind] = kinds.get(kind, 0) + 1

@@ -61,6 +61,17 @@ def main():
     for x in range(8):
         sel = xcc == x
         print(f"  xcc {x}: end mean {end[sel].mean():.2f} max {end[sel].max():.2f}")
+    # dispatch round = workgroup index / CUs; rank = order of arrival on its CU
+    n_cus = len(np.unique(cuid))
+    rnd = np.arange(n.value) // max(1, n_cus)
+    rank = np.zeros(n.value, dtype=np.int64)
+    for c in np.unique(cuid):
+        idx = np.nonzero(cuid == c)[0]
+        rank[idx[np.argsort(start[idx], kind="stable")]] = np.arange(len(idx))
+    for r in range(int(rnd.max()) + 1):
+        sel = rnd == r
+        print(f"  dispatch round {r}: start mean {start[sel].mean():.2f}  end mean {end[sel].mean():.2f} max {end[sel].max():.2f}  "
+              f"stages mean {stages[sel].mean():.1f}  arrival rank on the CU mean {rank[sel].mean():.2f}")
     per_cu = np.bincount(cuid)
     per_cu = per_cu[per_cu > 0]
     print(f"CUs used {len(per_cu)}  groups per CU: min {per_cu.min()} max {per_cu.max()}  histogram {np.bincount(per_cu).tolist()}")
