@@ -160,6 +160,7 @@ struct STORM_contiguous_s {
     uint64_t hip_rows_capacity;
     STORM_t* hip_lists;      /* the same rows as a STORM_t while EVERY row is below scalar_cutoff:   */
     uint32_t hip_lists_off;  /* such a container goes through the list-probe kernel (see storm_host.c) */
+    void* hip_pending;       /* positions of rows not yet on the device (STORM_contig_add; storm_host.c)    */
 };
 
 /* per-block API (reference storm.h:203-212, storm.c:372-380, :398-656) */

@@ -583,6 +583,7 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
+    if (ctx->d_positions) (void)hipFree(ctx->d_positions);
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
@@ -1040,23 +1041,36 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
     }
     const uint64_t n_pos = offsets[n_rows] - offsets[0];
     const uint64_t n_bits = (uint64_t)m->n_words * 64;
-    for (uint64_t p = 0; p < n_pos; ++p) {
-        if (positions[offsets[0] + p] >= n_bits) {
-            set_error("position %u outside the %llu-bit rows", positions[offsets[0] + p],
-                      (unsigned long long)n_bits);
+    uint32_t largest = 0;  // (a max reduction vectorises; an early exit per position does not)
+    for (uint64_t p = 0; p < n_pos; ++p) largest = std::max(largest, positions[offsets[0] + p]);
+    if (n_pos && largest >= n_bits) {
+        set_error("position %u outside the %llu-bit rows", largest, (unsigned long long)n_bits);
+        return STORM_HIP_EINVAL;
+    }
+    for (uint64_t r = 0; r < n_rows; ++r)
+        if (offsets[r + 1] < offsets[r]) {
+            set_error("set_rows_from_positions: offsets decrease at row %llu", (unsigned long long)r);
             return STORM_HIP_EINVAL;
         }
-    }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     if (n_pos == 0) return STORM_HIP_OK;
-    uint64_t* d_off = nullptr;
-    uint32_t* d_pos = nullptr;
-    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_off), (n_rows + 1) * sizeof(uint64_t)));
-    if (hipMalloc(reinterpret_cast<void**>(&d_pos), n_pos * sizeof(uint32_t)) != hipSuccess) {
-        (void)hipFree(d_off);
-        set_error("hipMalloc for %llu positions failed", (unsigned long long)n_pos);
-        return STORM_HIP_ENOMEM;
+    // staging buffer of the context (grow-only: STORM_contig_add streams batches of 256 rows through here, and
+    // a hipMalloc / hipFree pair per batch costs more than its copy)
+    const size_t off_bytes = ((n_rows + 1) * sizeof(uint64_t) + 255) / 256 * 256;
+    const size_t need = off_bytes + n_pos * sizeof(uint32_t);
+    if (need > ctx->positions_capacity) {
+        if (ctx->d_positions) STORM_HIP_TRY(hipFree(ctx->d_positions));
+        ctx->d_positions = nullptr;
+        ctx->positions_capacity = 0;
+        const size_t cap = std::max<size_t>(need + need / 2, 1u << 20);
+        if (hipMalloc(&ctx->d_positions, cap) != hipSuccess) {
+            set_error("hipMalloc for %llu positions failed", (unsigned long long)n_pos);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->positions_capacity = cap;
     }
+    uint64_t* d_off = static_cast<uint64_t*>(ctx->d_positions);
+    uint32_t* d_pos = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ctx->d_positions) + off_bytes);
     int rc = STORM_HIP_OK;
     if (hipMemcpyAsync(d_off, offsets, (n_rows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
                        ctx->stream) != hipSuccess ||
@@ -1067,13 +1081,12 @@ int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_mat
     } else {
         hipLaunchKernelGGL(set_bits_kernel, dim3((uint32_t)n_rows), dim3(kThreads), 0,
                            ctx->stream, m->d, m->stride_words, row0, d_off, d_pos);
+        // (the host buffers are pageable and the caller's: wait for the copies)
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) {
             set_error("set_bits_kernel failed");
             rc = STORM_HIP_EHIP;
         }
     }
-    (void)hipFree(d_off);
-    (void)hipFree(d_pos);
     return rc;
     });
 }

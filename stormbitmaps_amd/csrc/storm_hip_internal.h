@@ -138,6 +138,8 @@ struct storm_hip_ctx_s {
     size_t kernel_events_used = 0;
     uint32_t* d_band = nullptr;    // device staging of the host-output matrix calls (band x n_rows uint32)
     size_t band_capacity = 0;
+    void* d_positions = nullptr;   // staging of storm_hip_matrix_set_rows_from_positions: offsets, then positions
+    size_t positions_capacity = 0;
     uint32_t* d_counts = nullptr;  // row-count scratch of the matrix-output paths
     size_t counts_capacity = 0;
     unsigned long long* d_trace = nullptr;  // k2_ring = 18: per-item schedule trace of the strip kernel

@@ -1970,9 +1970,9 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kSbRowBytes = 64;                                  // 512 bits of k
 constexpr int kSbStageBytes = kStripBRows * kSbRowBytes;         // 4 KiB
-constexpr int kSbRing = 4;
 
 #ifdef STORM_HIP_PROBES  // superseded by bitstream_kernel (K2q); kept for A/B in the tools build
+constexpr int kSbRing = 4;
 __global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
     const uint8_t* __restrict__ X, uint64_t pitch64, const StripItem* __restrict__ items,
     unsigned long long* __restrict__ slots) {

@@ -646,6 +646,100 @@ STORM_contiguous_t* STORM_contig_new(size_t vector_length) {
 #define CONTIG_STREAM_ROWS 256u /* batch of finished rows STORM_contig_add streams to the device */
 static void contig_stream_rows(STORM_contiguous_t* h);
 
+/* Device-side construction (reference loop being replaced: the bit setting of STORM_contig_add,
+ * storm.c:1103-1115, as far as the DEVICE copy of a row goes; the host bitmap `data` is public and stays).
+ * A row reaches its device mirror as sorted positions (4 bytes each, OR-ed into the zeroed row by
+ * set_bits_kernel) instead of as its words when that is at most an eighth of the bytes: n <= W / 4 for a row
+ * of W words. (The bus moves a row's 8 KiB in 0.35 us; what the host spends per position on the way has to stay
+ * below that: tools/bench_contig_add, profiles/r03_f_contig_add.txt — at n = W the positions LOSE, 13 against
+ * 3.8 ms for 10000 rows.) Rows below scalar_cutoff have their list in `scalar` already; rows from the cutoff up
+ * keep a copy of their positions here from the add until the upload. STORM_HIP_ADD_POSITIONS=0 turns it off. */
+typedef struct {
+    uint64_t row0, n_rows, m_rows; /* rows [row0, row0 + n_rows) of the container, appended in order */
+    uint64_t* off;                 /* n_rows + 1 starts in pos; an empty range = the row goes as words */
+    uint32_t* pos;
+    uint64_t n_pos, m_pos;
+    uint64_t words_below; /* rows below this one travel as words (STORM_contig_hip_invalidate: edited in place) */
+    int broken;           /* an allocation failed: nothing more is kept */
+} contig_pending_t;
+
+static int contig_positions_enabled(void) {
+    static int enabled = -1;
+    if (enabled < 0) {
+        const char* e = getenv("STORM_HIP_ADD_POSITIONS");
+        enabled = !(e && e[0] == '0');
+    }
+    return enabled;
+}
+static void contig_pending_free(STORM_contiguous_t* h) {
+    contig_pending_t* p = (contig_pending_t*)h->hip_pending;
+    if (!p) return;
+    free(p->off);
+    free(p->pos);
+    free(p);
+    h->hip_pending = NULL;
+}
+/* row h->n_data (about to be counted) has `distinct` positions, first occurrences of values[0 .. n_values) */
+static void contig_pending_stop(contig_pending_t* p) {
+    p->broken = 1;
+    p->n_rows = 0;
+    p->n_pos = 0;
+}
+static void contig_pending_note(STORM_contiguous_t* h, const uint32_t* values, uint32_t n_values,
+                                uint32_t distinct) {
+    if (!contig_positions_enabled()) return;
+    contig_pending_t* p = (contig_pending_t*)h->hip_pending;
+    if (p && p->broken) return;
+    if (p && p->row0 + p->n_rows != h->n_data) { /* a gap: start over behind it */
+        p->row0 = h->n_data;
+        p->n_rows = 0;
+        p->n_pos = 0;
+    }
+    const int keep = distinct >= h->scalar_cutoff && (uint64_t)distinct * 4 <= h->n_bitmaps_vector;
+    if (!p) {
+        if (!keep) return; /* nothing to remember yet: rows before the first kept one are not covered */
+        p = (contig_pending_t*)calloc(1, sizeof(*p));
+        if (!p) return;
+        p->row0 = h->n_data;
+        h->hip_pending = p;
+    }
+    if (p->n_rows + 2 > p->m_rows) {
+        const uint64_t m = p->m_rows ? 2 * p->m_rows : 1024;
+        uint64_t* no = (uint64_t*)realloc(p->off, m * sizeof(uint64_t));
+        if (!no) { contig_pending_stop(p); return; }
+        p->off = no;
+        p->m_rows = m;
+    }
+    if (keep && p->n_pos + distinct > p->m_pos) {
+        const uint64_t m = 2 * p->m_pos + distinct + 65536;
+        uint32_t* np = (uint32_t*)realloc(p->pos, m * sizeof(uint32_t));
+        if (!np) { contig_pending_stop(p); return; }
+        p->pos = np;
+        p->m_pos = m;
+    }
+    p->off[p->n_rows] = p->n_pos;
+    if (keep)
+        for (uint32_t k = 0; k < n_values; ++k)
+            if (k == 0 || values[k] != values[k - 1]) p->pos[p->n_pos++] = values[k];
+    p->off[++p->n_rows] = p->n_pos;
+}
+/* positions of row r if it may travel as positions: from `scalar` or from the pending copy; NULL = as words */
+static const uint32_t* contig_row_positions(const STORM_contiguous_t* h, uint64_t r, uint32_t* n) {
+    if (!contig_positions_enabled()) return NULL;
+    const contig_pending_t* p = (const contig_pending_t*)h->hip_pending;
+    if (p && r < p->words_below) return NULL;
+    if (h->n_scalar[r] < h->scalar_cutoff && h->scalar) {
+        if ((uint64_t)h->n_scalar[r] * 4 > h->n_bitmaps_vector) return NULL;
+        *n = h->n_scalar[r];
+        return h->scalar + h->scalar_offset[r];
+    }
+    if (p && r >= p->row0 && r < p->row0 + p->n_rows && p->off[r - p->row0 + 1] > p->off[r - p->row0]) {
+        *n = (uint32_t)(p->off[r - p->row0 + 1] - p->off[r - p->row0]);
+        return p->pos + p->off[r - p->row0];
+    }
+    return NULL;
+}
+
 static void contig_drop_device(STORM_contiguous_t* h) {
     if (h->hip_matrix) {
         dense_state_release((dense_state_t*)h->hip_matrix);
@@ -679,6 +773,7 @@ static int contig_lists_enabled(void) {
 void STORM_contig_free(STORM_contiguous_t* h) {
     if (!h) return;
     contig_drop_device(h);
+    contig_pending_free(h);
     if (h->hip_lists) STORM_free(h->hip_lists);
     STORM_aligned_free(h->data);
     STORM_aligned_free(h->scalar);
@@ -688,10 +783,14 @@ void STORM_contig_free(STORM_contiguous_t* h) {
     free(h); /* the reference leaks the handle (storm.c:1020-1029); callers never free it */
 }
 
-/* rows grow by 512 (storm.c:1046, :1082); returns 0 on success */
+/* Row capacity; returns 0 on success. The reference grows by 512 rows at a time (storm.c:1046, :1082) and copies
+ * every row each time: 10000 rows of 8 KiB are copied 20 times, 0.8 GB, and that copy was most of what
+ * STORM_contig_add cost (tools/bench_contig_add: 183 ms for the adds, 4 ms for the upload). Here the capacity
+ * grows by half (in steps of 512 rows, 512 to begin with), and only the new rows are cleared. */
 static int contig_reserve_rows(STORM_contiguous_t* h) {
     if (h->data && h->n_data < h->m_data) return 0;
-    const uint64_t new_m = h->m_data + 512;
+    const uint64_t half = (h->m_data / 2 + 511) / 512 * 512;
+    const uint64_t new_m = h->m_data + (half > 512 ? half : 512);
     const size_t W = h->n_bitmaps_vector;
     uint64_t* nd = (uint64_t*)STORM_aligned_malloc(h->alignment, new_m * W * sizeof(uint64_t));
     uint32_t* nn = (uint32_t*)STORM_aligned_malloc(h->alignment, new_m * sizeof(uint32_t));
@@ -705,8 +804,8 @@ static int contig_reserve_rows(STORM_contiguous_t* h) {
         STORM_aligned_free(nn);
         return -1;
     }
-    memset(nd, 0, new_m * W * sizeof(uint64_t));
     if (h->data) memcpy(nd, h->data, h->n_data * W * sizeof(uint64_t));
+    memset(nd + h->n_data * W, 0, (new_m - h->n_data) * W * sizeof(uint64_t));
     if (h->n_scalar) memcpy(nn, h->n_scalar, h->n_data * sizeof(uint32_t));
     STORM_aligned_free(h->data);
     STORM_aligned_free(h->n_scalar);
@@ -790,6 +889,7 @@ int STORM_contig_add(STORM_contiguous_t* h, const uint32_t* values, const uint32
             if (!h->hip_lists || STORM_add(h->hip_lists, values, n_values) < 0) contig_lists_end(h);
         }
     }
+    contig_pending_note(h, values, n_values, distinct);
     ++h->n_data;
     if (h->n_data % CONTIG_STREAM_ROWS == 0) contig_stream_rows(h);
     return (int)n_values;
@@ -802,9 +902,61 @@ int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
     h->n_data = 0;
     h->tot_scalar = 0;
     contig_drop_device(h);
+    contig_pending_free(h);
     if (h->hip_lists) STORM_clear(h->hip_lists);
     h->hip_lists_off = 0;
     return 1;
+}
+
+/* where row r's positions live: 0 = it travels as words, 1 = in `scalar`, 2 = in the pending copy */
+static int contig_row_source(const STORM_contiguous_t* h, uint64_t r) {
+    uint32_t n = 0;
+    const uint32_t* src = contig_row_positions(h, r, &n);
+    if (!src) return 0;
+    return (h->scalar && src >= h->scalar && src < h->scalar + h->m_scalar) ? 1 : 2;
+}
+/* rows [r0, r1) to one replica: runs of rows that travel as positions through set_bits_kernel (the rows of a
+ * mirror beyond its synced rows are zero), the runs between them as words. The positions of consecutive rows
+ * are consecutive in their source (`scalar` or the pending copy), so a run is handed over where it lies.
+ * 0 on success. */
+static int contig_send_rows(STORM_contiguous_t* h, storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t r0,
+                            uint64_t r1) {
+    const uint64_t W = h->n_bitmaps_vector;
+    const contig_pending_t* p = (const contig_pending_t*)h->hip_pending;
+    uint64_t* off = NULL;
+    uint64_t m_off = 0;
+    int rc = 0;
+    uint64_t r = r0;
+    while (r < r1 && rc == 0) {
+        const int src = contig_row_source(h, r);
+        uint64_t e = r + 1;
+        while (e < r1 && contig_row_source(h, e) == src) ++e;
+        if (src == 2) {
+            if (storm_hip_matrix_set_rows_from_positions(ctx, m, r, e - r, p->off + (r - p->row0), p->pos) !=
+                STORM_HIP_OK)
+                rc = -1;
+        } else if (src == 1) {
+            if (e - r + 1 > m_off) {
+                free(off);
+                m_off = e - r + 1;
+                off = (uint64_t*)malloc(m_off * sizeof(uint64_t));
+            }
+            if (!off) { /* out of host memory: the run goes as words */
+                m_off = 0;
+                if (storm_hip_matrix_upload(ctx, m, r, e - r, h->data + r * W, W) != STORM_HIP_OK) rc = -1;
+            } else {
+                for (uint64_t i = r; i < e; ++i) off[i - r] = h->scalar_offset[i];
+                off[e - r] = h->scalar_offset[e - 1] + h->n_scalar[e - 1];
+                if (storm_hip_matrix_set_rows_from_positions(ctx, m, r, e - r, off, h->scalar) != STORM_HIP_OK)
+                    rc = -1;
+            }
+        } else if (storm_hip_matrix_upload(ctx, m, r, e - r, h->data + r * W, W) != STORM_HIP_OK) {
+            rc = -1;
+        }
+        r = e;
+    }
+    free(off);
+    return rc;
 }
 
 /* Rows [hip_rows_synced, upto) of `h` go to every replica of its device mirror (created on first
@@ -831,14 +983,16 @@ static int contig_upload_rows(STORM_contiguous_t* h, uint64_t upto) {
             storm_hip_matrix_create(ctx, h->m_data, h->n_bitmaps_vector, &st->m[d]) != STORM_HIP_OK)
             return -1;
         if (storm_hip_matrix_resize(ctx, st->m[d], upto) != STORM_HIP_OK) return -1;
-        if (upto > h->hip_rows_synced &&
-            storm_hip_matrix_upload(ctx, st->m[d], h->hip_rows_synced, upto - h->hip_rows_synced,
-                                    h->data + h->hip_rows_synced * h->n_bitmaps_vector,
-                                    h->n_bitmaps_vector) != STORM_HIP_OK)
-            return -1;
+        if (contig_send_rows(h, ctx, st->m[d], h->hip_rows_synced, upto) != 0) return -1;
     }
     h->hip_rows_synced = upto;
     h->hip_rows_capacity = h->m_data;
+    contig_pending_t* p = (contig_pending_t*)h->hip_pending;
+    if (p) { /* everything it covered is on the device now */
+        p->row0 = upto;
+        p->n_rows = 0;
+        p->n_pos = 0;
+    }
     return 0;
 }
 
@@ -1601,7 +1755,15 @@ int STORM_hip_invalidate(STORM_t* h) {
 int STORM_contig_hip_invalidate(STORM_contiguous_t* h) {
     if (!h) return -1;
     contig_drop_device(h);
-    contig_lists_end(h); /* rows edited in place: the list mirror cannot follow them */
+    contig_lists_end(h); /* rows edited in place: the list mirror cannot follow them ... */
+    if (!h->hip_pending) h->hip_pending = calloc(1, sizeof(contig_pending_t));
+    contig_pending_t* p = (contig_pending_t*)h->hip_pending;
+    if (p) { /* ... and the rows so far travel as the words they now are, not as the positions they were added with */
+        p->words_below = h->n_data;
+        p->row0 = h->n_data;
+        p->n_rows = 0;
+        p->n_pos = 0;
+    }
     return 0;
 }
 

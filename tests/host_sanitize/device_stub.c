@@ -67,6 +67,19 @@ int storm_hip_matrix_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_
     return STORM_HIP_OK;
 }
 
+int storm_hip_matrix_set_rows_from_positions(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, uint64_t row0,
+                                             uint64_t n_rows, const uint64_t* offsets,
+                                             const uint32_t* positions) {
+    (void)ctx;
+    if (row0 + n_rows > m->n_rows) return STORM_HIP_EINVAL;
+    for (uint64_t r = 0; r < n_rows; ++r) /* reads exactly what the real call reads */
+        for (uint64_t k = offsets[r]; k < offsets[r + 1]; ++k) {
+            if (positions[k] >= (uint64_t)m->n_words * 64) return STORM_HIP_EINVAL;
+            m->rows[(row0 + r) * m->n_words + positions[k] / 64] |= 1ULL << (positions[k] % 64);
+        }
+    return STORM_HIP_OK;
+}
+
 static uint64_t set_bits_of(const storm_hip_matrix_t* m) {
     uint64_t n = 0;
     for (uint64_t k = 0; k < m->n_rows * m->n_words; ++k) n += (uint64_t)__builtin_popcountll(m->rows[k]);

@@ -113,6 +113,57 @@ static int scenario(uint32_t n_rows, uint32_t width, uint32_t draws, int with_em
     return 0;
 }
 
+/* rows of every kind in one container: below the list cutoff (positions from `scalar`), between the cutoff and
+ * W words (positions kept from the add: STORM_contig_add's device-side construction), denser (words); all-pairs
+ * calls in between (partial uploads), rows edited in place + STORM_contig_hip_invalidate (everything as words) */
+static int scenario_mixed(uint32_t n_rows, uint32_t width) {
+    STORM_contiguous_t* dense = STORM_contig_new(width);
+    CHECK(dense);
+    const uint32_t W = (width + 63) / 64, cutoff = dense->scalar_cutoff;
+    const uint32_t max_draws = 4 * W + 8;
+    uint32_t* row = (uint32_t*)malloc((max_draws + 1) * sizeof(uint32_t));
+    const size_t words = W;
+    uint64_t* bits = (uint64_t*)calloc(words, sizeof(uint64_t));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_rows; ++i) {
+        uint32_t n;
+        switch (rnd() % 4) {
+            case 0: n = 1 + (uint32_t)(rnd() % (cutoff ? cutoff : 1)); break;  /* list kept in `scalar`   */
+            case 1: n = cutoff + (uint32_t)(rnd() % (W > cutoff ? W - cutoff : 1)); break; /* kept positions */
+            case 2: n = W + (uint32_t)(rnd() % (3 * W)); break;                   /* words                    */
+            default: n = (uint32_t)(rnd() % 2) ? W : cutoff; break;              /* the edges                */
+        }
+        if (n == 0) n = 1;
+        memset(bits, 0, words * sizeof(uint64_t));
+        for (uint32_t j = 0; j < n; ++j) {
+            row[j] = (uint32_t)(rnd() % width);
+            const uint64_t bit = 1ULL << (row[j] % 64);
+            if (!(bits[row[j] / 64] & bit)) ++total;
+            bits[row[j] / 64] |= bit;
+        }
+        qsort(row, n, sizeof(uint32_t), cmp_u32);
+        CHECK(STORM_contig_add(dense, row, n) == (int)n);
+        if (i % 61 == 7) CHECK(STORM_contig_pairw_intersect_cardinality(dense) == (dense->n_data < 2 ? 0 : total));
+        if (i == n_rows / 2) { /* a caller sets a bit behind the library's back */
+            uint64_t* w = dense->data; /* row 0, word 0 */
+            if (!(w[0] & 1ULL)) ++total;
+            w[0] |= 1ULL;
+            CHECK(STORM_contig_hip_invalidate(dense) == 0);
+            CHECK(STORM_contig_pairw_intersect_cardinality(dense) == (dense->n_data < 2 ? 0 : total));
+        }
+    }
+    CHECK(STORM_contig_pairw_intersect_cardinality(dense) == total);
+    CHECK(STORM_contig_clear(dense) == 1 && dense->n_data == 0);
+    row[0] = 0;
+    row[1] = width - 1;
+    CHECK(STORM_contig_add(dense, row, 2) == 2 && STORM_contig_add(dense, row, 1) == 1);
+    CHECK(STORM_contig_pairw_intersect_cardinality(dense) == 3);
+    free(bits);
+    free(row);
+    STORM_contig_free(dense);
+    return 0;
+}
+
 int main(void) {
     /* error conventions (storm.c:878, :1032-1034, :1150) */
     CHECK(STORM_contig_pairw_intersect_cardinality(NULL) == (uint64_t)-1);
@@ -131,6 +182,10 @@ int main(void) {
     if (scenario(300, 131071, 4200, 0)) return 1;   /* per-block counts around 4096/2      */
     if (scenario(3, 70, 5, 0)) return 1;
     if (scenario(600, 1000, 128, 0)) return 1;      /* the README's shape (duplicates)     */
+    if (scenario(700, 65536, 300, 0)) return 1;     /* rows between the list cutoff and W words: positions kept */
+    if (scenario_mixed(900, 65536)) return 1;
+    if (scenario_mixed(300, 20000)) return 1;
+    if (scenario_mixed(200, 1000)) return 1;        /* cutoff 5, W 16 */
     puts("host sanitize: ok");
     return 0;
 }

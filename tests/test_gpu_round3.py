@@ -2,6 +2,9 @@
 matrices of up to 8192 rows take by default — against the CPU oracle where the CPU can afford it, the
 column identity and the FP4 strips otherwise. Everything goes through the C-ABI."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +13,7 @@ import stormbitmaps_amd as sb
 from stormbitmaps_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -247,3 +251,49 @@ def test_native_rccl_reduce_over_two_gpus_when_the_box_has_them():
     for load in (32768, 262):
         totals = {int(r[2]) for r in rows if int(r[1]) == load}
         assert totals == {_golden_total(65536, 700, load)}, (load, totals)
+
+
+@pytest.mark.parametrize("M,N", [(65536, 700), (5000, 900), (1000, 300)])
+def test_contig_add_builds_device_rows_from_positions(orc, M, N):
+    """STORM_contig_add (storm.c:1031-1137) with the device copy of a row built from its POSITIONS
+    (set_bits_kernel) when they are fewer bytes than its words: rows below the list cutoff (positions from
+    `scalar`), between the cutoff and W (positions kept from the add), denser (words), mixed in one container;
+    all-pairs calls in the middle of construction (streamed batches + the partial last one); per-pair matrix;
+    the same totals as the oracle's blocked loop over the host bitmap (storm.c:1175-1241)."""
+    rng = np.random.default_rng(M + N)
+    W = (M + 63) // 64
+    cutoff = min(200, M // 200)
+    c = sb.StormContig(M)
+    mat = np.zeros((N, W), dtype=np.uint64)
+    for i in range(N):
+        kind = int(rng.integers(0, 4))
+        n = (int(rng.integers(1, max(2, cutoff))) if kind == 0 else
+             int(rng.integers(cutoff, max(cutoff + 1, W))) if kind == 1 else
+             int(rng.integers(W, 4 * W)) if kind == 2 else (W if rng.integers(0, 2) else max(1, cutoff)))
+        pos = np.sort(rng.integers(0, M, size=max(1, n), dtype=np.uint32))   # duplicates kept, as callers send them
+        assert c.add(pos) == pos.size
+        for p in pos:
+            mat[i, int(p) >> 6] |= np.uint64(1) << np.uint64(int(p) & 63)
+        if i in (N // 3, N // 3 + 1, 2 * N // 3):
+            assert c.pairw_intersect_cardinality() == orc.wrapper_diag_blocked(mat[: i + 1], 31), (M, N, i)
+    want = orc.wrapper_diag_blocked(mat, 31)
+    assert c.pairw_intersect_cardinality() == want
+    assert c.pairw_intersect_cardinality_blocked(17) == want
+    got = c.pairw_matrix("and")
+    assert int(got.sum(dtype=np.uint64)) == want
+    c.free()
+
+
+def test_contig_add_positions_can_be_turned_off_and_give_the_same_totals():
+    """STORM_HIP_ADD_POSITIONS=0 (rows always travel as words) in a child process: same total."""
+    code = ("import numpy as np, stormbitmaps_amd as sb\n"
+            "c = sb.StormContig(65536)\n"
+            "c.add_synthetic(600, 655, seed=9)\n"
+            "print(c.pairw_intersect_cardinality())\n")
+    outs = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, STORM_HIP_ADD_POSITIONS=flag, STORM_HIP_STREAM_ROWS="1")
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(int(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and outs[0] > 0
