@@ -166,6 +166,8 @@ def _stream_cover(n_rows, n_words, world, n_cus):
     (1100, 20, (1, 2, 5), 4),       # 5 tiles, last one ragged; a 4-CU device cuts segments in the middle
     (2048, 64, (1, 8), 16),         # 8 tiles, many cuts: continued segments bring A in without multiplying
     (2300, 8, (1, 3), 2),           # ONE k-slice
+    (4000, 64, (1, 2, 3), 2),       # many rounds on a 2-CU device: whole segments as shares + a cut last round
+    (2600, 200, (1, 4), 1),         # the same with ragged tiles and a ragged last k-slice
 ])
 def test_stream_plans_of_all_ranks_cover_every_block_pair_exactly_once(n_rows, n_words, worlds, n_cus):
     nb = (n_rows + 63) // 64
