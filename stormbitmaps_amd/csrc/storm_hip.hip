@@ -669,17 +669,23 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_strip_operands")) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) {
-            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup) or 4 (FP4 shadow)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4) {
+            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup), 3 (the same with a ring per wave) or 4 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
-        if (value == 1) {
-            set_error("k2_strip_operands = 1 (stripbits_kernel) is a form of the tools build (`make probes`), not of the shipped library");
+        if (value == 1 || value == 3) {
+            set_error("k2_strip_operands = 1 (stripbits_kernel) and 3 (bitwave_kernel) are forms of the tools build (`make probes`), not of the shipped library");
             return STORM_HIP_EINVAL;
         }
 #endif
         ctx->k2_strip_operands = (int)value;
+    } else if (!strcmp(key, "k2_wave_ring")) {
+        if (value != 0 && value != 3 && value != 4 && value != 6 && value != 8) {
+            set_error("k2_wave_ring must be 0 (by occupancy), 3, 4, 6 or 8");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_wave_ring = (int)value;
     } else if (!strcmp(key, "k2_stream_max_rows")) {
         if (value < 0 || value > (1ll << 31)) {
             set_error("k2_stream_max_rows must be 0 .. 2^31");

@@ -159,6 +159,7 @@ struct storm_hip_ctx_s {
     // K2q: length of the shares of the second / third workgroup of a CU in percent of the first one's, when the
     // stream is one round of 3 workgroups per CU (build_bitstream: the SIMD arbiter serves the oldest wave)
     int k2_stream_w3_1 = 120, k2_stream_w3_2 = 60;
+    int k2_wave_ring = 0;             // K2w: stages of a wave's private ring (0 = by workgroups per CU: 8 / 4 / 3)
     bool trace_is_stream = false;     // d_trace holds per-workgroup words of bitstream_kernel (no strip items)
     int k2_debug = 0;  // timing probes (wrong results): 1 = all items on tile (0,0), 2 = no XCD grouping
 };

@@ -2522,6 +2522,235 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     }
 }
 
+#ifdef STORM_HIP_PROBES
+// ------------------------------------------------------------------------------------------
+// K2w: the same stage stream with a PRIVATE ring per wave (option k2_strip_operands = 3; TOOLS BUILD ONLY:
+// measured slower than bitstream_kernel everywhere but at N = 512 — 11.1 against 12.3 us there, 25.1 / 19.8 at
+// N = 1024, 48.4 / 44.5 at 2048, 160 / 148 at 4096, 617 / 560 at 8192, same box, profiles/r03_g_wave_private_ring.txt:
+// what a lone workgroup loses at its barrier is less than what four times the L2 -> LDS traffic and a ring of
+// three stages cost).
+//
+// In bitstream_kernel the four waves of a workgroup share every B stage (one DMA piece each) and meet at a
+// barrier every two stages; a workgroup alone on its CU has nothing to cover that wait and the DMA's (~290
+// of 1670 clocks per stage), and the barrier couples four SIMDs. Here every wave DMAs the WHOLE stage (four
+// pieces of 16 rows x 64 B) into its own ring of kRing stages: no barrier before the final fold, only vmcnt;
+// the L2 -> LDS traffic is four times the shared ring's (16 B per clock and CU at the full rate: a quarter of
+// the path), the HBM traffic is unchanged.
+// What a stage is to a wave comes from ONE table word (bitwave tables, build_bitwave): bits 0..29 the start of
+// the stage's 64 rows (64-byte units), bit 31 "these are my A rows: take them", bit 30 "and multiply them, at
+// half weight" (a diagonal segment). A wave's list for a segment is its own block, the tile's later blocks
+// (diagonal segments), the run of later blocks; lists of the four waves differ in length by up to three
+// stages per diagonal segment and even out through the rotation of the blocks over the waves.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kBwOwn = 0x80000000u, kBwMul = 0x40000000u, kBwBase = 0x3fffffffu;
+
+template <int kRing>
+__global__ __launch_bounds__(kStripThreads, 3) void bitwave_kernel(
+    const uint8_t* __restrict__ X, uint64_t pitch64, const uint32_t* __restrict__ first,
+    const uint32_t* __restrict__ words, unsigned long long* __restrict__ slots,
+    unsigned long long* __restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripWaves * kRing * kSbStageBytes];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t pitch = (uint32_t)pitch64;
+    uint8_t* ring = lds_raw + wave * (kRing * kSbStageBytes);
+
+    const uint32_t goff = (lane >> 2) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
+    const uint32_t slot0 = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
+    const uint32_t baddr0 = lds_base + (lane & 31u) * kSbRowBytes + slot0 * 16u;
+    const uint32_t baddr1 = lds_base + (lane & 31u) * kSbRowBytes + (slot0 ^ 2u) * 16u;
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
+    v4i a[2][4][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[g][c][m] = v4i{};
+    uint32_t dbits = 0;
+
+    const uint32_t w0i = first[blockIdx.x * 4u + wave];
+    const uint32_t T = first[blockIdx.x * 4u + wave + 1u] - w0i;
+    const uint32_t* tab = words + w0i;
+    uint32_t issued = 0;
+    uint32_t next_word = T ? tab[0] : 0u;  // of stage `issued`
+    auto fire = [&]() {
+        if (issued < T) {
+            uint8_t* src = const_cast<uint8_t*>(X) + ((uint64_t)(next_word & kBwBase) << 6);
+            uint8_t* dst = ring + (issued % kRing) * kSbStageBytes;
+            // piece j: rows 16 j .. 16 j + 15 of the stage, 1 KiB further into the ring slot. ONE value of M0 per stage:
+            // the instruction offset moves the LDS address (and the global one, which the base takes back).
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(src, 0, -1, 0x00020000);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + j * 1024u), 16,
+                                                         (int)(goff + j * 16u * pitch), 0, 0, 0);
+            ++issued;
+            next_word = tab[min(issued, T - 1u)];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kRing - 1; ++k) fire();
+
+#define STORM_BS_FETCH(dst, t, n, g) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
+#define STORM_BS_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
+    {                                                                                                     \
+        acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
+            v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                      \
+            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const v4i en_ = NEXT;                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
+            v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                      \
+            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
+        enxt = en_;                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#define STORM_BS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define STORM_BS_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
+    // one stage; the next stage's first word is NOT fetched here (its DMA is waited for at the top of the loop)
+#define STORM_BW_STAGE(tc)                                          \
+    STORM_BS_FETCH(w1, tc, 1, 0);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(0, 0, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_BS_STEP(0, 0, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_BS_STEP(0, 0, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(0, 0, 3, e0, e0, tb_inflate<0>(w1));              \
+    STORM_BS_FETCH(w0, tc, 0, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(1, 0, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_BS_STEP(1, 0, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_BS_STEP(1, 0, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(1, 0, 3, e0, e0, tb_inflate<0>(w0));              \
+    STORM_BS_FETCH(w1, tc, 1, 1);                                   \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(0, 1, 0, e0, e0, tb_inflate<1>(w0));              \
+    STORM_BS_STEP(0, 1, 1, e0, e0, tb_inflate<2>(w0));              \
+    STORM_BS_STEP(0, 1, 2, e0, e0, tb_inflate<3>(w0));              \
+    STORM_BS_WAIT();                                                \
+    STORM_BS_STEP(0, 1, 3, e0, e0, tb_inflate<0>(w1));              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    STORM_BS_STEP(1, 1, 0, e0, e0, tb_inflate<1>(w1));              \
+    STORM_BS_STEP(1, 1, 1, e0, e0, tb_inflate<2>(w1));              \
+    STORM_BS_STEP(1, 1, 2, e0, e0, tb_inflate<3>(w1));              \
+    STORM_BS_STEP(1, 1, 3, e0, e0, e0)
+
+    v4i w0 = {}, w1 = {}, e0 = {};
+    int sb[4] = {tb_scale<0>(), tb_scale<1>(), tb_scale<2>(), tb_scale<3>()};
+    uint32_t cur_word = T ? tab[0] : 0u;
+#pragma unroll 1
+    for (uint32_t t = 0; t < T; ++t) {
+        // stage t has landed when at most the pieces of the kRing - 2 younger stages are in flight
+        if (issued >= t + (uint32_t)(kRing - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRing - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t word = cur_word;
+        cur_word = tab[min(t + 1u, T - 1u)];
+        fire();  // into the slot of stage t - 1: this wave's reads of it were waited for (lgkmcnt) in its stage
+        __builtin_amdgcn_sched_barrier(0);
+        const bool own = (word & kBwOwn) != 0u;
+        const bool mul = !own || (word & kBwMul) != 0u;
+        // The reads and the wait that covers them are ONE asm statement each: a read left in flight across
+        // compiler-visible code is not safe — for a wait that ties the words ("+v") hipcc copied w0 into the
+        // tied registers BEFORE the wait, i.e. before the data had landed (rows 32..63 of a block came out wrong).
+        const uint32_t rd0 = baddr0 + (t % kRing) * kSbStageBytes, rd1 = baddr1 + (t % kRing) * kSbStageBytes;
+        if (own) {
+            v4i x1, x2, x3;
+            asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:2048\n\t"
+                         "ds_read_b128 %2, %5 offset:0\n\tds_read_b128 %3, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(w0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                         : "v"(rd0), "v"(rd1)
+                         : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            a[0][0][0] = tb_inflate<0>(w0); a[0][1][0] = tb_inflate<1>(w0);
+            a[0][2][0] = tb_inflate<2>(w0); a[0][3][0] = tb_inflate<3>(w0);
+            a[0][0][1] = tb_inflate<0>(x1); a[0][1][1] = tb_inflate<1>(x1);
+            a[0][2][1] = tb_inflate<2>(x1); a[0][3][1] = tb_inflate<3>(x1);
+            a[1][0][0] = tb_inflate<0>(x2); a[1][1][0] = tb_inflate<1>(x2);
+            a[1][2][0] = tb_inflate<2>(x2); a[1][3][0] = tb_inflate<3>(x2);
+            a[1][0][1] = tb_inflate<0>(x3); a[1][1][1] = tb_inflate<1>(x3);
+            a[1][2][1] = tb_inflate<2>(x3); a[1][3][1] = tb_inflate<3>(x3);
+            if (mul) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    dbits += __builtin_popcount((uint32_t)w0[k]) + __builtin_popcount((uint32_t)x1[k]) +
+                             __builtin_popcount((uint32_t)x2[k]) + __builtin_popcount((uint32_t)x3[k]);
+            }
+        } else {
+            asm volatile("ds_read_b128 %0, %1 offset:0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0) : "v"(rd0) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (mul) {
+            const int half = own ? 1 : 0;
+            sb[0] = tb_scale<0>() - half;
+            sb[1] = tb_scale<1>() - half;
+            sb[2] = tb_scale<2>() - half;
+            sb[3] = tb_scale<3>() - half;
+            e0 = tb_inflate<0>(w0);
+            __builtin_amdgcn_sched_barrier(0);
+            STORM_BW_STAGE(t);
+            STORM_BS_WAIT();
+            STORM_BS_KEEP();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#undef STORM_BW_STAGE
+#undef STORM_BS_KEEP
+#undef STORM_BS_WAIT
+#undef STORM_BS_STEP
+#undef STORM_BS_FETCH
+
+    long long mine2 = 0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        uint32_t part = 0;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part += (uint32_t)(acc[m][n][r] * 2.0f);
+        mine2 += part;
+    }
+    mine2 -= (long long)dbits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine2 += __shfl_down(mine2, o, 64);
+    __builtin_amdgcn_s_barrier();
+    long long* wsum = reinterpret_cast<long long*>(lds_raw);
+    if (lane == 0) wsum[wave] = mine2;
+    __syncthreads();
+    if (tid == 0) {
+        const long long tot2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (tot2 != 0) atomicAdd(&slots[blockIdx.x & (kBsFoldSlots - 1)], (unsigned long long)(tot2 / 2));
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(&slots[kBsTicket], 1ull);
+        wsum[4] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
+    }
+    __syncthreads();
+    if (wsum[4] != 0 && wave == 0) {
+        __threadfence();
+        unsigned long long v = __hip_atomic_exchange(&slots[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) {
+            out[0] = v;
+            __hip_atomic_store(&slots[kBsTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+#endif  // STORM_HIP_PROBES (K2w)
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
@@ -3849,6 +4078,120 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
     return STORM_HIP_OK;
 }
 
+#ifdef STORM_HIP_PROBES
+// K2w: per-wave stage words of the same plan (bitwave_kernel). One buffer: first[4 G + 1] | words.
+static int ensure_bitwave(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges, uint32_t n_kslices,
+                          uint32_t shard_rank, uint32_t shard_count, uint64_t pitch) {
+    const uint64_t key[4] = {ranges_hash(ranges) ^ (pitch * 0x9e3779b97f4a7c15ull) ^ 0x77aa77aa77aa77aaull ^
+                                 ((uint64_t)ctx->k2_stream_w3_2 * 0xc2b2ae3d27d4eb4full),
+                             n_kslices, ((uint64_t)shard_rank << 32) | shard_count,
+                             ((uint64_t)(ctx->k2_stream_groups_per_cu & 0xff) << 32) |
+                                 ((uint64_t)(ctx->k2_stream_min_piece & 0xffff) << 16) |
+                                 (uint64_t)(ctx->k2_stream_min_run & 0xffff) |
+                                 ((uint64_t)(ctx->k2_stream_w3_1 & 0x3ff) << 40)};
+    if (ctx->d_bitfirst && !memcmp(key, ctx->bit_key, sizeof(key))) return STORM_HIP_OK;
+    BitstreamShaping sh;
+    sh.groups_per_cu = ctx->k2_stream_groups_per_cu;
+    sh.min_piece = std::max(1, ctx->k2_stream_min_piece);
+    sh.min_run = std::max(1, ctx->k2_stream_min_run);
+    sh.w3_1 = ctx->k2_stream_w3_1;
+    sh.w3_2 = ctx->k2_stream_w3_2;
+    BitstreamPlan plan;
+    build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), pitch, plan);
+    if (!ranges.empty() && ranges.back().r1 * pitch / 64 + n_kslices + 4 * pitch >= (1ull << 30)) {
+        set_error("K2w: the matrix is beyond the 30-bit stage addresses (64-byte units)");
+        return STORM_HIP_EINVAL;
+    }
+    std::vector<uint32_t> first, words;
+    first.reserve((size_t)plan.groups * 4 + 1);
+    uint32_t longest = 0;
+    for (uint32_t w = 0; w < plan.groups; ++w)
+        for (uint32_t v = 0; v < 4; ++v) {
+            first.push_back((uint32_t)words.size());
+            for (uint32_t si = plan.first[w]; si < plan.first[w + 1]; ++si) {
+                const BitSeg& sg = plan.segs[si];
+                auto base = [&](uint32_t blk) { return (uint32_t)((uint64_t)sg.ks + (uint64_t)blk * pitch); };
+                const uint32_t wm = (v + (sg.flags >> 8)) & 3u;
+                const bool diag = (sg.flags & kBsDiag) != 0u;
+                words.push_back(base(sg.a_blk + wm) | kBwOwn | (diag ? kBwMul : 0u));
+                if (diag)
+                    for (uint32_t b = wm + 1; b < 4u; ++b) words.push_back(base(sg.a_blk + b));
+                for (uint32_t i = 0; i < sg.n_b; ++i) {
+                    uint32_t rel = sg.b_first + i;
+                    if (rel >= sg.range_nb) rel -= sg.range_nb;
+                    words.push_back(base(sg.range_b0 + rel));
+                }
+            }
+            longest = std::max(longest, (uint32_t)words.size() - first.back());
+        }
+    first.push_back((uint32_t)words.size());
+    if (longest > kBsMaxStages) {
+        set_error("K2w: a wave of %u stages exceeds the exact range of its accumulators", longest);
+        return STORM_HIP_EINVAL;
+    }
+    std::vector<uint32_t> packed(first);
+    packed.insert(packed.end(), words.begin(), words.end());
+    const size_t bytes = std::max<size_t>(packed.size(), 1) * sizeof(uint32_t);
+    if (bytes > ctx->bitfirst_capacity) {
+        if (ctx->d_bitfirst) STORM_HIP_TRY(hipFree(ctx->d_bitfirst));
+        ctx->d_bitfirst = nullptr;
+        ctx->bitfirst_capacity = 0;
+        STORM_HIP_TRY(hipMalloc(&ctx->d_bitfirst, bytes));
+        ctx->bitfirst_capacity = bytes;
+    }
+    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitfirst, packed.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->n_bit_groups = plan.groups;
+    ctx->bit_stages = words.size();
+    ctx->bit_max_stages = longest;
+    ctx->n_bit_segs = (uint32_t)plan.segs.size();
+    memcpy(ctx->bit_key, key, sizeof(key));
+    return STORM_HIP_OK;
+}
+
+int launch_pairw_bitwave(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pitch,
+                         const std::vector<RowRange>& ranges, uint32_t n_kslices, uint32_t shard_rank,
+                         uint32_t shard_count, uint64_t* d_total) {
+    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || pitch % 64 != 0) {
+        set_error("K2w: rows of %llu bytes are outside the bit-operand stream's 32-bit DMA offsets",
+                  (unsigned long long)pitch);
+        return STORM_HIP_EINVAL;
+    }
+    if (int rc = ensure_bitwave(ctx, ranges, n_kslices, shard_rank, shard_count, pitch)) return rc;
+    ctx->n_items = 0;
+    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    ctx->last_info[0] = ctx->n_bit_groups;
+    ctx->last_info[1] = ctx->bit_max_stages;
+    ctx->last_info[2] = 1;
+    ctx->last_info[3] = ctx->n_bit_segs;
+    if (ctx->n_bit_groups == 0) {
+        STORM_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
+        return STORM_HIP_OK;
+    }
+    const uint32_t G = ctx->n_bit_groups, cus = (uint32_t)std::max(1, ctx->n_cus);
+    int ring = ctx->k2_wave_ring;
+    if (ring == 0) ring = G <= cus ? 8 : G <= 2 * cus ? 4 : 3;
+    const uint32_t* first = static_cast<const uint32_t*>(ctx->d_bitfirst);
+    const uint32_t* words = first + 4 * (size_t)G + 1;
+    kernel_time_mark(ctx);
+#define STORM_BW_LAUNCH(R)                                                                                      \
+    hipLaunchKernelGGL(bitwave_kernel<R>, dim3(G), dim3(kStripThreads), 0, ctx->stream,                         \
+                       reinterpret_cast<const uint8_t*>(X), pitch, first, words, ctx->d_slots,                  \
+                       reinterpret_cast<unsigned long long*>(d_total))
+    switch (ring) {
+        case 8: STORM_BW_LAUNCH(8); break;
+        case 6: STORM_BW_LAUNCH(6); break;
+        case 4: STORM_BW_LAUNCH(4); break;
+        default: STORM_BW_LAUNCH(3); break;
+    }
+#undef STORM_BW_LAUNCH
+    kernel_time_mark(ctx);
+    STORM_HIP_TRY(hipGetLastError());
+    return STORM_HIP_OK;
+}
+
+#endif  // STORM_HIP_PROBES (K2w)
+
 // The default pass: strips on bit operands over the matrix itself (no shadow, nothing to expand).
 static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                              uint32_t shard_count, int operands, uint64_t* d_total) {
@@ -3865,6 +4208,10 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     const uint32_t n_kslices = (m->n_words + 7u) / 8u;
     if (operands == 2)
         return launch_pairw_bitstream(ctx, m->d, pitch, ranges, n_kslices, shard_rank, shard_count, d_total);
+#ifdef STORM_HIP_PROBES
+    if (operands == 3)
+        return launch_pairw_bitwave(ctx, m->d, pitch, ranges, n_kslices, shard_rank, shard_count, d_total);
+#endif
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
@@ -3905,7 +4252,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         operands = (shard_count == 1 && m->n_rows <= (uint64_t)ctx->k2_stream_max_rows && ctx->k2_ring == kStripRingDefault &&
                     ctx->k2_shape == 16 && ctx->k2_lds_pad == 0)
                        ? 2 : 4;
-    if (strip_mode == 1 && (operands == 1 || operands == 2) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
+    if (strip_mode == 1 && (operands == 1 || operands == 2 || operands == 3) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
         m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))
     {

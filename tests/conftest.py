@@ -37,9 +37,9 @@ def hip_ctx():
 def shipped(ctx, key, values):
     """The values of a kernel-selecting option that THIS build of the library carries: the shipped
     libstorm_hip.so keeps one form per output kind plus one independent operand path; the slower alternative
-    forms (32x32x64 / wide / persistent strips, the other output kernels, stripbits_kernel) live in the tools
+    forms (32x32x64 / wide / persistent strips, the other output kernels, stripbits_kernel, bitwave_kernel) live in the tools
     build (`make probes`, STORM_HIP_LIB) and the shipped library refuses the options that select them."""
     probes = ctx.get_option("probes_build") == 1
     only_probes = {"variant": {5}, "k2_shape": {32}, "k2_persistent": {1}, "k2_tile_shape": {1, 16},
-                   "k2_strip_operands": {1}}.get(key, set())
+                   "k2_strip_operands": {1, 3}}.get(key, set())
     return tuple(v for v in values if probes or v not in only_probes)

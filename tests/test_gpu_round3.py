@@ -297,3 +297,26 @@ def test_contig_add_positions_can_be_turned_off_and_give_the_same_totals():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(int(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] and outs[0] > 0
+
+
+def test_stream_operand_forms_agree_and_the_shipped_library_refuses_the_tools_forms(hip_ctx):
+    """k2_strip_operands: 2 (K2q, shipped) and 4 (FP4 strips, shipped) against the column identity; 1 (one item per
+    workgroup) and 3 (K2w: a private ring per wave) exist in the tools build only — there they must give the same
+    totals, here the option is refused."""
+    from tests.conftest import shipped
+    try:
+        forms = shipped(hip_ctx, "k2_strip_operands", (2, 4, 1, 3))
+        for M, N in ((65536, 1024), (5000, 777), (512, 300), (4096, 2300)):
+            m = hip_ctx.matrix(N, (M + 63) // 64)
+            m.fill_synthetic(M, M // 3, seed=11)
+            want = m.column_identity()
+            for ops in forms:
+                hip_ctx.set_option("k2_strip_operands", ops)
+                assert [m.pairw(), m.pairw()] == [want, want], (M, N, ops)
+            m.close()
+        if hip_ctx.get_option("probes_build") != 1:
+            for ops in (1, 3):
+                with pytest.raises(Exception):
+                    hip_ctx.set_option("k2_strip_operands", ops)
+    finally:
+        _reset(hip_ctx)
