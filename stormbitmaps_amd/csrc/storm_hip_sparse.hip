@@ -182,10 +182,22 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     if (e + tid < head_end) visit(pos16[e + tid]);
     e = head_end;
     const uint32_t body_end = e + ((it.b_end - e) & ~7u);
-    for (uint32_t q = e + tid * 8u; q < body_end; q += kProbeThreads * 8u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&pos16[q]);
-        visit(v.x); visit(v.x >> 16); visit(v.y); visit(v.y >> 16);
-        visit(v.z); visit(v.z >> 16); visit(v.w); visit(v.w >> 16);
+    // (two loads ahead of the one being looked up: with one wave's 16 bytes per lane in flight the stream was
+    //  latency-bound)
+    {
+        constexpr uint32_t kStep = kProbeThreads * 8u;
+        uint32_t q = e + tid * 8u;
+        auto load = [&](uint32_t at) {
+            return at < body_end ? *reinterpret_cast<const uint4*>(&pos16[at]) : uint4{0u, 0u, 0u, 0u};
+        };
+        uint4 v0 = load(q), v1 = load(q + kStep);
+        for (; q < body_end; q += kStep) {
+            const uint4 v2 = load(q + 2u * kStep);
+            visit(v0.x); visit(v0.x >> 16); visit(v0.y); visit(v0.y >> 16);
+            visit(v0.z); visit(v0.z >> 16); visit(v0.w); visit(v0.w >> 16);
+            v0 = v1;
+            v1 = v2;
+        }
     }
     if (body_end + tid < it.b_end) visit(pos16[body_end + tid]);
     uint64_t mine = count;
@@ -447,6 +459,41 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     probe_elems[(size_t)cursor[i]++] = ((uint32_t)local << 16) | (l[k] & ((1u << kProbeOctBits) - 1u));
                 }
             }
+            // LDS banks: a lookup reads the 16-byte entry of its position, entry p lies in bank group p % 16, and
+            // the 8 lanes the LDS serves per clock look up elements that lie 8 apart in the stream (a lane takes 8
+            // consecutive ones). In position order those residues are random and every second clock is a conflict
+            // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.66 at c4's denser loads). Counting does not care about
+            // the order inside a row, so every row's elements of an octant are dealt by residue, eight of one residue,
+            // then eight of the next: elements 8 apart then differ in their residue as far as the row's positions allow.
+            {
+                std::vector<uint32_t> tmp;
+                for (size_t i = 0; i < row_start.size(); ++i) {
+                    const std::vector<uint32_t>& rs = row_start[i];
+                    const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
+                    for (size_t k = 0; k < rs.size(); ++k) {
+                        const uint32_t s0 = rs[k], s1 = k + 1 < rs.size() ? rs[k + 1] : end;
+                        const uint32_t n = s1 - s0;
+                        if (n < 32u) continue;
+                        uint32_t cnt[17] = {0};
+                        for (uint32_t j = s0; j < s1; ++j) cnt[(probe_elems[j] & 15u) + 1u]++;
+                        for (int r = 0; r < 16; ++r) cnt[r + 1] += cnt[r];
+                        uint32_t at_r[16], end_r[16];
+                        for (int r = 0; r < 16; ++r) { at_r[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
+                        tmp.resize(n);
+                        {
+                            uint32_t fill[16];
+                            for (int r = 0; r < 16; ++r) fill[r] = cnt[r];
+                            for (uint32_t j = s0; j < s1; ++j) tmp[fill[probe_elems[j] & 15u]++] = probe_elems[j];
+                        }
+                        uint32_t out = s0;
+                        while (out < s1)
+                            for (int r = 0; r < 16; ++r) {
+                                const uint32_t take = std::min(8u, end_r[r] - at_r[r]);
+                                for (uint32_t t = 0; t < take; ++t) probe_elems[out++] = tmp[at_r[r]++];
+                            }
+                    }
+                }
+            }
             // far work of all groups -> positions per item: about 4096 items over all probe columns, between
             // 2^15 and 2^21 positions each (an item zeroes and scatters its 128 KiB table first)
             uint64_t far_work = 0;
@@ -473,9 +520,12 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     if (rs[a1] == rs[a0]) continue;  // no listed position of the A rows in this octant
                     // first item of the group: the A rows' own elements against the rows before them + the
                     // first chunk of the rows behind the group; further chunks follow as items of their own
+                    // (chunks end where a row ends: the elements of a row are in no particular order any more)
                     bool first = true;
-                    for (uint64_t b0 = rs[a1]; first || b0 < rs[n_c]; b0 += kProbeChunk) {
-                        const uint32_t b1 = (uint32_t)std::min<uint64_t>(rs[n_c], b0 + kProbeChunk);
+                    for (uint64_t b0 = rs[a1], b_next = 0; first || b0 < rs[n_c]; b0 = b_next) {
+                        const uint64_t want_end = std::min<uint64_t>(rs[n_c], b0 + kProbeChunk);
+                        const uint32_t b1 = *std::lower_bound(rs.begin() + a1, rs.end(), (uint32_t)want_end);
+                        b_next = std::max<uint64_t>(b1, b0 + 1);
                         const uint32_t n0 = first ? rs[a0] : 0u, n1 = first ? rs[a1] : 0u;
                         if (n1 > n0 || b1 > (uint32_t)b0)
                             s->probe_items.push_back({rs[a0], rs[a1], n0, n1, std::min((uint32_t)b0, b1), b1, a0, e});
