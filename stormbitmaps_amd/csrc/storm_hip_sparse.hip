@@ -140,6 +140,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
     unsigned long long* __restrict__ slots) {
     __shared__ __attribute__((aligned(16))) uint32_t T[(1u << kProbeOctBits) * kProbeWords];  // kProbeRows bits per position
+    __shared__ uint16_t Cn[1u << kProbeOctBits];  // how many of the A rows list the position = popcount of its entry
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
     for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) * kProbeWords; w += kProbeThreads * 4u)
@@ -153,6 +154,14 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     }
     __syncthreads();
     const uint4* T4 = reinterpret_cast<const uint4*>(T);
+    // A far lookup needs the NUMBER of A rows that list the position, not which: the popcount of an entry is taken
+    // once per item here instead of once per lookup (v_bcnt_u32_b32 is half rate: four of them per lookup were what
+    // bounded the kernel — 40 issue cycles per wave-lookup against 12 for an address, a 2-byte read and an add).
+    for (uint32_t p = tid; p < (1u << kProbeOctBits); p += kProbeThreads) {
+        const uint4 m = T4[p];
+        Cn[p] = (uint16_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+    }
+    __syncthreads();
     uint32_t count = 0;
     // near: an A row's own elements against the A rows before it
     for (uint32_t e = it.n_begin + tid; e < it.n_end; e += kProbeThreads) {
@@ -170,33 +179,37 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
         }
     }
     // far: head up to a 16-byte boundary, body 8 positions per load, tail
-    auto visit = [&](uint32_t p) {
-#pragma unroll
-        for (uint32_t q = 0; q < kProbeWords / 4u; ++q) {
-            const uint4 m = T4[(p & kPosMask) * (kProbeWords / 4u) + q];
-            count += __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w);
-        }
-    };
+    auto visit = [&](uint32_t p) { count += Cn[p & kPosMask]; };
     uint32_t e = it.b_begin;
     const uint32_t head_end = min(it.b_end, (it.b_begin + 7u) & ~7u);
     if (e + tid < head_end) visit(pos16[e + tid]);
     e = head_end;
     const uint32_t body_end = e + ((it.b_end - e) & ~7u);
-    // (two loads ahead of the one being looked up: with one wave's 16 bytes per lane in flight the stream was
-    //  latency-bound)
-    {
+    // Body: FOUR 16-byte pieces per lane and trip, loaded together (unconditionally: the address is clamped, not
+    // the load skipped), and the eight lookups of a piece issued together before the first of them is added. With
+    // one piece per trip the stream was latency-bound — 16 KiB in flight per CU, 5.1 TB/s whatever the L2 hit rate —
+    // and software-pipelining it by hand does not survive hipcc (register rotation by copies makes it wait for the
+    // youngest load; without copies it sinks the loads to their uses).
+    if (body_end > e) {
+        static_assert(kProbeWords == 4, "one 16-byte entry per position");
         constexpr uint32_t kStep = kProbeThreads * 8u;
-        uint32_t q = e + tid * 8u;
-        auto load = [&](uint32_t at) {
-            return at < body_end ? *reinterpret_cast<const uint4*>(&pos16[at]) : uint4{0u, 0u, 0u, 0u};
+        const uint32_t last = body_end - 8u;
+        auto lookups = [&](const uint4& v) {
+            const uint32_t p[8] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16,
+                                   v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c[k] = Cn[p[k] & kPosMask];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) count += c[k];
         };
-        uint4 v0 = load(q), v1 = load(q + kStep);
-        for (; q < body_end; q += kStep) {
-            const uint4 v2 = load(q + 2u * kStep);
-            visit(v0.x); visit(v0.x >> 16); visit(v0.y); visit(v0.y >> 16);
-            visit(v0.z); visit(v0.z >> 16); visit(v0.w); visit(v0.w >> 16);
-            v0 = v1;
-            v1 = v2;
+        for (uint32_t q = e + tid * 8u; q < body_end; q += 4u * kStep) {
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4*>(&pos16[min(q + j * kStep, last)]);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j)
+                if (q + j * kStep < body_end) lookups(v[j]);
         }
     }
     if (body_end + tid < it.b_end) visit(pos16[body_end + tid]);
@@ -399,6 +412,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     // ---- probe data (K4): columns whose blocks are all lists and that have at most 65535 rows. Per column
     //      and octant (8192 positions of the block) the listed positions in row order.
     std::vector<uint32_t> probe_elems;
+    std::vector<uint16_t> probe_pos16;  // the far stream's copy of the positions, in its own order (below)
     {
         std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
         s->col_probe.assign(s->cols.size(), 0);
@@ -459,37 +473,39 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     probe_elems[(size_t)cursor[i]++] = ((uint32_t)local << 16) | (l[k] & ((1u << kProbeOctBits) - 1u));
                 }
             }
-            // LDS banks: a lookup reads the 16-byte entry of its position, entry p lies in bank group p % 16, and
-            // the 8 lanes the LDS serves per clock look up elements that lie 8 apart in the stream (a lane takes 8
-            // consecutive ones). In position order those residues are random and every second clock is a conflict
-            // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.66 at c4's denser loads). Counting does not care about
-            // the order inside a row, so every row's elements of an octant are dealt by residue, eight of one residue,
-            // then eight of the next: elements 8 apart then differ in their residue as far as the row's positions allow.
+            // The far stream (pos16) in an order of its own. A far lookup only needs the POSITION — which row listed
+            // it does not matter — so inside every atom of the stream (the elements of one group of kProbeRows rows in
+            // one octant; items begin and end on atoms) the positions may stand in any order, and the order decides the
+            // LDS bank conflicts: a lookup reads the 2-byte count of its position, count p lies in bank (p / 2) % 32,
+            // and a 2- or 4-byte read is served in two groups of 32 lanes that each want 32 distinct banks. A lane takes
+            // 8 consecutive elements, so at every one of its 8 lookups the lanes of a group read elements 8 apart. In
+            // position order the banks are random (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.68 for the 16-byte
+            // entries the kernel used to read). Dealt by bank — eight positions of bank 0, eight of bank 1, ... round
+            // after round — element i has bank (i / 8) % 32 wherever the atom starts, and the 32 lanes of a group meet
+            // 32 different banks.
+            probe_pos16.resize(probe_elems.size());
+            for (size_t j = 0; j < probe_elems.size(); ++j) probe_pos16[j] = (uint16_t)probe_elems[j];
             {
-                std::vector<uint32_t> tmp;
+                std::vector<uint16_t> tmp;
                 for (size_t i = 0; i < row_start.size(); ++i) {
                     const std::vector<uint32_t>& rs = row_start[i];
                     const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
-                    for (size_t k = 0; k < rs.size(); ++k) {
-                        const uint32_t s0 = rs[k], s1 = k + 1 < rs.size() ? rs[k + 1] : end;
+                    for (size_t k = 0; k < rs.size(); k += kProbeRows) {
+                        const uint32_t s0 = rs[k], s1 = k + kProbeRows < rs.size() ? rs[k + kProbeRows] : end;
                         const uint32_t n = s1 - s0;
-                        if (n < 32u) continue;
-                        uint32_t cnt[17] = {0};
-                        for (uint32_t j = s0; j < s1; ++j) cnt[(probe_elems[j] & 15u) + 1u]++;
-                        for (int r = 0; r < 16; ++r) cnt[r + 1] += cnt[r];
-                        uint32_t at_r[16], end_r[16];
-                        for (int r = 0; r < 16; ++r) { at_r[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
+                        if (n < 256u) continue;
+                        uint32_t cnt[33] = {0};
+                        for (uint32_t j = s0; j < s1; ++j) cnt[((probe_pos16[j] >> 1) & 31u) + 1u]++;
+                        for (int r = 0; r < 32; ++r) cnt[r + 1] += cnt[r];
+                        uint32_t at_r[32], end_r[32], fill[32];
+                        for (int r = 0; r < 32; ++r) { at_r[r] = fill[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
                         tmp.resize(n);
-                        {
-                            uint32_t fill[16];
-                            for (int r = 0; r < 16; ++r) fill[r] = cnt[r];
-                            for (uint32_t j = s0; j < s1; ++j) tmp[fill[probe_elems[j] & 15u]++] = probe_elems[j];
-                        }
+                        for (uint32_t j = s0; j < s1; ++j) tmp[fill[(probe_pos16[j] >> 1) & 31u]++] = probe_pos16[j];
                         uint32_t out = s0;
                         while (out < s1)
-                            for (int r = 0; r < 16; ++r) {
+                            for (int r = 0; r < 32; ++r) {
                                 const uint32_t take = std::min(8u, end_r[r] - at_r[r]);
-                                for (uint32_t t = 0; t < take; ++t) probe_elems[out++] = tmp[at_r[r]++];
+                                for (uint32_t t = 0; t < take; ++t) probe_pos16[out++] = tmp[at_r[r]++];
                             }
                     }
                 }
@@ -507,42 +523,84 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     far_work += end - (a1 < n_c ? rs[a1] : end);
                 }
             }
-            const uint32_t kProbeChunk =
-                (uint32_t)std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 15, far_work / 4096)) & ~7u;
+            // Chunks of the far stream are the SAME for every group of a (column, octant) stream: a fixed grid of runs
+            // of atoms, ~far_work / 4096 positions each and at most 2^19 (1 MiB of positions: a quarter of an XCD's
+            // L2). A group needs the rest of the chunk its own atom lies in and every later chunk. The items that read
+            // one chunk are a FAMILY; a family goes to one XCD, its items one after the other, so that the XCD's 32 CUs
+            // work through the same MiB at the same time and HBM delivers it once (the kernel fetched 16 GB per launch
+            // at c4's 20971 draws — every group streaming its own 4 MiB chunks through an L2 that hit 9 % of the time —
+            // and ran at the HBM rate with the LDS half idle).
+            const uint64_t kProbeChunk =
+                std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 15, far_work / 4096)) & ~7ull;
+            struct Family {
+                uint64_t work = 0;
+                std::vector<storm_hip_sparse_s::ProbeItemHost> items;
+            };
+            std::vector<Family> families;
             for (size_t i = 0; i < row_start.size(); ++i) {
                 std::vector<uint32_t>& rs = row_start[i];
                 if (rs.empty()) continue;
                 const uint32_t n_c = (uint32_t)rs.size();
                 rs.push_back((uint32_t)(oct_base[i] + oct_count[i]));  // end of the octant
                 const uint32_t e = (uint32_t)(i / kProbeOctants);
-                for (uint32_t a0 = 0; a0 < n_c; a0 += kProbeRows) {
-                    const uint32_t a1 = std::min(a0 + kProbeRows, n_c);
+                // atoms t = 0 .. n_atoms - 1: rows [128 t, 128 t + 128); chunk grid over atoms 1 .. (atom 0 is nobody's far part)
+                const uint32_t n_atoms = (n_c + kProbeRows - 1) / kProbeRows;
+                auto atom_start = [&](uint32_t t) { return rs[std::min(t * (uint32_t)kProbeRows, n_c)]; };
+                std::vector<uint32_t> chunk_first;  // first atom of every chunk, + n_atoms
+                for (uint32_t t = 1; t < n_atoms;) {
+                    chunk_first.push_back(t);
+                    const uint64_t from = atom_start(t);
+                    ++t;
+                    while (t < n_atoms && atom_start(t) - from < kProbeChunk) ++t;
+                }
+                chunk_first.push_back(n_atoms);
+                const size_t fam0 = families.size();
+                families.resize(fam0 + chunk_first.size());  // one per chunk (+ one for groups without a far part)
+                for (uint32_t g = 0; g < n_atoms; ++g) {
+                    const uint32_t a0 = g * kProbeRows, a1 = std::min(a0 + (uint32_t)kProbeRows, n_c);
                     if (rs[a1] == rs[a0]) continue;  // no listed position of the A rows in this octant
-                    // first item of the group: the A rows' own elements against the rows before them + the
-                    // first chunk of the rows behind the group; further chunks follow as items of their own
-                    // (chunks end where a row ends: the elements of a row are in no particular order any more)
+                    // first item of the group: the A rows' own elements against the rows before them + the rest of
+                    // the chunk the next atom lies in; one item per later chunk
+                    size_t c = 0;
+                    while (c + 1 < chunk_first.size() && chunk_first[c + 1] <= g + 1) ++c;
                     bool first = true;
-                    for (uint64_t b0 = rs[a1], b_next = 0; first || b0 < rs[n_c]; b0 = b_next) {
-                        const uint64_t want_end = std::min<uint64_t>(rs[n_c], b0 + kProbeChunk);
-                        const uint32_t b1 = *std::lower_bound(rs.begin() + a1, rs.end(), (uint32_t)want_end);
-                        b_next = std::max<uint64_t>(b1, b0 + 1);
+                    if (g + 1 >= n_atoms) {  // the last group: near part only
+                        families[fam0 + chunk_first.size() - 1].items.push_back({rs[a0], rs[a1], rs[a0], rs[a1], rs[a1], rs[a1], a0, e});
+                        families[fam0 + chunk_first.size() - 1].work += rs[a1] - rs[a0];
+                        continue;
+                    }
+                    for (; c + 1 < chunk_first.size(); ++c) {
+                        const uint32_t b0 = first ? rs[a1] : atom_start(chunk_first[c]);
+                        const uint32_t b1 = atom_start(chunk_first[c + 1]);
                         const uint32_t n0 = first ? rs[a0] : 0u, n1 = first ? rs[a1] : 0u;
-                        if (n1 > n0 || b1 > (uint32_t)b0)
-                            s->probe_items.push_back({rs[a0], rs[a1], n0, n1, std::min((uint32_t)b0, b1), b1, a0, e});
+                        if (n1 > n0 || b1 > b0) {
+                            families[fam0 + c].items.push_back({rs[a0], rs[a1], n0, n1, std::min(b0, b1), b1, a0, e});
+                            families[fam0 + c].work += (uint64_t)(b1 - std::min(b0, b1)) + (n1 - n0) + 4096;
+                        }
                         first = false;
                     }
                 }
             }
-            // longest first: the launch ends on small items. (Dealing the groups of one (column, octant) to one
-            // XCD, neighbours at the same time, so that they share their stream through its L2 — at the denser
-            // loads the kernel fetches 17 GB per launch from HBM, L2 hit rate 9 %, profiles/r03_b_* — was measured
-            // and is slower: 4.42 against 3.67 ms at c4's 20971 draws; an XCD then works through one pair at a
-            // time and idles at every pair's tail.)
-            std::stable_sort(s->probe_items.begin(), s->probe_items.end(),
-                             [](const storm_hip_sparse_s::ProbeItemHost& x, const storm_hip_sparse_s::ProbeItemHost& y) {
-                                 return (uint64_t)(x.b_end - x.b_begin) + (x.n_end - x.n_begin) >
-                                        (uint64_t)(y.b_end - y.b_begin) + (y.n_end - y.n_begin);
-                             });
+            // families to XCDs: heaviest first onto the lightest queue; block b of the launch runs on XCD b % 8
+            // (observed; speed only), so the launch order takes one item of every queue in turn
+            std::vector<size_t> order(families.size());
+            for (size_t f = 0; f < order.size(); ++f) order[f] = f;
+            std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return families[x].work > families[y].work; });
+            std::vector<std::vector<storm_hip_sparse_s::ProbeItemHost>> queue(8);
+            uint64_t load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (size_t f : order) {
+                if (families[f].items.empty()) continue;
+                int q = 0;
+                for (int x = 1; x < 8; ++x)
+                    if (load[x] < load[q]) q = x;
+                queue[q].insert(queue[q].end(), families[f].items.begin(), families[f].items.end());
+                load[q] += families[f].work;
+            }
+            size_t longest = 0;
+            for (int x = 0; x < 8; ++x) longest = std::max(longest, queue[x].size());
+            for (size_t pos = 0; pos < longest; ++pos)
+                for (int x = 0; x < 8; ++x)
+                    if (pos < queue[x].size()) s->probe_items.push_back(queue[x][pos]);
         }
     }
 
@@ -567,9 +625,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
         if (!probe_elems.empty()) {
             if ((rc = upload(&s->d_probe_elems, probe_elems.data(), probe_elems.size(), ctx->stream))) break;
-            std::vector<uint16_t> pos16(probe_elems.size());
-            for (size_t i = 0; i < probe_elems.size(); ++i) pos16[i] = (uint16_t)probe_elems[i];
-            if ((rc = upload(&s->d_probe_pos16, pos16.data(), pos16.size(), ctx->stream))) break;
+            if ((rc = upload(&s->d_probe_pos16, probe_pos16.data(), probe_pos16.size(), ctx->stream))) break;
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = STORM_HIP_EHIP; break; }  // pos16 leaves scope
         }
         // the list pool (or the whole serialized stream) goes up once
