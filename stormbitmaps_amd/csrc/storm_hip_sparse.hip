@@ -157,9 +157,18 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
         for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads * 4u)
             *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
         __syncthreads();
-        for (uint32_t e = it.a_begin + tid; e < it.a_end; e += kProbeThreads) {
-            const uint32_t pos = elems[e] & kPosMask;
-            atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
+        // (eight loads per lane in flight: one per trip is a chain of ~40 memory latencies per item — the tables of
+        //  c4's 20971 draws took 0.5 of the far kernel's 1.08 ms and most of the own-row kernel's 0.72)
+        for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += kProbeThreads * 8u) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.a_end - 1u)];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+                if (e0 + k * kProbeThreads < it.a_end) {
+                    const uint32_t pos = v[k] & kPosMask;
+                    atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
+                }
         }
         __syncthreads();
     } else {
@@ -167,10 +176,16 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) * kProbeWords; w += kProbeThreads * 4u)
         *reinterpret_cast<uint4*>(&T[w]) = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
-    for (uint32_t e = it.a_begin + tid; e < it.a_end; e += kProbeThreads) {
-        const uint32_t v = elems[e];
-        const uint32_t pos = v & kPosMask, r = (v >> 16) - it.a0;  // r in 0 .. kProbeRows - 1
-        atomicOr(&T[pos * kProbeWords + (r >> 5)], 1u << (r & 31u));
+    for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += kProbeThreads * 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.a_end - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k)
+            if (e0 + k * kProbeThreads < it.a_end) {
+                const uint32_t pos = v[k] & kPosMask, r = (v[k] >> 16) - it.a0;  // r in 0 .. kProbeRows - 1
+                atomicOr(&T[pos * kProbeWords + (r >> 5)], 1u << (r & 31u));
+            }
     }
     __syncthreads();
     const uint4* T4 = reinterpret_cast<const uint4*>(T);
@@ -184,20 +199,25 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
         }
         __syncthreads();
     }
-    // near: an A row's own elements against the A rows before it
-    for (uint32_t e = it.n_begin + tid; e < it.n_end; e += kProbeThreads) {
-        const uint32_t v = elems[e];
-        const uint32_t jr = (v >> 16) - it.a0;
-        auto below = [&](uint32_t w) {  // mask of the rows < jr inside word w
-            const uint32_t lo = 32u * w;
-            return jr >= lo + 32u ? 0xffffffffu : jr <= lo ? 0u : (1u << (jr - lo)) - 1u;
-        };
+    // near: an A row's own elements against the A rows before it (four loads, then four lookups, per trip)
+    for (uint32_t e0 = it.n_begin + tid; e0 < it.n_end; e0 += kProbeThreads * 4u) {
+        uint32_t v[4];
+        uint4 m[4];
 #pragma unroll
-        for (uint32_t q = 0; q < kProbeWords / 4u; ++q) {
-            const uint4 m = T4[(v & kPosMask) * (kProbeWords / 4u) + q];
-            count += __popc(m.x & below(4u * q)) + __popc(m.y & below(4u * q + 1u)) +
-                     __popc(m.z & below(4u * q + 2u)) + __popc(m.w & below(4u * q + 3u));
-        }
+        for (uint32_t k = 0; k < 4; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.n_end - 1u)];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) m[k] = T4[v[k] & kPosMask];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (e0 + k * kProbeThreads < it.n_end) {
+                const uint32_t jr = (v[k] >> 16) - it.a0;
+                auto below = [&](uint32_t w) {  // mask of the rows < jr inside word w
+                    const uint32_t lo = 32u * w;
+                    return jr >= lo + 32u ? 0xffffffffu : jr <= lo ? 0u : (1u << (jr - lo)) - 1u;
+                };
+                count += __popc(m[k].x & below(0u)) + __popc(m[k].y & below(1u)) + __popc(m[k].z & below(2u)) +
+                         __popc(m[k].w & below(3u));
+            }
     }
     }  // kFirst
     // far: head up to a 16-byte boundary, body 8 positions per load, tail

@@ -22,20 +22,23 @@ LDS_LOOKUPS_PER_CLK_CU, CUS, CLK = 32, 256, 2.4e9
 
 
 def counters(path):
+    """Per pass: the kernel runs in two forms (far-only items, own-row items), one launch each — their means add."""
     acc = {}
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "probe_lists_kernel" in r["Kernel_Name"]:
-                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                acc.setdefault(r["Counter_Name"], {}).setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return {k: sum(sum(v) / len(v) for v in forms.values()) for k, forms in acc.items()}
 
 
 def kernel_us(path):
+    total, calls = 0.0, 0
     for f in glob.glob(path + "/**/*kernel_stats.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if "probe_lists_kernel" in r["Name"]:
-                return float(r["AverageNs"]) / 1e3, int(r["Calls"])
-    return None, 0
+                total += float(r["AverageNs"]) / 1e3
+                calls = max(calls, int(r["Calls"]))
+    return (total or None), calls
 
 
 def main():
