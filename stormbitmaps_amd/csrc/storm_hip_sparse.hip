@@ -43,12 +43,11 @@ struct storm_hip_sparse_s {
     uint32_t* d_probe_elems = nullptr;  // (row in column) << 16 | position in block, column by column, row order
     uint16_t* d_probe_pos16 = nullptr;  // the positions alone, same indexing
     struct ProbeItemHost { uint32_t a_begin, a_end, n_begin, n_end, b_begin, b_end, a0, col; };
-    std::vector<ProbeItemHost> probe_items;        // far-only items of all eligible columns (family order); filtered per launch
-    std::vector<ProbeItemHost> probe_first_items;  // one per group of rows: its own rows among themselves
+    std::vector<ProbeItemHost> probe_items;  // all eligible columns (family order); filtered per launch
     void* d_probe_items = nullptr;
     size_t probe_items_capacity = 0;
     uint64_t probe_key = ~0ull;
-    uint32_t n_probe_launch = 0, n_probe_first_launch = 0, n_probe_far_items = 0, n_probe_cols_launch = 0;
+    uint32_t n_probe_launch = 0, n_probe_cols_launch = 0;
     // segment table cache (per shard)
     Seg* d_segs = nullptr;
     uint32_t n_segs = 0;
@@ -132,50 +131,33 @@ constexpr int kProbeThreads = 1024;
 // (256 rows x 4096 positions — half the passes over the elements, two 16-byte reads per lookup — is slower:
 //  4.57 against 3.67 ms at c4's 20971 draws; the LDS reads are the larger half of the time)
 constexpr uint32_t kProbeRows = 128;        // A rows per item
-constexpr uint32_t kProbeWords = kProbeRows / 32u;
+[[maybe_unused]] constexpr uint32_t kProbeWords = kProbeRows / 32u;  // (the mask words of the bitmap form)
 constexpr uint32_t kProbeOctBits = 13;      // positions per table: 2^13 of the block's 2^16 (table = 2^13 x 16 B)
 constexpr uint32_t kProbeOctants = 1u << (16 - kProbeOctBits);
 
-// Two forms. kFirst: the item has own rows to count among themselves (near part) and needs the masks — 128 KiB,
-// one workgroup per CU. !kFirst: the item only streams positions of later rows against the group (far part: 95 % of
-// the lookups at the denser loads); what it needs is the count table alone, which an LDS histogram of the group's
-// elements builds without the masks — 16 KiB, two workgroups of 1024 threads per CU, twice the waves to wait for
-// the stream with.
-template <bool kFirst>
+// One workgroup = one item = one group of kProbeRows rows x one octant of the block, against a chunk of the positions
+// of the rows behind the group. All it needs of the group is HOW MANY of its rows list each position: Cn, built by an
+// LDS histogram of the group's elements (16 KiB: two workgroups of 1024 threads per CU).
+//   * pairs inside the group (the group's first item only): C(Cn[p], 2) per position;
+//   * pairs with a later row: Cn[p] per listed position p of that row — one 2-byte LDS read and one add.
+// (Rounds 2 / 3 kept the group as a transposed BITMAP — 128-bit masks per position, 128 KiB — and took
+//  popcount(mask & rows_before) per own element and popcount(mask) per later element; the counts are what those
+//  popcounts add up to, and v_bcnt_u32_b32 is half rate: profiles/r03_b_sparse_probe_ab.txt has every step.)
 __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
     unsigned long long* __restrict__ slots) {
-    // how many of the A rows list a position (two 16-bit counts per word: a group has at most kProbeRows = 128 rows)
+    // two 16-bit counts per word: a group has at most kProbeRows = 128 rows
     __shared__ __attribute__((aligned(16))) uint32_t Cn32[(1u << kProbeOctBits) / 2u];
-    uint16_t* Cn = reinterpret_cast<uint16_t*>(Cn32);
+    const uint16_t* Cn = reinterpret_cast<const uint16_t*>(Cn32);
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kPosMask = (1u << kProbeOctBits) - 1u;
-    uint32_t count = 0;
-    if constexpr (!kFirst) {
-        for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads * 4u)
-            *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
-        __syncthreads();
-        // (eight loads per lane in flight: one per trip is a chain of ~40 memory latencies per item — the tables of
-        //  c4's 20971 draws took 0.5 of the far kernel's 1.08 ms and most of the own-row kernel's 0.72)
-        for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += kProbeThreads * 8u) {
-            uint32_t v[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.a_end - 1u)];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-                if (e0 + k * kProbeThreads < it.a_end) {
-                    const uint32_t pos = v[k] & kPosMask;
-                    atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
-                }
-        }
-        __syncthreads();
-    } else {
-    __shared__ __attribute__((aligned(16))) uint32_t T[(1u << kProbeOctBits) * kProbeWords];  // kProbeRows bits per position
-    for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) * kProbeWords; w += kProbeThreads * 4u)
-        *reinterpret_cast<uint4*>(&T[w]) = uint4{0u, 0u, 0u, 0u};
+    static_assert(kProbeRows <= 0xffffu, "16-bit counts");
+    for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads * 4u)
+        *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
+    // (eight loads per lane in flight: one per trip is a chain of ~40 memory latencies per item)
     for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += kProbeThreads * 8u) {
         uint32_t v[8];
 #pragma unroll
@@ -183,43 +165,18 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
             if (e0 + k * kProbeThreads < it.a_end) {
-                const uint32_t pos = v[k] & kPosMask, r = (v[k] >> 16) - it.a0;  // r in 0 .. kProbeRows - 1
-                atomicOr(&T[pos * kProbeWords + (r >> 5)], 1u << (r & 31u));
+                const uint32_t pos = v[k] & kPosMask;
+                atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
             }
     }
     __syncthreads();
-    const uint4* T4 = reinterpret_cast<const uint4*>(T);
-    // A far lookup needs the NUMBER of A rows that list the position, not which: the popcount of an entry is taken
-    // once per item here instead of once per lookup (v_bcnt_u32_b32 is half rate: four of them per lookup were what
-    // bounded the kernel — 40 issue cycles per wave-lookup against 12 for an address, a 2-byte read and an add).
-    if (it.b_end > it.b_begin) {
-        for (uint32_t p = tid; p < (1u << kProbeOctBits); p += kProbeThreads) {
-            const uint4 m = T4[p];
-            Cn[p] = (uint16_t)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+    uint32_t count = 0;
+    if (it.n_end > it.n_begin) {  // the group's own rows among themselves
+        for (uint32_t w = tid; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads) {
+            const uint32_t c2 = Cn32[w], lo = c2 & 0xffffu, hi = c2 >> 16;
+            count += (lo * (lo - 1u) + hi * (hi - 1u)) >> 1;  // both products are even
         }
-        __syncthreads();
     }
-    // near: an A row's own elements against the A rows before it (four loads, then four lookups, per trip)
-    for (uint32_t e0 = it.n_begin + tid; e0 < it.n_end; e0 += kProbeThreads * 4u) {
-        uint32_t v[4];
-        uint4 m[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.n_end - 1u)];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) m[k] = T4[v[k] & kPosMask];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k)
-            if (e0 + k * kProbeThreads < it.n_end) {
-                const uint32_t jr = (v[k] >> 16) - it.a0;
-                auto below = [&](uint32_t w) {  // mask of the rows < jr inside word w
-                    const uint32_t lo = 32u * w;
-                    return jr >= lo + 32u ? 0xffffffffu : jr <= lo ? 0u : (1u << (jr - lo)) - 1u;
-                };
-                count += __popc(m[k].x & below(0u)) + __popc(m[k].y & below(1u)) + __popc(m[k].z & below(2u)) +
-                         __popc(m[k].w & below(3u));
-            }
-    }
-    }  // kFirst
     // far: head up to a 16-byte boundary, body 8 positions per load, tail
     auto visit = [&](uint32_t p) { count += Cn[p & kPosMask]; };
     uint32_t e = it.b_begin;
@@ -233,7 +190,6 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     // and software-pipelining it by hand does not survive hipcc (register rotation by copies makes it wait for the
     // youngest load; without copies it sinks the loads to their uses).
     if (body_end > e) {
-        static_assert(kProbeWords == 4, "one 16-byte entry per position");
         constexpr uint32_t kStep = kProbeThreads * 8u;
         const uint32_t last = body_end - 8u;
         auto lookups = [&](const uint4& v) {
@@ -601,19 +557,23 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 for (uint32_t g = 0; g < n_atoms; ++g) {
                     const uint32_t a0 = g * kProbeRows, a1 = std::min(a0 + (uint32_t)kProbeRows, n_c);
                     if (rs[a1] == rs[a0]) continue;  // no listed position of the A rows in this octant
-                    // the group's own rows among themselves: an item of the form with the masks
-                    s->probe_first_items.push_back({rs[a0], rs[a1], rs[a0], rs[a1], rs[a1], rs[a1], a0, e});
-                    if (g + 1 >= n_atoms) continue;  // the last group has nobody behind it
-                    // the rows behind it: the rest of the chunk the next atom lies in, then one item per later chunk
+                    // first item of the group: its own rows among themselves (n range set) + the rest of the chunk the
+                    // next atom lies in; one item per later chunk
+                    if (g + 1 >= n_atoms) {  // the last group has nobody behind it
+                        families[fam0 + chunk_first.size() - 1].items.push_back({rs[a0], rs[a1], rs[a0], rs[a1], rs[a1], rs[a1], a0, e});
+                        families[fam0 + chunk_first.size() - 1].work += 8192;
+                        continue;
+                    }
                     size_t c = 0;
                     while (c + 1 < chunk_first.size() && chunk_first[c + 1] <= g + 1) ++c;
                     bool first = true;
                     for (; c + 1 < chunk_first.size(); ++c) {
                         const uint32_t b0 = first ? rs[a1] : atom_start(chunk_first[c]);
                         const uint32_t b1 = atom_start(chunk_first[c + 1]);
-                        if (b1 > b0) {
-                            families[fam0 + c].items.push_back({rs[a0], rs[a1], 0u, 0u, b0, b1, a0, e});
-                            families[fam0 + c].work += (uint64_t)(b1 - b0) + 4096;
+                        const uint32_t n0 = first ? rs[a0] : 0u, n1 = first ? rs[a1] : 0u;
+                        if (n1 > n0 || b1 > b0) {
+                            families[fam0 + c].items.push_back({rs[a0], rs[a1], n0, n1, std::min(b0, b1), b1, a0, e});
+                            families[fam0 + c].work += (uint64_t)(b1 - std::min(b0, b1)) + 8192;
                         }
                         first = false;
                     }
@@ -940,17 +900,12 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
             for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;
             if (key != s->probe_key) {
-                std::vector<ProbeItem> mine;  // the far-only items, then the groups' own-row items
+                std::vector<ProbeItem> mine;
                 uint32_t cols_used = 0;
                 for (size_t e = 0; e < use_probe.size(); ++e) cols_used += use_probe[e];
                 for (const auto& pi : s->probe_items)
                     if (use_probe[pi.col])
                         mine.push_back({pi.a_begin, pi.a_end, pi.n_begin, pi.n_end, pi.b_begin, pi.b_end, pi.a0});
-                const size_t n_far = mine.size();
-                for (const auto& pi : s->probe_first_items)
-                    if (use_probe[pi.col])
-                        mine.push_back({pi.a_begin, pi.a_end, pi.n_begin, pi.n_end, pi.b_begin, pi.b_end, pi.a0});
-                const size_t n_first = mine.size() - n_far;
                 if (mine.size() > s->probe_items_capacity) {
                     if (s->d_probe_items) STORM_HIP_TRY(hipFree(s->d_probe_items));
                     s->d_probe_items = nullptr;
@@ -963,27 +918,17 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                                                  hipMemcpyHostToDevice, ctx->stream));
                     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
                 }
-                // shard r of G takes items r, r + G, ... of either kind: a grid covers ceil((n - r) / G) of them
-                auto share = [&](size_t n) {
-                    return n > shard_rank ? (uint32_t)((n - shard_rank + shard_count - 1) / shard_count) : 0u;
-                };
-                s->n_probe_launch = share(n_far);
-                s->n_probe_first_launch = share(n_first);
-                s->n_probe_far_items = (uint32_t)n_far;
+                // shard r of G takes items r, r + G, ...: the grid covers ceil((n - r) / G) of them
+                s->n_probe_launch = mine.size() > shard_rank
+                                        ? (uint32_t)((mine.size() - shard_rank + shard_count - 1) / shard_count)
+                                        : 0u;
                 s->n_probe_cols_launch = cols_used;
                 s->probe_key = key;
             }
         }
         if (s->n_probe_launch > 0) {
-            hipLaunchKernelGGL(probe_lists_kernel<false>, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
+            hipLaunchKernelGGL(probe_lists_kernel, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
                                s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
-                               shard_rank, ctx->d_slots);
-            STORM_HIP_TRY(hipGetLastError());
-        }
-        if (s->n_probe_first_launch > 0) {
-            hipLaunchKernelGGL(probe_lists_kernel<true>, dim3(s->n_probe_first_launch), dim3(kProbeThreads), 0, ctx->stream,
-                               s->d_probe_elems, s->d_probe_pos16,
-                               static_cast<const ProbeItem*>(s->d_probe_items) + s->n_probe_far_items, shard_count,
                                shard_rank, ctx->d_slots);
             STORM_HIP_TRY(hipGetLastError());
         }
