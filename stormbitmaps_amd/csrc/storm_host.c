@@ -749,13 +749,18 @@ static void contig_drop_device(STORM_contiguous_t* h) {
     h->hip_rows_synced = 0;
 }
 
-/* A container whose rows are ALL below scalar_cutoff (the regime in which the reference diverts to its
- * list variants, storm.c:1151-1162) is mirrored row by row into a private STORM_t: its all-pairs total then
- * costs work proportional to the listed positions (list-probe kernel K4) instead of a dense pass over
- * N x M bits — at M = 65536, N = 10000: 0.094 ms at 65 positions per row, 0.034 ms at 5, against 0.82 ms.
- * The first row at or above the cutoff, a failed allocation or STORM_contig_hip_invalidate ends it for
- * this container (until STORM_contig_clear); the dense mirror is then brought up to date on demand.
+/* A container whose rows are ALL sparse is mirrored row by row into a private STORM_t: its all-pairs total then
+ * costs work proportional to the listed positions (list-probe kernel K4) instead of a dense pass over N x M bits.
+ * The reference diverts to its list variants when rows are below scalar_cutoff (<= 200 positions, storm.c:1151-1162);
+ * here "sparse" is a row of at most M / 16 positions — 4096 per 65536-bit block on average, the density up to which
+ * a STORM_t keeps blocks as lists and K4 beats the matrix cores (M = 65536, N = 10000, tools/storm_benchmark: 0.41 ms
+ * against 0.84 at 2621 positions per row, 0.08 against 0.83 at 655, 0.03 at 5; level from 6553 up, where the rows
+ * are bitmaps either way). The first denser row, a failed allocation or STORM_contig_hip_invalidate ends it for this
+ * container (until STORM_contig_clear); the dense mirror is then brought up to date on demand.
  * STORM_HIP_CONTIG_LISTS=0 in the environment turns it off. */
+static int contig_row_is_sparse(const STORM_contiguous_t* h, uint32_t distinct) {
+    return (uint64_t)distinct * 16u <= h->vector_length || distinct < h->scalar_cutoff;
+}
 static void contig_lists_end(STORM_contiguous_t* h) {
     if (h->hip_lists) STORM_free(h->hip_lists);
     h->hip_lists = NULL;
@@ -882,7 +887,7 @@ int STORM_contig_add(STORM_contiguous_t* h, const uint32_t* values, const uint32
     h->n_scalar[h->n_data] = distinct; /* storm.c:1132-1134 */
     h->bitmaps[h->n_data].n_scalar = distinct;
     if (!h->hip_lists_off) { /* list mirror: only while every row is sparse */
-        if (distinct >= h->scalar_cutoff || !contig_lists_enabled()) {
+        if (!contig_row_is_sparse(h, distinct) || !contig_lists_enabled()) {
             contig_lists_end(h);
         } else {
             if (!h->hip_lists && (h->hip_lists = STORM_new())) h->hip_lists->hip_private = 1;

@@ -507,15 +507,15 @@ def test_strips_on_bit_operands(hip_ctx, orc):
 
 
 def test_sparse_contiguous_containers_take_the_list_path(lib, orc):
-    """A STORM_contiguous_t whose rows are ALL below scalar_cutoff (the reference's list regime,
-    storm.c:1151-1162) is mirrored into a private STORM_t and totalled by the list-probe kernel; the first
-    row at or above the cutoff ends that for good, STORM_contig_clear starts over, an in-place edit
+    """A STORM_contiguous_t whose rows are ALL sparse (at most M / 16 positions: the reference's list regime,
+    storm.c:1151-1162, widened to the density up to which blocks stay lists) is mirrored into a private STORM_t and
+    totalled by the list-probe kernel; the first denser row ends that for good, STORM_contig_clear starts over, an in-place edit
     (STORM_contig_hip_invalidate) ends it too. Every state against the oracle's container; the timing
     line pins that the list path is the one that ran (an order of magnitude at 20 positions per row)."""
     import time
     M, N = 131072, 6000
     rows = synth.positions(M, N + 2, 20, seed=5)           # 20 draws per row, cutoff 200
-    dense_row = synth.positions(M, 1, 3000, seed=6)[0]     # >= cutoff
+    dense_row = synth.positions(M, 1, 20000, seed=6)[0]    # > M / 16 positions
     c, oc = sb.StormContig(M), orc.contig(M, ())
     for r in rows[:N]:
         c.add(r)
