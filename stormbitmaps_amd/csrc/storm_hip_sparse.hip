@@ -41,7 +41,7 @@ struct storm_hip_sparse_s {
     std::vector<uint8_t> col_probe;  // per entry of `cols`: 1 = has probe data (its list blocks among themselves)
     std::vector<uint32_t> col_avg_len;  // per entry of `cols`: mean list length (probe columns)
     uint32_t* d_probe_elems = nullptr;  // (row in column) << 16 | position in block, column by column, row order
-    uint16_t* d_probe_pos16 = nullptr;  // the positions alone, same indexing
+    uint16_t* d_probe_pos16 = nullptr;  // 2 x the positions alone (byte offsets into a count table), same index ranges, own order
     struct ProbeItemHost { uint32_t a_begin, a_end, n_begin, n_end, b_begin, b_end, a0, col; };
     std::vector<ProbeItemHost> probe_items;  // all eligible columns (family order); filtered per launch
     void* d_probe_items = nullptr;
@@ -149,7 +149,6 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     unsigned long long* __restrict__ slots) {
     // two 16-bit counts per word: a group has at most kProbeRows = 128 rows
     __shared__ __attribute__((aligned(16))) uint32_t Cn32[(1u << kProbeOctBits) / 2u];
-    const uint16_t* Cn = reinterpret_cast<const uint16_t*>(Cn32);
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kPosMask = (1u << kProbeOctBits) - 1u;
@@ -177,37 +176,39 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
             count += (lo * (lo - 1u) + hi * (hi - 1u)) >> 1;  // both products are even
         }
     }
-    // far: head up to a 16-byte boundary, body 8 positions per load, tail
-    auto visit = [&](uint32_t p) { count += Cn[p & kPosMask]; };
+    // far: head up to a 16-byte boundary, body 8 positions per load, tail. pos16 holds 2 x the position: the byte
+    // offset of its count (one instruction per address instead of two).
+    const uint8_t* Cb = reinterpret_cast<const uint8_t*>(Cn32);
+    auto visit = [&](uint32_t p2) { count += *reinterpret_cast<const uint16_t*>(Cb + (p2 & (2u * kPosMask))); };
     uint32_t e = it.b_begin;
     const uint32_t head_end = min(it.b_end, (it.b_begin + 7u) & ~7u);
     if (e + tid < head_end) visit(pos16[e + tid]);
     e = head_end;
     const uint32_t body_end = e + ((it.b_end - e) & ~7u);
-    // Body: FOUR 16-byte pieces per lane and trip, loaded together (unconditionally: the address is clamped, not
-    // the load skipped), and the eight lookups of a piece issued together before the first of them is added. With
-    // one piece per trip the stream was latency-bound — 16 KiB in flight per CU, 5.1 TB/s whatever the L2 hit rate —
-    // and software-pipelining it by hand does not survive hipcc (register rotation by copies makes it wait for the
-    // youngest load; without copies it sinks the loads to their uses).
+    // Body: FOUR 16-byte pieces per lane and trip, loaded together and looked up whether or not they lie inside the
+    // item (the address is clamped to the item's last piece, whose positions are valid ones; a piece outside counts
+    // for nothing): behind a branch hipcc sinks the load to its use and waits for it with vmcnt(0). The eight
+    // lookups of a piece are issued together before the first of them is added. With one piece per trip the stream
+    // was latency-bound — 16 KiB in flight per CU, 5.1 TB/s whatever the L2 hit rate — and software-pipelining it by
+    // hand does not survive hipcc (register rotation by copies makes it wait for the youngest load; without copies
+    // it sinks the loads to their uses).
     if (body_end > e) {
         constexpr uint32_t kStep = kProbeThreads * 8u;
         const uint32_t last = body_end - 8u;
-        auto lookups = [&](const uint4& v) {
-            const uint32_t p[8] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16,
-                                   v.z & 0xffffu, v.z >> 16, v.w & 0xffffu, v.w >> 16};
-            uint32_t c[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c[k] = Cn[p[k] & kPosMask];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) count += c[k];
-        };
         for (uint32_t q = e + tid * 8u; q < body_end; q += 4u * kStep) {
             uint4 v[4];
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const uint4*>(&pos16[min(q + j * kStep, last)]);
 #pragma unroll
-            for (uint32_t j = 0; j < 4; ++j)
-                if (q + j * kStep < body_end) lookups(v[j]);
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t p[8] = {v[j].x & 0xffffu, v[j].x >> 16, v[j].y & 0xffffu, v[j].y >> 16,
+                                       v[j].z & 0xffffu, v[j].z >> 16, v[j].w & 0xffffu, v[j].w >> 16};
+                uint32_t c[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = *reinterpret_cast<const uint16_t*>(Cb + p[k]);
+                const uint32_t s8 = c[0] + c[1] + c[2] + c[3] + c[4] + c[5] + c[6] + c[7];
+                count += (q + j * kStep < body_end) ? s8 : 0u;
+            }
         }
     }
     if (body_end + tid < it.b_end) visit(pos16[body_end + tid]);
@@ -508,6 +509,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     }
                 }
             }
+            for (size_t j = 0; j < probe_pos16.size(); ++j) probe_pos16[j] = (uint16_t)(probe_pos16[j] << 1);  // byte offsets of the counts
             // far work of all groups -> positions per item: about 4096 items over all probe columns, between
             // 2^15 and 2^21 positions each (an item zeroes and scatters its 128 KiB table first)
             uint64_t far_work = 0;
