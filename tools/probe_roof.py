@@ -5,7 +5,7 @@ Unit of work: one streamed position = one 2-byte read from L2 (the items that re
 one XCD at the same time) + one 2-byte LDS lookup of "how many of the item's 128 A rows list this position" + one
 add (round 3, late: the popcount of the 16-byte entry is taken once per item, not once per lookup). Roofs per
 MI355X_MICROARCH.md: 2- and 4-byte LDS reads are served 32 lanes per clock = 32 lookups/clk/CU x 256 CUs when the
-32 lanes meet 32 banks; VALU: ~3 full-rate instructions per lookup = 64 / 3 = 21 lookups/clk/CU; clock taken as
+32 lanes meet 32 banks; VALU: ~2 full-rate instructions per lookup (one address, half a three-input add, loop share) = 32 lookups/clk/CU; clock taken as
 2.4 GHz (spec peak). Algorithmic lookups for the synthetic c4
 container: per block column E = N x u listed positions (u = 65536 (1 - exp(-d / 65536)) unique positions per
 block of d = load / 8 draws), N / 128 groups of A rows, every group meets the positions of the rows behind it
@@ -76,7 +76,7 @@ def main():
                 line += (f" {sq.get('SQ_INSTS_LDS', 0):9.3e}  {sq.get('SQ_LDS_BANK_CONFLICT', 0) / max(sq.get('SQ_LDS_IDX_ACTIVE', 1), 1):8.3f}"
                          f"  {sq.get('SQ_WAIT_INST_LDS', 0) / max(sq.get('SQ_WAVE_CYCLES', 1), 1):8.3f}")
         print(line)
-    print(f"# LDS roof: {LDS_LOOKUPS_PER_CLK_CU} two-byte lookups/clk/CU x {CUS} CUs x {CLK / 1e9} GHz = {roof:.3e} lookups/s; VALU roof (3 instructions per lookup): {64 / 3 * CUS * CLK:.3e}")
+    print(f"# LDS roof: {LDS_LOOKUPS_PER_CLK_CU} two-byte lookups/clk/CU x {CUS} CUs x {CLK / 1e9} GHz = {roof:.3e} lookups/s; VALU roof (2 instructions per lookup): {64 / 2 * CUS * CLK:.3e}")
 
 
 if __name__ == "__main__":
