@@ -276,10 +276,11 @@ int STORM_hip_comm_unique_id(uint8_t id[128]);
 int STORM_hip_comm_init(const uint8_t id[128]);
 int STORM_hip_comm_finalize(void);
 /* Threading. Like the reference (no locks anywhere in storm.c), a HANDLE is not thread-safe: one thread at a
- * time per STORM_t / STORM_contiguous_t. The process-wide device state behind the handles (contexts, the
- * device selection above) is set up on first use and by the two setters: call those while no other thread is
- * inside the library. The raw-buffer wrappers (STORM_wrapper_*) share one cached device matrix per GPU and
- * take a lock: concurrent calls are safe and run one after the other.
+ * time per STORM_t / STORM_contiguous_t. Different handles may be used from different threads: every entry point
+ * that touches a device (the all-pairs calls, STORM_contig_pairw_matrix, the raw-buffer wrappers, the streaming of
+ * STORM_contig_add) takes one process-wide lock — the device contexts behind the handles are shared — so
+ * concurrent passes are safe and run one after the other. The device selection (the two setters above, the
+ * environment) is read on first use: change it only while no other thread is inside the library.
  * STORM_hip_shutdown(): releases the wrappers' cached device matrices and every device context (handles that
  * still hold device copies re-create them on their next all-pairs call). Returns 0. */
 int STORM_hip_shutdown(void);

@@ -320,3 +320,37 @@ def test_stream_operand_forms_agree_and_the_shipped_library_refuses_the_tools_fo
                     hip_ctx.set_option("k2_strip_operands", ops)
     finally:
         _reset(hip_ctx)
+
+
+def test_different_handles_from_different_threads():
+    """storm.h: a handle is one thread's at a time, but different handles may be used from different threads — the
+    device contexts behind them are shared and every pass takes one process-wide lock. Three threads (ctypes drops
+    the GIL inside the calls): a STORM_t of 5000 rows (its arena fingerprint runs on helper threads from 4096 rows),
+    a dense STORM_contiguous_t and the raw-buffer wrapper, 25 calls each, every total as in a quiet process."""
+    import threading
+    M = 65536
+    s = sb.Storm()
+    assert s.add_synthetic(M, 5000, 300, seed=3) == 5000
+    c = sb.StormContig(M)
+    assert c.add_synthetic(700, 20000, seed=4) == 700
+    mat = synth.dense_matrix_c(M, 300, 9000, seed=5)
+    want = (s.pairw_intersect_cardinality_blocked(0), c.pairw_intersect_cardinality(), sb.wrapper_diag_blocked(mat, 31))
+    assert min(want) > 0
+    bad = []
+
+    def loop(fn, expect, name):
+        for _ in range(25):
+            got = fn()
+            if got != expect:
+                bad.append((name, got, expect))
+
+    ts = [threading.Thread(target=loop, args=(lambda: s.pairw_intersect_cardinality_blocked(0), want[0], "storm_t")),
+          threading.Thread(target=loop, args=(c.pairw_intersect_cardinality, want[1], "contig")),
+          threading.Thread(target=loop, args=(lambda: sb.wrapper_diag_blocked(mat, 31), want[2], "wrapper"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:3]
+    s.free()
+    c.free()
