@@ -437,7 +437,15 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 const int64_t e = col_entry[block_id[b]];
                 if (e < 0 || !s->col_probe[(size_t)e] || block_kind[b] != 0) continue;
                 const uint16_t* l = list_pool + block_data_offset[b];
-                for (uint32_t k = 0; k < block_n[b]; ++k) oct_count[(size_t)e * kProbeOctants + (l[k] >> kProbeOctBits)]++;
+                bool ascending = true;  // the probe kernel counts every listed element: a repeated one would count twice
+                for (uint32_t k = 0; k < block_n[b]; ++k) {
+                    oct_count[(size_t)e * kProbeOctants + (l[k] >> kProbeOctBits)]++;
+                    ascending &= k == 0 || l[k] > l[k - 1];
+                }
+                if (!ascending) {
+                    set_error("sparse_create: a list block of column %u is not strictly ascending", block_id[b]);
+                    return STORM_HIP_EINVAL;
+                }
             }
             uint64_t at = 0;
             for (size_t i = 0; i < oct_count.size(); ++i) {

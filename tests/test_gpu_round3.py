@@ -354,3 +354,28 @@ def test_different_handles_from_different_threads():
     assert not bad, bad[:3]
     s.free()
     c.free()
+
+
+def test_flat_array_arena_refuses_lists_that_are_not_strictly_ascending(hip_ctx):
+    """storm_hip_sparse_create (the flat-array C-ABI): the list-probe kernel counts every listed element, so a list
+    with a repeated or descending position must not become an arena (STORM_deserialize and the serialized walker
+    refuse the same)."""
+    lib = sb.load()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for lists, ok in (([5, 9, 70, 5, 9, 71], True), ([5, 9, 9, 5, 9, 71], False), ([5, 9, 70, 9, 5, 71], False)):
+        row_off = np.array([0, 1, 2], dtype=np.uint64)
+        ids = np.array([0, 0], dtype=np.uint32)
+        kinds = np.array([0, 0], dtype=np.uint8)
+        offs = np.array([0, 3], dtype=np.uint64)
+        lens = np.array([3, 3], dtype=np.uint32)
+        a_lists = np.array(lists, dtype=np.uint16)
+        words = np.zeros(1, dtype=np.uint64)
+        h = C.c_void_p()
+        rc = lib.storm_hip_sparse_create(hip_ctx._h, 2, 2, p(row_off), p(ids), p(kinds), p(offs), p(lens),
+                                         p(a_lists), a_lists.size, p(words), 0, C.byref(h))
+        assert (rc == 0) == ok, (lists, rc, lib.storm_hip_last_error())
+        if rc == 0:
+            out = C.c_uint64()
+            assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, 0, 1, C.byref(out)) == 0
+            assert out.value == 2       # {5, 9} are shared
+            lib.storm_hip_sparse_destroy(hip_ctx._h, h)
