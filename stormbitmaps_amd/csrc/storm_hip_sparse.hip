@@ -20,9 +20,12 @@
 #include "storm_hip_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <memory>
+#include <thread>
 
 using namespace storm;
 
@@ -270,6 +273,14 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         set_error("sparse_create: too many blocks");
         return STORM_HIP_EINVAL;
     }
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (getenv("STORM_HIP_TIMING")) {
+            auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[build_arena] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+            T0 = t;
+        }
+    };
     // ---- validate + count blocks per column ----
     if (n_blocks > 0 && n_rows == 0) {
         set_error("sparse_create: %llu blocks but no rows", (unsigned long long)n_blocks);
@@ -388,6 +399,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         return STORM_HIP_EINVAL;
     }
 
+    lap("validate");
     // ---- pool row of every block (rows are visited in order => row order inside a column)
     std::vector<uint32_t> list_row, dense_row, list_len;
     std::vector<uint64_t> list_off, dense_src;
@@ -408,10 +420,14 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
     }
 
+    lap("pool rows");
     // ---- probe data (K4): columns whose blocks are all lists and that have at most 65535 rows. Per column
     //      and octant (8192 positions of the block) the listed positions in row order.
-    std::vector<uint32_t> probe_elems;
-    std::vector<uint16_t> probe_pos16;  // the far stream's copy of the positions, in its own order (below)
+    // (plain arrays, not vectors: the threads that fill them touch their pages first — a zero fill of 1.3 GB on one
+    //  thread was 0.3 s of c4's first call)
+    std::unique_ptr<uint32_t[]> probe_elems;
+    std::unique_ptr<uint16_t[]> probe_pos16;  // the far stream's copy of the positions, in its own order (below)
+    size_t n_probe_elems = 0;
     {
         std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
         s->col_probe.assign(s->cols.size(), 0);
@@ -433,18 +449,29 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             // 16-byte boundary of the uint16 position array
             const size_t n_e = s->cols.size();
             std::vector<uint64_t> oct_count(n_e * kProbeOctants, 0), oct_base(n_e * kProbeOctants, 0);
+            // A list is sorted, so its elements of one octant are one run: the runs' ends per block (binary search),
+            // then where every run goes, then the copy — the first two are a walk over the block records, the copy
+            // (c4 at 20971 draws: 210 M elements, 0.39 s on one thread) is split over helper threads by block range.
+            constexpr uint32_t kNoBlock = 0xffffffffu;
+            std::vector<uint32_t> probe_blocks;  // the list blocks of probe columns, in row order
             for (uint64_t b = 0; b < n_blocks; ++b) {
                 const int64_t e = col_entry[block_id[b]];
-                if (e < 0 || !s->col_probe[(size_t)e] || block_kind[b] != 0) continue;
+                if (e >= 0 && s->col_probe[(size_t)e] && block_kind[b] == 0) probe_blocks.push_back((uint32_t)b);
+            }
+            std::vector<uint32_t> run_end(probe_blocks.size() * kProbeOctants);   // end of octant o's run inside the list
+            std::vector<uint32_t> run_dst(probe_blocks.size() * kProbeOctants);   // where the run starts in the element arrays
+            std::vector<uint32_t> block_local(probe_blocks.size(), kNoBlock);     // the block's row inside its column's list rows
+            for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
+                const uint64_t b = probe_blocks[pb];
+                const size_t e = (size_t)col_entry[block_id[b]];
                 const uint16_t* l = list_pool + block_data_offset[b];
-                bool ascending = true;  // the probe kernel counts every listed element: a repeated one would count twice
-                for (uint32_t k = 0; k < block_n[b]; ++k) {
-                    oct_count[(size_t)e * kProbeOctants + (l[k] >> kProbeOctBits)]++;
-                    ascending &= k == 0 || l[k] > l[k - 1];
-                }
-                if (!ascending) {
-                    set_error("sparse_create: a list block of column %u is not strictly ascending", block_id[b]);
-                    return STORM_HIP_EINVAL;
+                uint32_t from = 0;
+                for (uint32_t o = 0; o < kProbeOctants; ++o) {
+                    const uint32_t end = (uint32_t)(std::lower_bound(l + from, l + block_n[b], (o + 1u) << kProbeOctBits,
+                                                                     [](uint16_t x, uint32_t lim) { return (uint32_t)x < lim; }) - l);
+                    run_end[pb * kProbeOctants + o] = end;
+                    oct_count[e * kProbeOctants + o] += end - from;
+                    from = end;
                 }
             }
             uint64_t at = 0;
@@ -453,7 +480,17 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 oct_base[i] = at;
                 at += oct_count[i];
             }
-            probe_elems.assign((size_t)at + 8, 0);
+            n_probe_elems = (size_t)at + 8;
+            probe_elems.reset(new uint32_t[n_probe_elems]);
+            probe_pos16.reset(new uint16_t[n_probe_elems]);
+            for (size_t i = 0; i < oct_count.size(); ++i) {  // the alignment gaps behind every octant
+                const size_t g0 = (size_t)(oct_base[i] + oct_count[i]);
+                const size_t g1 = i + 1 < oct_count.size() ? (size_t)oct_base[i + 1] : n_probe_elems;
+                for (size_t j = g0; j < g1; ++j) {
+                    probe_elems[j] = 0;
+                    probe_pos16[j] = 0;
+                }
+            }
             for (size_t i = 0; i < oct_count.size(); ++i)
                 if (oct_count[i])
                     s->probe_regions.push_back({(uint32_t)oct_base[i], (uint32_t)(oct_base[i] + oct_count[i]),
@@ -466,20 +503,69 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 if (s->col_probe[e])
                     for (uint32_t o = 0; o < kProbeOctants; ++o)
                         row_start[e * kProbeOctants + o].reserve((size_t)(s->cols[e].r1 - s->col_list0[e]) + 1);
-            for (uint64_t b = 0; b < n_blocks; ++b) {
-                const uint32_t c = block_id[b];
-                if (block_kind[b] != 0) continue;
-                const uint64_t local = next[c]++;
-                const int64_t e = col_entry[c];
-                if (e < 0 || !s->col_probe[(size_t)e]) continue;
-                for (uint32_t o = 0; o < kProbeOctants; ++o)
-                    row_start[(size_t)e * kProbeOctants + o].push_back((uint32_t)cursor[(size_t)e * kProbeOctants + o]);
-                const uint16_t* l = list_pool + block_data_offset[b];
-                for (uint32_t k = 0; k < block_n[b]; ++k) {
-                    const size_t i = (size_t)e * kProbeOctants + (l[k] >> kProbeOctBits);
-                    probe_elems[(size_t)cursor[i]++] = ((uint32_t)local << 16) | (l[k] & ((1u << kProbeOctBits) - 1u));
+            {
+                size_t pb = 0;
+                for (uint64_t b = 0; b < n_blocks; ++b) {
+                    if (block_kind[b] != 0) continue;
+                    const uint32_t c = block_id[b];
+                    const uint64_t local = next[c]++;
+                    const int64_t e = col_entry[c];
+                    if (e < 0 || !s->col_probe[(size_t)e]) continue;
+                    block_local[pb] = (uint32_t)local;
+                    uint32_t from = 0;
+                    for (uint32_t o = 0; o < kProbeOctants; ++o) {
+                        const size_t i = (size_t)e * kProbeOctants + o;
+                        row_start[i].push_back((uint32_t)cursor[i]);
+                        run_dst[pb * kProbeOctants + o] = (uint32_t)cursor[i];
+                        cursor[i] += run_end[pb * kProbeOctants + o] - from;
+                        from = run_end[pb * kProbeOctants + o];
+                    }
+                    ++pb;
                 }
             }
+            const unsigned n_threads = at >= (1u << 22) ? 4u : 1u;
+            auto on_threads = [&](auto&& body) {  // body(part, parts); exceptions of a helper end up in `failed`
+                std::atomic<bool> failed{false};
+                std::vector<std::thread> helpers;
+                for (unsigned t = 1; t < n_threads; ++t)
+                    helpers.emplace_back([&, t] {
+                        try { body(t, n_threads); } catch (...) { failed = true; }
+                    });
+                try { body(0u, n_threads); } catch (...) { failed = true; }
+                for (std::thread& h : helpers) h.join();
+                return !failed.load();
+            };
+            std::atomic<uint32_t> bad_block{kNoBlock};  // the probe kernel counts every listed element: none may repeat
+            if (!on_threads([&](unsigned part, unsigned parts) {
+                    const size_t p0 = probe_blocks.size() * part / parts, p1 = probe_blocks.size() * (part + 1) / parts;
+                    for (size_t pb = p0; pb < p1; ++pb) {
+                        const uint64_t b = probe_blocks[pb];
+                        const uint16_t* l = list_pool + block_data_offset[b];
+                        const uint32_t tag = block_local[pb] << 16;
+                        bool ascending = true;
+                        uint32_t from = 0;
+                        for (uint32_t o = 0; o < kProbeOctants; ++o) {
+                            const uint32_t end = run_end[pb * kProbeOctants + o];
+                            uint32_t dst = run_dst[pb * kProbeOctants + o];
+                            for (uint32_t k = from; k < end; ++k, ++dst) {
+                                const uint32_t pos = l[k] & ((1u << kProbeOctBits) - 1u);
+                                probe_elems[dst] = tag | pos;
+                                probe_pos16[dst] = (uint16_t)(pos << 1);  // the byte offset of the position's count
+                                ascending &= k == 0 || l[k] > l[k - 1];
+                            }
+                            from = end;
+                        }
+                        if (!ascending) bad_block = (uint32_t)b;
+                    }
+                })) {
+                set_error("sparse_create: out of memory while laying out the list elements");
+                return STORM_HIP_ENOMEM;
+            }
+            if (bad_block.load() != kNoBlock) {
+                set_error("sparse_create: a list block of column %u is not strictly ascending", block_id[bad_block.load()]);
+                return STORM_HIP_EINVAL;
+            }
+            lap("probe count+fill");
             // The far stream (pos16) in an order of its own. A far lookup only needs the POSITION — which row listed
             // it does not matter — so inside every atom of the stream (the elements of one group of kProbeRows rows in
             // one octant; items begin and end on atoms) the positions may stand in any order, and the order decides the
@@ -490,34 +576,35 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             // entries the kernel used to read). Dealt by bank — eight positions of bank 0, eight of bank 1, ... round
             // after round — element i has bank (i / 8) % 32 wherever the atom starts, and the 32 lanes of a group meet
             // 32 different banks.
-            probe_pos16.resize(probe_elems.size());
-            for (size_t j = 0; j < probe_elems.size(); ++j) probe_pos16[j] = (uint16_t)probe_elems[j];
-            {
-                std::vector<uint16_t> tmp;
-                for (size_t i = 0; i < row_start.size(); ++i) {
-                    const std::vector<uint32_t>& rs = row_start[i];
-                    const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
-                    for (size_t k = 0; k < rs.size(); k += kProbeRows) {
-                        const uint32_t s0 = rs[k], s1 = k + kProbeRows < rs.size() ? rs[k + kProbeRows] : end;
-                        const uint32_t n = s1 - s0;
-                        if (n < 256u) continue;
-                        uint32_t cnt[33] = {0};
-                        for (uint32_t j = s0; j < s1; ++j) cnt[((probe_pos16[j] >> 1) & 31u) + 1u]++;
-                        for (int r = 0; r < 32; ++r) cnt[r + 1] += cnt[r];
-                        uint32_t at_r[32], end_r[32], fill[32];
-                        for (int r = 0; r < 32; ++r) { at_r[r] = fill[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
-                        tmp.resize(n);
-                        for (uint32_t j = s0; j < s1; ++j) tmp[fill[(probe_pos16[j] >> 1) & 31u]++] = probe_pos16[j];
-                        uint32_t out = s0;
-                        while (out < s1)
-                            for (int r = 0; r < 32; ++r) {
-                                const uint32_t take = std::min(8u, end_r[r] - at_r[r]);
-                                for (uint32_t t = 0; t < take; ++t) probe_pos16[out++] = tmp[at_r[r]++];
-                            }
+            if (!on_threads([&](unsigned part, unsigned parts) {
+                    std::vector<uint16_t> tmp;
+                    for (size_t i = part; i < row_start.size(); i += parts) {
+                        const std::vector<uint32_t>& rs = row_start[i];
+                        const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
+                        for (size_t k = 0; k < rs.size(); k += kProbeRows) {
+                            const uint32_t s0 = rs[k], s1 = k + kProbeRows < rs.size() ? rs[k + kProbeRows] : end;
+                            const uint32_t n = s1 - s0;
+                            if (n < 256u) continue;
+                            uint32_t cnt[33] = {0};
+                            for (uint32_t j = s0; j < s1; ++j) cnt[((probe_pos16[j] >> 2) & 31u) + 1u]++;
+                            for (int r = 0; r < 32; ++r) cnt[r + 1] += cnt[r];
+                            uint32_t at_r[32], end_r[32], fill[32];
+                            for (int r = 0; r < 32; ++r) { at_r[r] = fill[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
+                            tmp.resize(n);
+                            for (uint32_t j = s0; j < s1; ++j) tmp[fill[(probe_pos16[j] >> 2) & 31u]++] = probe_pos16[j];
+                            uint32_t out = s0;
+                            while (out < s1)
+                                for (int r = 0; r < 32; ++r) {
+                                    const uint32_t take = std::min(8u, end_r[r] - at_r[r]);
+                                    for (uint32_t t = 0; t < take; ++t) probe_pos16[out++] = tmp[at_r[r]++];
+                                }
+                        }
                     }
-                }
+                })) {
+                set_error("sparse_create: out of memory while ordering the far stream");
+                return STORM_HIP_ENOMEM;
             }
-            for (size_t j = 0; j < probe_pos16.size(); ++j) probe_pos16[j] = (uint16_t)(probe_pos16[j] << 1);  // byte offsets of the counts
+            lap("pos16 + deal");
             // far work of all groups -> positions per item: about 4096 items over all probe columns, between
             // 2^15 and 2^21 positions each (an item zeroes and scatters its 128 KiB table first)
             uint64_t far_work = 0;
@@ -612,6 +699,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
     }
 
+    lap("items");
     // ---- device pool ----
     int rc = STORM_HIP_OK;
     uint32_t *d_lrow = nullptr, *d_llen = nullptr, *d_drow = nullptr;
@@ -631,9 +719,9 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             rc = STORM_HIP_EHIP;
             break;
         }
-        if (!probe_elems.empty()) {
-            if ((rc = upload(&s->d_probe_elems, probe_elems.data(), probe_elems.size(), ctx->stream))) break;
-            if ((rc = upload(&s->d_probe_pos16, probe_pos16.data(), probe_pos16.size(), ctx->stream))) break;
+        if (n_probe_elems) {
+            if ((rc = upload(&s->d_probe_elems, probe_elems.get(), n_probe_elems, ctx->stream))) break;
+            if ((rc = upload(&s->d_probe_pos16, probe_pos16.get(), n_probe_elems, ctx->stream))) break;
             if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = STORM_HIP_EHIP; break; }  // pos16 leaves scope
         }
         // the list pool (or the whole serialized stream) goes up once
