@@ -680,13 +680,15 @@ typedef struct {
     int broken;           /* an allocation failed: nothing more is kept */
 } contig_pending_t;
 
-static int contig_positions_enabled(void) {
+static int contig_positions_enabled(void) { /* (adders of different handles may run on different threads) */
     static int enabled = -1;
-    if (enabled < 0) {
+    int v = __atomic_load_n(&enabled, __ATOMIC_RELAXED);
+    if (v < 0) {
         const char* e = getenv("STORM_HIP_ADD_POSITIONS");
-        enabled = !(e && e[0] == '0');
+        v = !(e && e[0] == '0');
+        __atomic_store_n(&enabled, v, __ATOMIC_RELAXED);
     }
-    return enabled;
+    return v;
 }
 static void contig_pending_free(STORM_contiguous_t* h) {
     contig_pending_t* p = (contig_pending_t*)h->hip_pending;
@@ -785,11 +787,13 @@ static void contig_lists_end(STORM_contiguous_t* h) {
 }
 static int contig_lists_enabled(void) {
     static int enabled = -1;
-    if (enabled < 0) {
+    int v = __atomic_load_n(&enabled, __ATOMIC_RELAXED);
+    if (v < 0) {
         const char* e = getenv("STORM_HIP_CONTIG_LISTS");
-        enabled = !(e && e[0] == '0');
+        v = !(e && e[0] == '0');
+        __atomic_store_n(&enabled, v, __ATOMIC_RELAXED);
     }
-    return enabled;
+    return v;
 }
 
 void STORM_contig_free(STORM_contiguous_t* h) {

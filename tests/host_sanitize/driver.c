@@ -183,6 +183,7 @@ int main(void) {
     if (scenario(3, 70, 5, 0)) return 1;
     if (scenario(600, 1000, 128, 0)) return 1;      /* the README's shape (duplicates)     */
     if (scenario(700, 65536, 300, 0)) return 1;     /* rows between the list cutoff and W words: positions kept */
+    if (scenario(4500, 65536, 9, 1)) return 1;      /* >= 4096 rows: the arena fingerprint runs on its helper threads */
     if (scenario_mixed(900, 65536)) return 1;
     if (scenario_mixed(300, 20000)) return 1;
     if (scenario_mixed(200, 1000)) return 1;        /* cutoff 5, W 16 */

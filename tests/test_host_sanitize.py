@@ -29,3 +29,25 @@ def test_host_containers_under_asan_ubsan(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert "host sanitize: ok" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="needs gcc")
+def test_host_side_with_three_caller_threads_under_tsan(tmp_path):
+    """storm.h promises that different handles may be used from different threads: three threads, each with a
+    STORM_t of 4500 rows (the arena fingerprint then runs on its helper threads) and a STORM_contiguous_t of its own,
+    twenty all-pairs calls each, under ThreadSanitizer on the device stub."""
+    exe = tmp_path / "host_threads"
+    srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
+            os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c"),
+            os.path.join(ROOT, "tests", "host_sanitize", "device_stub.c"),
+            os.path.join(ROOT, "tests", "host_sanitize", "threads.c")]
+    build = subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=thread", "-pthread",
+                            "-I" + os.path.join(ROOT, "include"), *srcs, "-o", str(exe), "-lm", "-ldl"],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in build.stderr.lower() and "cannot find" in build.stderr.lower():
+        pytest.skip("libtsan not installed")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+    assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
+    assert "mt ok" in run.stdout and "ThreadSanitizer" not in run.stderr
