@@ -669,8 +669,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_strip_operands")) {
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4) {
-            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup), 3 (the same with a ring per wave) or 4 (FP4 shadow)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5) {
+            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup), 3 (the same with a ring per wave), 4 (FP4 shadow) or 5 (bit operands, FP4 image built in the LDS)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
@@ -680,6 +680,16 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
         ctx->k2_strip_operands = (int)value;
+    } else if (!strcmp(key, "k2_bit_ring")) {
+        if (value != 3 && value != 4) {
+            set_error("k2_bit_ring must be 3 or 4 stages");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_bit_ring = (int)value;
+    } else if (!strcmp(key, "k2_matrix_pad")) {
+        ctx->k2_matrix_pad = value < 0 ? -1 : value != 0;
+    } else if (!strcmp(key, "k2_fold_inline")) {
+        ctx->k2_fold_inline = value != 0;
     } else if (!strcmp(key, "k2_wave_ring")) {
         if (value != 0 && value != 3 && value != 4 && value != 6 && value != 8) {
             set_error("k2_wave_ring must be 0 (by occupancy), 3, 4, 6 or 8");
@@ -805,6 +815,9 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_strip_operands")) return ctx->k2_strip_operands;
     if (!strcmp(key, "k2_operands_used")) return ctx->k2_operands_used;
     if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
+    if (!strcmp(key, "k2_bit_ring")) return ctx->k2_bit_ring;
+    if (!strcmp(key, "k2_fold_inline")) return ctx->k2_fold_inline;
+    if (!strcmp(key, "k2_matrix_pad")) return ctx->k2_matrix_pad;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
@@ -906,7 +919,8 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     // k-slice into a handful of L2 sets and memory channels, so one more chunk of zero words per row breaks
     // the pattern (same finding as shadow_pitch, storm_hip_mfma.hip). The FP4 paths copy the rows into
     // their own padded shadow and keep the dense pitch.
-    if (ctx->k2_strip_operands == 1 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
+    const bool pad = ctx->k2_matrix_pad < 0 ? (ctx->k2_strip_operands == 1) : ctx->k2_matrix_pad != 0;
+    if (pad && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

@@ -919,6 +919,336 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_fp4_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K2b: the 16x16x128 strips on BIT operands — no FP4 shadow, no expansion pass, one launch.
+//
+// strip16_fp4_kernel's stage loop is fed from an FP4 image of the B stage in the LDS; where that
+// image comes from is all that changes. There the image is DMA'd from a shadow matrix that an
+// HBM-bound pass (expand_fp4_kernel: 84 MB in, 335 MB out, 70 us of the headline shape's 823)
+// rebuilt in front of every call. Here the workgroup builds the image itself, once per stage, from
+// the bits:
+//   * k-slice `ks` of an item = 256 bit-MACs per row pair, as before, but taken out of the 64-byte
+//     CHUNK ks / 2 of the bit rows (512 bits) as two of its four bit CLASSES: class c = the bits
+//     4n + c of every dword, which already sit in nibble n. Rotating the dword right by c - 1 and
+//     masking with 0x22222222 turns class c into E2M1 code 0b0010 = 1.0 per set bit (two VALU
+//     operations per dword; the rotation wraps only into bits the mask drops). ks & 1 selects the
+//     classes {0, 1} or {2, 3}. A sum over k does not care in which order k is walked as long as A
+//     and B agree, and both sides are built by the same function.
+//   * B stage: 64 rows x 64 B of bits = 4 KiB, ONE LDS-DMA instruction per wave (the FP4 strips: two,
+//     8 KiB) into a ring of kBitRing stages in which every wave only ever touches its OWN 1 KiB
+//     piece (it waits for its own DMA with vmcnt; no barrier is involved). Two stages ahead of the
+//     multiplication the wave reads its piece back (one ds_read_b128 per lane), inflates the two
+//     classes (16 VALU operations per wave and stage, against 32 MFMAs) and writes the two k-steps of
+//     its 16 rows into the FP4 image (2 x ds_write_b128, the FP4 strips' XOR swizzle: conflict free).
+//   * FP4 images: ring of 3 x 8 KiB. Iteration t multiplies image t (and, in its last three steps,
+//     already reads the first fragments of image t + 1) while every wave writes its quarter of
+//     image t + 2 into the slot image t - 1 left. ONE barrier per stage, as before: barrier t
+//     separates the reads of image t - 1 from the writes of image t + 2 and publishes image t + 1.
+//     LDS operations of a wave complete in order, so the fragment-read rotation's lgkmcnt waits also
+//     retire the image writes in front of them — no extra waits.
+//   * A operand: the wave's 64 rows x 64 B of bits come straight from global memory (4 x 16 B per
+//     lane) and are inflated once per item into the same 32 registers the FP4 strips hold.
+//   * the partial sums are folded by the last workgroup to arrive (ticket behind the slots, as in
+//     bitstream_kernel) when `out` is given: a pass is ONE launch.
+// 40 KiB of LDS and <= 128 registers: four workgroups per CU, as the FP4 strips need
+// (profiles/r02_b_panels.txt). Work items, launch order, diagonal phase and the multi-GPU
+// ownership are the FP4 strips' (build_strip_items); slices 2j and 2j + 1 read the same bits and go
+// to the same XCD. Reference loop being replaced: storm.c:1199-1238 with the leaf of
+// storm.c:1205,1217,1227,1236.
+// ------------------------------------------------------------------------------------------
+constexpr int kSb16ImgRing = 3;                                   // FP4 images (8 KiB each)
+constexpr int kSb16BitRing = 3;                                   // bit stages (4 KiB each; a wave touches only its own 1 KiB piece)
+constexpr int kSb16BitStage = kStripBRows * 64;                   // 4 KiB of bits per B stage
+constexpr uint32_t kSb16ImgBytes = kSb16ImgRing * kStripStageBytes;
+constexpr uint32_t kSb16Mask = 0x22222222u;
+constexpr int kSb16Ticket = kSlots + 6;                          // arrival counter behind the slots (zero between passes; bitstream_kernel uses the same word)
+
+__device__ __forceinline__ v4i sb16_inflate(v4i w, uint32_t rot) {
+    v4i e;
+    e.x = (int)(__builtin_amdgcn_alignbit((uint32_t)w.x, (uint32_t)w.x, rot) & kSb16Mask);
+    e.y = (int)(__builtin_amdgcn_alignbit((uint32_t)w.y, (uint32_t)w.y, rot) & kSb16Mask);
+    e.z = (int)(__builtin_amdgcn_alignbit((uint32_t)w.z, (uint32_t)w.z, rot) & kSb16Mask);
+    e.w = (int)(__builtin_amdgcn_alignbit((uint32_t)w.w, (uint32_t)w.w, rot) & kSb16Mask);
+    return e;
+}
+
+__global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
+    const uint8_t* __restrict__ X, uint64_t row_bytes, const StripItem* __restrict__ items,
+    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSb16ImgBytes + kSb16BitRing * kSb16BitStage];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave;
+    const StripItem it = items[blockIdx.x];
+    const uint64_t kbyte = (uint64_t)(it.ks >> 1) * 64u;
+    // class pair of this k-slice: rotate right by c - 1 (mod 32)
+    const uint32_t rot0 = (it.ks & 1u) ? 1u : 31u;   // classes 2 / 0
+    const uint32_t rot1 = (it.ks & 1u) ? 2u : 0u;    // classes 3 / 1
+    const uint32_t D = it.diag ? (uint32_t)(kStripATile / kStripBRows) : 0u;
+    const uint32_t T = D + (it.j1 - it.j0);
+    // Stage s lives in ring slot (s + cslot) % 3 of both rings, with cslot chosen so that the first
+    // pipelined stage (s = D) sits in slot 0: the three instances of the loop body below then address
+    // their images and pieces with IMMEDIATE offsets (the first version computed five addresses and three
+    // remainders per stage: 33 vector and 57 scalar instructions per 32 MFMAs, profiles/r04_a_*).
+    const uint32_t cslot = (3u - D % 3u) % 3u;
+
+    const uint32_t lds_base =
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds_raw[0];
+    // the wave's piece of a B stage: 16 rows x four 16-byte quarters. Lanes 4g .. 4g + 3 hold the quarters of
+    // one row, and the two rows of a store's 8-lane group are 8 apart: their image slots then differ in the
+    // swizzle's top bit and the group's 8 x 16 bytes land on 32 different banks (rows r, r + 1 share a swizzle:
+    // every ds_write_b128 would be a two-way conflict)
+    const uint32_t pr = wave * 16u + (lane >> 3) + 8u * ((lane >> 2) & 1u);
+    const uint32_t goff0 = pr * (uint32_t)row_bytes + (lane & 3u) * 16u;
+    const uint32_t bits_rd = lds_base + kSb16ImgBytes + wave * 1024u + lane * 16u;
+    // where that piece's two k-steps go in an FP4 image: row pr, slot (kk * 4 + quarter) ^ (pr / 2) % 8
+    const uint32_t img_wr0 = lds_base + pr * (uint32_t)kStripRowBytes + (((lane & 3u) ^ ((pr >> 1) & 7u)) * 16u);
+    const uint32_t img_wr1 = img_wr0 ^ 64u;
+
+    // LDS-DMA of the wave's piece of stage s into bit slot `slot`. Stages beyond the last one re-read the
+    // last block (never consumed): every iteration issues exactly one piece, so every wait is vmcnt(2).
+    auto issue = [&](uint32_t s, uint32_t slot) {
+        const uint32_t sc = min(s, T - 1u);
+        const uint32_t blk = sc < D ? it.a_row0 / (uint32_t)kStripBRows + sc : it.j1 - 1u - (sc - D);
+        const uint8_t* base = X + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (lptr_t)(lds_raw + kSb16ImgBytes + slot * kSb16BitStage + wave * 1024u), 16,
+            (int)goff0, 0, 0, 0);
+    };
+
+    // A fragments: rows wm*64 + m*16 + (lane & 15), quarter lane >> 4 of the chunk; a[kk][m] = class kk.
+    // (loaded in front of the DMA pieces, so that the wait for them leaves the pieces in flight)
+    v4i a[2][4];
+    {
+        const uint8_t* ap = X + (uint64_t)(it.a_row0 + wm * 64u + (lane & 15u)) * row_bytes + kbyte +
+                            (lane >> 4) * 16u;
+        v4i aw[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) aw[m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 16u * row_bytes);
+        issue(0u, cslot);
+        issue(1u, (cslot + 1u) % 3u);
+        issue(2u, (cslot + 2u) % 3u);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a[0][m] = sb16_inflate(aw[m], rot0);
+            a[1][m] = sb16_inflate(aw[m], rot1);
+        }
+    }
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = v4f{};
+
+    // fragment (kk, n) of an image: row n*16 + (lane & 15), 16-byte slot kk*4 + (lane >> 4), swizzled
+    const uint32_t swz = ((lane & 15u) >> 1) & 7u;
+    uint32_t boff[2];
+    boff[0] = lds_base + (lane & 15u) * kStripRowBytes + (((lane >> 4) ^ swz) * 16u);
+    boff[1] = boff[0] ^ 64u;
+
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[kk][m]));  // retire the A loads here
+
+    // fragment of step s (k-step s >> 2, B block s & 3) of the image at byte offset `img` (a constant)
+#define STORM_FETCH16(dst, img, s)                                                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                          \
+                 : "=&v"(dst)                                                             \
+                 : "v"(boff[(s) >> 2]), "n"((img) + ((s) & 3) * 16 * kStripRowBytes))
+#define STORM_FETCH16V(dst, img, s)                                                       \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                          \
+                 : "=&v"(dst)                                                             \
+                 : "v"(boff[(s) >> 2] + (img)), "n"(((s) & 3) * 16 * kStripRowBytes))
+#define STORM_MUL16(s, frag)                                                              \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                         \
+        acc[m][(s) & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
+            v8i{a[(s) >> 2][m].x, a[(s) >> 2][m].y, a[(s) >> 2][m].z, a[(s) >> 2][m].w, 0, 0, 0, 0}, \
+            v8i{frag.x, frag.y, frag.z, frag.w, 0, 0, 0, 0}, acc[m][(s) & 3], 4, 4, 0, 0, 0, 0)
+#define STORM_LGKM(n)                                       \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+#define STORM_VM2()                                         \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        \
+    __builtin_amdgcn_sched_barrier(0)
+
+    v4i wb = {};
+    // the wave's quarter of the image of stage s, start to finish (prologue and diagonal phase)
+    auto build_image = [&](uint32_t s) {
+        const uint32_t slot = (s + cslot) % 3u;
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(wb) : "v"(bits_rd + slot * (uint32_t)kSb16BitStage));
+        STORM_LGKM(0);
+        const v4i e0 = sb16_inflate(wb, rot0);
+        asm volatile("ds_write_b128 %0, %1" ::"v"(img_wr0 + slot * (uint32_t)kStripStageBytes), "v"(e0) : "memory");
+        const v4i e1 = sb16_inflate(wb, rot1);
+        asm volatile("ds_write_b128 %0, %1" ::"v"(img_wr1 + slot * (uint32_t)kStripStageBytes), "v"(e1) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
+    // Invariant at the top of iteration t, in front of its issue: the pieces of stages <= t + 3 have been
+    // issued, those of stages <= t + 1 have landed and been turned into images.
+    STORM_VM2();        // stage 0 (1 and 2 in flight)
+    build_image(0u);
+    STORM_LGKM(0);      // the piece has been read: its slot takes stage 3
+    issue(3u, cslot);
+    STORM_VM2();        // stage 1
+    build_image(1u);
+
+    v4i b0 = {}, b1 = {}, b2 = {}, b3 = {};
+    uint32_t t = 0;
+    // ---- the A tile's own 4 blocks: wave wm skips the blocks before its own rows, keeps the
+    //      strict upper triangle of its own 64 x 64 block and takes the later blocks whole
+#pragma unroll 1
+    for (; t < D; ++t) {
+        STORM_LGKM(0);                   // own image writes
+        __builtin_amdgcn_s_barrier();    // images t and t + 1 complete, the slot of image t - 1 free
+        issue(t + 4u, (t + 1u + cslot) % 3u);
+        STORM_VM2();                     // stage t + 2
+        build_image(t + 2u);
+        if (t >= wm) {
+            const uint32_t sb = ((t + cslot) % 3u) * kStripStageBytes;
+            STORM_FETCH16V(b0, sb, 0);
+            STORM_FETCH16V(b1, sb, 1);
+            STORM_FETCH16V(b2, sb, 2);
+            STORM_FETCH16V(b3, sb, 3);
+            STORM_LGKM(3); STORM_MUL16(0, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16V(b0, sb, 4);
+            STORM_LGKM(3); STORM_MUL16(1, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16V(b1, sb, 5);
+            STORM_LGKM(3); STORM_MUL16(2, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16V(b2, sb, 6);
+            STORM_LGKM(3); STORM_MUL16(3, b3); __builtin_amdgcn_sched_barrier(0);
+            STORM_FETCH16V(b3, sb, 7);
+            STORM_LGKM(3); STORM_MUL16(4, b0); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(2); STORM_MUL16(5, b1); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(1); STORM_MUL16(6, b2); __builtin_amdgcn_sched_barrier(0);
+            STORM_LGKM(0); STORM_MUL16(7, b3); __builtin_amdgcn_sched_barrier(0);
+            if (t == wm) {
+                // The accumulators hold exactly this wave's own 64 x 64 block (earlier stages were
+                // skipped): clear the pairs i >= j in place. C/D map: col = lane & 15,
+                // row = 4 * (lane >> 4) + reg.
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        if (m > n) acc[m][n] = v4f{};
+                        if (m == n) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t row = 4u * (lane >> 4) + (uint32_t)r;
+                                acc[m][n][r] = row < (lane & 15u) ? acc[m][n][r] : 0.0f;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    // ---- later blocks, software-pipelined across stage boundaries. Iteration t, behind barrier t:
+    //      LDS operations in flight on entry: the fragments of steps 0 and 1 of image t (fa, fb). Fragments
+    //      are read TWO steps ahead into a rotation of three registers (the FP4 strips: three ahead, four
+    //      registers — the four this kernel needs for the piece and its inflated classes; with four waves
+    //      per SIMD a step of 4 MFMAs is ~250 clocks of wall time, twice the LDS latency). 8 steps per
+    //      stage rotate the three names by two and the ring slot by one: the body is instantiated three
+    //      times, I = the slot of the image it multiplies. The piece of stage t + 2 is read behind the
+    //      fragments, inflated beside the MFMAs and written as image t + 2; the lgkmcnt values count the
+    //      operations that may stay in flight behind the fragment needed. Beyond the last stage the next
+    //      image, the piece and the image written are stale and never consumed: the body is branch-free.
+#define STORM_SB16_BODY(I, fa, fb, fc)                                                                      \
+    {                                                                                                       \
+        issue(t + 4u, ((I) + 1) % 3);   /* into the slot of stage t + 1, read an iteration ago */           \
+        STORM_VM2();                    /* the piece of stage t + 2 has landed */                           \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(wb) : "v"(bits_rd), "n"((((I) + 2) % 3) * kSb16BitStage)); \
+        v4i e0, e1;                                                                                         \
+        STORM_FETCH16(fc, (I) * kStripStageBytes, 2); STORM_LGKM(3); STORM_MUL16(0, fa); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fa, (I) * kStripStageBytes, 3); STORM_LGKM(3); STORM_MUL16(1, fb); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fb, (I) * kStripStageBytes, 4); STORM_LGKM(2);   /* the piece and fc have landed */   \
+        e0 = sb16_inflate(wb, rot0); STORM_MUL16(2, fc); __builtin_amdgcn_sched_barrier(0);                 \
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr0), "v"(e0), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory"); \
+        STORM_FETCH16(fc, (I) * kStripStageBytes, 5); STORM_LGKM(3);                                        \
+        e1 = sb16_inflate(wb, rot1); STORM_MUL16(3, fa); __builtin_amdgcn_sched_barrier(0);                 \
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr1), "v"(e1), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory"); \
+        STORM_FETCH16(fa, (I) * kStripStageBytes, 6); STORM_LGKM(4); STORM_MUL16(4, fb); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fb, (I) * kStripStageBytes, 7); STORM_LGKM(3); STORM_MUL16(5, fc); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fc, (((I) + 1) % 3) * kStripStageBytes, 0); STORM_LGKM(2); STORM_MUL16(6, fa); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fa, (((I) + 1) % 3) * kStripStageBytes, 1); STORM_LGKM(2); STORM_MUL16(7, fb); __builtin_amdgcn_sched_barrier(0); \
+        ++t;                                                                                                \
+        if (t >= T) break;                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                       \
+    }
+    if (t < T) {
+        STORM_LGKM(0);
+        __builtin_amdgcn_s_barrier();
+        STORM_FETCH16(b0, 0, 0);   // stage D sits in slot 0
+        STORM_FETCH16(b1, 0, 1);
+        for (;;) {
+            STORM_SB16_BODY(0, b0, b1, b2)   // leaves steps 0, 1 of the next image in b2, b0
+            STORM_SB16_BODY(1, b2, b0, b1)   // ... in b1, b2
+            STORM_SB16_BODY(2, b1, b2, b0)   // ... in b0, b1
+        }
+        STORM_LGKM(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued beyond the last stage: none may land in a successor's LDS
+#undef STORM_SB16_BODY
+#undef STORM_VM2
+#undef STORM_FETCH16V
+#undef STORM_FETCH16
+#undef STORM_MUL16
+#undef STORM_LGKM
+
+    uint64_t mine = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // 16 x 64 entries below 2^24 each: a uint32 cannot overflow
+        uint32_t part = 0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += (uint32_t)acc[m][n][r];
+        mine += part;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    // (lane and thread index are taken afresh: kept alive across the stage loop they cost two registers
+    //  the loop does not have — the first build spilled them)
+    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t tid_e = wave * 64u + lane_e;
+    if (lane_e == 0 && mine != 0)
+        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+                  (unsigned long long)mine);
+    if (out == nullptr) return;
+    // ---- the fold, by the last workgroup to arrive: every wave's add is ordered before its
+    //      workgroup's ticket. Slots and ticket are left zeroed for the next pass.
+    //      (One ticket word for tens of thousands of workgroups: 1.8 ms instead of 0.8 at the headline
+    //       shape, profiles/r04_a_*: kept for short launches only, see launch_pairw_bits.)
+    __threadfence();
+    __syncthreads();
+    uint32_t* flag = reinterpret_cast<uint32_t*>(lds_raw);
+    if (tid_e == 0) {
+        const unsigned long long arrived = atomicAdd(&slots[kSb16Ticket], 1ull);
+        flag[0] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (flag[0] == 0u) return;
+    __threadfence();
+    unsigned long long v = 0;
+    for (uint32_t i = tid_e; i < (uint32_t)kSlots; i += (uint32_t)kStripThreads)
+        v += __hip_atomic_exchange(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(lds_raw + 64);
+    if (lane_e == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid_e == 0) {
+        out[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __hip_atomic_store(&slots[kSb16Ticket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2t16: write-mode tile kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (materialised XX^T, AND /
 // OR / XOR counts, triangle / band / rectangle). Same items and output conventions as
 // pairw_fp4_kernel<., true>; the dataflow borrows what made the strips fast:
@@ -2892,6 +3222,7 @@ static inline uint32_t strip_item_cost(const StripItem& it, uint32_t per_tile) {
 // longest run first.
 struct StripShaping {  // work-list shaping knobs (context options of the same names)
     int max_run = 128, tail_run = 32, tail_slices = 3, lpt_rounds = 6;
+    int xcd_group = 1;  // consecutive slices that share an XCD (2 for the bit-operand strips: slices 2j, 2j + 1 read the same bits)
     bool persistent = false, one_slice_probe = false;
 };
 // Pure host computation (no device): the list, in launch order, and for the persistent form the
@@ -2909,8 +3240,9 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
     std::vector<std::vector<uint32_t>> slices_of(8);
     uint32_t local = 0;
     const uint32_t modulo_slices = strip_modulo_slices(n_kslices, shard_count);
+    const uint32_t xg = (uint32_t)std::max(1, sh.xcd_group);
     for (uint32_t ks = 0; ks < modulo_slices; ++ks)
-        if (strip_owns_slice(ks, shard_rank, shard_count)) slices_of[local++ % 8].push_back(ks);
+        if (strip_owns_slice(ks, shard_rank, shard_count)) slices_of[(local++ / xg) % 8].push_back(ks);
     // One slice = every A tile against the B blocks behind it; `max_run` caps the stages per item.
     auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
         // k2_debug & 16 (timing probe, wrong results): every XCD re-reads one k-slice, i.e. the
@@ -2951,7 +3283,7 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
             std::stable_sort(all.begin(), all.end(), [&](const StripItem& p, const StripItem& q) {
                 return strip_item_cost(p, kPerTile) > strip_item_cost(q, kPerTile);
             });
-            const uint32_t xcd = local++ % 8;  // one slice stays on one XCD's L2
+            const uint32_t xcd = (local++ / xg) % 8;  // one slice stays on one XCD's L2
             for (const StripItem& it : all) {
                 const uint32_t r = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
                 load[r] += strip_item_cost(it, kPerTile);
@@ -3011,8 +3343,8 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
 
 static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
-                              uint32_t a_tile) {
-    const uint64_t key[4] = {ranges_hash(ranges), n_kslices,
+                              uint32_t a_tile, int xcd_group = 1) {
+    const uint64_t key[4] = {ranges_hash(ranges) ^ ((uint64_t)xcd_group << 56), n_kslices,
                              ((uint64_t)shard_rank << 32) | shard_count,
                              ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
                                  ((uint64_t)(ctx->k2_persistent != 0) << 47) |
@@ -3026,6 +3358,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     sh.tail_run = ctx->k2_tail_run;
     sh.tail_slices = ctx->k2_tail_slices;
     sh.lpt_rounds = ctx->k2_lpt_rounds;
+    sh.xcd_group = xcd_group;
     sh.persistent = ctx->k2_persistent != 0;
     sh.one_slice_probe = (ctx->k2_debug & 16) != 0;
     std::vector<StripItem> items;
@@ -4214,6 +4547,30 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
 #endif
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    if (operands == 5) {
+        // K2b: the FP4 strips' items over slices of 256 bit-MACs = one class pair of a 512-bit chunk
+        if (int rc = ensure_strip_items(ctx, ranges, n_kslices * 2u, shard_rank, shard_count,
+                                        (uint32_t)kStripATile, 2))
+            return rc;
+        const uint32_t n_strip = ctx->n_strip_items;
+        ctx->last_info[0] = n_strip;
+        ctx->last_info[1] = ctx->k2_stages_per_item;
+        ctx->last_info[2] = 1;
+        ctx->last_info[3] = 0;
+        const bool fold_inline = ctx->k2_fold_inline != 0 && n_strip > 0;
+        if (n_strip > 0) {
+            kernel_time_mark(ctx);
+            const uint8_t* xb = reinterpret_cast<const uint8_t*>(m->d);
+            const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
+            unsigned long long* outp = fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr;
+            const dim3 sgrid(n_strip), sblock(kStripThreads);
+            hipLaunchKernelGGL(strip16_bits_kernel, sgrid, sblock, (size_t)ctx->k2_lds_pad, ctx->stream,
+                               xb, pitch, sit, ctx->d_slots, outp);
+            kernel_time_mark(ctx);
+            STORM_HIP_TRY(hipGetLastError());
+        }
+        return fold_inline ? STORM_HIP_OK : launch_fold_slots(ctx, d_total);
+    }
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
         return rc;
 #ifndef STORM_HIP_PROBES
@@ -4252,7 +4609,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         operands = (shard_count == 1 && m->n_rows <= (uint64_t)ctx->k2_stream_max_rows && ctx->k2_ring == kStripRingDefault &&
                     ctx->k2_shape == 16 && ctx->k2_lds_pad == 0)
                        ? 2 : 4;
-    if (strip_mode == 1 && (operands == 1 || operands == 2 || operands == 3) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
+    if (strip_mode == 1 && (operands == 1 || operands == 2 || operands == 3 || operands == 5) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
         m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))
     {
