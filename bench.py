@@ -334,7 +334,8 @@ def main():
     # matrix is kept in HBM between calls (library option keep_shadow, what the storm.h handles
     # do) — i.e. without the O(N*M) expansion at the head of every pass.
     shadow_resident = None
-    if not args.no_shadow_resident:
+    operands_used = ctx.get_option("k2_operands_used")
+    if not args.no_shadow_resident and ctx.get_option("variant_used") >= 4 and operands_used == 4:
         ctx.set_option("keep_shadow", 1)
         step(); fence()
         n2 = max(1, args.steps // 2)
@@ -390,16 +391,23 @@ def main():
             roof = {"bound": "mfma", "achieved": achieved, "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP4_PEAK_TFLOPS, "traffic": traffic if world == 1 else None,
                     "traffic_note": traffic_note,
-                    # the same FLOPs over everything one step contains (expansion, fold, launch
-                    # gaps, all-reduce): wall time of the timed loop / steps
+                    # the same FLOPs over everything one step contains (fold, launch gaps, all-reduce;
+                    # the FP4-shadow form: its expansion pass too): wall time of the timed loop / steps
                     "frac_whole_pass": alg_flop_launch / (step_ms * 1e-3) / 1e12 / FP4_PEAK_TFLOPS,
-                    "kernel": ("storm::strip16_fp4_kernel<4>" if ctx.get_option("k2_shape") == 16 else
-                               "storm::strip_fp4_kernel") if used >= 4 else "storm::pairw_fp4_kernel",
+                    "kernel": ({5: "storm::strip16_bits_kernel", 2: "storm::bitstream_kernel<false>",
+                                1: "storm::stripbits_kernel"}.get(operands_used,
+                                "storm::strip16_fp4_kernel<4>" if ctx.get_option("k2_shape") == 16 else
+                                "storm::strip_fp4_kernel")) if used >= 4 else "storm::pairw_fp4_kernel",
+                    "operand_form": ({5: "bit rows read as they are; the FP4 image of every 64-row B stage is built in "
+                                         "the LDS by the workgroup (no shadow matrix, no expansion pass)",
+                                      2: "bit rows inflated in registers, one stage stream per workgroup",
+                                      4: "FP4 shadow matrix rebuilt by expand_fp4_kernel in front of every pass"}
+                                     .get(operands_used, str(operands_used))) if used >= 4 else "FP4 shadow",
                     "kernel_ms": kernel_ms, "kernel_ms_samples": dom_n, "pass_ms_untimed": launch_ms,
                     "algorithmic_flop_per_launch": alg_flop_launch,
                     "measured_fp4_mfma_peak_frac": (pairs * W / world / (kernel_ms * 1e-3)) / FP4_MEASURED_WORDPAIRS,
                     "hbm_algorithmic_gb_s": hbm_gbs, "hbm_algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
-                    "note": "1 word pair = 64 bit-MACs = 128 FLOP on v_mfma_scale_f32_16x16x128_f8f6f4 (FP4). The "
+                    "note": "1 word pair = 64 bit-MACs = 128 FLOP on v_mfma_f32_16x16x128_f8f6f4 (FP4 operands). The "
                             "reference's no-reuse byte accounting (16 B per word pair, benchmark.cpp:131) is "
                             "kept as hbm_algorithmic_*; on-chip reuse puts it far above the HBM peak."}
         else:

@@ -680,12 +680,6 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
         ctx->k2_strip_operands = (int)value;
-    } else if (!strcmp(key, "k2_bit_ring")) {
-        if (value != 3 && value != 4) {
-            set_error("k2_bit_ring must be 3 or 4 stages");
-            return STORM_HIP_EINVAL;
-        }
-        ctx->k2_bit_ring = (int)value;
     } else if (!strcmp(key, "k2_matrix_pad")) {
         ctx->k2_matrix_pad = value < 0 ? -1 : value != 0;
     } else if (!strcmp(key, "k2_fold_inline")) {
@@ -815,7 +809,6 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_strip_operands")) return ctx->k2_strip_operands;
     if (!strcmp(key, "k2_operands_used")) return ctx->k2_operands_used;
     if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
-    if (!strcmp(key, "k2_bit_ring")) return ctx->k2_bit_ring;
     if (!strcmp(key, "k2_fold_inline")) return ctx->k2_fold_inline;
     if (!strcmp(key, "k2_matrix_pad")) return ctx->k2_matrix_pad;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
@@ -914,13 +907,12 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     m->generation = next_matrix_generation();
     m->n_rows_pad = std::max<uint64_t>(kRowPad, (n_rows + kRowPad - 1) / kRowPad * kRowPad);
     m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
-    // Bit-operand strips (option k2_strip_operands = 1 at creation) read 64-byte pieces of 64+ consecutive
-    // rows straight from this buffer: rows whose byte length is a multiple of 1 KiB would put the rows of a
-    // k-slice into a handful of L2 sets and memory channels, so one more chunk of zero words per row breaks
-    // the pattern (same finding as shadow_pitch, storm_hip_mfma.hip). The FP4 paths copy the rows into
-    // their own padded shadow and keep the dense pitch.
-    const bool pad = ctx->k2_matrix_pad < 0 ? (ctx->k2_strip_operands == 1) : ctx->k2_matrix_pad != 0;
-    if (pad && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
+    // The bit-operand strips read 64-byte pieces of 64 consecutive rows straight from this buffer: rows whose
+    // byte length is a multiple of 1 KiB would put the rows of a k-slice into a handful of L2 sets and memory
+    // channels, so one more chunk of zero words per row breaks the pattern (same finding as shadow_pitch,
+    // storm_hip_mfma.hip; K2b at the headline shape 769 -> 758 us, at M = 524288 6.69 -> 6.40 ms,
+    // profiles/r04_a_pitch_pad.txt). Option k2_matrix_pad = 0 keeps the dense pitch.
+    if (ctx->k2_matrix_pad != 0 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

@@ -4598,17 +4598,15 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
     // (a matrix created before the option was set may lack the zero rows up to a multiple of 256)
-    // Which strips (option k2_strip_operands; 0 = by measurement, same box, M = 65536, tools/midsize_pass.py):
-    // the one-launch stream on bit operands (K2q) is ahead up to N ~ 9000 — 12.6 us against 20.7 at N = 512,
-    // 20.1 / 33.8 at 1024, 46.8 / 60.5 at 2048, 161 / 174 at 4096, 581 / 594 at 8192 — where the FP4 strips'
-    // faster stage loop has made up for their expansion pass and two extra launches (872 / 848 at N = 10000).
-    // A shard of a multi-GPU pass stays on the FP4 strips (whole k-slices per shard make its expansion cheap:
-    // 0.120 against 0.122 ms for an eighth of the headline matrix), and with them on the planner's ownership.
+    // Which strips (option k2_strip_operands; 0 = by measurement, same box, M = 65536, tools/sweep_k2b.py,
+    // profiles/r04_a_sweep_k2b.jsonl): the strips on bit operands with the FP4 image built in the LDS (K2b,
+    // strip16_bits_kernel) are ahead of the one-launch stream (K2q) and of the FP4 strips at every size —
+    // 8.2 / 9.5 / 14.9 us at N = 256, 17.1 / 20.2 / 31.8 at 1024, 41.9 / 43.4 / 60.4 at 2048, 142 / 143 / 169 at
+    // 4096, 537 / 539 / 591 at 8192, 752 / 809 / 817 at 10000 (K2q is ahead around N = 6144 only: 311 against
+    // 325) — and for the shards of a multi-GPU pass (an eighth of the headline matrix: 103 against 119 us).
     int operands = ctx->k2_strip_operands;
     if (operands == 0)
-        operands = (shard_count == 1 && m->n_rows <= (uint64_t)ctx->k2_stream_max_rows && ctx->k2_ring == kStripRingDefault &&
-                    ctx->k2_shape == 16 && ctx->k2_lds_pad == 0)
-                       ? 2 : 4;
+        operands = (ctx->k2_ring == kStripRingDefault && ctx->k2_shape == 16) ? 5 : 4;
     if (strip_mode == 1 && (operands == 1 || operands == 2 || operands == 3 || operands == 5) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
         m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))

@@ -459,7 +459,8 @@ def test_multi_rank_rehearsal_of_bench_on_one_gpu(ranks):
     assert out["distinct_gpus"] == 1 and all(r["device"] == 0 and r["pci_bus_id"] for r in out["per_rank"])
     assert len({r["pid"] for r in out["per_rank"]}) == ranks
     assert out["config"]["kernel_variant"] == 4
-    assert out["shadow_resident"]["total_matches"] is True
+    assert "shadow_resident" not in out   # the default path (K2b) has no FP4 shadow to keep
+    assert out["roofline"]["kernel"] == "storm::strip16_bits_kernel"
     # the per-rank diagnostics a scaling run is read by
     assert [r["rank"] for r in out["per_rank"]] == list(range(ranks))
     assert all(r["kernel_ms"] > 0 and r["work_items"] > 0 for r in out["per_rank"])
@@ -780,9 +781,9 @@ def test_rows_beyond_the_dma_offsets_are_multiplied_in_k_chunks(hip_ctx, orc):
     mat[:, -1] &= np.uint64((1 << (M % 64)) - 1) if M % 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
     m = hip_ctx.matrix_from_host(mat)
     want = orc.wrapper_diag(mat)
-    # default path: three rows take the one-launch stream on bit operands, whose DMA reaches rows of 2^29 bits
+    # default path: the strips on bit operands (K2b), whose DMA reaches rows of 2^29 bits
     assert m.pairw() == want
-    assert hip_ctx.get_option("variant_used") == 4 and hip_ctx.get_option("k2_operands_used") == 2
+    assert hip_ctx.get_option("variant_used") == 4 and hip_ctx.get_option("k2_operands_used") == 5
     hip_ctx.set_option("k2_strip_operands", 4)     # the FP4 strips: k-chunked
     try:
         assert m.pairw() == want

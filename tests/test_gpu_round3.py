@@ -36,14 +36,14 @@ def _reset(ctx):
         ctx.set_option(k, v)
 
 
-def test_stream_kernel_is_the_default_up_to_8192_rows_and_matches_the_oracle(hip_ctx, orc):
-    """Default path by size: K2q up to k2_stream_max_rows rows on one device, the FP4 strips beyond and for
-    every shard of a multi-device pass. Shapes around every edge of the decomposition: one block, one tile,
+def test_stream_kernel_matches_the_oracle(hip_ctx, orc):
+    """K2q (option k2_strip_operands = 2; round 3's default up to 8192 rows, since round 4 K2b is the default at every size). Shapes around every edge of the decomposition: one block, one tile,
     2 / 3 / 4 / 5 tiles (the cyclic deal of tile pairs has an odd and an even form), ragged last blocks and
     tiles, one k-slice, a ragged last k-slice, rows of zero."""
     shapes = ((64, 2), (100, 3), (4096, 63), (4096, 64), (640, 65), (4096, 200), (4096, 256), (1000, 257),
               (8192, 511), (4160, 513), (9000, 700), (30000, 1000), (4096, 1100), (12345, 1500))
     try:
+        hip_ctx.set_option("k2_strip_operands", 2)   # (round 3's default up to 8192 rows; since round 4 an option)
         for M, N in shapes:
             for d in (M // 2, max(1, M // 50)):
                 mat = synth.dense_matrix_c(M, N, d, seed=N + M)
@@ -54,22 +54,12 @@ def test_stream_kernel_is_the_default_up_to_8192_rows_and_matches_the_oracle(hip
                 assert got == [want] * 3, (M, N, d, got, want)
                 assert hip_ctx.get_option("k2_operands_used") == 2 and hip_ctx.get_option("variant_used") == 4
                 assert m.column_identity() == want
-                # a shard of a multi-device pass stays on the FP4 strips; the stream can be sharded too
+                # the stream can be sharded too (contiguous parts of its k-slice-major stage stream)
                 assert sum(m.pairw(r, 3) for r in range(3)) == want
-                assert hip_ctx.get_option("k2_operands_used") == 4
-                hip_ctx.set_option("k2_strip_operands", 2)
+                assert hip_ctx.get_option("k2_operands_used") == 2
                 for world in (2, 5):
                     assert sum(m.pairw(r, world) for r in range(world)) == want, (M, N, d, world)
-                hip_ctx.set_option("k2_strip_operands", 0)
                 m.close()
-        # beyond the threshold: FP4 strips; the threshold is an option
-        m = hip_ctx.matrix(8300, 64)
-        m.fill_synthetic(4096, 1500, seed=3)
-        want = m.column_identity()
-        assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 4
-        hip_ctx.set_option("k2_stream_max_rows", 10000)
-        assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 2
-        m.close()
     finally:
         _reset(hip_ctx)
 
@@ -120,13 +110,17 @@ def test_stream_kernel_at_full_mid_sizes_against_the_column_identity(hip_ctx):
     """The sizes tools/midsize_pass.py reports (M = 65536, dense): totals against the size-independent
     identity sum_c C(n_c, 2), repeated (the last workgroup to arrive folds the partial sums and leaves
     slots and ticket zeroed for the next pass)."""
-    for N in (512, 1024, 2048, 4096, 8192):
-        m = hip_ctx.matrix(N, 1024)
-        m.fill_synthetic(65536, 32768, seed=42)
-        want = m.column_identity()
-        assert [m.pairw() for _ in range(5)] == [want] * 5, N
-        assert hip_ctx.get_option("k2_operands_used") == 2
-        m.close()
+    try:
+        hip_ctx.set_option("k2_strip_operands", 2)
+        for N in (512, 1024, 2048, 4096, 8192):
+            m = hip_ctx.matrix(N, 1024)
+            m.fill_synthetic(65536, 32768, seed=42)
+            want = m.column_identity()
+            assert [m.pairw() for _ in range(5)] == [want] * 5, N
+            assert hip_ctx.get_option("k2_operands_used") == 2
+            m.close()
+    finally:
+        _reset(hip_ctx)
 
 
 def test_block_columns_of_mixed_kinds_split_per_block(orc):

@@ -1,0 +1,141 @@
+"""Round-4 GPU parity tests: K2b (strip16_bits_kernel) — the 16x16x128 strips on BIT operands, the FP4 image of
+every B stage built in the LDS by the workgroup — is the default all-pairs path at every size and for every
+shard. Against the CPU oracle where the CPU can afford it (incl. the headline configuration, pair by pair),
+the column identity, the other operand forms and its own shards. Everything goes through the C-ABI."""
+import numpy as np
+import pytest
+
+import stormbitmaps_amd as sb
+from stormbitmaps_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_ctx():
+    ctx = sb.HipContext(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from tests._orc import Oracle
+    return Oracle()
+
+
+def _reset(ctx):
+    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", 0), ("k2_matrix_pad", 1), ("variant", -1)):
+        ctx.set_option(k, v)
+
+
+def test_bit_operand_strips_are_the_default_and_match_the_oracle(hip_ctx, orc):
+    """Default path: K2b on one device and for every shard. Shapes around every edge of the strip
+    decomposition: one block, one tile (only the diagonal phase runs), 2..6 tiles, ragged last blocks and
+    tiles, one k-slice (one class pair of one chunk holds all the data), ragged last chunks (n_words not a
+    multiple of 8: the second class pair of the last chunk multiplies zero padding), rows of zero, item runs
+    of 1, 2 and 3 stages (shorter than the pipeline's look-ahead: the pieces issued beyond the last stage are
+    never consumed)."""
+    shapes = ((64, 2), (100, 3), (4096, 63), (4096, 64), (640, 65), (4096, 200), (4096, 256), (1000, 257),
+              (8192, 511), (4160, 513), (9000, 700), (30000, 1000), (4096, 1100), (12345, 1500), (300, 320),
+              (256, 384), (200, 448))
+    try:
+        for M, N in shapes:
+            for d in (M // 2, max(1, M // 50)):
+                mat = synth.dense_matrix_c(M, N, d, seed=N + M)
+                mat[N // 2] = 0                                   # an empty row in the middle
+                want = orc.wrapper_diag_blocked(mat, 31)
+                m = hip_ctx.matrix_from_host(mat)
+                got = [m.pairw() for _ in range(3)]               # (run to run: the race a skipped wait gives)
+                assert got == [want] * 3, (M, N, d, got, want)
+                assert hip_ctx.get_option("k2_operands_used") == 5 and hip_ctx.get_option("variant_used") == 4
+                assert m.column_identity() == want
+                for world in (2, 3, 5):
+                    assert sum(m.pairw(r, world) for r in range(world)) == want, (M, N, d, world)
+                assert hip_ctx.get_option("k2_operands_used") == 5
+                for other in (2, 4):                              # the stage stream and the FP4 strips agree
+                    hip_ctx.set_option("k2_strip_operands", other)
+                    assert m.pairw() == want, (M, N, d, other)
+                    assert hip_ctx.get_option("k2_operands_used") == other
+                hip_ctx.set_option("k2_strip_operands", 0)
+                m.close()
+    finally:
+        _reset(hip_ctx)
+
+
+def test_bit_operand_strips_with_and_without_the_pitch_pad_and_with_the_in_kernel_fold(hip_ctx):
+    """k2_matrix_pad (rows that are a multiple of 1 KiB get 512 more bytes of pitch: tuning) and k2_fold_inline
+    (the last workgroup to arrive folds the partial sums and leaves slots and ticket zeroed; slower, kept as an
+    option) do not change the total; repeated passes see clean slots."""
+    try:
+        for pad in (0, 1):
+            hip_ctx.set_option("k2_matrix_pad", pad)
+            for M, N in ((65536, 1024), (8192, 3000), (20000, 2300), (1024, 5000)):
+                m = hip_ctx.matrix(N, (M + 63) // 64)
+                assert ((m.stride_words * 8) % 1024 != 0) == (pad == 1 or (M + 63) // 64 % 128 != 0) or M % 8192 != 0
+                m.fill_synthetic(M, M // 3, seed=9)
+                want = m.column_identity()
+                for fold in (0, 1, 0):
+                    hip_ctx.set_option("k2_fold_inline", fold)
+                    assert [m.pairw() for _ in range(3)] == [want] * 3, (M, N, pad, fold)
+                    assert sum(m.pairw(r, 4) for r in range(4)) == want
+                m.close()
+    finally:
+        _reset(hip_ctx)
+
+
+def test_headline_configuration_against_the_oracle_pair_by_pair(hip_ctx, orc):
+    """BASELINE configs[1] at full size (N = 10000, M = 65536, 32768 draws per row, seed 42 — bench.py's
+    workload): the default path's total against the CPU oracle's blocked loop over ALL 49 995 000 pairs (the
+    restatement of storm.c:1175-1241 with the harness's block size, benchmark.cpp:823-824; ~3 s with the
+    AVX-512 leaf, ~25 s with the scalar one), the column identity, 8-way shards and the other two operand
+    forms."""
+    N, M = 10000, 65536
+    m = hip_ctx.matrix(N, M // 64)
+    try:
+        m.fill_synthetic(M, M // 2, seed=42)
+        got = m.pairw()
+        assert hip_ctx.get_option("k2_operands_used") == 5
+        mat = m.download()
+        want = orc.wrapper_diag_blocked(mat, max(5, 256000 // (M // 64 * 8)))
+        assert got == want == m.column_identity()
+        assert sum(m.pairw(r, 8) for r in range(8)) == want
+        for other in (2, 4):
+            hip_ctx.set_option("k2_strip_operands", other)
+            assert m.pairw() == want
+    finally:
+        _reset(hip_ctx)
+        m.close()
+
+
+def test_rows_of_half_a_million_bits_and_more(hip_ctx):
+    """c3's shape (M = 524288; fewer rows) and a row length whose pitch x 64 rows is close to the strips' 32-bit
+    DMA offsets: K2b, against the column identity and the FP4 strips (k-chunked there)."""
+    try:
+        for M, N in ((524288, 1500), (1 << 24, 300)):
+            m = hip_ctx.matrix(N, M // 64)
+            m.fill_synthetic(M, M // 4, seed=11)
+            want = m.column_identity()
+            assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 5
+            assert sum(m.pairw(r, 3) for r in range(3)) == want
+            hip_ctx.set_option("k2_strip_operands", 4)
+            assert m.pairw() == want
+            hip_ctx.set_option("k2_strip_operands", 0)
+            m.close()
+    finally:
+        _reset(hip_ctx)
+
+
+def test_default_path_through_the_storm_h_containers(orc):
+    """STORM_contiguous_t containers (storm.h) reach K2b through STORM_contig_pairw_intersect_cardinality[_blocked]:
+    same totals as the oracle's blocked loop (storm.c:1175-1241) and as the raw-buffer wrappers."""
+    M, N, d = 65536, 1200, 20000
+    mat = synth.dense_matrix_c(M, N, d, seed=78)
+    want = orc.wrapper_diag_blocked(mat, 31)
+    c = sb.StormContig(M)
+    for r in synth.positions_from_dense(mat):
+        c.add(r)
+    assert c.pairw_intersect_cardinality_blocked(31) == want
+    assert c.pairw_intersect_cardinality() == want
+    assert sb.wrapper_diag_blocked(mat, 31) == want
+    c.free()
