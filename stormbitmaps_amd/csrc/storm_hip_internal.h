@@ -182,6 +182,9 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
                              uint64_t shadow_generation = 0, uint32_t n_words_logical = 0);
+int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch_bytes,
+                             const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
+                             uint32_t shard_count, uint64_t* d_total);
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull,
                         bool sync = true);

@@ -4525,6 +4525,39 @@ int launch_pairw_bitwave(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pitch
 
 #endif  // STORM_HIP_PROBES (K2w)
 
+// K2b over arbitrary row ranges of a bit matrix X (pitch bytes per row): the FP4 strips' items over slices of
+// 256 bit-MACs = one class pair of a 512-bit chunk (n_kslices2 = 2 x the chunks that hold data). The rows of
+// every range's last A tile beyond its r1 must be readable and zero in X. Dense container: the matrix;
+// sparse container: the pool rows of its block columns.
+int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch,
+                             const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
+                             uint32_t shard_count, uint64_t* d_total) {
+    if (pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
+        set_error("K2b: rows of %llu bytes are beyond the strips' 32-bit DMA offsets", (unsigned long long)pitch);
+        return STORM_HIP_EINVAL;
+    }
+    ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
+    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+    if (int rc = ensure_strip_items(ctx, ranges, n_kslices2, shard_rank, shard_count, (uint32_t)kStripATile, 2))
+        return rc;
+    const uint32_t n_strip = ctx->n_strip_items;
+    ctx->k2_operands_used = 5;
+    ctx->last_info[0] = n_strip;
+    ctx->last_info[1] = ctx->k2_stages_per_item;
+    ctx->last_info[2] = 1;
+    ctx->last_info[3] = 0;
+    const bool fold_inline = ctx->k2_fold_inline != 0 && n_strip > 0;
+    if (n_strip > 0) {
+        kernel_time_mark(ctx);
+        hipLaunchKernelGGL(strip16_bits_kernel, dim3(n_strip), dim3(kStripThreads), (size_t)ctx->k2_lds_pad,
+                           ctx->stream, X, pitch, static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots,
+                           fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr);
+        kernel_time_mark(ctx);
+        STORM_HIP_TRY(hipGetLastError());
+    }
+    return fold_inline ? STORM_HIP_OK : launch_fold_slots(ctx, d_total);
+}
+
 // The default pass: strips on bit operands over the matrix itself (no shadow, nothing to expand).
 static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                              uint32_t shard_count, int operands, uint64_t* d_total) {
@@ -4547,30 +4580,9 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
 #endif
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
-    if (operands == 5) {
-        // K2b: the FP4 strips' items over slices of 256 bit-MACs = one class pair of a 512-bit chunk
-        if (int rc = ensure_strip_items(ctx, ranges, n_kslices * 2u, shard_rank, shard_count,
-                                        (uint32_t)kStripATile, 2))
-            return rc;
-        const uint32_t n_strip = ctx->n_strip_items;
-        ctx->last_info[0] = n_strip;
-        ctx->last_info[1] = ctx->k2_stages_per_item;
-        ctx->last_info[2] = 1;
-        ctx->last_info[3] = 0;
-        const bool fold_inline = ctx->k2_fold_inline != 0 && n_strip > 0;
-        if (n_strip > 0) {
-            kernel_time_mark(ctx);
-            const uint8_t* xb = reinterpret_cast<const uint8_t*>(m->d);
-            const StripItem* sit = static_cast<const StripItem*>(ctx->d_strip_items);
-            unsigned long long* outp = fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr;
-            const dim3 sgrid(n_strip), sblock(kStripThreads);
-            hipLaunchKernelGGL(strip16_bits_kernel, sgrid, sblock, (size_t)ctx->k2_lds_pad, ctx->stream,
-                               xb, pitch, sit, ctx->d_slots, outp);
-            kernel_time_mark(ctx);
-            STORM_HIP_TRY(hipGetLastError());
-        }
-        return fold_inline ? STORM_HIP_OK : launch_fold_slots(ctx, d_total);
-    }
+    if (operands == 5)
+        return launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(m->d), pitch, ranges, n_kslices * 2u,
+                                        shard_rank, shard_count, d_total);
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
         return rc;
 #ifndef STORM_HIP_PROBES

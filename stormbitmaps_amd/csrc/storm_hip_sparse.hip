@@ -1049,6 +1049,18 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             if (int rc = ensure_full_pool(ctx, s)) return rc;
         // (only the rows the dense pass multiplies are expanded: the probe columns lie behind them)
         const uint64_t rows_dst = (rows_needed + 511) / 512 * 512;
+        // The strips on bit operands (K2b) multiply the pool rows as they are: no FP4 shadow of the pool (2.6 GB
+        // at c4), no expansion pass. The rows behind a column's last one up to the next multiple of 512 are zero
+        // in the pool (columns start on multiples of 512 and nothing writes between them).
+        if (variant == 4 && (ctx->k2_strip_operands == 0 || ctx->k2_strip_operands == 5) && ctx->k2_debug == 0 &&
+            !ctx->k2_persistent && ctx->k2_shape == 16 && rows_dst <= s->pool_rows_ready + 512) {
+            if (int rc = launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(s->d_pool), kBlockWords * 8ull,
+                                                  ranges, kBlockWords / 4u, shard_rank, shard_count,
+                                                  reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+                return rc;
+            ctx->last_info[3] = s->n_probe_cols_launch;
+            return STORM_HIP_OK;
+        }
         if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->pool_rows_ready + 512,
                                               std::max<uint64_t>(rows_dst, 512), ranges,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
