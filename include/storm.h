@@ -161,6 +161,7 @@ struct STORM_contiguous_s {
     STORM_t* hip_lists;      /* the same rows as a STORM_t while EVERY row is below scalar_cutoff:   */
     uint32_t hip_lists_off;  /* such a container goes through the list-probe kernel (see storm_host.c) */
     void* hip_pending;       /* positions of rows not yet on the device (STORM_contig_add; storm_host.c)    */
+    uint64_t hip_words_below; /* rows below this one were edited in place (STORM_contig_hip_invalidate): sent as words */
 };
 
 /* per-block API (reference storm.h:203-212, storm.c:372-380, :398-656) */

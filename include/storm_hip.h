@@ -269,6 +269,8 @@ int storm_hip_comm_unique_id(uint8_t id[STORM_HIP_COMM_ID_BYTES]);
 int storm_hip_comm_init_rank(storm_hip_ctx_t* ctx, const uint8_t id[STORM_HIP_COMM_ID_BYTES], uint32_t rank,
                              uint32_t world, storm_hip_comm_t** out);
 int storm_hip_comm_allreduce_u64(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* value);
+/* up to 8 words in one collective (e.g. {partial, failure flag}: a failed rank still enters it) */
+int storm_hip_comm_allreduce_u64s(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* values, uint32_t n);
 int storm_hip_comm_allreduce_result(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* total);
 uint32_t storm_hip_comm_rank(const storm_hip_comm_t* comm);
 uint32_t storm_hip_comm_world(const storm_hip_comm_t* comm);

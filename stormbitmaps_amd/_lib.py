@@ -69,6 +69,7 @@ SIGNATURES = {
     "storm_hip_comm_unique_id": (C.c_int, [vp]),
     "storm_hip_comm_init_rank": (C.c_int, [vp, vp, u32, u32, P(vp)]),
     "storm_hip_comm_allreduce_u64": (C.c_int, [vp, vp, P(u64)]),
+    "storm_hip_comm_allreduce_u64s": (C.c_int, [vp, vp, P(u64), C.c_uint32]),
     "storm_hip_comm_allreduce_result": (C.c_int, [vp, vp, P(u64)]),
     "storm_hip_comm_rank": (u32, [vp]),
     "storm_hip_comm_world": (u32, [vp]),

@@ -117,18 +117,24 @@ int storm_hip_comm_init_rank(storm_hip_ctx_t* ctx, const uint8_t id[STORM_HIP_CO
 // In place: *value becomes the sum of every rank's *value. Ordered on the context's stream behind
 // whatever produced the value there; returns when the sum is on the host.
 int storm_hip_comm_allreduce_u64(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* value) {
-    if (!ctx || !comm || !value) {
-        set_error("comm_allreduce_u64: NULL argument");
+    return storm_hip_comm_allreduce_u64s(ctx, comm, value, 1);
+}
+
+// The same for up to 8 words at once (one collective): e.g. {partial total, failure flag}, so that a rank whose
+// pass failed still enters the collective and every rank learns of the failure.
+int storm_hip_comm_allreduce_u64s(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* values, uint32_t n) {
+    if (!ctx || !comm || !values || n == 0 || n > 8) {
+        set_error("comm_allreduce_u64s: NULL argument or a word count outside 1..8");
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
-    *comm->h_word = *value;
-    STORM_HIP_TRY(hipMemcpyAsync(comm->d_word, comm->h_word, sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = g_rccl.AllReduce(comm->d_word, comm->d_word, 1, kNcclUint64, kNcclSum, comm->comm, ctx->stream))
+    memcpy(comm->h_word, values, n * sizeof(uint64_t));
+    STORM_HIP_TRY(hipMemcpyAsync(comm->d_word, comm->h_word, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = g_rccl.AllReduce(comm->d_word, comm->d_word, n, kNcclUint64, kNcclSum, comm->comm, ctx->stream))
         return rccl_fail("ncclAllReduce", rc);
-    STORM_HIP_TRY(hipMemcpyAsync(comm->h_word, comm->d_word, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    STORM_HIP_TRY(hipMemcpyAsync(comm->h_word, comm->d_word, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    *value = *comm->h_word;
+    memcpy(values, comm->h_word, n * sizeof(uint64_t));
     return STORM_HIP_OK;
 }
 

@@ -4327,6 +4327,7 @@ static int ensure_bitstream(storm_hip_ctx_t* ctx, const std::vector<RowRange>& r
     std::vector<uint32_t> packed(plan.first);
     packed.insert(packed.end(), plan.first_stage.begin(), plan.first_stage.end());
     packed.insert(packed.end(), plan.bases.begin(), plan.bases.end());
+    packed.push_back(0u);  // a trailing workgroup without stages reads bases[total stages] (bitstream_kernel: prep)
     const size_t first_bytes = packed.size() * sizeof(uint32_t);
     if (seg_bytes > ctx->bitsegs_capacity) {
         if (ctx->d_bitsegs) STORM_HIP_TRY(hipFree(ctx->d_bitsegs));

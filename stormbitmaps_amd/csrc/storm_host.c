@@ -255,15 +255,20 @@ int STORM_hip_comm_finalize(void) {
     return 0;
 }
 
-/* the total an entry point returns: this process's partial, summed over the ranks when a communicator is attached */
+/* The total an entry point returns: this process's partial, summed over the ranks when a communicator is attached.
+ * EVERY rank enters the collective, also one whose pass failed (partial == ALL_PAIRS_FAILED: out of memory, a
+ * rebuild that failed, ...): two words travel, {partial, failed}, and every rank returns the failure if any rank
+ * failed. A rank that returned early instead left the others blocked in ncclAllReduce for good.
+ * All failing paths of the all-pairs entry points behind the point where the ranks are known to have taken the
+ * same decisions go through here. */
 static uint64_t across_ranks(uint64_t partial) {
-    if (!g_comm || partial == ALL_PAIRS_FAILED) return partial;
-    uint64_t v = partial;
-    if (storm_hip_comm_allreduce_u64(g_ctx[0], g_comm, &v) != STORM_HIP_OK) {
+    if (!g_comm) return partial;
+    uint64_t v[2] = {partial == ALL_PAIRS_FAILED ? 0 : partial, partial == ALL_PAIRS_FAILED ? 1u : 0u};
+    if (!g_ctx[0] || storm_hip_comm_allreduce_u64s(g_ctx[0], g_comm, v, 2) != STORM_HIP_OK) {
         device_error("all-reduce of the shard totals");
         return ALL_PAIRS_FAILED;
     }
-    return v;
+    return v[1] ? ALL_PAIRS_FAILED : v[0];
 }
 
 /* a STORM_compute_func is only an identity token on the device path (libalgebra.h) */
@@ -399,7 +404,7 @@ static uint64_t dense_state_pairw(dense_state_t* st) {
     dense_job_t j;
     j.st = st;
     memset(j.part, 0, sizeof(j.part));
-    if (run_on_devices(dense_job, &j, "all-pairs pass (dense)")) return ALL_PAIRS_FAILED;
+    if (run_on_devices(dense_job, &j, "all-pairs pass (dense)")) return across_ranks(ALL_PAIRS_FAILED);
     uint64_t total = 0;
     for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
     return across_ranks(total);
@@ -676,7 +681,6 @@ typedef struct {
     uint64_t* off;                 /* n_rows + 1 starts in pos; an empty range = the row goes as words */
     uint32_t* pos;
     uint64_t n_pos, m_pos;
-    uint64_t words_below; /* rows below this one travel as words (STORM_contig_hip_invalidate: edited in place) */
     int broken;           /* an allocation failed: nothing more is kept */
 } contig_pending_t;
 
@@ -746,7 +750,7 @@ static void contig_pending_note(STORM_contiguous_t* h, const uint32_t* values, u
 static const uint32_t* contig_row_positions(const STORM_contiguous_t* h, uint64_t r, uint32_t* n) {
     if (!contig_positions_enabled()) return NULL;
     const contig_pending_t* p = (const contig_pending_t*)h->hip_pending;
-    if (p && r < p->words_below) return NULL;
+    if (r < h->hip_words_below) return NULL; /* edited in place (STORM_contig_hip_invalidate): as the words they now are */
     if (h->n_scalar[r] < h->scalar_cutoff && h->scalar) {
         if ((uint64_t)h->n_scalar[r] * 4 > h->n_bitmaps_vector) return NULL;
         *n = h->n_scalar[r];
@@ -931,6 +935,7 @@ int STORM_contig_clear(STORM_contiguous_t* h) { /* storm.c:1139-1147 */
     contig_pending_free(h);
     if (h->hip_lists) STORM_clear(h->hip_lists);
     h->hip_lists_off = 0;
+    h->hip_words_below = 0;
     return 1;
 }
 
@@ -1093,7 +1098,7 @@ static uint64_t contig_pairw_device_locked(STORM_contiguous_t* h) {
         contig_lists_end(h);
     }
     dense_state_t* st = contig_mirror(h);
-    return st ? dense_state_pairw(st) : ALL_PAIRS_FAILED;
+    return st ? dense_state_pairw(st) : across_ranks(ALL_PAIRS_FAILED);
 }
 
 uint64_t STORM_contig_n_rows(const STORM_contiguous_t* h) { return h ? h->n_data : 0; }
@@ -1675,7 +1680,7 @@ static uint64_t serialized_pairw_locked(const void* buf, uint64_t n_bytes) {
     }
     for (int d = 0; d < MAX_DEVICES; ++d)
         if (arena[d]) storm_hip_sparse_destroy(g_ctx[d], arena[d]);
-    return ok ? across_ranks(total) : ALL_PAIRS_FAILED;
+    return across_ranks(ok ? total : ALL_PAIRS_FAILED);
 }
 
 /* Fingerprint of what the device arena was built from: rows, blocks per row, and per block its
@@ -1879,7 +1884,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
     int verified = 0;
     if (!h->hip_arena || h->hip_dirty || h->hip_generation != g_config_generation) {
         storm_drop_device(h);
-        if (storm_build_arena(h)) return ALL_PAIRS_FAILED;
+        if (storm_build_arena(h)) return across_ranks(ALL_PAIRS_FAILED);
         verified = 1; /* built from the container as it is now */
     }
     for (;;) {
@@ -1888,10 +1893,10 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         j.check = (!verified && !h->hip_private) ? h : NULL;
         j.fingerprint = 0;
         memset(j.part, 0, sizeof(j.part));
-        if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return ALL_PAIRS_FAILED;
+        if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return across_ranks(ALL_PAIRS_FAILED);
         if (j.check && j.fingerprint != h->hip_fingerprint) {
             storm_drop_device(h);
-            if (storm_build_arena(h)) return ALL_PAIRS_FAILED;
+            if (storm_build_arena(h)) return across_ranks(ALL_PAIRS_FAILED);
             verified = 1;
             continue;
         }
@@ -1914,10 +1919,11 @@ int STORM_contig_hip_invalidate(STORM_contiguous_t* h) {
     if (!h) return -1;
     contig_drop_device(h);
     contig_lists_end(h); /* rows edited in place: the list mirror cannot follow them ... */
-    if (!h->hip_pending) h->hip_pending = calloc(1, sizeof(contig_pending_t));
+    /* ... and the rows so far travel as the words they now are, not as the positions they were added with (the
+     * watermark lives in the handle: nothing here depends on an allocation) */
+    h->hip_words_below = h->n_data;
     contig_pending_t* p = (contig_pending_t*)h->hip_pending;
-    if (p) { /* ... and the rows so far travel as the words they now are, not as the positions they were added with */
-        p->words_below = h->n_data;
+    if (p) {
         p->row0 = h->n_data;
         p->n_rows = 0;
         p->n_pos = 0;

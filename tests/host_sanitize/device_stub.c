@@ -183,4 +183,8 @@ int storm_hip_comm_allreduce_u64(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, u
     (void)ctx; (void)comm; (void)value;
     return STORM_HIP_OK;
 }
+int storm_hip_comm_allreduce_u64s(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, uint64_t* values, uint32_t n) {
+    (void)ctx; (void)comm; (void)values; (void)n;   /* a one-rank world: the sum is the value */
+    return STORM_HIP_OK;
+}
 void storm_hip_comm_destroy(storm_hip_comm_t* comm) { free(comm); }

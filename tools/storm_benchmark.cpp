@@ -130,6 +130,15 @@ int main(int argc, char** argv) {
         // One process per GPU. The fork comes BEFORE any HIP call (a process that has initialised the GPU must
         // not be forked), so the device count is not looked at here: every child checks its own device.
         if (ranks > 16) { fprintf(stderr, "--ranks %d: at most 16\n", ranks); return EXIT_FAILURE; }
+        // Under a profiler the preloaded tool library has brought HIP up before main(): the children would inherit
+        // a forked HIP/HSA runtime (undefined behaviour). bench.py refuses the same case.
+        const char* preload = getenv("LD_PRELOAD");
+        if (getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+            (preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer")))) {
+            fprintf(stderr, "--ranks under a profiler: the GPU runtime is already initialised in this process and must "
+                            "not be forked; profile with --gpus N, or one rank per profiler invocation\n");
+            return EXIT_FAILURE;
+        }
         int id_pipe[2];
         if (pipe(id_pipe) != 0) { perror("pipe"); return EXIT_FAILURE; }
         std::vector<pid_t> kids;
