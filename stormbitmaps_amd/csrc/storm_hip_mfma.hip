@@ -412,297 +412,8 @@ struct StripQueues {
 };
 [[maybe_unused]] constexpr uint32_t kNoItem = 0xffffffffu;
 
-#ifdef STORM_HIP_PROBES  // 32x32x64 strips (plain, wide, persistent) and their timing probes: the shipped strips are strip16_fp4_kernel
-template <int kStripRing, int kProbe = 0, int kMB = 2, bool kPersist = false>
-__global__ __launch_bounds__(kStripThreads, (kMB == 2 ? 4 : 2)) void strip_fp4_kernel(
-    const uint8_t* __restrict__ X4, uint64_t row_bytes, const StripItem* __restrict__ items,
-    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ trace = nullptr,
-    StripQueues queues = {}, unsigned int* __restrict__ heads = nullptr) {
-    // the ring, plus one word through which thread 0 hands the next item to the other waves
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripRing * kStripStageBytes + (kPersist ? 64 : 0)];
-    auto lds = reinterpret_cast<uint8_t(*)[kStripStageBytes]>(lds_raw);
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
-    uint32_t item_idx = blockIdx.x;
-    const uint32_t my_queue = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;  // XCC_ID
-    for (;;) {
-    if constexpr (kPersist) {
-        const uint32_t word = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[kStripRing][0];
-        if (tid == 0) {
-            uint32_t got = kNoItem;
-            for (uint32_t r = 0; r < 8u && got == kNoItem; ++r) {  // own queue first, then steal
-                const uint32_t q = (my_queue + r) & 7u;
-                if (queues.count[q] == 0) continue;
-                const uint32_t i = atomicAdd(&heads[q], 1u);
-                if (i < queues.count[q]) got = queues.base[q] + i;
-            }
-            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(word), "v"(got) : "memory");
-        }
-        // also: every wave is done with the previous item's ring before the next DMA lands
-        __builtin_amdgcn_s_barrier();
-        uint32_t got_v;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got_v) : "v"(word) : "memory");
-        item_idx = __builtin_amdgcn_readfirstlane(got_v);
-        if (item_idx == kNoItem) break;
-    }
-    // kProbe bit 3: schedule trace — per item {start, end (100 MHz counter), HW_ID, XCC_ID}
-    unsigned long long t_start = 0, t_ready = 0, t_diag = 0, t_main = 0;
-    if constexpr ((kProbe & 8) != 0) t_start = __builtin_amdgcn_s_memrealtime();
-    constexpr uint32_t kWaveRows = 32u * kMB;                 // A rows of one wave
-    constexpr uint32_t kATile = kWaveRows * kStripWaves;      // A rows of the workgroup
-    constexpr uint32_t kBPW = kMB / 2;                        // 64-row B blocks per wave's rows
-    static_assert(kMB == 2 || kMB == 4, "A rows per wave: 64 or 128");
-    const StripItem it = items[item_idx];
-    const uint64_t kbyte = (uint64_t)it.ks * kStripRowBytes;
-    // Stage order: first (if it.diag) the 4 blocks of the A tile itself — wave wm contributes
-    // nothing for blocks before its own rows, the strict upper triangle of its own 64x64 block,
-    // and everything after — then the later blocks from the LAST one down.
-    const uint32_t D = it.diag ? kATile / (uint32_t)kStripBRows : 0u;
-    const uint32_t T = D + (it.j1 - it.j0);
-
-    // B stage = 8 LDS-DMA instructions of 8 rows x 128 B; wave w issues instructions w and
-    // w + 4. Piece p = n*64 + lane is row p/8, 16-byte slot (p%8) ^ ((row/2)%8) of the stage;
-    // stepping n by 4 adds 32 rows and leaves the swizzle unchanged, so one per-lane offset
-    // serves both and the rest is a scalar base (host guarantees 64 * row_bytes < 2^32).
-    const uint32_t r0 = (wave * 64u + lane) >> 3;
-    const uint32_t goff0 = r0 * (uint32_t)row_bytes + (((lane & 7u) ^ ((r0 >> 1) & 7u)) * 16u);
-    auto issue = [&](uint32_t t) {
-        if constexpr ((kProbe & 2) != 0) return;
-        // B blocks are walked from the LAST one down: all items of one k-slice then start on
-        // the same block at the same time and stay aligned (the shorter ones just stop
-        // earlier), so one of them misses in L2 and the others hit. Walking up from j0, item I
-        // trails item I+1 by four stages and the slice was re-fetched ~7x (profiles/r01_e_*).
-        const uint32_t blk = t < D ? it.a_row0 / (uint32_t)kStripBRows + t
-                                   : it.j1 - 1u - (t - D);
-        const uint8_t* base = X4 + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
-        uint8_t* dst = lds[t % kStripRing] + wave * 1024u;
-        // LDS-DMA as buffer loads (scalar descriptor of the stage + 32-bit lane offsets), not
-        // global_load_lds with 64-bit lane addresses: beside MFMA bursts the latter costs the
-        // wave 18.3 ns per MFMA at 3-4 waves per SIMD, the former 14.2 — as much as no load at
-        // all (tools/ubench_feed, profiles/r01_h_ubench_feed.txt).
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)dst, 16, (int)goff0, 0, 0, 0);
-        if constexpr (kStripPieces == 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + 4096u), 16, (int)goff0,
-                                                     (int)(32u * (uint32_t)row_bytes), 0, 0);
-    };
-
-    // A fragments first (older in the VMEM queue than the DMAs, so waiting for them does not
-    // drain the ring), then the first stages of B
-    v4i a[4][kMB];
-    {
-        const uint8_t* ap = X4 + (uint64_t)(it.a_row0 + wm * kWaveRows + (lane & 31u)) *
-                                     row_bytes + kbyte + (lane >> 5) * 16u;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int m = 0; m < kMB; ++m)
-                a[kk][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 32u * row_bytes +
-                                                         kk * 32);
-    }
-#pragma unroll
-    for (uint32_t t = 0; t < kStripRing - 1; ++t)
-        if (t < T) issue(t);
-
-    v16f acc[kMB][2];
-#pragma unroll
-    for (int m = 0; m < kMB; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
-
-    // per-lane LDS byte offset of its 16-byte B piece inside a stage, per k-step
-    const uint32_t swz = (lane >> 1) & 7u;
-    const uint32_t lds_base =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
-    uint32_t boff[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        boff[kk] = lds_base + (lane & 31u) * kStripRowBytes +
-                   ((((uint32_t)kk * 2u + (lane >> 5)) ^ swz) * 16u);
-    // The B-fragment reads are inline asm with hand-counted lgkmcnt: the two ds_read_b128 of
-    // k-step k+1 are issued BEFORE the 4 MFMAs of k-step k and retired by lgkmcnt(2) ("all but
-    // the 2 youngest") one step later; sched_barrier(0) keeps hipcc from moving MFMAs across
-    // the asm (cdna guide §5.4 rule 18). hipcc's own waits for ds_reads it can see are
-    // lgkmcnt(0) right behind the read.
-    auto fetch = [&](uint32_t t, int kk, v4i (&b)[2]) {
-        if constexpr ((kProbe & 4) != 0) {
-            asm volatile("" : "+v"(b[0]), "+v"(b[1]));  // keep the fragments opaque, read nothing
-            return;
-        }
-        const uint32_t addr = boff[kk] + (t % kStripRing) * kStripStageBytes;
-        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"
-                     : "=&v"(b[0]), "=&v"(b[1])
-                     : "v"(addr));
-    };
-    auto multiply = [&](int kk, const v4i (&b)[2]) {
-        if constexpr ((kProbe & 16) != 0) __builtin_amdgcn_s_setprio(2);  // probe: MFMA bursts first
-#pragma unroll
-        for (int m = 0; m < kMB; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                    v8i{a[kk][m].x, a[kk][m].y, a[kk][m].z, a[kk][m].w, 0, 0, 0, 0},
-                    v8i{b[n].x, b[n].y, b[n].z, b[n].w, 0, 0, 0, 0}, acc[m][n], 4, 4, 0, 0, 0, 0);
-        if constexpr ((kProbe & 16) != 0) __builtin_amdgcn_s_setprio(0);
-    };
-#define STORM_LGKM(n)                                       \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0)
-#define STORM_STEP(q, cur, nxt_fetch, wait) \
-    nxt_fetch;                               \
-    wait;                                    \
-    multiply(q, cur);                        \
-    __builtin_amdgcn_sched_barrier(0)
-
-    // Make hipcc retire the A-fragment loads HERE (they are older than the DMAs, so its counted
-    // wait leaves the ring in flight). Without this use it cannot prove inside the loop that the
-    // loads are done and drains vmcnt(0) in front of the first MFMA of every stage.
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-        for (int m = 0; m < kMB; ++m) asm volatile("" ::"v"(a[kk][m]));
-
-    // Ring protocol. Stages 0..2 are issued by the prologue; every wave issues 2 LDS-DMA
-    // instructions per stage. retire(t, newest): wait until this wave's share of stage t has
-    // landed — the younger stages issued so far (up to `newest`) may stay in flight, hence
-    // vmcnt(2 x their number) — then the barrier makes every wave's share visible and proves that every wave is
-    // done with the stages it read before arriving here.
-    auto retire = [&](uint32_t t, uint32_t newest_issued) {
-        const uint32_t younger = min(T - 1u, newest_issued) - t;  // issued stages newer than t
-        if constexpr (kStripPieces == 2) {
-            if (younger >= 3u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (younger == 2u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (younger == 1u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (younger >= 3u) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (younger == 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (younger == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if constexpr ((kProbe & 1) == 0) __builtin_amdgcn_s_barrier();
-    };
-    static_assert(kStripRing >= 3 && kStripRing <= 5, "vmcnt cases above cover rings of 3..5");
-
-    v4i b0[2] = {}, b1[2] = {};
-    uint32_t t = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
-    if constexpr ((kProbe & 8) != 0) {  // trace only: when are the A fragments in?
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        t_ready = __builtin_amdgcn_s_memrealtime();
-    }
-    // ---- the A tile's own 4 blocks (strict upper triangle), not software-pipelined: wave wm
-    //      skips the blocks before its own rows (only pairs with i > j there), masks its own
-    //      64x64 block, and takes the later ones whole. Kept apart from the main loop so that
-    //      the main loop stays free of selects (hipcc turned an `if (x) frag = 0` inside it into
-    //      v_cndmask on every k-step, which costs MFMA issue slots).
-#pragma unroll 1
-    for (; t < D; ++t) {
-        // (stages up to t + kStripRing - 2 are in the ring; everyone finished stage t-1, so its
-        //  buffer may take stage t + kStripRing - 1)
-        retire(t, t + kStripRing - 2);
-        if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t >= kBPW * wm) {
-            fetch(t, 0, b0);
-            fetch(t, 1, b1);
-            STORM_LGKM(2);
-            multiply(0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(t, 2, b0);
-            STORM_LGKM(2);
-            multiply(1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(t, 3, b1);
-            STORM_LGKM(2);
-            multiply(2, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            STORM_LGKM(0);
-            multiply(3, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            // Block t = kBPW * wm + q holds the q-th 64 rows of this wave (MFMA blocks 2q and
-            // 2q+1). Up to here blocks 2q.. of the accumulators have seen nothing but this
-            // stage (the earlier ones were cleared below), so the pairs with i >= j can be
-            // cleared in place: the blocks of later rows entirely, (2q+1, 0) entirely, and the
-            // two 32x32 blocks on the diagonal down to their strict upper triangle.
-            // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-#pragma unroll
-            for (int q = 0; q < (int)kBPW; ++q) {
-                if (t != kBPW * wm + q) continue;
-#pragma unroll
-                for (int m = 2 * q + 2; m < kMB; ++m) acc[m][0] = acc[m][1] = v16f{};
-                acc[2 * q + 1][0] = v16f{};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const bool keep = row < (lane & 31u);
-                    acc[2 * q][0][r] = keep ? acc[2 * q][0][r] : 0.0f;
-                    acc[2 * q + 1][1][r] = keep ? acc[2 * q + 1][1][r] : 0.0f;
-                }
-            }
-        }
-    }
-    // ---- later blocks, software-pipelined: stage t is retired one iteration early so that the
-    //      fragments of its first k-step are fetched while stage t-1 is still being multiplied;
-    //      iteration t therefore retires stage t+1, and refills the ring with stage t+3 (whose
-    //      buffer held stage t-1: every wave finished it before this iteration's barrier).
-    if constexpr ((kProbe & 8) != 0) t_diag = __builtin_amdgcn_s_memrealtime();
-    if (t < T) {
-        retire(t, t + kStripRing - 2);
-        fetch(t, 0, b0);
-        for (; t < T; ++t) {
-            if (t + 1 < T) retire(t + 1, t + kStripRing - 2);  // the refill comes after the barrier
-            else __builtin_amdgcn_s_barrier();
-            if (t + kStripRing - 1 < T) issue(t + kStripRing - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            STORM_STEP(0, b0, fetch(t, 1, b1), STORM_LGKM(2));
-            STORM_STEP(1, b1, fetch(t, 2, b0), STORM_LGKM(2));
-            STORM_STEP(2, b0, fetch(t, 3, b1), STORM_LGKM(2));
-            // (after the last stage this re-reads k-step 0 of the same stage: never consumed;
-            //  keeping the loop body branch-free lets hipcc accumulate in place — with a
-            //  two-armed tail it ping-ponged between two accumulator sets and spilled)
-            STORM_STEP(3, b1, fetch(t + 1 < T ? t + 1 : t, 0, b0), STORM_LGKM(2));
-        }
-        STORM_LGKM(0);
-    }
-#undef STORM_STEP
-#undef STORM_LGKM
-    if constexpr ((kProbe & 8) != 0) t_main = __builtin_amdgcn_s_memrealtime();
-
-    uint64_t mine = 0;
-#pragma unroll
-    for (int m = 0; m < kMB; ++m) {  // one 32x64 strip at a time stays below 2^32
-        uint32_t part = 0;
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part += (uint32_t)acc[m][n][r];
-        mine += part;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    if (lane == 0 && mine != 0)
-        atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
-                  (unsigned long long)mine);
-    if constexpr ((kProbe & 8) != 0) {
-        if (tid == 0 && trace) {
-            trace[item_idx * 4ull + 0] = t_start;
-            trace[item_idx * 4ull + 1] = __builtin_amdgcn_s_memrealtime();
-            // phase marks relative to the start, 16 bits each in 10 ns units:
-            // A fragments + first stages in | diagonal phase done | main loop done
-            trace[item_idx * 4ull + 2] = ((t_ready - t_start) & 0xffffull) |
-                                         (((t_diag - t_start) & 0xffffull) << 16) |
-                                         (((t_main - t_start) & 0xffffull) << 32);
-            trace[item_idx * 4ull + 3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
-        }
-    }
-    if constexpr (!kPersist) break;
-    }  // items
-}
+#ifdef STORM_HIP_PROBES  // 32x32x64 strips (plain, wide, persistent) and their timing probes: tools build (make probes)
+#include "../../tools/probes/strip_fp4_32.hip"
 #endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
@@ -1287,199 +998,8 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
 constexpr int kT16RowBytes = 128;                       // two k-steps of 128 bits
 [[maybe_unused]] constexpr int kT16StageBytes = kTile * kT16RowBytes;    // B only: 32 KiB
 
-#ifdef STORM_HIP_PROBES  // FP4-shadow output kernel, 45 % slower than tilebits8_kernel; tools build
-__global__ __launch_bounds__(kMfmaThreads, 2) void tile16_fp4_kernel(
-    const uint8_t* __restrict__ X4, uint64_t row_bytes, const MfmaItem* __restrict__ items,
-    uint32_t* __restrict__ out, uint64_t ld, uint32_t n_rows, const uint32_t* __restrict__ row_counts,
-    uint32_t and_weight, uint32_t j_base, uint32_t j_count, uint32_t split_from, uint32_t i_lo,
-    uint32_t n_cols) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[kT16Ring][kT16StageBytes];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t item_idx = blockIdx.x;
-    const MfmaItem it = items[item_idx];
-    const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
-    // items count 64-byte stages (MfmaItem, shared with the 32x32 kernel): two per stage here; an odd
-    // count cannot occur (rows are padded to 64 words = 32 such stages, k-parts are cut on even stages)
-    const uint32_t S = it.n_stages / 2u;
-    const uint64_t kbyte0 = (uint64_t)it.stage0 * kStageBytes;
-
-    // B stage DMA: instruction n fills LDS bytes [1024 n, +1024) = rows 8 n .. 8 n + 7; piece
-    // p = 64 n + lane is row p / 8, physical slot p % 8, which holds the row's logical 16-byte slot
-    // (p % 8) ^ ((row / 2) % 8). Wave w issues instructions w, w + 8, w + 16, w + 24 (rows + 64 each:
-    // same swizzle), so one per-lane offset serves all four.
-    const uint32_t brow = wave * 8u + (lane >> 3);
-    const uint32_t boff = brow * (uint32_t)row_bytes + (((lane & 7u) ^ ((brow >> 1) & 7u)) * 16u);
-    auto issue_b = [&](uint32_t s) {
-        const uint8_t* base = X4 + (uint64_t)b_row0 * row_bytes + kbyte0 + (uint64_t)s * kT16RowBytes;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
-        uint8_t* dst = lds[s % kT16Ring] + wave * 1024u;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + q * 8192u), 16, (int)boff,
-                                                     (int)(q * 64u * (uint32_t)row_bytes), 0, 0);
-    };
-    // A fragments of stage s: rows a_row0 + 32 w + 16 m + (lane & 15), bytes 128 s + 64 kk + 16 (lane >> 4)
-    // (inline asm: hipcc then leaves the waiting to the counted vmcnt below; for loads it can see it
-    //  drains vmcnt(0) — and with it the DMA ring — in front of the first MFMA of a loop body)
-    const uint8_t* ap = X4 + (uint64_t)(a_row0 + wave * 32u + (lane & 15u)) * row_bytes + kbyte0 +
-                        (lane >> 4) * 16u;
-    v4i aA[2][2], aB[2][2];  // [kk][m]; stage s lives in aA for even s, aB for odd s
-    auto load_a = [&](uint32_t s, v4i (&dst)[2][2]) {
-        const uint8_t* p0 = ap + (uint64_t)s * kT16RowBytes;
-        const uint8_t* p1 = p0 + 16ull * row_bytes;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %5, off\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %5, off offset:64"
-                     : "=&v"(dst[0][0]), "=&v"(dst[0][1]), "=&v"(dst[1][0]), "=&v"(dst[1][1])
-                     : "v"(p0), "v"(p1)
-                     : "memory");
-    };
-
-    v4f acc[2][16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 16; ++n) acc[m][n] = v4f{};
-
-    // B fragment (k-step kk, block n) of a stage: row 16 n + (lane & 15), logical slot 4 kk + (lane >> 4)
-    const uint32_t lds_base =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
-    const uint32_t swz = ((lane & 15u) >> 1) & 7u;
-    uint32_t frag[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-        frag[kk] = lds_base + (lane & 15u) * kT16RowBytes + ((((uint32_t)kk * 4u + (lane >> 4)) ^ swz) * 16u);
-
-    // prologue, in the loop's issue order: the stages that are older than everything, then the
-    // pseudo-iteration -1
-    issue_b(0);
-    if (1 < S) issue_b(1);
-    load_a(0, aA);
-    if (2 < S) issue_b(2);
-
-#define STORM_T16_FETCH(dst, stage_base, kk, n) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(frag[kk] + (stage_base)), "n"((n) * 16 * kT16RowBytes))
-#define STORM_T16_MUL(kk, n, av, bv)                                                                \
-    acc[0][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                   \
-        v8i{av[kk][0].x, av[kk][0].y, av[kk][0].z, av[kk][0].w, 0, 0, 0, 0},                        \
-        v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, 0, 0, 0);                      \
-    acc[1][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                                   \
-        v8i{av[kk][1].x, av[kk][1].y, av[kk][1].z, av[kk][1].w, 0, 0, 0, 0},                        \
-        v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, 0, 0, 0)
-    // step t: waves 4-7 issue the stage's DMA in front of step 16 (see "stagger" above)
-#define STORM_T16_STEP(kk, n, av, cur, nxt, nxt_base, nxt_kk, nxt_n, t)  \
-    if ((t) == 16 && late_dma && dma_stage < S) issue_b(dma_stage);      \
-    STORM_T16_FETCH(nxt, nxt_base, nxt_kk, nxt_n);                       \
-    asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                   \
-    __builtin_amdgcn_sched_barrier(0);                                   \
-    STORM_T16_MUL(kk, n, av, cur);                                       \
-    __builtin_amdgcn_sched_barrier(0)
-#define STORM_T16_STAGE(av) \
-    STORM_T16_STEP(0, 0, av, b0, b3, sb, 0, 3, 0); \
-    STORM_T16_STEP(0, 1, av, b1, b0, sb, 0, 4, 1); \
-    STORM_T16_STEP(0, 2, av, b2, b1, sb, 0, 5, 2); \
-    STORM_T16_STEP(0, 3, av, b3, b2, sb, 0, 6, 3); \
-    STORM_T16_STEP(0, 4, av, b0, b3, sb, 0, 7, 4); \
-    STORM_T16_STEP(0, 5, av, b1, b0, sb, 0, 8, 5); \
-    STORM_T16_STEP(0, 6, av, b2, b1, sb, 0, 9, 6); \
-    STORM_T16_STEP(0, 7, av, b3, b2, sb, 0, 10, 7); \
-    STORM_T16_STEP(0, 8, av, b0, b3, sb, 0, 11, 8); \
-    STORM_T16_STEP(0, 9, av, b1, b0, sb, 0, 12, 9); \
-    STORM_T16_STEP(0, 10, av, b2, b1, sb, 0, 13, 10); \
-    STORM_T16_STEP(0, 11, av, b3, b2, sb, 0, 14, 11); \
-    STORM_T16_STEP(0, 12, av, b0, b3, sb, 0, 15, 12); \
-    STORM_T16_STEP(0, 13, av, b1, b0, sb, 1, 0, 13); \
-    STORM_T16_STEP(0, 14, av, b2, b1, sb, 1, 1, 14); \
-    STORM_T16_STEP(0, 15, av, b3, b2, sb, 1, 2, 15); \
-    STORM_T16_STEP(1, 0, av, b0, b3, sb, 1, 3, 16); \
-    STORM_T16_STEP(1, 1, av, b1, b0, sb, 1, 4, 17); \
-    STORM_T16_STEP(1, 2, av, b2, b1, sb, 1, 5, 18); \
-    STORM_T16_STEP(1, 3, av, b3, b2, sb, 1, 6, 19); \
-    STORM_T16_STEP(1, 4, av, b0, b3, sb, 1, 7, 20); \
-    STORM_T16_STEP(1, 5, av, b1, b0, sb, 1, 8, 21); \
-    STORM_T16_STEP(1, 6, av, b2, b1, sb, 1, 9, 22); \
-    STORM_T16_STEP(1, 7, av, b3, b2, sb, 1, 10, 23); \
-    STORM_T16_STEP(1, 8, av, b0, b3, sb, 1, 11, 24); \
-    STORM_T16_STEP(1, 9, av, b1, b0, sb, 1, 12, 25); \
-    STORM_T16_STEP(1, 10, av, b2, b1, sb, 1, 13, 26); \
-    STORM_T16_STEP(1, 11, av, b3, b2, sb, 1, 14, 27); \
-    STORM_T16_STEP(1, 12, av, b0, b3, sb, 1, 15, 28); \
-    STORM_T16_STEP(1, 13, av, b1, b0, sn, 0, 0, 29); \
-    STORM_T16_STEP(1, 14, av, b2, b1, sn, 0, 1, 30); \
-    STORM_T16_STEP(1, 15, av, b3, b2, sn, 0, 2, 31);
-
-    const bool late_dma = wave >= 4u;
-    v4i b0 = {}, b1 = {}, b2 = {}, b3 = {};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
-    // stage 0 must be in the LDS before its first three fragments are fetched (later stages: fetched
-    // by the stage before); draining the prologue's prefetch once per item costs nothing measurable
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    STORM_T16_FETCH(b0, 0u, 0, 0);
-    STORM_T16_FETCH(b1, 0u, 0, 1);
-    STORM_T16_FETCH(b2, 0u, 0, 2);
-    // One stage: A(s) in `use`, A(s+1) loaded into `into`. The loop body is two stages long so that
-    // the alternation of the A registers is a matter of names, not of branches or moves (a
-    // multi-armed body made hipcc keep several accumulator sets and spill).
-#define STORM_T16_BODY(s, use, into)                                                           \
-    {                                                                                          \
-        /* A(s) and the B stages up to s + 1 are in once only stage s + 2's 4 DMAs remain */   \
-        if ((s) + kT16Ring - 1 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  \
-        __builtin_amdgcn_s_barrier();                                                          \
-        const uint32_t sb = ((s) % kT16Ring) * kT16StageBytes;                                 \
-        /* (after the last stage `sn` re-reads the same stage: never consumed; branch-free body) */ \
-        const uint32_t sn = (((s) + 1 < S ? (s) + 1 : (s)) % kT16Ring) * kT16StageBytes;       \
-        const uint32_t dma_stage = (s) + kT16Ring - 1;                                         \
-        if ((s) + 1 < S) load_a((s) + 1, into);                                                \
-        if (!late_dma && dma_stage < S) issue_b(dma_stage);                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                     \
-        STORM_T16_STAGE(use);                                                                  \
-    }
-    uint32_t s = 0;
-    for (; s + 2 <= S; s += 2) {
-        STORM_T16_BODY(s, aA, aB);
-        STORM_T16_BODY(s + 1, aB, aA);
-    }
-    if (s < S) {
-        STORM_T16_BODY(s, aA, aB);
-        ++s;
-    }
-#undef STORM_T16_BODY
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef STORM_T16_STAGE
-#undef STORM_T16_STEP
-#undef STORM_T16_MUL
-#undef STORM_T16_FETCH
-
-    // ---- epilogue: C/D map of the 16x16 form: col = lane & 15, row = 4 * (lane >> 4) + reg
-    const bool rect = j_count != 0;
-#pragma unroll
-    for (int n = 0; n < 16; ++n) {
-        const uint32_t j = b_row0 + (uint32_t)n * 16u + (lane & 15u);
-        const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
-        const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const uint32_t i = a_row0 + wave * 32u + (uint32_t)m * 16u + 4u * (lane >> 4) + (uint32_t)r;
-                if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
-                    const uint32_t c = (uint32_t)acc[m][n][r];
-                    uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
-                    if (item_idx < split_from) {
-                        *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
-                    } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
-                        const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
-                        atomicAdd(dst, row_counts ? once - and_weight * c : c);
-                    }
-                }
-            }
-    }
-}
+#ifdef STORM_HIP_PROBES  // FP4-shadow output kernel on 16x16x128 MFMAs (45 % slower than tilebits8_kernel): tools build (make probes)
+#include "../../tools/probes/tile16_fp4.hip"
 #endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
@@ -1580,432 +1100,8 @@ __device__ __forceinline__ void tb_store_interior(const v16f (&acc)[MB][4], uint
 }
 
 
-#ifdef STORM_HIP_PROBES  // one wave per SIMD: 3 % slower than tilebits8_kernel; tools build
-__global__ __launch_bounds__(kTbThreads, 1) void tilebits_kernel(
-    TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
-    uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
-    uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbRing][kTbStageBytes];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wa = wave & 1u, wb = wave >> 1;
-    const uint32_t item_idx = blockIdx.x;
-    const MfmaItem it = items[item_idx];
-    const uint32_t a_row0 = (uint32_t)it.I * kTile, b_row0 = (uint32_t)it.J * kTile;
-    const uint32_t S = it.n_stages / 4u;                  // items count 128-bit stages; cuts fall on 4
-    const uint32_t kbyte0 = it.stage0 * 16u;              // byte of the row where this item starts
-    const uint32_t pitch = (uint32_t)ops.pitch;
-
-    // operand windows: base of the tile's first row and the bytes of it that exist
-    auto window = [&](uint32_t v0, const uint8_t*& base, uint32_t& bytes) {
-        const bool second = v0 >= ops.split;
-        const uint32_t r0 = second ? v0 - ops.split : v0;
-        const uint32_t have = second ? ops.rows_b : ops.rows_a;
-        const uint32_t rows = have > r0 ? min(have - r0, (uint32_t)kTile) : 0u;
-        base = (second ? ops.xb : ops.xa) + (uint64_t)r0 * ops.pitch;
-        bytes = rows * pitch;
-    };
-    const uint8_t *a_base, *b_base;
-    uint32_t a_bytes, b_bytes;
-    window(a_row0, a_base, a_bytes);
-    window(b_row0, b_base, b_bytes);
-
-    // DMA: an image is 16 wave-instructions of 1 KiB (16 rows each). Piece p of a stage (one per class
-    // phase): instruction w + 4 (p % 4) of the A image (p < 4) or of the B image. Lane L fills row
-    // L / 4 of the instruction, physical slot L % 4 = logical slot (L % 4) ^ ((L / 16) % 4).
-    const uint32_t voff0 = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
-    auto issue_piece = [&](uint32_t s, uint32_t p) {
-        const uint32_t koff = kbyte0 + s * kTbRowBytes;
-        const bool second = p >= 4u;
-        // (past the last stage the piece is still issued, with an empty range: a branch-free loop
-        //  body keeps every piece where it is written, and the count below stays the same)
-        const uint32_t bytes = s < S ? (second ? b_bytes : a_bytes) : 0u;
-        // (a window with rows has koff < pitch <= bytes; written as a select on `bytes != 0`, not as
-        //  a saturating subtraction, which has no scalar form and turns the descriptor divergent)
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>((second ? b_base : a_base) + koff), 0, bytes ? bytes - koff : 0u, 0x00020000);
-        uint8_t* dst = lds[s % kTbRing] + (second ? kTbImageBytes : 0) + (wave + 4u * (p & 3u)) * 1024u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)dst, 16, (int)(voff0 + (p & 3u) * 64u * pitch), 0, 0, 0);
-    };
-    auto issue = [&](uint32_t s) {
-#pragma unroll
-        for (uint32_t p = 0; p < 8; ++p) issue_piece(s, p);
-    };
-
-    v16f acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = v16f{};
-
-    // fragment of block t in k-group g: row 32 t + (lane & 31), logical slot 2 g + (lane >> 5)
-    const uint32_t lds_base =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
-    const uint32_t slot = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
-    const uint32_t a_frag0 = lds_base + (wa * 128u + (lane & 31u)) * kTbRowBytes + slot * 16u;
-    const uint32_t a_frag1 = lds_base + (wa * 128u + (lane & 31u)) * kTbRowBytes + (slot ^ 2u) * 16u;
-    const uint32_t b_delta = kTbImageBytes + wb * 128u * kTbRowBytes - wa * 128u * kTbRowBytes;
-
-    issue(0);
-    issue(1);
-    issue(2);
-
-    // (every look-ahead read of these kernels feeds a loop-carried value, alive to the wait behind the loop:
-    //  no read's output is dead in hipcc's eyes while it is still in flight — see STORM_SB_KEEP below)
-#define STORM_TB_FETCH(dst, addr, n) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"((n) * 32 * kTbRowBytes))
-#define STORM_TB_MUL(C, m, n, av, bv)                                                               \
-    acc[m][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                    \
-        v8i{av[m].x, av[m].y, av[m].z, av[m].w, 0, 0, 0, 0}, v8i{bv.x, bv.y, bv.z, bv.w, 0, 0, 0, 0}, \
-        acc[m][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>())
-
-    v4i xa[4], xb[4], ya[4], yb[4];  // bits of the k-group in use / of the next one (x: even groups)
-    v4i ao[4], an[4], bo, bn = {};   // inflated A blocks of the running / next class phase, B block
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-        const uint32_t b0 = a_frag0 + b_delta;
-        STORM_TB_FETCH(xa[0], a_frag0, 0);
-        STORM_TB_FETCH(xa[1], a_frag0, 1);
-        STORM_TB_FETCH(xa[2], a_frag0, 2);
-        STORM_TB_FETCH(xa[3], a_frag0, 3);
-        STORM_TB_FETCH(xb[0], b0, 0);
-        STORM_TB_FETCH(xb[1], b0, 1);
-        STORM_TB_FETCH(xb[2], b0, 2);
-        STORM_TB_FETCH(xb[3], b0, 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) ao[m] = tb_inflate<0>(xa[m]);
-        bo = tb_inflate<0>(xb[0]);
-    }
-    // At the top of stage s the wave's DMA pieces of stage s + 1 must have landed (only stage
-    // s + 2's eight may stay in flight): the second k-group reads one k-group ahead, into it. The
-    // barrier makes that true of every wave's share and says that every wave is done with stage
-    // s - 1, whose slot stage s + 3 takes.
-    for (uint32_t s = 0; s < S; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // (after the last stage the look-ahead re-reads the same stage: never consumed)
-        const uint32_t cur = (s % kTbRing) * kTbStageBytes;
-        const uint32_t nxs = ((s + 1 < S ? s + 1 : s) % kTbRing) * kTbStageBytes;
-        const uint32_t a1 = a_frag1 + cur, b1 = a1 + b_delta;
-        const uint32_t a0n = a_frag0 + nxs, b0n = a0n + b_delta;
-        const uint32_t dma_stage = s + kTbRing - 1;
-        // k-group 0, class 0
-        issue_piece(dma_stage, 0);
-        STORM_TB_FETCH(ya[0], a1, 0);
-        STORM_TB_FETCH(ya[1], a1, 1);
-        STORM_TB_FETCH(ya[2], a1, 2);
-        STORM_TB_FETCH(ya[3], a1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 0, ao, bo);
-        bn = tb_inflate<0>(xb[1]);
-        STORM_TB_MUL(0, 1, 0, ao, bo);
-        an[0] = tb_inflate<1>(xa[0]);
-        STORM_TB_MUL(0, 2, 0, ao, bo);
-        STORM_TB_MUL(0, 3, 0, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 1, ao, bn);
-        bo = tb_inflate<0>(xb[2]);
-        STORM_TB_MUL(0, 1, 1, ao, bn);
-        an[1] = tb_inflate<1>(xa[1]);
-        STORM_TB_MUL(0, 2, 1, ao, bn);
-        STORM_TB_MUL(0, 3, 1, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 2, ao, bo);
-        bn = tb_inflate<0>(xb[3]);
-        STORM_TB_MUL(0, 1, 2, ao, bo);
-        an[2] = tb_inflate<1>(xa[2]);
-        STORM_TB_MUL(0, 2, 2, ao, bo);
-        STORM_TB_MUL(0, 3, 2, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 3, ao, bn);
-        bo = tb_inflate<1>(xb[0]);
-        STORM_TB_MUL(0, 1, 3, ao, bn);
-        an[3] = tb_inflate<1>(xa[3]);
-        STORM_TB_MUL(0, 2, 3, ao, bn);
-        STORM_TB_MUL(0, 3, 3, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 1
-        issue_piece(dma_stage, 1);
-        STORM_TB_FETCH(yb[0], b1, 0);
-        STORM_TB_FETCH(yb[1], b1, 1);
-        STORM_TB_FETCH(yb[2], b1, 2);
-        STORM_TB_FETCH(yb[3], b1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 0, an, bo);
-        bn = tb_inflate<1>(xb[1]);
-        STORM_TB_MUL(1, 1, 0, an, bo);
-        ao[0] = tb_inflate<2>(xa[0]);
-        STORM_TB_MUL(1, 2, 0, an, bo);
-        STORM_TB_MUL(1, 3, 0, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 1, an, bn);
-        bo = tb_inflate<1>(xb[2]);
-        STORM_TB_MUL(1, 1, 1, an, bn);
-        ao[1] = tb_inflate<2>(xa[1]);
-        STORM_TB_MUL(1, 2, 1, an, bn);
-        STORM_TB_MUL(1, 3, 1, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 2, an, bo);
-        bn = tb_inflate<1>(xb[3]);
-        STORM_TB_MUL(1, 1, 2, an, bo);
-        ao[2] = tb_inflate<2>(xa[2]);
-        STORM_TB_MUL(1, 2, 2, an, bo);
-        STORM_TB_MUL(1, 3, 2, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 3, an, bn);
-        bo = tb_inflate<2>(xb[0]);
-        STORM_TB_MUL(1, 1, 3, an, bn);
-        ao[3] = tb_inflate<2>(xa[3]);
-        STORM_TB_MUL(1, 2, 3, an, bn);
-        STORM_TB_MUL(1, 3, 3, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 2
-        issue_piece(dma_stage, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 0, ao, bo);
-        bn = tb_inflate<2>(xb[1]);
-        STORM_TB_MUL(2, 1, 0, ao, bo);
-        an[0] = tb_inflate<3>(xa[0]);
-        STORM_TB_MUL(2, 2, 0, ao, bo);
-        STORM_TB_MUL(2, 3, 0, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 1, ao, bn);
-        bo = tb_inflate<2>(xb[2]);
-        STORM_TB_MUL(2, 1, 1, ao, bn);
-        an[1] = tb_inflate<3>(xa[1]);
-        STORM_TB_MUL(2, 2, 1, ao, bn);
-        STORM_TB_MUL(2, 3, 1, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 2, ao, bo);
-        bn = tb_inflate<2>(xb[3]);
-        STORM_TB_MUL(2, 1, 2, ao, bo);
-        an[2] = tb_inflate<3>(xa[2]);
-        STORM_TB_MUL(2, 2, 2, ao, bo);
-        STORM_TB_MUL(2, 3, 2, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 3, ao, bn);
-        bo = tb_inflate<3>(xb[0]);
-        STORM_TB_MUL(2, 1, 3, ao, bn);
-        an[3] = tb_inflate<3>(xa[3]);
-        STORM_TB_MUL(2, 2, 3, ao, bn);
-        STORM_TB_MUL(2, 3, 3, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 0, class 3
-        issue_piece(dma_stage, 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 0, an, bo);
-        bn = tb_inflate<3>(xb[1]);
-        STORM_TB_MUL(3, 1, 0, an, bo);
-        ao[0] = tb_inflate<0>(ya[0]);
-        STORM_TB_MUL(3, 2, 0, an, bo);
-        STORM_TB_MUL(3, 3, 0, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 1, an, bn);
-        bo = tb_inflate<3>(xb[2]);
-        STORM_TB_MUL(3, 1, 1, an, bn);
-        ao[1] = tb_inflate<0>(ya[1]);
-        STORM_TB_MUL(3, 2, 1, an, bn);
-        STORM_TB_MUL(3, 3, 1, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 2, an, bo);
-        bn = tb_inflate<3>(xb[3]);
-        STORM_TB_MUL(3, 1, 2, an, bo);
-        ao[2] = tb_inflate<0>(ya[2]);
-        STORM_TB_MUL(3, 2, 2, an, bo);
-        STORM_TB_MUL(3, 3, 2, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 3, an, bn);
-        bo = tb_inflate<0>(yb[0]);
-        STORM_TB_MUL(3, 1, 3, an, bn);
-        ao[3] = tb_inflate<0>(ya[3]);
-        STORM_TB_MUL(3, 2, 3, an, bn);
-        STORM_TB_MUL(3, 3, 3, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 0
-        issue_piece(dma_stage, 4);
-        STORM_TB_FETCH(xa[0], a0n, 0);
-        STORM_TB_FETCH(xa[1], a0n, 1);
-        STORM_TB_FETCH(xa[2], a0n, 2);
-        STORM_TB_FETCH(xa[3], a0n, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 0, ao, bo);
-        bn = tb_inflate<0>(yb[1]);
-        STORM_TB_MUL(0, 1, 0, ao, bo);
-        an[0] = tb_inflate<1>(ya[0]);
-        STORM_TB_MUL(0, 2, 0, ao, bo);
-        STORM_TB_MUL(0, 3, 0, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 1, ao, bn);
-        bo = tb_inflate<0>(yb[2]);
-        STORM_TB_MUL(0, 1, 1, ao, bn);
-        an[1] = tb_inflate<1>(ya[1]);
-        STORM_TB_MUL(0, 2, 1, ao, bn);
-        STORM_TB_MUL(0, 3, 1, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 2, ao, bo);
-        bn = tb_inflate<0>(yb[3]);
-        STORM_TB_MUL(0, 1, 2, ao, bo);
-        an[2] = tb_inflate<1>(ya[2]);
-        STORM_TB_MUL(0, 2, 2, ao, bo);
-        STORM_TB_MUL(0, 3, 2, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(0, 0, 3, ao, bn);
-        bo = tb_inflate<1>(yb[0]);
-        STORM_TB_MUL(0, 1, 3, ao, bn);
-        an[3] = tb_inflate<1>(ya[3]);
-        STORM_TB_MUL(0, 2, 3, ao, bn);
-        STORM_TB_MUL(0, 3, 3, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 1
-        issue_piece(dma_stage, 5);
-        STORM_TB_FETCH(xb[0], b0n, 0);
-        STORM_TB_FETCH(xb[1], b0n, 1);
-        STORM_TB_FETCH(xb[2], b0n, 2);
-        STORM_TB_FETCH(xb[3], b0n, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 0, an, bo);
-        bn = tb_inflate<1>(yb[1]);
-        STORM_TB_MUL(1, 1, 0, an, bo);
-        ao[0] = tb_inflate<2>(ya[0]);
-        STORM_TB_MUL(1, 2, 0, an, bo);
-        STORM_TB_MUL(1, 3, 0, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 1, an, bn);
-        bo = tb_inflate<1>(yb[2]);
-        STORM_TB_MUL(1, 1, 1, an, bn);
-        ao[1] = tb_inflate<2>(ya[1]);
-        STORM_TB_MUL(1, 2, 1, an, bn);
-        STORM_TB_MUL(1, 3, 1, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 2, an, bo);
-        bn = tb_inflate<1>(yb[3]);
-        STORM_TB_MUL(1, 1, 2, an, bo);
-        ao[2] = tb_inflate<2>(ya[2]);
-        STORM_TB_MUL(1, 2, 2, an, bo);
-        STORM_TB_MUL(1, 3, 2, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(1, 0, 3, an, bn);
-        bo = tb_inflate<2>(yb[0]);
-        STORM_TB_MUL(1, 1, 3, an, bn);
-        ao[3] = tb_inflate<2>(ya[3]);
-        STORM_TB_MUL(1, 2, 3, an, bn);
-        STORM_TB_MUL(1, 3, 3, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 2
-        issue_piece(dma_stage, 6);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 0, ao, bo);
-        bn = tb_inflate<2>(yb[1]);
-        STORM_TB_MUL(2, 1, 0, ao, bo);
-        an[0] = tb_inflate<3>(ya[0]);
-        STORM_TB_MUL(2, 2, 0, ao, bo);
-        STORM_TB_MUL(2, 3, 0, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 1, ao, bn);
-        bo = tb_inflate<2>(yb[2]);
-        STORM_TB_MUL(2, 1, 1, ao, bn);
-        an[1] = tb_inflate<3>(ya[1]);
-        STORM_TB_MUL(2, 2, 1, ao, bn);
-        STORM_TB_MUL(2, 3, 1, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 2, ao, bo);
-        bn = tb_inflate<2>(yb[3]);
-        STORM_TB_MUL(2, 1, 2, ao, bo);
-        an[2] = tb_inflate<3>(ya[2]);
-        STORM_TB_MUL(2, 2, 2, ao, bo);
-        STORM_TB_MUL(2, 3, 2, ao, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(2, 0, 3, ao, bn);
-        bo = tb_inflate<3>(yb[0]);
-        STORM_TB_MUL(2, 1, 3, ao, bn);
-        an[3] = tb_inflate<3>(ya[3]);
-        STORM_TB_MUL(2, 2, 3, ao, bn);
-        STORM_TB_MUL(2, 3, 3, ao, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        // k-group 1, class 3
-        issue_piece(dma_stage, 7);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 0, an, bo);
-        bn = tb_inflate<3>(yb[1]);
-        STORM_TB_MUL(3, 1, 0, an, bo);
-        ao[0] = tb_inflate<0>(xa[0]);
-        STORM_TB_MUL(3, 2, 0, an, bo);
-        STORM_TB_MUL(3, 3, 0, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 1, an, bn);
-        bo = tb_inflate<3>(yb[2]);
-        STORM_TB_MUL(3, 1, 1, an, bn);
-        ao[1] = tb_inflate<0>(xa[1]);
-        STORM_TB_MUL(3, 2, 1, an, bn);
-        STORM_TB_MUL(3, 3, 1, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 2, an, bo);
-        bn = tb_inflate<3>(yb[3]);
-        STORM_TB_MUL(3, 1, 2, an, bo);
-        ao[2] = tb_inflate<0>(xa[2]);
-        STORM_TB_MUL(3, 2, 2, an, bo);
-        STORM_TB_MUL(3, 3, 2, an, bo);
-        __builtin_amdgcn_sched_barrier(0);
-        STORM_TB_MUL(3, 0, 3, an, bn);
-        bo = tb_inflate<0>(xb[0]);
-        STORM_TB_MUL(3, 1, 3, an, bn);
-        ao[3] = tb_inflate<0>(xa[3]);
-        STORM_TB_MUL(3, 2, 3, an, bn);
-        STORM_TB_MUL(3, 3, 3, an, bn);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the empty pieces of the tail, too
-#undef STORM_TB_MUL
-#undef STORM_TB_FETCH
-
-    // ---- epilogue: C/D map of the 32x32 form: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    const bool rect = j_count != 0;
-    {
-        const uint32_t col0 = b_row0 - j_base;  // rect: j_base <= b_row0 is implied by the range test
-        const bool interior =
-            item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
-            (rect ? (b_row0 >= j_base && col0 + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
-            (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
-        if (interior) {
-            __builtin_amdgcn_s_barrier();  // every wave has left the ring
-            tb_store_interior<4>(acc, &lds[0][0] + wave * 16384u,
-                                 &out[(uint64_t)(a_row0 + wa * 128u - i_lo) * ld + col0 + wb * 128u], ld, lane,
-                                 row_counts, a_row0 + wa * 128u, b_row0 + wb * 128u, and_weight);
-            return;
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const uint32_t j = b_row0 + wb * 128u + (uint32_t)n * 32u + (lane & 31u);
-        const bool j_ok = rect ? (j >= j_base && j - j_base < j_count) : j < n_cols;
-        const uint32_t nj = (row_counts && j_ok) ? row_counts[j] : 0u;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t i = a_row0 + wa * 128u + (uint32_t)m * 32u + (uint32_t)((r & 3) + 8 * (r >> 2)) +
-                                   4u * (lane >> 5);
-                if (j_ok && i >= i_lo && i < n_rows && (rect || i < j)) {
-                    const uint32_t c = (uint32_t)acc[m][n][r];
-                    uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
-                    if (item_idx < split_from) {
-                        *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
-                    } else {  // partial over k: the n_i + n_j term once, mod 2^32 throughout
-                        const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
-                        atomicAdd(dst, row_counts ? once - and_weight * c : c);
-                    }
-                }
-            }
-    }
-}
+#ifdef STORM_HIP_PROBES  // bit-operand output kernel, one wave per SIMD (3 % slower than tilebits8_kernel): tools build (make probes)
+#include "../../tools/probes/tilebits.hip"
 #endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
@@ -2301,210 +1397,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
 constexpr int kSbRowBytes = 64;                                  // 512 bits of k
 constexpr int kSbStageBytes = kStripBRows * kSbRowBytes;         // 4 KiB
 
-#ifdef STORM_HIP_PROBES  // superseded by bitstream_kernel (K2q); kept for A/B in the tools build
-constexpr int kSbRing = 4;
-__global__ __launch_bounds__(kStripThreads, 3) void stripbits_kernel(
-    const uint8_t* __restrict__ X, uint64_t pitch64, const StripItem* __restrict__ items,
-    unsigned long long* __restrict__ slots) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSbRing * kSbStageBytes];
-    auto lds = reinterpret_cast<uint8_t(*)[kSbStageBytes]>(lds_raw);
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave;  // waves stacked along A; every wave multiplies all 64 B rows
-    const uint32_t item_idx = blockIdx.x;
-    const StripItem it = items[item_idx];
-    const uint32_t pitch = (uint32_t)pitch64;
-    const uint8_t* Xk = X + (uint64_t)it.ks * kSbRowBytes;  // the item's k-slice of row 0
-    constexpr uint32_t kATile = (uint32_t)kStripATile;
-    const uint32_t D = it.diag ? kATile / (uint32_t)kStripBRows : 0u;
-    const uint32_t T = D + (it.j1 - it.j0);
-
-    // B stage = 4 LDS-DMA pieces of 16 rows x 64 B, one per wave. Lane L fills row L / 4 of the piece,
-    // physical slot L % 4 = logical slot (L % 4) ^ ((L / 16) % 4)  (image: slot s of row r at s ^ ((r / 4) % 4))
-    const uint32_t goff = (wave * 16u + (lane >> 2)) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
-    auto issue = [&](uint32_t t) {
-        const uint32_t blk = t < D ? it.a_row0 / (uint32_t)kStripBRows + t : it.j1 - 1u - (t - D);
-        const uint8_t* base = Xk + (uint64_t)blk * ((uint64_t)kStripBRows * pitch64);
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(lds[t % kSbRing] + wave * 1024u), 16, (int)goff, 0,
-                                                 0, 0);
-    };
-
-    // A bits first (older in the VMEM queue than the DMAs)
-    v4i abits[2][2];  // [k-group][row block]
-    {
-        const uint8_t* ap = Xk + (uint64_t)(it.a_row0 + wm * 64u + (lane & 31u)) * pitch64 + (lane >> 5) * 16u;
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-                abits[g][m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 32u * pitch64 + g * 32);
-    }
-#pragma unroll
-    for (uint32_t t = 0; t < kSbRing - 1; ++t)
-        if (t < T) issue(t);
-
-    v16f acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
-
-    // fragment (block n, k-group g): row 32 n + (lane & 31), logical slot 2 g + (lane >> 5)
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds[0][0];
-    const uint32_t slot0 = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
-    const uint32_t baddr0 = lds_base + (lane & 31u) * kSbRowBytes + slot0 * 16u;
-    const uint32_t baddr1 = lds_base + (lane & 31u) * kSbRowBytes + (slot0 ^ 2u) * 16u;
-
-    // the A operands, all four classes (retires the A loads: older than the DMAs, the ring stays in flight)
-    v4i a[2][4][2];  // [k-group][class][row block]
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            a[g][0][m] = tb_inflate<0>(abits[g][m]);
-            a[g][1][m] = tb_inflate<1>(abits[g][m]);
-            a[g][2][m] = tb_inflate<2>(abits[g][m]);
-            a[g][3][m] = tb_inflate<3>(abits[g][m]);
-        }
-
-    // retire(t, ahead): this wave's piece of stage t has landed — `ahead` younger pieces (one per stage)
-    // may stay in flight while that many stages exist beyond t, else everything is drained — and the
-    // barrier makes every wave's piece visible and says that every wave is done with the stages before.
-    auto retire = [&](uint32_t t, uint32_t ahead) {
-        if (ahead == 2u && t + 2u < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else if (ahead == 1u && t + 1u < T) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-
-    // An inline-asm read completes long after hipcc thinks it has: a fetched word must stay LIVE (in hipcc's
-    // eyes) until the wait that covers it. The first version's diagonal phase ended every stage with the same
-    // look-ahead read as the main loop but never used its result; hipcc gave the dead output's registers to
-    // the next inflated operand, the LDS data landed on top of it some 100 cycles later, and the totals came
-    // out different from run to run — only with several workgroups per CU, where the LDS answers late enough
-    // (tools/mfma_war_probe: the hardware itself never lets an LDS return overtake an MFMA's operand read).
-    // STORM_SB_KEEP marks the words as used behind the wait.
-#define STORM_SB_FETCH(dst, t, n, g) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kSbRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
-#define STORM_SB_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
-    acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
-        v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                          \
-        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>()); \
-    acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                          \
-        v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                          \
-        v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, tb_scale<C>()); \
-    enxt = NEXT;                                                                                          \
-    __builtin_amdgcn_sched_barrier(0)
-#define STORM_SB_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define STORM_SB_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
-    // One stage. On entry w0 holds the bits of (block 0, k-group 0) of stage `tc` and e0 their class 0; on
-    // exit the same of stage `tn` (the look-ahead: the next stage, or a re-read that is never consumed).
-    // Word order: (n, g) = (0,0) (1,0) (0,1) (1,1) in w0, w1, w0, w1; every word is fetched while the one
-    // before it runs its first three classes.
-#define STORM_SB_STAGE(tc, tn)                                      \
-    STORM_SB_FETCH(w1, tc, 1, 0);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_SB_STEP(0, 0, 0, e0, e0, tb_inflate<1>(w0));              \
-    STORM_SB_STEP(0, 0, 1, e0, e0, tb_inflate<2>(w0));              \
-    STORM_SB_STEP(0, 0, 2, e0, e0, tb_inflate<3>(w0));              \
-    STORM_SB_WAIT();                                                \
-    STORM_SB_STEP(0, 0, 3, e0, e0, tb_inflate<0>(w1));              \
-    STORM_SB_FETCH(w0, tc, 0, 1);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_SB_STEP(1, 0, 0, e0, e0, tb_inflate<1>(w1));              \
-    STORM_SB_STEP(1, 0, 1, e0, e0, tb_inflate<2>(w1));              \
-    STORM_SB_STEP(1, 0, 2, e0, e0, tb_inflate<3>(w1));              \
-    STORM_SB_WAIT();                                                \
-    STORM_SB_STEP(1, 0, 3, e0, e0, tb_inflate<0>(w0));              \
-    STORM_SB_FETCH(w1, tc, 1, 1);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_SB_STEP(0, 1, 0, e0, e0, tb_inflate<1>(w0));              \
-    STORM_SB_STEP(0, 1, 1, e0, e0, tb_inflate<2>(w0));              \
-    STORM_SB_STEP(0, 1, 2, e0, e0, tb_inflate<3>(w0));              \
-    STORM_SB_WAIT();                                                \
-    STORM_SB_STEP(0, 1, 3, e0, e0, tb_inflate<0>(w1));              \
-    STORM_SB_FETCH(w0, tn, 0, 0);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_SB_STEP(1, 1, 0, e0, e0, tb_inflate<1>(w1));              \
-    STORM_SB_STEP(1, 1, 1, e0, e0, tb_inflate<2>(w1));              \
-    STORM_SB_STEP(1, 1, 2, e0, e0, tb_inflate<3>(w1));              \
-    STORM_SB_WAIT();                                                \
-    STORM_SB_STEP(1, 1, 3, e0, e0, tb_inflate<0>(w0))
-
-    v4i w0 = {}, w1 = {}, e0 = {};  // one inflated operand: the next one is computed behind the step's second MFMA
-    uint32_t t = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
-    // ---- the A tile's own 4 blocks (strict upper triangle), not pipelined across stages: wave wm skips
-    //      the blocks before its own rows, masks its own 64 x 64 block, takes the later ones whole
-#pragma unroll 1
-    for (; t < D; ++t) {
-        retire(t, 2u);
-        if (t + kSbRing - 1 < T) issue(t + kSbRing - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (t >= wm) {
-            STORM_SB_FETCH(w0, t, 0, 0);
-            STORM_SB_WAIT();
-            e0 = tb_inflate<0>(w0);
-            STORM_SB_STAGE(t, t);
-            STORM_SB_WAIT();  // the look-ahead read, not consumed in this phase ...
-            STORM_SB_KEEP();  // ... but alive until it has landed
-            if (t == wm) {
-                // the accumulators have seen nothing but this stage: clear the pairs with i >= j in place
-                // (C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
-                acc[1][0] = v16f{};
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const bool keep = row < (lane & 31u);
-                    acc[0][0][r] = keep ? acc[0][0][r] : 0.0f;
-                    acc[1][1][r] = keep ? acc[1][1][r] : 0.0f;
-                }
-            }
-        }
-    }
-    // ---- later blocks: stage t + 1 is retired at the top of iteration t, so that its first word can be
-    //      fetched while stage t still multiplies; the refill of the ring follows the barrier
-    if (t < T) {
-        retire(t, 2u);
-        STORM_SB_FETCH(w0, t, 0, 0);
-        STORM_SB_WAIT();
-        e0 = tb_inflate<0>(w0);
-        for (; t < T; ++t) {
-            if (t + 1 < T) retire(t + 1, 1u);
-            else __builtin_amdgcn_s_barrier();
-            if (t + kSbRing - 1 < T) issue(t + kSbRing - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t tn = t + 1 < T ? t + 1 : t;
-            STORM_SB_STAGE(t, tn);
-        }
-        STORM_SB_WAIT();
-        STORM_SB_KEEP();
-    }
-#undef STORM_SB_STAGE
-#undef STORM_SB_KEEP
-#undef STORM_SB_WAIT
-#undef STORM_SB_STEP
-#undef STORM_SB_FETCH
-
-    uint64_t mine = 0;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {  // one 32 x 64 strip at a time stays below 2^32
-        uint32_t part = 0;
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part += (uint32_t)acc[m][n][r];
-        mine += part;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    if (lane == 0 && mine != 0)
-        atomicAdd(&slots[(item_idx * (uint32_t)kStripWaves + wave) & (kSlots - 1)], (unsigned long long)mine);
-}
+#ifdef STORM_HIP_PROBES  // bit-operand strips, one item per workgroup, operands inflated in registers (superseded by K2q and K2b): tools build (make probes)
+#include "../../tools/probes/stripbits.hip"
 #endif  // STORM_HIP_PROBES
 
 // ------------------------------------------------------------------------------------------
@@ -2852,234 +1746,9 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     }
 }
 
-#ifdef STORM_HIP_PROBES
-// ------------------------------------------------------------------------------------------
-// K2w: the same stage stream with a PRIVATE ring per wave (option k2_strip_operands = 3; TOOLS BUILD ONLY:
-// measured slower than bitstream_kernel everywhere but at N = 512 — 11.1 against 12.3 us there, 25.1 / 19.8 at
-// N = 1024, 48.4 / 44.5 at 2048, 160 / 148 at 4096, 617 / 560 at 8192, same box, profiles/r03_g_wave_private_ring.txt:
-// what a lone workgroup loses at its barrier is less than what four times the L2 -> LDS traffic and a ring of
-// three stages cost).
-//
-// In bitstream_kernel the four waves of a workgroup share every B stage (one DMA piece each) and meet at a
-// barrier every two stages; a workgroup alone on its CU has nothing to cover that wait and the DMA's (~290
-// of 1670 clocks per stage), and the barrier couples four SIMDs. Here every wave DMAs the WHOLE stage (four
-// pieces of 16 rows x 64 B) into its own ring of kRing stages: no barrier before the final fold, only vmcnt;
-// the L2 -> LDS traffic is four times the shared ring's (16 B per clock and CU at the full rate: a quarter of
-// the path), the HBM traffic is unchanged.
-// What a stage is to a wave comes from ONE table word (bitwave tables, build_bitwave): bits 0..29 the start of
-// the stage's 64 rows (64-byte units), bit 31 "these are my A rows: take them", bit 30 "and multiply them, at
-// half weight" (a diagonal segment). A wave's list for a segment is its own block, the tile's later blocks
-// (diagonal segments), the run of later blocks; lists of the four waves differ in length by up to three
-// stages per diagonal segment and even out through the rotation of the blocks over the waves.
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t kBwOwn = 0x80000000u, kBwMul = 0x40000000u, kBwBase = 0x3fffffffu;
-
-template <int kRing>
-__global__ __launch_bounds__(kStripThreads, 3) void bitwave_kernel(
-    const uint8_t* __restrict__ X, uint64_t pitch64, const uint32_t* __restrict__ first,
-    const uint32_t* __restrict__ words, unsigned long long* __restrict__ slots,
-    unsigned long long* __restrict__ out) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kStripWaves * kRing * kSbStageBytes];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t pitch = (uint32_t)pitch64;
-    uint8_t* ring = lds_raw + wave * (kRing * kSbStageBytes);
-
-    const uint32_t goff = (lane >> 2) * pitch + (((lane & 3u) ^ ((lane >> 4) & 3u)) * 16u);
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)ring;
-    const uint32_t slot0 = (lane >> 5) ^ (((lane & 31u) >> 2) & 3u);
-    const uint32_t baddr0 = lds_base + (lane & 31u) * kSbRowBytes + slot0 * 16u;
-    const uint32_t baddr1 = lds_base + (lane & 31u) * kSbRowBytes + (slot0 ^ 2u) * 16u;
-
-    v16f acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = v16f{};
-    v4i a[2][4][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[g][c][m] = v4i{};
-    uint32_t dbits = 0;
-
-    const uint32_t w0i = first[blockIdx.x * 4u + wave];
-    const uint32_t T = first[blockIdx.x * 4u + wave + 1u] - w0i;
-    const uint32_t* tab = words + w0i;
-    uint32_t issued = 0;
-    uint32_t next_word = T ? tab[0] : 0u;  // of stage `issued`
-    auto fire = [&]() {
-        if (issued < T) {
-            uint8_t* src = const_cast<uint8_t*>(X) + ((uint64_t)(next_word & kBwBase) << 6);
-            uint8_t* dst = ring + (issued % kRing) * kSbStageBytes;
-            // piece j: rows 16 j .. 16 j + 15 of the stage, 1 KiB further into the ring slot. ONE value of M0 per stage:
-            // the instruction offset moves the LDS address (and the global one, which the base takes back).
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(src, 0, -1, 0x00020000);
-#pragma unroll
-            for (uint32_t j = 0; j < 4; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lptr_t)(dst + j * 1024u), 16,
-                                                         (int)(goff + j * 16u * pitch), 0, 0, 0);
-            ++issued;
-            next_word = tab[min(issued, T - 1u)];
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < kRing - 1; ++k) fire();
-
-#define STORM_BS_FETCH(dst, t, n, g) \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(((g) ? baddr1 : baddr0) + ((t) % kRing) * kSbStageBytes), "n"((n) * 32 * kSbRowBytes))
-#define STORM_BS_STEP(n, g, C, ecur, enxt, NEXT)                                                          \
-    {                                                                                                     \
-        acc[0][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
-            v8i{a[g][C][0].x, a[g][C][0].y, a[g][C][0].z, a[g][C][0].w, 0, 0, 0, 0},                      \
-            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[0][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        const v4i en_ = NEXT;                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        acc[1][n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(                                      \
-            v8i{a[g][C][1].x, a[g][C][1].y, a[g][C][1].z, a[g][C][1].w, 0, 0, 0, 0},                      \
-            v8i{ecur.x, ecur.y, ecur.z, ecur.w, 0, 0, 0, 0}, acc[1][n], 4, 4, 0, tb_scale<C>(), 0, sb[C]); \
-        enxt = en_;                                                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-    }
-#define STORM_BS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#define STORM_BS_KEEP() asm volatile("" ::"v"(w0), "v"(w1), "v"(e0))
-    // one stage; the next stage's first word is NOT fetched here (its DMA is waited for at the top of the loop)
-#define STORM_BW_STAGE(tc)                                          \
-    STORM_BS_FETCH(w1, tc, 1, 0);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_BS_STEP(0, 0, 0, e0, e0, tb_inflate<1>(w0));              \
-    STORM_BS_STEP(0, 0, 1, e0, e0, tb_inflate<2>(w0));              \
-    STORM_BS_STEP(0, 0, 2, e0, e0, tb_inflate<3>(w0));              \
-    STORM_BS_WAIT();                                                \
-    STORM_BS_STEP(0, 0, 3, e0, e0, tb_inflate<0>(w1));              \
-    STORM_BS_FETCH(w0, tc, 0, 1);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_BS_STEP(1, 0, 0, e0, e0, tb_inflate<1>(w1));              \
-    STORM_BS_STEP(1, 0, 1, e0, e0, tb_inflate<2>(w1));              \
-    STORM_BS_STEP(1, 0, 2, e0, e0, tb_inflate<3>(w1));              \
-    STORM_BS_WAIT();                                                \
-    STORM_BS_STEP(1, 0, 3, e0, e0, tb_inflate<0>(w0));              \
-    STORM_BS_FETCH(w1, tc, 1, 1);                                   \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_BS_STEP(0, 1, 0, e0, e0, tb_inflate<1>(w0));              \
-    STORM_BS_STEP(0, 1, 1, e0, e0, tb_inflate<2>(w0));              \
-    STORM_BS_STEP(0, 1, 2, e0, e0, tb_inflate<3>(w0));              \
-    STORM_BS_WAIT();                                                \
-    STORM_BS_STEP(0, 1, 3, e0, e0, tb_inflate<0>(w1));              \
-    __builtin_amdgcn_sched_barrier(0);                              \
-    STORM_BS_STEP(1, 1, 0, e0, e0, tb_inflate<1>(w1));              \
-    STORM_BS_STEP(1, 1, 1, e0, e0, tb_inflate<2>(w1));              \
-    STORM_BS_STEP(1, 1, 2, e0, e0, tb_inflate<3>(w1));              \
-    STORM_BS_STEP(1, 1, 3, e0, e0, e0)
-
-    v4i w0 = {}, w1 = {}, e0 = {};
-    int sb[4] = {tb_scale<0>(), tb_scale<1>(), tb_scale<2>(), tb_scale<3>()};
-    uint32_t cur_word = T ? tab[0] : 0u;
-#pragma unroll 1
-    for (uint32_t t = 0; t < T; ++t) {
-        // stage t has landed when at most the pieces of the kRing - 2 younger stages are in flight
-        if (issued >= t + (uint32_t)(kRing - 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRing - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t word = cur_word;
-        cur_word = tab[min(t + 1u, T - 1u)];
-        fire();  // into the slot of stage t - 1: this wave's reads of it were waited for (lgkmcnt) in its stage
-        __builtin_amdgcn_sched_barrier(0);
-        const bool own = (word & kBwOwn) != 0u;
-        const bool mul = !own || (word & kBwMul) != 0u;
-        // The reads and the wait that covers them are ONE asm statement each: a read left in flight across
-        // compiler-visible code is not safe — for a wait that ties the words ("+v") hipcc copied w0 into the
-        // tied registers BEFORE the wait, i.e. before the data had landed (rows 32..63 of a block came out wrong).
-        const uint32_t rd0 = baddr0 + (t % kRing) * kSbStageBytes, rd1 = baddr1 + (t % kRing) * kSbStageBytes;
-        if (own) {
-            v4i x1, x2, x3;
-            asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:2048\n\t"
-                         "ds_read_b128 %2, %5 offset:0\n\tds_read_b128 %3, %5 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(w0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                         : "v"(rd0), "v"(rd1)
-                         : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            a[0][0][0] = tb_inflate<0>(w0); a[0][1][0] = tb_inflate<1>(w0);
-            a[0][2][0] = tb_inflate<2>(w0); a[0][3][0] = tb_inflate<3>(w0);
-            a[0][0][1] = tb_inflate<0>(x1); a[0][1][1] = tb_inflate<1>(x1);
-            a[0][2][1] = tb_inflate<2>(x1); a[0][3][1] = tb_inflate<3>(x1);
-            a[1][0][0] = tb_inflate<0>(x2); a[1][1][0] = tb_inflate<1>(x2);
-            a[1][2][0] = tb_inflate<2>(x2); a[1][3][0] = tb_inflate<3>(x2);
-            a[1][0][1] = tb_inflate<0>(x3); a[1][1][1] = tb_inflate<1>(x3);
-            a[1][2][1] = tb_inflate<2>(x3); a[1][3][1] = tb_inflate<3>(x3);
-            if (mul) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    dbits += __builtin_popcount((uint32_t)w0[k]) + __builtin_popcount((uint32_t)x1[k]) +
-                             __builtin_popcount((uint32_t)x2[k]) + __builtin_popcount((uint32_t)x3[k]);
-            }
-        } else {
-            asm volatile("ds_read_b128 %0, %1 offset:0\n\ts_waitcnt lgkmcnt(0)" : "=&v"(w0) : "v"(rd0) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (mul) {
-            const int half = own ? 1 : 0;
-            sb[0] = tb_scale<0>() - half;
-            sb[1] = tb_scale<1>() - half;
-            sb[2] = tb_scale<2>() - half;
-            sb[3] = tb_scale<3>() - half;
-            e0 = tb_inflate<0>(w0);
-            __builtin_amdgcn_sched_barrier(0);
-            STORM_BW_STAGE(t);
-            STORM_BS_WAIT();
-            STORM_BS_KEEP();
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#undef STORM_BW_STAGE
-#undef STORM_BS_KEEP
-#undef STORM_BS_WAIT
-#undef STORM_BS_STEP
-#undef STORM_BS_FETCH
-
-    long long mine2 = 0;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        uint32_t part = 0;
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part += (uint32_t)(acc[m][n][r] * 2.0f);
-        mine2 += part;
-    }
-    mine2 -= (long long)dbits;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine2 += __shfl_down(mine2, o, 64);
-    __builtin_amdgcn_s_barrier();
-    long long* wsum = reinterpret_cast<long long*>(lds_raw);
-    if (lane == 0) wsum[wave] = mine2;
-    __syncthreads();
-    if (tid == 0) {
-        const long long tot2 = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (tot2 != 0) atomicAdd(&slots[blockIdx.x & (kBsFoldSlots - 1)], (unsigned long long)(tot2 / 2));
-        __threadfence();
-        const unsigned long long arrived = atomicAdd(&slots[kBsTicket], 1ull);
-        wsum[4] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1 : 0;
-    }
-    __syncthreads();
-    if (wsum[4] != 0 && wave == 0) {
-        __threadfence();
-        unsigned long long v = __hip_atomic_exchange(&slots[lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) {
-            out[0] = v;
-            __hip_atomic_store(&slots[kBsTicket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-#endif  // STORM_HIP_PROBES (K2w)
+#ifdef STORM_HIP_PROBES  // K2w: the stage stream with a private ring per wave: tools build (make probes)
+#include "../../tools/probes/bitwave.hip"
+#endif  // STORM_HIP_PROBES
 
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
@@ -3542,84 +2211,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             const int sel = 4;  // (the shipped library refuses the options that select the other forms)
 #endif
             switch (sel) {  // ring depth: tuning probe
-#ifdef STORM_HIP_PROBES  // 32x32x64 forms, timing probes and the schedule trace: tools build (make probes)
-                case 204:
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 2, true>), pgrid, sblock,
-                                       (size_t)ctx->k2_lds_pad, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots, nullptr, queues, heads);
-                    break;
-                case 218: {
-                    const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
-                    if (need > ctx->trace_capacity) {
-                        if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
-                        ctx->d_trace = nullptr;
-                        ctx->trace_capacity = 0;
-                        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace), need));
-                        ctx->trace_capacity = need;
-                    }
-                    ctx->trace_items = n_strip;
-                    ctx->trace_is_stream = false;
-                    ctx->trace_is_stream = false;
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 8, 2, true>), pgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace, queues, heads);
-                    break;
-                }
-                case 103:
-                    hipLaunchKernelGGL((strip_fp4_kernel<3, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots);
-                    break;
-                case 104:
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots);
-                    break;
-                case 105:
-                    hipLaunchKernelGGL((strip_fp4_kernel<5, 0, 4>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots);
-                    break;
-#define STORM_WIDE_PROBE_CASE(n)                                                                  \
-    case 110 + n:                                                                                 \
-        hipLaunchKernelGGL((strip_fp4_kernel<4, n, 4>), sgrid, sblock, 0, ctx->stream, ctx->d_x4, \
-                           pitch, sit, ctx->d_slots);                                         \
-        break;
-                STORM_WIDE_PROBE_CASE(1) STORM_WIDE_PROBE_CASE(2) STORM_WIDE_PROBE_CASE(4)
-                STORM_WIDE_PROBE_CASE(6) STORM_WIDE_PROBE_CASE(7)
-#undef STORM_WIDE_PROBE_CASE
-                case 3:
-                    hipLaunchKernelGGL(strip_fp4_kernel<3>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
-                                       pitch, sit, ctx->d_slots);
-                    break;
-                case 5:
-                    hipLaunchKernelGGL(strip_fp4_kernel<5>, sgrid, sblock, 0, ctx->stream, ctx->d_x4,
-                                       pitch, sit, ctx->d_slots);
-                    break;
-#define STORM_PROBE_CASE(n)                                                                   \
-    case 10 + n:                                                                              \
-        hipLaunchKernelGGL((strip_fp4_kernel<4, n>), sgrid, sblock, 0, ctx->stream, ctx->d_x4, \
-                           pitch, sit, ctx->d_slots);                                      \
-        break;
-                STORM_PROBE_CASE(1) STORM_PROBE_CASE(2) STORM_PROBE_CASE(4) STORM_PROBE_CASE(6)
-                STORM_PROBE_CASE(7)
-#undef STORM_PROBE_CASE
-                case 26:  // probe: s_setprio around the MFMA bursts (results stay correct)
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 16>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots);
-                    break;
-                case 18: {  // schedule trace (results stay correct)
-                    const size_t need = (size_t)n_strip * 4 * sizeof(unsigned long long);
-                    if (need > ctx->trace_capacity) {
-                        if (ctx->d_trace) STORM_HIP_TRY(hipFree(ctx->d_trace));
-                        ctx->d_trace = nullptr;
-                        ctx->trace_capacity = 0;
-                        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_trace), need));
-                        ctx->trace_capacity = need;
-                    }
-                    ctx->trace_items = n_strip;
-                    ctx->trace_is_stream = false;
-                    ctx->trace_is_stream = false;
-                    hipLaunchKernelGGL((strip_fp4_kernel<4, 8>), sgrid, sblock, 0, ctx->stream,
-                                       ctx->d_x4, pitch, sit, ctx->d_slots, ctx->d_trace);
-                    break;
-                }
+#ifdef STORM_HIP_PROBES  // launch cases of the 32x32x64 strips, their timing probes and the schedule trace (inside launch_pairw_mfma_ranges' switch): tools build (make probes)
+#include "../../tools/probes/strip_fp4_32_launch.hip"
 #endif  // STORM_HIP_PROBES
                 default:
                     // k2_lds_pad: unused dynamic LDS, only to cap the workgroups per CU (tuning)
@@ -4412,119 +3005,9 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
     return STORM_HIP_OK;
 }
 
-#ifdef STORM_HIP_PROBES
-// K2w: per-wave stage words of the same plan (bitwave_kernel). One buffer: first[4 G + 1] | words.
-static int ensure_bitwave(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges, uint32_t n_kslices,
-                          uint32_t shard_rank, uint32_t shard_count, uint64_t pitch) {
-    const uint64_t key[4] = {ranges_hash(ranges) ^ (pitch * 0x9e3779b97f4a7c15ull) ^ 0x77aa77aa77aa77aaull ^
-                                 ((uint64_t)ctx->k2_stream_w3_2 * 0xc2b2ae3d27d4eb4full),
-                             n_kslices, ((uint64_t)shard_rank << 32) | shard_count,
-                             ((uint64_t)(ctx->k2_stream_groups_per_cu & 0xff) << 32) |
-                                 ((uint64_t)(ctx->k2_stream_min_piece & 0xffff) << 16) |
-                                 (uint64_t)(ctx->k2_stream_min_run & 0xffff) |
-                                 ((uint64_t)(ctx->k2_stream_w3_1 & 0x3ff) << 40)};
-    if (ctx->d_bitfirst && !memcmp(key, ctx->bit_key, sizeof(key))) return STORM_HIP_OK;
-    BitstreamShaping sh;
-    sh.groups_per_cu = ctx->k2_stream_groups_per_cu;
-    sh.min_piece = std::max(1, ctx->k2_stream_min_piece);
-    sh.min_run = std::max(1, ctx->k2_stream_min_run);
-    sh.w3_1 = ctx->k2_stream_w3_1;
-    sh.w3_2 = ctx->k2_stream_w3_2;
-    BitstreamPlan plan;
-    build_bitstream(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)std::max(1, ctx->n_cus), pitch, plan);
-    if (!ranges.empty() && ranges.back().r1 * pitch / 64 + n_kslices + 4 * pitch >= (1ull << 30)) {
-        set_error("K2w: the matrix is beyond the 30-bit stage addresses (64-byte units)");
-        return STORM_HIP_EINVAL;
-    }
-    std::vector<uint32_t> first, words;
-    first.reserve((size_t)plan.groups * 4 + 1);
-    uint32_t longest = 0;
-    for (uint32_t w = 0; w < plan.groups; ++w)
-        for (uint32_t v = 0; v < 4; ++v) {
-            first.push_back((uint32_t)words.size());
-            for (uint32_t si = plan.first[w]; si < plan.first[w + 1]; ++si) {
-                const BitSeg& sg = plan.segs[si];
-                auto base = [&](uint32_t blk) { return (uint32_t)((uint64_t)sg.ks + (uint64_t)blk * pitch); };
-                const uint32_t wm = (v + (sg.flags >> 8)) & 3u;
-                const bool diag = (sg.flags & kBsDiag) != 0u;
-                words.push_back(base(sg.a_blk + wm) | kBwOwn | (diag ? kBwMul : 0u));
-                if (diag)
-                    for (uint32_t b = wm + 1; b < 4u; ++b) words.push_back(base(sg.a_blk + b));
-                for (uint32_t i = 0; i < sg.n_b; ++i) {
-                    uint32_t rel = sg.b_first + i;
-                    if (rel >= sg.range_nb) rel -= sg.range_nb;
-                    words.push_back(base(sg.range_b0 + rel));
-                }
-            }
-            longest = std::max(longest, (uint32_t)words.size() - first.back());
-        }
-    first.push_back((uint32_t)words.size());
-    if (longest > kBsMaxStages) {
-        set_error("K2w: a wave of %u stages exceeds the exact range of its accumulators", longest);
-        return STORM_HIP_EINVAL;
-    }
-    std::vector<uint32_t> packed(first);
-    packed.insert(packed.end(), words.begin(), words.end());
-    const size_t bytes = std::max<size_t>(packed.size(), 1) * sizeof(uint32_t);
-    if (bytes > ctx->bitfirst_capacity) {
-        if (ctx->d_bitfirst) STORM_HIP_TRY(hipFree(ctx->d_bitfirst));
-        ctx->d_bitfirst = nullptr;
-        ctx->bitfirst_capacity = 0;
-        STORM_HIP_TRY(hipMalloc(&ctx->d_bitfirst, bytes));
-        ctx->bitfirst_capacity = bytes;
-    }
-    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_bitfirst, packed.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->n_bit_groups = plan.groups;
-    ctx->bit_stages = words.size();
-    ctx->bit_max_stages = longest;
-    ctx->n_bit_segs = (uint32_t)plan.segs.size();
-    memcpy(ctx->bit_key, key, sizeof(key));
-    return STORM_HIP_OK;
-}
-
-int launch_pairw_bitwave(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pitch,
-                         const std::vector<RowRange>& ranges, uint32_t n_kslices, uint32_t shard_rank,
-                         uint32_t shard_count, uint64_t* d_total) {
-    if (pitch * (uint64_t)kStripBRows >= (1ull << 32) || pitch % 64 != 0) {
-        set_error("K2w: rows of %llu bytes are outside the bit-operand stream's 32-bit DMA offsets",
-                  (unsigned long long)pitch);
-        return STORM_HIP_EINVAL;
-    }
-    if (int rc = ensure_bitwave(ctx, ranges, n_kslices, shard_rank, shard_count, pitch)) return rc;
-    ctx->n_items = 0;
-    memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
-    ctx->last_info[0] = ctx->n_bit_groups;
-    ctx->last_info[1] = ctx->bit_max_stages;
-    ctx->last_info[2] = 1;
-    ctx->last_info[3] = ctx->n_bit_segs;
-    if (ctx->n_bit_groups == 0) {
-        STORM_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
-        return STORM_HIP_OK;
-    }
-    const uint32_t G = ctx->n_bit_groups, cus = (uint32_t)std::max(1, ctx->n_cus);
-    int ring = ctx->k2_wave_ring;
-    if (ring == 0) ring = G <= cus ? 8 : G <= 2 * cus ? 4 : 3;
-    const uint32_t* first = static_cast<const uint32_t*>(ctx->d_bitfirst);
-    const uint32_t* words = first + 4 * (size_t)G + 1;
-    kernel_time_mark(ctx);
-#define STORM_BW_LAUNCH(R)                                                                                      \
-    hipLaunchKernelGGL(bitwave_kernel<R>, dim3(G), dim3(kStripThreads), 0, ctx->stream,                         \
-                       reinterpret_cast<const uint8_t*>(X), pitch, first, words, ctx->d_slots,                  \
-                       reinterpret_cast<unsigned long long*>(d_total))
-    switch (ring) {
-        case 8: STORM_BW_LAUNCH(8); break;
-        case 6: STORM_BW_LAUNCH(6); break;
-        case 4: STORM_BW_LAUNCH(4); break;
-        default: STORM_BW_LAUNCH(3); break;
-    }
-#undef STORM_BW_LAUNCH
-    kernel_time_mark(ctx);
-    STORM_HIP_TRY(hipGetLastError());
-    return STORM_HIP_OK;
-}
-
-#endif  // STORM_HIP_PROBES (K2w)
+#ifdef STORM_HIP_PROBES  // host side of K2w: ensure_bitwave, launch_pairw_bitwave: tools build (make probes)
+#include "../../tools/probes/bitwave_launch.hip"
+#endif  // STORM_HIP_PROBES
 
 // K2b over arbitrary row ranges of a bit matrix X (pitch bytes per row): the FP4 strips' items over slices of
 // 256 bit-MACs = one class pair of a 512-bit chunk (n_kslices2 = 2 x the chunks that hold data). The rows of
