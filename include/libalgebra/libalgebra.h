@@ -10,8 +10,12 @@
  * NULL or any leaf exported below (they all denote sum popcount(a & b)) and rejects foreign
  * function pointers (it cannot run caller code on the GPU).
  *
- * No STORM_HAVE_AVX512 / AVX2 / SSE42 macro is defined: the reference harness compiles its
- * direct-to-SIMD rows only under those macros (benchmark.cpp:949,996,1021).
+ * STORM_HAVE_SSE42 / AVX2 / AVX512 are defined on x86-64 hosts and the direct SIMD leaves behind them
+ * (STORM_intersect_count_sse4 / _avx2 / _avx512; the reference harness compiles its direct-to-SIMD rows
+ * under those macros and calls them when STORM_get_cpuid() reports the ISA, benchmark.cpp:949-1045) are
+ * exported as HOST functions (stormbitmaps_amd/csrc/storm_leaves.c): one-pair leaves for a caller's own loops
+ * — tools/storm_benchmark.cpp times them as CPU rows beside the GPU rows. The all-pairs entry points never
+ * run them.
  */
 #ifndef STORM_LIBALGEBRA_COMPAT_H_
 #define STORM_LIBALGEBRA_COMPAT_H_
@@ -31,6 +35,11 @@ extern "C" {
 #define STORM_ALIGN(n) __attribute__((aligned(n)))
 
 #define STORM_HAVE_CPUID 1
+#if defined(__x86_64__)
+#define STORM_HAVE_SSE42 1
+#define STORM_HAVE_AVX2 1
+#define STORM_HAVE_AVX512 1
+#endif
 #define STORM_CPUID_runtime_bit_SSE42 (1 << 0)
 #define STORM_CPUID_runtime_bit_AVX2 (1 << 1)
 #define STORM_CPUID_runtime_bit_AVX512BW (1 << 2)
@@ -49,6 +58,12 @@ uint64_t STORM_intersect_count_scalar_list(const uint64_t* STORM_RESTRICT b1,
                                            const uint32_t* STORM_RESTRICT l1,
                                            const uint32_t* STORM_RESTRICT l2, const size_t n1,
                                            const size_t n2);
+#if defined(__x86_64__)
+/* benchmark.cpp:961, :1013, :1031 — call only when STORM_get_cpuid() has the matching STORM_CPUID_runtime_bit_* */
+uint64_t STORM_intersect_count_sse4(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n);
+uint64_t STORM_intersect_count_avx2(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n);
+uint64_t STORM_intersect_count_avx512(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n);
+#endif
 STORM_compute_func STORM_get_intersect_count_func(const size_t n_bitmaps_vector);
 uint32_t STORM_get_alignment(void);
 void* STORM_aligned_malloc(size_t alignment, size_t size); /* alignment first: storm.c:452 */

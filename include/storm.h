@@ -265,6 +265,10 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids);
 int STORM_hip_invalidate(STORM_t* bitmap);
 int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
+/* What the last all-pairs call ran, over this process's devices (storm_hip.h: storm_hip_last_pass_report):
+ * out[0] mask of STORM_HIP_RAN_*, out[1] dense 64-bit word pairs, out[2] list-probe lookups, out[3] rows a
+ * lookup stands for. For harnesses that price a row against the roof of the kernel that ran. */
+int STORM_hip_last_pass(uint64_t out[4]);
 const char* STORM_hip_error(void);
 /* Multi-PROCESS runs, one process per GPU: every process sets its shard (STORM_hip_set_shard) and joins one
  * RCCL communicator; from then on every all-pairs entry point above returns the SUM over all processes (the

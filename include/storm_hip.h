@@ -235,6 +235,17 @@ int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]);
 int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
                          uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
                          uint64_t* n_items);
+/* The same with the operand form and the ownership mode spelled out (storm_hip_strip_plan = form 0, mode 0):
+ *   form 0: the FP4-shadow strips: slice ks = bits [256 ks, 256 ks + 256) of every row;
+ *   form 1: the strips on bit operands (K2b, the DEFAULT path): slice ks = class pair ks & 1 — the bits b of
+ *           the 512-bit chunk ks / 2 (bits [512 (ks / 2), +512)) with (b % 4) / 2 == ks & 1 — 256 bit positions
+ *           as well; 2 x ceil(n_words / 8) slices;
+ *   pair_space 0: whole k-slices first, leftover slices along the pair space (above);
+ *   pair_space 1: EVERY slice is cut along the pair space (context option k2_shard_pairs): a shard multiplies
+ *           its share of every slice's items (longest first onto the least loaded shard, the load carried
+ *           from slice to slice). */
+int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,
+                          int form, int pair_space, uint32_t* out, uint64_t capacity_items, uint64_t* n_items);
 
 /* The same for the one-launch stage stream on bit operands (K2q, the default for matrices of up to 8192
  * rows on one device): the segments shard `shard_rank` of `shard_count` walks on a device of
@@ -265,6 +276,19 @@ int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank
  * tools/storm_benchmark.cpp --ranks N is a complete example (fork before any HIP call, id through a pipe). */
 #define STORM_HIP_COMM_ID_BYTES 128
 typedef struct storm_hip_comm_s storm_hip_comm_t;
+/* What the last all-pairs pass of this context ran: out[0] = mask of STORM_HIP_RAN_*; out[1] = 64-bit word pairs
+ * multiplied by the dense kernels (pairs x words, this shard's share); out[2] = positions streamed by the
+ * list-probe kernel (= its lookups: one 2-byte LDS read + one add each); out[3] = rows of the group one lookup
+ * stands for (128: a lookup is 128 of the reference's per-pair list tests, storm.c:4-73, folded into a count).
+ * For a harness that prices a row against the roof of the kernel that ran (tools/storm_benchmark.cpp). */
+#define STORM_HIP_RAN_POPCOUNT 1u   /* pairw_dense_kernel (VALU popcount)                 roof: VALU issue     */
+#define STORM_HIP_RAN_FP4_TILES 2u  /* pairw_fp4_kernel on the FP4 shadow                 roof: FP4 matrix cores */
+#define STORM_HIP_RAN_FP4_STRIPS 4u /* strip16_fp4_kernel on the FP4 shadow               roof: FP4 matrix cores */
+#define STORM_HIP_RAN_BITSTREAM 8u  /* bitstream_kernel (K2q), bit operands               roof: FP4 matrix cores */
+#define STORM_HIP_RAN_BIT_STRIPS 16u /* strip16_bits_kernel (K2b), bit operands (default) roof: FP4 matrix cores */
+#define STORM_HIP_RAN_LIST_PROBE 32u /* probe_lists_kernel (K4), list x list blocks       roof: LDS lookups    */
+int storm_hip_last_pass_report(storm_hip_ctx_t* ctx, uint64_t out[4]);
+
 int storm_hip_comm_unique_id(uint8_t id[STORM_HIP_COMM_ID_BYTES]);
 int storm_hip_comm_init_rank(storm_hip_ctx_t* ctx, const uint8_t id[STORM_HIP_COMM_ID_BYTES], uint32_t rank,
                              uint32_t world, storm_hip_comm_t** out);

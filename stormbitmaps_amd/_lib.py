@@ -57,6 +57,7 @@ SIGNATURES = {
     "storm_hip_pairw_matrix_band_begin": (C.c_int, [vp, vp, C.c_int, u64, u64, vp, u64]),
     "storm_hip_pairw_matrix_band_end": (C.c_int, [vp]),
     "storm_hip_strip_plan": (C.c_int, [u64, u32, u32, u32, vp, u64, vp]),
+    "storm_hip_strip_plan2": (C.c_int, [u64, u32, u32, u32, C.c_int, C.c_int, vp, u64, vp]),
     "storm_hip_stream_plan": (C.c_int, [u64, u32, u32, u32, u32, vp, u64, vp, vp]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "storm_hip_comm_init_rank": (C.c_int, [vp, vp, u32, u32, P(vp)]),
     "storm_hip_comm_allreduce_u64": (C.c_int, [vp, vp, P(u64)]),
     "storm_hip_comm_allreduce_u64s": (C.c_int, [vp, vp, P(u64), C.c_uint32]),
+    "storm_hip_last_pass_report": (C.c_int, [vp, P(u64)]),
     "storm_hip_comm_allreduce_result": (C.c_int, [vp, vp, P(u64)]),
     "storm_hip_comm_rank": (u32, [vp]),
     "storm_hip_comm_world": (u32, [vp]),

@@ -259,6 +259,15 @@ class HipContext:
         return {"items": out[0], "chunks_per_item": out[1], "word_pairs_executed": out[2],
                 "segments": out[3]}
 
+    def last_pass_report(self) -> dict:
+        """What the last all-pairs pass ran (storm_hip.h: storm_hip_last_pass_report)."""
+        out = (C.c_uint64 * 4)()
+        check(self._lib.storm_hip_last_pass_report(self._h, C.byref(out)), "storm_hip_last_pass_report")
+        names = {1: "pairw_dense_kernel", 2: "pairw_fp4_kernel", 4: "strip16_fp4_kernel", 8: "bitstream_kernel",
+                 16: "strip16_bits_kernel", 32: "probe_lists_kernel"}
+        return {"kernels": [n for b, n in names.items() if out[0] & b], "dense_word_pairs": int(out[1]),
+                "probe_lookups": int(out[2]), "rows_per_lookup": int(out[3])}
+
     def matrix(self, n_rows: int, n_words: int) -> "HipMatrix":
         return HipMatrix(self, n_rows, n_words)
 

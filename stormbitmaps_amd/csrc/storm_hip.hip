@@ -680,6 +680,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
         ctx->k2_strip_operands = (int)value;
+    } else if (!strcmp(key, "k2_shard_pairs")) {
+        ctx->k2_shard_pairs = value != 0;
     } else if (!strcmp(key, "k2_matrix_pad")) {
         ctx->k2_matrix_pad = value < 0 ? -1 : value != 0;
     } else if (!strcmp(key, "k2_fold_inline")) {
@@ -811,6 +813,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_stream_max_rows")) return ctx->k2_stream_max_rows;
     if (!strcmp(key, "k2_fold_inline")) return ctx->k2_fold_inline;
     if (!strcmp(key, "k2_matrix_pad")) return ctx->k2_matrix_pad;
+    if (!strcmp(key, "k2_shard_pairs")) return ctx->k2_shard_pairs;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;
@@ -880,6 +883,12 @@ int storm_hip_debug_strip_trace(storm_hip_ctx_t* ctx, uint64_t* out, uint64_t ca
     }
     return STORM_HIP_OK;
     });
+}
+
+int storm_hip_last_pass_report(storm_hip_ctx_t* ctx, uint64_t out[4]) {
+    if (check_ctx(ctx) || !out) return STORM_HIP_EINVAL;
+    memcpy(out, ctx->pass_report, sizeof(ctx->pass_report));
+    return STORM_HIP_OK;
 }
 
 int storm_hip_last_launch_info(storm_hip_ctx_t* ctx, uint64_t out[4]) {
@@ -1273,6 +1282,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
     int variant = ctx->variant;
     if (variant < 0) variant = 4;
     ctx->variant_used = variant;
+    memset(ctx->pass_report, 0, sizeof(ctx->pass_report));
     if (variant >= 3) {
         const int saved = ctx->variant;
         ctx->variant = variant;
@@ -1281,6 +1291,8 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
         return rc;
     }
     if (int rc = ensure_segments(ctx, m->n_rows, shard_rank, shard_count)) return rc;
+    ctx->pass_report[0] |= STORM_HIP_RAN_POPCOUNT;
+    ctx->pass_report[1] += m->n_rows * (m->n_rows - (m->n_rows != 0)) / 2 * m->n_words / shard_count;
     return launch_pairw_segments(ctx, m->d, m->stride_words, ctx->d_segs, ctx->n_segs,
                                  ctx->seg_row_sum, d_total);
     });

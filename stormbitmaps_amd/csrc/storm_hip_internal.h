@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <exception>
@@ -97,6 +98,11 @@ struct storm_hip_ctx_s {
     // info of the last dense launch
     uint64_t last_info[4] = {0, 0, 0, 0};
     uint64_t sparse_census[4] = {0, 0, 0, 0};
+    // What the last all-pairs pass ran (storm_hip_last_pass_report): [0] kernels, a mask of STORM_HIP_RAN_*;
+    // [1] 64-bit word pairs multiplied on the matrix cores or by the popcount kernel (this shard's share,
+    // algorithmic: pairs x words); [2] positions the list-probe kernel streamed = its lookups; [3] rows one
+    // lookup stands for (128). A harness prices every row against the roof of the kernel that ran.
+    uint64_t pass_report[4] = {0, 0, 0, 0};
     // K2 (MFMA FP4) state: nibble-expanded shadow of the matrix + item table
     uint8_t* d_x4 = nullptr;
     size_t x4_capacity = 0;
@@ -114,6 +120,7 @@ struct storm_hip_ctx_s {
     int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
     int k2_strip_operands = 0;  // strips: 0 = K2b; 5 = bit operands, FP4 image of every B stage built in the LDS (strip16_bits_kernel, K2b); 2 = bit operands, one stage stream per workgroup, one launch (bitstream_kernel, K2q); 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel); 1 = bit operands, one item per workgroup (stripbits_kernel)
     int k2_stream_max_rows = 8192;  // auto: matrices up to this many rows take K2q
+    int k2_shard_pairs = 0;         // ownership among shards: 0 = whole k-slices first (leftover slices along the pair space), 1 = every slice along the pair space
     int k2_matrix_pad = 1;          // matrices created from now on: rows that are a multiple of 1 KiB get 512 more bytes of pitch (0: dense pitch)
     int k2_fold_inline = 0;         // K2b: the last workgroup to arrive folds the partial sums (0: a fold launch behind the strips)
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
@@ -185,6 +192,15 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch_bytes,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
                              uint32_t shard_count, uint64_t* d_total);
+// pairs x words of a set of row ranges, divided among shard_count shards (the report's algorithmic word pairs)
+static inline uint64_t ranges_word_pairs(const std::vector<RowRange>& ranges, uint64_t words, uint32_t shard_count) {
+    uint64_t pairs = 0;
+    for (const RowRange& rg : ranges) {
+        const uint64_t n = rg.r1 - rg.r0, a = rg.a_end ? std::min(rg.a_end, rg.r1) - rg.r0 : n;
+        pairs += a * (a - (a != 0)) / 2 + a * (n - a);
+    }
+    return pairs * words / (shard_count ? shard_count : 1);
+}
 int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int op, uint32_t* d_out,
                         uint64_t ld, uint64_t band_row0 = 0, uint64_t band_rows = ~0ull,
                         bool sync = true);

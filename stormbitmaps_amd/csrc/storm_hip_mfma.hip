@@ -1893,6 +1893,11 @@ struct StripShaping {  // work-list shaping knobs (context options of the same n
     int max_run = 128, tail_run = 32, tail_slices = 3, lpt_rounds = 6;
     int xcd_group = 1;  // consecutive slices that share an XCD (2 for the bit-operand strips: slices 2j, 2j + 1 read the same bits)
     bool persistent = false, one_slice_probe = false;
+    // Ownership among the shards: false = whole k-slices first, the leftover slices cut along the pair space
+    // (above); true = EVERY slice is cut along the pair space (north_star's literal split: a shard multiplies
+    // its share of the tile pairs over all of k). Option k2_shard_pairs; rehearsed side by side in
+    // tools/bench_shards.py.
+    bool pair_space = false;
 };
 // Pure host computation (no device): the list, in launch order, and for the persistent form the
 // per-XCD queue bounds.
@@ -1908,12 +1913,14 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
     // The slices of this shard, dealt to the XCDs in turn.
     std::vector<std::vector<uint32_t>> slices_of(8);
     uint32_t local = 0;
-    const uint32_t modulo_slices = strip_modulo_slices(n_kslices, shard_count);
+    const bool pair_mode = sh.pair_space && shard_count > 1;
+    const uint32_t modulo_slices = pair_mode ? n_kslices : strip_modulo_slices(n_kslices, shard_count);
     const uint32_t xg = (uint32_t)std::max(1, sh.xcd_group);
     for (uint32_t ks = 0; ks < modulo_slices; ++ks)
-        if (strip_owns_slice(ks, shard_rank, shard_count)) slices_of[(local++ / xg) % 8].push_back(ks);
+        if (pair_mode || strip_owns_slice(ks, shard_rank, shard_count)) slices_of[(local++ / xg) % 8].push_back(ks);
     // One slice = every A tile against the B blocks behind it; `max_run` caps the stages per item.
-    auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
+    std::vector<uint64_t> pair_load(shard_count, 0);  // pair mode: stages dealt to every shard so far
+    auto emit_slice_all = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
         // k2_debug & 16 (timing probe, wrong results): every XCD re-reads one k-slice, i.e. the
         // launch as it would run if nothing ever missed in L2
         const uint32_t ks_data = sh.one_slice_probe ? ks % 8u : ks;
@@ -1936,6 +1943,21 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
             }
         }
     };
+    // pair mode: this shard's share of the slice — the slice's items, longest first onto the least loaded shard
+    // (every shard walks the slices in the same order and computes the same deal)
+    auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
+        if (!pair_mode) return emit_slice_all(ks, max_run, dst);
+        std::vector<StripItem> all;
+        emit_slice_all(ks, max_run, all);
+        std::stable_sort(all.begin(), all.end(), [&](const StripItem& p, const StripItem& q) {
+            return strip_item_cost(p, kPerTile) > strip_item_cost(q, kPerTile);
+        });
+        for (const StripItem& it : all) {
+            const uint32_t r = (uint32_t)(std::min_element(pair_load.begin(), pair_load.end()) - pair_load.begin());
+            pair_load[r] += strip_item_cost(it, kPerTile);
+            if (r == shard_rank) dst.push_back(it);
+        }
+    };
     // An XCD runs its list in order on ~128 workgroup slots. Long items keep the per-item cost
     // (A fragments, ring fill, diagonal phase) low, but whatever is still running when the list
     // runs dry sets the tail: with whole-length items the last slices leave most slots idle for
@@ -1948,7 +1970,7 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
         std::vector<uint64_t> load(shard_count, 0);
         for (uint32_t ks = modulo_slices; ks < n_kslices; ++ks) {
             std::vector<StripItem> all;
-            emit_slice(ks, std::min(kMaxRun, kTailRun), all);
+            emit_slice_all(ks, std::min(kMaxRun, kTailRun), all);
             std::stable_sort(all.begin(), all.end(), [&](const StripItem& p, const StripItem& q) {
                 return strip_item_cost(p, kPerTile) > strip_item_cost(q, kPerTile);
             });
@@ -2013,7 +2035,7 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
 static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
                               uint32_t a_tile, int xcd_group = 1) {
-    const uint64_t key[4] = {ranges_hash(ranges) ^ ((uint64_t)xcd_group << 56), n_kslices,
+    const uint64_t key[4] = {ranges_hash(ranges) ^ ((uint64_t)xcd_group << 56) ^ ((uint64_t)(ctx->k2_shard_pairs != 0) << 55), n_kslices,
                              ((uint64_t)shard_rank << 32) | shard_count,
                              ((uint64_t)a_tile << 48) | ((uint64_t)(ctx->k2_debug & 16) << 40) |
                                  ((uint64_t)(ctx->k2_persistent != 0) << 47) |
@@ -2028,6 +2050,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     sh.tail_slices = ctx->k2_tail_slices;
     sh.lpt_rounds = ctx->k2_lpt_rounds;
     sh.xcd_group = xcd_group;
+    sh.pair_space = ctx->k2_shard_pairs != 0;
     sh.persistent = ctx->k2_persistent != 0;
     sh.one_slice_probe = (ctx->k2_debug & 16) != 0;
     std::vector<StripItem> items;
@@ -2165,7 +2188,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
     // the rule runs over the chunk's own slice numbers, as its work list does), or its own
     // k-groups (tile kernel)
     const ExpandOwn own = strips ? ExpandOwn{shard_rank, shard_count, 5u,
-                                             strip_modulo_slices(chunk_slices, shard_count) / kOwnSlices}
+                                             ctx->k2_shard_pairs ? 0u   // pair-space ownership: every shard expands every column
+                                                                 : strip_modulo_slices(chunk_slices, shard_count) / kOwnSlices}
                                  : ExpandOwn{shard_rank, shard_count, 7u, 0xffffffffu};
     const uint32_t nib = (ctx->k2_debug >> 8) ? (uint32_t)(ctx->k2_debug >> 8) & 15u : 2u;
     const uint64_t n_src = std::min(n_rows_src, n_rows_dst);
@@ -2254,6 +2278,10 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
             kernel_time_mark(ctx);
             STORM_HIP_TRY(hipGetLastError());
         }
+    }
+    if (ctx->n_items + n_strip > 0) {
+        ctx->pass_report[0] |= strips ? STORM_HIP_RAN_FP4_STRIPS : STORM_HIP_RAN_FP4_TILES;
+        ctx->pass_report[1] += ranges_word_pairs(ranges, n_words_logical ? n_words_logical : stride_words, shard_count);
     }
     ctx->last_info[0] = ctx->n_items + n_strip;
     ctx->last_info[1] = ctx->k2_stages_per_item;
@@ -2961,6 +2989,8 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
         return STORM_HIP_EINVAL;
     }
     if (int rc = ensure_bitstream(ctx, ranges, n_kslices, shard_rank, shard_count, pitch)) return rc;
+    ctx->pass_report[0] |= STORM_HIP_RAN_BITSTREAM;
+    ctx->pass_report[1] += ranges_word_pairs(ranges, (uint64_t)n_kslices * 8u, shard_count);
     ctx->n_items = 0;
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
     ctx->last_info[0] = ctx->n_bit_groups;
@@ -3026,6 +3056,10 @@ int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pi
         return rc;
     const uint32_t n_strip = ctx->n_strip_items;
     ctx->k2_operands_used = 5;
+    if (n_strip > 0) {
+        ctx->pass_report[0] |= STORM_HIP_RAN_BIT_STRIPS;
+        ctx->pass_report[1] += ranges_word_pairs(ranges, (uint64_t)n_kslices2 * 4u, shard_count);  // a slice = 256 bit-MACs per pair = 4 words
+    }
     ctx->last_info[0] = n_strip;
     ctx->last_info[1] = ctx->k2_stages_per_item;
     ctx->last_info[2] = 1;
@@ -3125,22 +3159,26 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 // Host-only view of the default path's work decomposition (no device is touched): what a shard
 // of a multi-GPU run multiplies, so that the partition of the pair space can be checked — and
 // rehearsed with CPU partials — without a GPU (tests/test_dist_cpu.py).
-extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
-                                    uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
-                                    uint64_t* n_items) {
+extern "C" int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                                     uint32_t shard_count, int form, int pair_space, uint32_t* out,
+                                     uint64_t capacity_items, uint64_t* n_items) {
     using namespace storm;
-    if (!n_items || shard_count == 0 || shard_rank >= shard_count || n_words == 0) {
+    if (!n_items || shard_count == 0 || shard_rank >= shard_count || n_words == 0 || (form != 0 && form != 1)) {
         set_error("strip_plan: bad arguments");
         return STORM_HIP_EINVAL;
     }
     try {
-        const uint32_t n_kslices = (n_words + 3u) / 4u;  // slices that hold data (launch_pairw_mfma_ranges)
+        // slices that hold data: form 0 (FP4 shadow, launch_pairw_mfma_ranges): 256 consecutive bits each;
+        // form 1 (K2b, launch_pairw_bits_ranges): slice ks = class pair ks & 1 of the 512-bit chunk ks / 2
+        const uint32_t n_kslices = form == 0 ? (n_words + 3u) / 4u : 2u * ((n_words + 7u) / 8u);
         std::vector<RowRange> ranges;
         if (n_rows > 1) ranges.push_back({0, n_rows});
         std::vector<StripItem> items;
         uint32_t qb[8], qc[8];
-        build_strip_items(StripShaping{}, ranges, n_kslices, shard_rank, shard_count,
-                          (uint32_t)kStripATile, items, qb, qc);
+        StripShaping sh;
+        sh.xcd_group = form == 0 ? 1 : 2;
+        sh.pair_space = pair_space != 0;
+        build_strip_items(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile, items, qb, qc);
         *n_items = items.size();
         if (out)
             for (uint64_t i = 0; i < std::min<uint64_t>(capacity_items, items.size()); ++i) {
@@ -3155,6 +3193,12 @@ extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t 
         return STORM_HIP_ENOMEM;
     }
     return STORM_HIP_OK;
+}
+
+extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                                    uint32_t shard_count, uint32_t* out, uint64_t capacity_items,
+                                    uint64_t* n_items) {
+    return storm_hip_strip_plan2(n_rows, n_words, shard_rank, shard_count, 0, 0, out, capacity_items, n_items);
 }
 
 extern "C" int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,

@@ -51,6 +51,7 @@ struct storm_hip_sparse_s {
     size_t probe_items_capacity = 0;
     uint64_t probe_key = ~0ull;
     uint32_t n_probe_launch = 0, n_probe_cols_launch = 0;
+    uint64_t probe_lookups_launch = 0;  // positions the launched items stream + their own rows' elements (this shard)
     // segment table cache (per shard)
     Seg* d_segs = nullptr;
     uint32_t n_segs = 0;
@@ -977,6 +978,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     storm_hip_sparse_t* s = const_cast<storm_hip_sparse_t*>(cs);
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     memcpy(ctx->sparse_census, s->census, sizeof(s->census));
+    memset(ctx->pass_report, 0, sizeof(ctx->pass_report));
     // Matrix-core path when the columns are big enough to fill the chip (same rule as the dense
     // container): every column is an independent all-pairs problem over its pool rows.
     uint64_t widest = 0;
@@ -1021,10 +1023,17 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                                         ? (uint32_t)((mine.size() - shard_rank + shard_count - 1) / shard_count)
                                         : 0u;
                 s->n_probe_cols_launch = cols_used;
+                // lookups of this shard's items: the streamed far positions + the own rows' elements
+                s->probe_lookups_launch = 0;
+                for (size_t k = shard_rank; k < mine.size(); k += shard_count)
+                    s->probe_lookups_launch += (uint64_t)(mine[k].b_end - mine[k].b_begin) + (mine[k].n_end - mine[k].n_begin);
                 s->probe_key = key;
             }
         }
         if (s->n_probe_launch > 0) {
+            ctx->pass_report[0] |= STORM_HIP_RAN_LIST_PROBE;
+            ctx->pass_report[2] += s->probe_lookups_launch;
+            ctx->pass_report[3] = kProbeRows;
             hipLaunchKernelGGL(probe_lists_kernel, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
                                s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
                                shard_rank, ctx->d_slots);

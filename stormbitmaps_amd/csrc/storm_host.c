@@ -75,6 +75,22 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     return 0;
 }
 
+/* What the last all-pairs call of this process ran, over its configured devices (storm_hip_last_pass_report per
+ * context: kernel mask OR-ed, work summed). -1 NULL argument. */
+int STORM_hip_last_pass(uint64_t out[4]) {
+    if (!out) return -1;
+    memset(out, 0, 4 * sizeof(uint64_t));
+    for (int d = 0; d < g_n_devices; ++d) {
+        uint64_t r[4];
+        if (!g_ctx[d] || storm_hip_last_pass_report(g_ctx[d], r) != STORM_HIP_OK) continue;
+        out[0] |= r[0];
+        out[1] += r[1];
+        out[2] += r[2];
+        if (r[3]) out[3] = r[3];
+    }
+    return 0;
+}
+
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count) {
     if (shard_count == 0 || shard_rank >= shard_count) return -1;
     g_shard_rank = shard_rank;
@@ -273,7 +289,11 @@ static uint64_t across_ranks(uint64_t partial) {
 
 /* a STORM_compute_func is only an identity token on the device path (libalgebra.h) */
 static int leaf_is_ours(STORM_compute_func f) {
-    return f == NULL || f == STORM_intersect_count_scalar;
+    if (f == NULL || f == STORM_intersect_count_scalar) return 1;
+#if defined(__x86_64__)
+    if (f == STORM_intersect_count_sse4 || f == STORM_intersect_count_avx2 || f == STORM_intersect_count_avx512) return 1;
+#endif
+    return 0;
 }
 static int lleaf_is_ours(STORM_compute_lfunc f) {
     return f == NULL || f == (STORM_compute_lfunc)STORM_intersect_count_scalar_list;

@@ -52,9 +52,11 @@ def init_process_group(backend: str):
     return dist
 
 
-def strip_plan(n_rows: int, n_words: int, rank: int, world: int):
-    """The work items rank `rank` of `world` multiplies on the default path, as an [n, 5] uint32
-    array of {a_row0, diag, j0, j1, ks} (see storm_hip_strip_plan in include/storm_hip.h).
+def strip_plan(n_rows: int, n_words: int, rank: int, world: int, form: int = 1, pair_space: int = 0):
+    """The work items rank `rank` of `world` multiplies, as an [n, 5] uint32 array of {a_row0, diag, j0, j1, ks}
+    (see storm_hip_strip_plan2 in include/storm_hip.h). form 1 = the default path (K2b: slice ks = class pair
+    ks & 1 of the 512-bit chunk ks / 2), form 0 = the FP4-shadow strips (slice ks = 256 consecutive bits);
+    pair_space 1 = every slice cut along the pair space (option k2_shard_pairs).
     Host-only: computed by libstorm_hip.so without touching a device."""
     import ctypes as C
 
@@ -63,13 +65,25 @@ def strip_plan(n_rows: int, n_words: int, rank: int, world: int):
     from . import _lib
     lib = _lib.load()
     n = C.c_uint64(0)
-    _lib.check(lib.storm_hip_strip_plan(n_rows, n_words, rank, world, None, 0, C.byref(n)),
-               "storm_hip_strip_plan")
+    _lib.check(lib.storm_hip_strip_plan2(n_rows, n_words, rank, world, form, pair_space, None, 0, C.byref(n)),
+               "storm_hip_strip_plan2")
     out = np.zeros((int(n.value), 5), dtype=np.uint32)
     if n.value:
-        _lib.check(lib.storm_hip_strip_plan(n_rows, n_words, rank, world, out.ctypes.data_as(C.c_void_p),
-                                            n.value, C.byref(n)), "storm_hip_strip_plan")
+        _lib.check(lib.storm_hip_strip_plan2(n_rows, n_words, rank, world, form, pair_space,
+                                             out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "storm_hip_strip_plan2")
     return out
+
+
+def slice_columns(mat, ks: int, form: int = 1):
+    """The bits of k-slice `ks` of a bit matrix [rows, words] as a matrix of the same row count (what an item of
+    strip_plan(form) multiplies): form 0 = words [4 ks, 4 ks + 4); form 1 = the words [8 c, 8 c + 8) of chunk
+    c = ks // 2 masked to the class pair ks & 1 (bits b with (b % 4) // 2 == ks & 1)."""
+    import numpy as np
+    if form == 0:
+        return np.ascontiguousarray(mat[:, 4 * ks:4 * ks + 4])
+    c = ks // 2
+    mask = np.uint64(0xCCCCCCCCCCCCCCCC if ks & 1 else 0x3333333333333333)
+    return np.ascontiguousarray(mat[:, 8 * c:8 * c + 8] & mask)
 
 
 def stream_plan(n_rows: int, n_words: int, rank: int = 0, world: int = 1, n_cus: int = 256):

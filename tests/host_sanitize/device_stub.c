@@ -166,6 +166,11 @@ int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
 
 /* the multi-process exchange (storm_hip_comm_*): one rank, the sum of one value is the value */
 struct storm_hip_comm_s { uint32_t rank, world; };
+int storm_hip_last_pass_report(storm_hip_ctx_t* ctx, uint64_t out[4]) {
+    (void)ctx;
+    memset(out, 0, 4 * sizeof(uint64_t));
+    return STORM_HIP_OK;
+}
 int storm_hip_comm_unique_id(uint8_t id[STORM_HIP_COMM_ID_BYTES]) {
     memset(id, 7, STORM_HIP_COMM_ID_BYTES);
     return STORM_HIP_OK;

@@ -178,3 +178,33 @@ def test_benchmark_cli_is_built_and_refuses_bad_arguments():
     assert res.returncode != 0 and "Usage" in res.stderr
     res = subprocess.run([exe, "0", "10"], capture_output=True, text=True)
     assert res.returncode != 0 and "non-positive" in res.stderr
+
+
+def test_simd_leaves_of_the_libalgebra_surface_match_the_scalar_leaf(lib, orc):
+    """STORM_intersect_count_sse4 / _avx2 / _avx512 (benchmark.cpp:961,1013,1031; host functions of the product,
+    stormbitmaps_amd/csrc/storm_leaves.c): every one the host CPU supports (STORM_get_cpuid, as the reference's
+    harness gates them, benchmark.cpp:949-1022) equals the scalar leaf and the oracle's leaf on lengths around
+    every vector width and round boundary, aligned and unaligned."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 1 << 63, size=2100, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=2100, dtype=np.uint64)
+    b = rng.integers(0, 1 << 63, size=2100, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=2100, dtype=np.uint64)
+    cpuid = lib.STORM_get_cpuid()
+    leaves = [("STORM_intersect_count_scalar", 0), ("STORM_intersect_count_sse4", 1),
+              ("STORM_intersect_count_avx2", 2), ("STORM_intersect_count_avx512", 4)]
+    ran = 0
+    for name, bit in leaves:
+        assert hasattr(lib, name), name
+        if bit and not (cpuid & bit):
+            continue
+        f = getattr(lib, name)
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        for off in (0, 1, 3):
+            for n in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 1024, 2047]:
+                want = int(sum(bin(int(x) & int(y)).count("1") for x, y in zip(a[off:off + n], b[off:off + n]))) if n < 70 \
+                    else int(np.unpackbits((a[off:off + n] & b[off:off + n]).view(np.uint8)).sum())
+                got = int(f(a[off:].ctypes.data, b[off:].ctypes.data, n))
+                assert got == want, (name, off, n, got, want)
+        ran += 1
+    assert ran >= 1

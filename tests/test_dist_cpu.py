@@ -15,21 +15,24 @@ import torch.multiprocessing as mp
 from stormbitmaps_amd import dist as sdist
 from stormbitmaps_amd import synth
 
-A_TILE, B_BLOCK, SLICE_WORDS = 256, 64, 4
+A_TILE, B_BLOCK = 256, 64
+# (form, pair_space): the default path (K2b, class-pair slices) with both ownership modes, and the FP4-shadow strips
+MODES = ((1, 0), (1, 1), (0, 0))
 
 
-def _n_kslices(n_words):
-    return (n_words + SLICE_WORDS - 1) // SLICE_WORDS   # slices that hold data (padding is never multiplied)
+def _n_kslices(n_words, form=1):
+    """slices that hold data (padding is never multiplied): form 0: 256 consecutive bits; form 1: a class pair of a 512-bit chunk"""
+    return (n_words + 3) // 4 if form == 0 else 2 * ((n_words + 7) // 8)
 
 
-def _cover(n_rows, n_words, world):
+def _cover(n_rows, n_words, world, form=1, pair_space=0):
     """cover[ks][i, j] = how many items of all ranks count pair (i, j) in k-slice ks; per-rank cost."""
     pad = (n_rows + A_TILE - 1) // A_TILE * A_TILE
-    ks_n = _n_kslices(n_words)
+    ks_n = _n_kslices(n_words, form)
     cover = np.zeros((ks_n, pad, pad), dtype=np.uint8)
     cost = []
     for r in range(world):
-        items = sdist.strip_plan(n_rows, n_words, r, world)
+        items = sdist.strip_plan(n_rows, n_words, r, world, form, pair_space)
         c = 0
         for a0, diag, j0, j1, ks in items.tolist():
             if diag:
@@ -45,41 +48,44 @@ def _cover(n_rows, n_words, world):
     (1500, 4, (1, 2, 3, 5, 8)),   # ONE k-slice: fewer slices than ranks -> pure pair-space split
     (300, 100, (2, 3, 7)),        # 25 slices, 7 ranks: 3 whole each + 4 leftover
 ])
-def test_strip_plans_of_all_ranks_tile_the_work_exactly_once(n_rows, n_words, worlds):
+@pytest.mark.parametrize("form,pair_space", MODES)
+def test_strip_plans_of_all_ranks_tile_the_work_exactly_once(n_rows, n_words, worlds, form, pair_space):
     pad = (n_rows + A_TILE - 1) // A_TILE * A_TILE
     want = np.zeros((pad, pad), dtype=np.uint8)
     want[:n_rows, :] = np.triu(np.ones((n_rows, pad), np.uint8), k=1)   # B blocks run to the padded edge
     for world in worlds:
-        cover, cost = _cover(n_rows, n_words, world)
+        cover, cost = _cover(n_rows, n_words, world, form, pair_space)
+        assert cover.shape[0] == _n_kslices(n_words, form)
         for ks in range(cover.shape[0]):
             # every real pair i < j < n_rows exactly once; padded (all-zero) rows may be visited, never twice
             assert np.array_equal(cover[ks][:n_rows, :n_rows], want[:n_rows, :n_rows]), (world, ks)
             assert cover[ks].max() <= 1
-        assert sum(cost) == _cover(n_rows, n_words, 1)[1][0] or world == 1
+        if not pair_space:   # (pair mode cuts every slice into the same items: same stage count by construction)
+            assert sum(cost) == _cover(n_rows, n_words, 1, form, pair_space)[1][0] or world == 1
 
 
-def test_headline_shape_balances_within_three_percent_for_any_world():
+@pytest.mark.parametrize("form,pair_space", MODES)
+def test_headline_shape_balances_within_three_percent_for_any_world(form, pair_space):
     """c2 (N = 10000, W = 1024: 256 k-slices): stage counts per rank for G = 2..8."""
     for world in (2, 3, 4, 5, 6, 7, 8):
         cost = []
         for r in range(world):
-            it = sdist.strip_plan(10000, 1024, r, world)
+            it = sdist.strip_plan(10000, 1024, r, world, form, pair_space)
             cost.append(int((it[:, 3] - it[:, 2]).sum() + 4 * it[:, 1].sum()))
         assert max(cost) <= 1.03 * (sum(cost) / world), (world, cost)
-    # a matrix with a single k-slice still splits 8 ways (pair-space sharding)
+    # a matrix with a single k-slice (form 1: one chunk = two class-pair slices) still splits 8 ways (pair-space sharding)
     cost = []
     for r in range(8):
-        it = sdist.strip_plan(10000, 4, r, 8)
+        it = sdist.strip_plan(10000, 4, r, 8, form, pair_space)
         cost.append(int((it[:, 3] - it[:, 2]).sum() + 4 * it[:, 1].sum()))
     assert min(cost) > 0 and max(cost) <= 1.03 * (sum(cost) / 8), cost
 
 
-def _item_total(orc, mat, item):
+def _item_total(orc, mat, item, form=1):
     """Oracle partial of one strip item: pairs (A tile x B blocks [+ own triangle]) on k-slice ks."""
     a0, diag, j0, j1, ks = (int(x) for x in item)
     n = mat.shape[0]
-    w0 = ks * SLICE_WORDS
-    sl = np.ascontiguousarray(mat[:, w0:w0 + SLICE_WORDS])
+    sl = sdist.slice_columns(mat, ks, form)
     if sl.shape[1] == 0:
         return 0
     a1 = min(a0 + A_TILE, n)
@@ -92,7 +98,7 @@ def _item_total(orc, mat, item):
     return total
 
 
-def _worker(rank, world, port, n_rows, n_bits, want, q):
+def _worker(rank, world, port, n_rows, n_bits, want, q, form=1, pair_space=0):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from tests._orc import Oracle
@@ -101,7 +107,7 @@ def _worker(rank, world, port, n_rows, n_bits, want, q):
     mat = synth.dense_matrix(n_bits, n_rows, 700, seed=42)
 
     def partial(r, w):
-        return sum(_item_total(orc, mat, it) for it in sdist.strip_plan(n_rows, mat.shape[1], r, w))
+        return sum(_item_total(orc, mat, it, form) for it in sdist.strip_plan(n_rows, mat.shape[1], r, w, form, pair_space))
 
     total = sdist.sharded_pairw(partial)
     q.put((rank, total, partial(rank, world)))
@@ -110,8 +116,13 @@ def _worker(rank, world, port, n_rows, n_bits, want, q):
     assert total == want
 
 
-@pytest.mark.parametrize("n_bits", (2048, 700))   # 8 k-slices: whole slices only | 3 slices: 1 whole each + 1 leftover
-def test_two_rank_gloo_allreduce_equals_single_rank(orc, n_bits):
+@pytest.mark.parametrize("n_bits,form,pair_space", [
+    (2048, 1, 0),   # default path (K2b): 8 class-pair slices: whole slices only
+    (700, 1, 0),    # 4 class-pair slices (one of them over the ragged last chunk): leftover slices along the pair space
+    (2048, 1, 1),   # every slice along the pair space (k2_shard_pairs)
+    (700, 0, 0),    # FP4-shadow strips: 3 slices of 256 consecutive bits
+])
+def test_two_rank_gloo_allreduce_equals_single_rank(orc, n_bits, form, pair_space):
     n_rows = 700
     mat = synth.dense_matrix(n_bits, n_rows, 700, seed=42)
     want = orc.wrapper_diag(mat)
@@ -120,7 +131,7 @@ def test_two_rank_gloo_allreduce_equals_single_rank(orc, n_bits):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_bits, want, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_rows, n_bits, want, q, form, pair_space)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(2))

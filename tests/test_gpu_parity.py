@@ -503,21 +503,33 @@ def test_benchmark_cli_rows_agree_with_golden_totals():
     exe = os.path.join(root, "stormbitmaps_amd", "storm_benchmark")
     gold = {(c["M"], c["N"], c["draws"]): c["total"] for c in _load("synth_totals.json")["dense"]}
     for M, N, loads, methods in ((4096, 256, "2048,40,5", 3), (65536, 700, "32768,262,1", 5)):
-        res = subprocess.run([exe, str(M), str(N), loads, "--reps", "1"], capture_output=True, text=True,
-                             timeout=600)
+        res = subprocess.run([exe, str(M), str(N), loads, "--reps", "2", "--cpu-seconds", "0.05"], capture_output=True,
+                             text=True, timeout=600)
         assert res.returncode == 0, res.stderr
         lines = res.stdout.strip().splitlines()
         assert lines[0].startswith("Samples\tAlts\tMethod")
-        assert lines[1].startswith("#Method\tAlts\t") and lines[1].endswith("fp4_mfma_frac")
-        rows = [l.split("\t") for l in lines[2:]]
-        n_cols = len(lines[1].split("\t"))
-        assert all(len(r) == n_cols for r in rows), [len(r) for r in rows]
-        assert all(0.0 < float(r[-1]) < 1.0 and float(r[-3]) > 0 for r in rows)   # FP4 fraction, GB/s
+        assert lines[1].startswith("#Method\tAlts\t") and lines[1].endswith("rows_per_lookup\tnote")
+        cols = lines[1].split("\t")
+        rows = [dict(zip(cols, l.split("\t"))) for l in lines[2:]]
+        assert all(len(l.split("\t")) == len(cols) for l in lines[2:])
+        gpu_rows = [r for r in rows if int(r["GPUs"]) > 0]
+        cpu_rows = [r for r in rows if int(r["GPUs"]) == 0]
+        # every GPU row: priced against the roof of the kernel that ran, never above it; one call timed first
+        for r in gpu_rows:
+            assert r["kernel"] != "-" and r["roof"] != "-", r
+            assert 0.0 <= float(r["roof_frac"]) <= 1.0, r
+            assert float(r["time_ms"]) == float(r["first_call_ms"]) > 0 and float(r["steady_ms"]) > 0
+            assert float(r["cycles"]) > 0 and float(r["cycles_word"]) > 0
+        # the host rows: the library's own SIMD leaves under the harness's blocked loop (a row sample)
+        assert {r["#Method"].split("-")[1] for r in cpu_rows} >= {"scalar"}
+        assert all("==" in r["note"] and "extrapolated" in r["note"] for r in cpu_rows), cpu_rows
         for load in (int(x) for x in loads.split(",")):
-            totals = {int(r[2]) for r in rows if int(r[1]) == load}
-            names = [r[0] for r in rows if int(r[1]) == load]
+            totals = {int(r["total"]) for r in gpu_rows if int(r["Alts"]) == load}
+            names = [r["#Method"] for r in gpu_rows if int(r["Alts"]) == load]
             assert len(names) == methods, names
             assert totals == {gold[(M, N, load)]}, (M, N, load, totals)
+            if N <= 256:   # the CPU sample is the whole matrix: its total is the matrix's
+                assert {int(r["total"]) for r in cpu_rows if int(r["Alts"]) == load} <= {gold[(M, N, load)]}
 
 
 def test_repeated_launches_are_stable(hip_ctx):

@@ -226,8 +226,8 @@ def test_native_rccl_reduce_for_c_callers_with_one_rank():
     dlopen'ed, a communicator of ONE rank is created and the storm.h entry points return the all-reduced
     total — through tools/storm_benchmark.cpp --ranks 1, which forks its rank before any HIP call and hands
     the id over a pipe, exactly as it does for N ranks. Totals against the committed oracle vectors."""
-    rows = _benchmark_rows(["4096", "256", "2048,40", "--ranks", "1", "--reps", "1"])
-    assert rows and all(int(r[-5]) == 1 for r in rows)          # GPUs column
+    rows = _benchmark_rows(["4096", "256", "2048,40", "--ranks", "1", "--reps", "1", "--cpu-seconds", "0"])
+    assert rows and all(int(r[-10]) == 1 for r in rows)          # GPUs column
     for load in (2048, 40):
         totals = {int(r[2]) for r in rows if int(r[1]) == load}
         assert totals == {_golden_total(4096, 256, load)}, (load, totals)
@@ -240,8 +240,8 @@ def test_native_rccl_reduce_over_two_gpus_when_the_box_has_them():
     n_dev = sb.load().storm_hip_device_count()
     if n_dev < 2:
         pytest.skip(f"{n_dev} GPU visible: RCCL needs one GPU per rank")
-    rows = _benchmark_rows(["65536", "700", "32768,262", "--ranks", "2", "--reps", "2"])
-    assert rows and all(int(r[-5]) == 2 for r in rows)
+    rows = _benchmark_rows(["65536", "700", "32768,262", "--ranks", "2", "--reps", "2", "--cpu-seconds", "0"])
+    assert rows and all(int(r[-10]) == 2 for r in rows)
     for load in (32768, 262):
         totals = {int(r[2]) for r in rows if int(r[1]) == load}
         assert totals == {_golden_total(65536, 700, load)}, (load, totals)

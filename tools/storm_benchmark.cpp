@@ -2,7 +2,7 @@
 //
 // Counterpart of benchmark.cpp (intersect_test :644-1059, benchmark_large :505-642, main
 // :1085-1125), written from scratch against include/storm.h + libstorm_hip.so:
-//     storm_benchmark <M> <N> [load1,load2,...] [--gpus G | --ranks R] [--seed S] [--reps R]
+//     storm_benchmark <M> <N> [load1,load2,...] [--gpus G | --ranks R] [--seed S] [--reps R] [--cpu-seconds T]
 // --gpus G : one process drives G GPUs (STORM_hip_set_devices; partials added on the host).
 // --ranks R: R processes, one per GPU — forked HERE, before anything touches HIP — each computes its shard
 //            (STORM_hip_set_shard) and the storm.h entry points return the RCCL all-reduced total
@@ -11,16 +11,30 @@
 // zero/duplicate rules (:695, :715-730), same routing (M < 256000 -> both containers, else
 // STORM_t only, :1117-1121; STORM_t rows only when M >= 65536, :832), same optimal block size
 // (:823-824), same TSV row shape: name \t load \t [size] \t + the 11 bench_t fields (:74-87).
-// Differences, all forced by the platform: inputs come from the repo's deterministic generator
-// (storm_synth.h) instead of std::random_device (:756-757); the CPU PMU fields (cycles,
-// instructions, branch/cache misses) are printed as 0 — there is no perf_event on the device;
-// time is printed in ms with 3 decimals (a pass takes ~1 ms, the reference prints whole ms);
-// CRoaring and the direct-to-SIMD rows do not exist; five extra columns are appended:
-// GPUs used, 64-bit words/s, algorithmic GB/s (the reference's no-reuse accounting, 8 B per word,
-// benchmark.cpp:131), that rate as a fraction of the GPUs' HBM peak (8 TB/s each; on-chip reuse
-// puts it far above 1) and the fraction of the GPUs' dense FP4 matrix-core peak (10 PFLOP/s each;
-// one word pair = 128 FLOP) — every figure over the WALL time of the call, host synchronisation and
-// (bitmap-hip row) the PCIe copy included. `--describe` prints one line per column.
+// What a row means here:
+//   * time_ms is ONE call, the first of the row — the reference times exactly one call per row right after
+//     construction (benchmark.cpp:605-613, :896-918) — and so includes whatever that call has to bring to the
+//     device (the rest of the rows, the sparse arena). The best of the following --reps - 1 calls is the extra
+//     column steady_ms; the reference-shaped fields (throughput, cycles) are of the first call, the appended
+//     rate columns of the steady one.
+//   * cycles / cycles_word: the reference reads the CPU's cycle counter; a GPU row prints wall time x 2.4 GHz
+//     (the MI355X's peak engine clock) x GPUs, a CPU row the host's time stamp counter. Instructions, branch and
+//     cache misses stay 0: nothing counts them on the device.
+//   * kernel / roof / roof_frac: the kernels the call ran (STORM_hip_last_pass) and the fraction of THEIR roof
+//     the steady call reached: dense word pairs x 128 FLOP against 10 PFLOP/s FP4 per GPU (matrix-core
+//     kernels), word pairs against the VALU popcount ceiling 1.97e13/s (popcount kernel), list-probe lookups
+//     against the LDS ceiling 1.97e13 lookups/s (32 two-byte lookups per clock and CU); a call that ran two
+//     kinds is priced as the sum of both parts' minimum times. One lookup of the list-probe kernel stands for
+//     `rows_per_lookup` (128) of the reference's per-pair list tests (storm.c:4-73): lookups_per_s x 128 is the
+//     pair-test rate, the roof fraction is on the lookups the kernel really does.
+//   * CPU rows (bitmap-<leaf>-blocked-<b>-cpu): the reference's fwrapper_blocked<leaf> rows (benchmark.cpp:256-316,
+//     :949-1045) — this harness's own blocked loop over the raw buffer calling the library's exported one-pair
+//     leaf (STORM_intersect_count_scalar / _sse4 / _avx2 / _avx512, stormbitmaps_amd/csrc/storm_leaves.c) on ONE
+//     host thread, over the first R rows only (R chosen for --cpu-seconds, default 0.5 s per leaf) and
+//     EXTRAPOLATED to N rows by the pair count (note column). GPUs = 0 marks them.
+// Other differences, forced by the platform: inputs come from the repo's deterministic generator
+// (storm_synth.h) instead of std::random_device (:756-757); time has 3 decimals (a pass takes ~1 ms, the
+// reference prints whole ms); no CRoaring rows. `--describe` prints one line per column.
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -32,61 +46,192 @@
 
 #include <sys/wait.h>
 #include <unistd.h>
+#if defined(__x86_64__)
+#include <x86intrin.h>
+#endif
 
 #include "storm.h"
 #include "storm_hip.h"
 #include "storm_synth.h"
 
+static const double kGpuClockHz = 2.4e9;          // MI355X peak engine clock (MI355X_MICROARCH.md)
+static const double kFp4FlopPerS = 1e16;          // dense FP4 matrix-core peak per GPU
+static const double kValuWordPairsPerS = 1.97e13; // VALU popcount ceiling per GPU
+static const double kLdsLookupsPerS = 1.97e13;    // 32 two-byte LDS lookups per clock and CU x 256 CUs x 2.4 GHz
+
+static int g_ranks = 0;  // --ranks: every process reports its own share of the work
+
 struct Row {
-    uint64_t total;
-    double ms;
+    uint64_t total = 0;
+    double first_ms = 0, steady_ms = 0;
+    double cycles = 0;          // CPU rows: time stamp counter of the timed call
+    int gpus = 1;               // 0: a CPU row
+    uint64_t pass[4] = {0, 0, 0, 0};
+    std::string note;
 };
 
 template <class F>
-static Row timed(F&& f, int reps) {
-    Row best{0, 1e300};
-    for (int r = 0; r < reps; ++r) {
+static Row timed(F&& f, int reps, int gpus) {
+    Row r;
+    r.gpus = gpus;
+    r.steady_ms = 1e300;
+    for (int k = 0; k < reps; ++k) {
         const auto t0 = std::chrono::high_resolution_clock::now();
         const uint64_t total = f();
         const auto t1 = std::chrono::high_resolution_clock::now();
         const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        if (ms < best.ms) best = {total, ms};
+        if (k == 0) { r.first_ms = ms; r.total = total; }
+        else if (ms < r.steady_ms) r.steady_ms = ms;
+        if (total != r.total) r.note = "TOTALS DIFFER BETWEEN CALLS";
     }
-    return best;
+    if (reps < 2) r.steady_ms = r.first_ms;
+    STORM_hip_last_pass(r.pass);
+    if (g_ranks > 1) {  // this rank's share of a sharded call: the job's work is (close to) `ranks` times that
+        r.pass[1] *= (uint64_t)g_ranks;
+        r.pass[2] *= (uint64_t)g_ranks;
+    }
+    return r;
+}
+
+static std::string kernel_names(uint64_t mask) {
+    static const struct { uint64_t bit; const char* name; } k[] = {
+        {STORM_HIP_RAN_POPCOUNT, "pairw_dense_kernel"}, {STORM_HIP_RAN_FP4_TILES, "pairw_fp4_kernel"},
+        {STORM_HIP_RAN_FP4_STRIPS, "strip16_fp4_kernel"}, {STORM_HIP_RAN_BITSTREAM, "bitstream_kernel"},
+        {STORM_HIP_RAN_BIT_STRIPS, "strip16_bits_kernel"}, {STORM_HIP_RAN_LIST_PROBE, "probe_lists_kernel"}};
+    std::string out;
+    for (const auto& e : k)
+        if (mask & e.bit) out += (out.empty() ? "" : "+") + std::string(e.name);
+    return out.empty() ? "-" : out;
 }
 
 static void print_row(const std::string& name, uint32_t load, const char* extra, const Row& r,
-                      uint64_t n_variants, uint64_t n_ints, int gpus) {
-    // throughput as benchmark.cpp:128-131: pairs * 2 * W * 8 bytes / 2^20 per second
+                      uint64_t n_variants, uint64_t n_ints) {
+    // throughput as benchmark.cpp:128-131: pairs * 2 * W * 8 bytes / 2^20 per second, of the (first) timed call
     const double n_comps = (double)n_variants * (n_variants - 1) / 2.0;
     const double words = n_comps * 2.0 * (double)n_ints;
-    const double mbs = words * 8.0 / (1024.0 * 1024.0) / (r.ms / 1000.0);
-    const double secs = r.ms / 1000.0;
-    const double gbs = words * 8.0 / 1e9 / secs;                  // algorithmic (no reuse credit)
-    const double hbm_frac = gbs / (8000.0 * gpus);                // of 8 TB/s per GPU
-    const double fp4_frac = words / 2.0 * 128.0 / secs / (1e16 * gpus);  // of 10 PFLOP/s per GPU
-    printf("%s\t%u\t%s%llu\t%.2f\t%.3f\t%.3f\t%llu\t%llu\t%llu\t%llu\t%llu\t%.2f\t%.3f\t%d\t%.4e\t%.1f\t%.3f\t%.3e\n",
-           name.c_str(), load, extra, (unsigned long long)r.total, 0.0, 0.0, 0.0, 0ull, 0ull, 0ull,
-           0ull, 0ull, mbs, r.ms, gpus, words / secs, gbs, hbm_frac, fp4_frac);
+    const double mbs = words * 8.0 / (1024.0 * 1024.0) / (r.first_ms / 1000.0);
+    const double cycles = r.gpus > 0 ? r.first_ms / 1000.0 * kGpuClockHz * r.gpus : r.cycles;
+    const double secs = r.steady_ms / 1000.0;
+    const double gbs = words * 8.0 / 1e9 / secs;                      // algorithmic (no reuse credit)
+    const int g = r.gpus > 0 ? r.gpus : 1;
+    // minimum time of what the call really did, part by part, at each kernel's own roof
+    double t_min = 0;
+    std::string roof = "-";
+    if (r.gpus > 0) {
+        const bool matrix = r.pass[0] & (STORM_HIP_RAN_FP4_TILES | STORM_HIP_RAN_FP4_STRIPS | STORM_HIP_RAN_BITSTREAM | STORM_HIP_RAN_BIT_STRIPS);
+        const bool valu = (r.pass[0] & STORM_HIP_RAN_POPCOUNT) != 0, probe = (r.pass[0] & STORM_HIP_RAN_LIST_PROBE) != 0;
+        if (matrix) t_min += (double)r.pass[1] * 128.0 / (kFp4FlopPerS * g);
+        else if (valu) t_min += (double)r.pass[1] / (kValuWordPairsPerS * g);
+        if (probe) t_min += (double)r.pass[2] / (kLdsLookupsPerS * g);
+        roof = std::string(matrix ? "fp4_mfma" : valu ? "valu_popcount" : "") + ((matrix || valu) && probe ? "+" : "") + (probe ? "lds_lookups" : "");
+        if (roof.empty()) roof = "-";
+    }
+    printf("%s\t%u\t%s%llu\t%.2f\t%.4e\t%.2f\t%.0f\t%llu\t%llu\t%llu\t%llu\t%.2f\t%.3f\t%.3f\t%.3f\t%d\t%.4e\t%.1f\t%.3f\t%s\t%s\t%.4f\t%.3e\t%llu\t%s\n",
+           name.c_str(), load, extra, (unsigned long long)r.total, 0.0, cycles / words, 0.0, cycles, 0ull, 0ull, 0ull,
+           0ull, mbs, r.first_ms, r.first_ms, r.steady_ms, r.gpus, words / secs, gbs, gbs / (8000.0 * g),
+           r.gpus > 0 ? kernel_names(r.pass[0]).c_str() : "host", roof.c_str(), r.gpus > 0 ? t_min / secs : 0.0,
+           r.gpus > 0 ? (double)r.pass[2] / secs : 0.0, (unsigned long long)r.pass[3], r.note.empty() ? "-" : r.note.c_str());
     fflush(stdout);
 }
 
 static void describe_columns() {
     fprintf(stderr,
             "columns of a result row (tab separated; reference row = name, load, [size], then bench_t::PrintPretty, benchmark.cpp:74-87):\n"
-            "  1 Method                 row name of the reference (storm, storm-blocked, STORM-contig, STORM-contig-<b>); bitmap-hip-blocked-<b> = STORM_wrapper_diag_blocked on the raw buffer\n"
+            "  1 Method                 row name of the reference (storm, storm-blocked, STORM-contig, STORM-contig-<b>); bitmap-hip-blocked-<b> = STORM_wrapper_diag_blocked on the raw buffer;\n"
+            "                           bitmap-<leaf>-blocked-<b>-cpu = the harness's blocked loop over the library's host leaf, one thread, row sample, extrapolated\n"
             "  2 Alts                   values drawn per row (the load)\n"
             "  [3 size]                 STORM_serialized_size, only in the M >= 256000 form (benchmark.cpp:609)\n"
-            "  + total                  bench_t.total: sum over row pairs of popcount(A & B)\n"
-            "  + instructions_cycle, cycles_word, instructions_word, cycles, instructions, MinBranchMiss, MinCacheRef, MinCacheMiss\n"
-            "                           CPU PMU fields of bench_t (:76-84): printed as 0, the work runs on the GPU\n"
-            "  + throughput             bench_t.throughput: pairs * 2 * W * 8 B / 2^20 / s (:129-131), MiB/s\n"
-            "  + time_ms                bench_t.time_ms, best of --reps calls, 3 decimals (the reference prints whole ms)\n"
-            "  + GPUs                   devices the call was sharded over (--gpus)\n"
-            "  + words_per_s            pairs * 2 * W / s: the BASELINE metric\n"
+            "  + total                  bench_t.total: sum over row pairs of popcount(A & B) (CPU rows: of the row sample)\n"
+            "  + instructions_cycle     0 (no instruction counter on the device)\n"
+            "  + cycles_word            cycles / (pairs * 2 * W)\n"
+            "  + instructions_word      0\n"
+            "  + cycles                 GPU rows: time_ms x 2.4 GHz (peak engine clock) x GPUs; CPU rows: the host's time stamp counter, extrapolated like the time\n"
+            "  + instructions, MinBranchMiss, MinCacheRef, MinCacheMiss   0\n"
+            "  + throughput             bench_t.throughput of the timed (first) call: pairs * 2 * W * 8 B / 2^20 / s (:129-131), MiB/s\n"
+            "  + time_ms                bench_t.time_ms: ONE call, the first of the row, as the reference times it (3 decimals)\n"
+            "  + first_call_ms          the same number again, named\n"
+            "  + steady_ms              best of the following --reps - 1 calls (device state cached)\n"
+            "  + GPUs                   devices the call was sharded over (--gpus / --ranks); 0 = a CPU row\n"
+            "  + words_per_s            pairs * 2 * W / steady s: the BASELINE metric\n"
             "  + GB_per_s_algorithmic   words_per_s * 8 / 1e9 (no-reuse accounting of the reference)\n"
-            "  + hbm_frac_algorithmic   that over 8 TB/s per GPU (exceeds 1: operands are reused on chip)\n"
-            "  + fp4_mfma_frac          pairs * W * 128 FLOP / s over 10 PFLOP/s per GPU (the binding roof of the default path)\n");
+            "  + hbm_frac_algorithmic   that over 8 TB/s per GPU (exceeds 1 by design: operands are reused on chip, and the sparse paths skip absent blocks)\n"
+            "  + kernel                 the kernels the call ran (STORM_hip_last_pass)\n"
+            "  + roof                   what bounds them: fp4_mfma (10 PFLOP/s per GPU, 128 FLOP per word pair), valu_popcount (1.97e13 word pairs/s), lds_lookups (1.97e13/s)\n"
+            "  + roof_frac              minimum time of the work the call really did at those roofs / steady time (never above 1)\n"
+            "  + lookups_per_s          list-probe lookups per steady second (0 when that kernel did not run)\n"
+            "  + rows_per_lookup        rows of the group one lookup stands for (128): lookups x 128 = the reference's per-pair list tests\n"
+            "  + note                   CPU rows: the sample and that the time is extrapolated\n");
+}
+
+// ---- CPU rows: this harness's blocked upper-triangle loop (the shape of fwrapper_blocked, benchmark.cpp:256-316:
+// diagonal blocks, then each block against the blocks behind it) over a one-pair host leaf of the library
+typedef uint64_t (*leaf_t)(const uint64_t*, const uint64_t*, size_t);
+static uint64_t cpu_blocked(leaf_t leaf, const uint64_t* vals, uint64_t rows, uint32_t n_ints, uint32_t bsize) {
+    uint64_t total = 0;
+    for (uint64_t i0 = 0; i0 < rows; i0 += bsize) {
+        const uint64_t i1 = i0 + bsize < rows ? i0 + bsize : rows;
+        for (uint64_t i = i0; i < i1; ++i)
+            for (uint64_t j = i + 1; j < i1; ++j) total += leaf(vals + i * n_ints, vals + j * n_ints, n_ints);
+        for (uint64_t j0 = i1; j0 < rows; j0 += bsize) {
+            const uint64_t j1 = j0 + bsize < rows ? j0 + bsize : rows;
+            for (uint64_t i = i0; i < i1; ++i)
+                for (uint64_t j = j0; j < j1; ++j) total += leaf(vals + i * n_ints, vals + j * n_ints, n_ints);
+        }
+    }
+    return total;
+}
+static inline uint64_t tsc() {
+#if defined(__x86_64__)
+    return __rdtsc();
+#else
+    return 0;
+#endif
+}
+// vals holds the first `have` rows of an N-row matrix
+static void cpu_rows(const uint64_t* vals, uint64_t have, uint64_t N, uint32_t n_ints, uint32_t load, uint32_t bsize,
+                     double seconds, const char* extra) {
+    struct Leaf { const char* name; leaf_t f; int bit; };
+    std::vector<Leaf> leaves = {{"scalar", STORM_intersect_count_scalar, 0}};
+#if defined(STORM_HAVE_SSE42)
+    leaves.push_back({"sse4", STORM_intersect_count_sse4, STORM_CPUID_runtime_bit_SSE42});
+#endif
+#if defined(STORM_HAVE_AVX2)
+    leaves.push_back({"avx2", STORM_intersect_count_avx2, STORM_CPUID_runtime_bit_AVX2});
+#endif
+#if defined(STORM_HAVE_AVX512)
+    leaves.push_back({"avx512", STORM_intersect_count_avx512, STORM_CPUID_runtime_bit_AVX512BW});
+#endif
+    const int cpuid = STORM_get_cpuid();
+    const uint64_t R0 = have < 64 ? have : 64;   // calibration and cross-check sample
+    const uint64_t want0 = cpu_blocked(STORM_intersect_count_scalar, vals, R0, n_ints, bsize);
+    for (const Leaf& l : leaves) {
+        if (l.bit && !(cpuid & l.bit)) continue;
+        // calibrate on 64 rows (and check the leaf against the scalar one there), then the sample whose pair count fits the budget
+        uint64_t R = R0;
+        auto t0 = std::chrono::high_resolution_clock::now();
+        const bool agrees = cpu_blocked(l.f, vals, R, n_ints, bsize) == want0;
+        double s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        const double per_pair = s / ((double)R * (R - 1) / 2.0 + 1.0);
+        uint64_t fit = (uint64_t)std::sqrt(2.0 * seconds / (per_pair > 0 ? per_pair : 1e-9));
+        R = fit < 64 ? 64 : fit;
+        if (R > have) R = have;
+        t0 = std::chrono::high_resolution_clock::now();
+        const uint64_t c0 = tsc();
+        const uint64_t total = cpu_blocked(l.f, vals, R, n_ints, bsize);
+        const uint64_t c1 = tsc();
+        s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        const double scale = ((double)N * (N - 1) / 2.0) / ((double)R * (R - 1) / 2.0);
+        Row r;
+        r.gpus = 0;
+        r.total = total;
+        r.first_ms = r.steady_ms = s * 1e3 * scale;
+        r.cycles = (double)(c1 - c0) * scale;
+        char note[320];
+        snprintf(note, sizeof(note), "cpu 1 thread; first %llu of %llu rows timed (%.3f s), time and cycles extrapolated x%.1f by pair count; total is the sample's; leaf %s the scalar leaf on the first %llu rows",
+                 (unsigned long long)R, (unsigned long long)N, s, scale, agrees ? "==" : "!=", (unsigned long long)R0);
+        r.note = note;
+        print_row(std::string("bitmap-") + l.name + "-blocked-" + std::to_string(bsize) + "-cpu", load, extra, r, N, n_ints);
+    }
 }
 
 static std::vector<uint32_t> default_loads(uint32_t M) {
@@ -98,18 +243,20 @@ int main(int argc, char** argv) {
         fprintf(stderr,
                 "\nAbout:   Computes sum(popcnt(A & B)) for the all-vs-all comparison of N integer\n"
                 "         lists bounded by [0, M) on the MI355X.\n"
-                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G | --ranks R] [--seed S] [--reps R] [--describe]\n\n");
+                "Usage:   storm_benchmark <M> <N> [v1[,v2]] [--gpus G | --ranks R] [--seed S] [--reps R] [--cpu-seconds T (0: no CPU rows)] [--describe]\n\n");
         return EXIT_FAILURE;
     }
     int64_t n_samples = 0, n_vals = 10000;  // one-argument form uses N = 10000 (benchmark.cpp:1102)
     std::vector<uint32_t> loads;
     int gpus = 1, reps = 3, positional = 0, ranks = 0;
+    double cpu_seconds = 0.5;
     uint64_t seed = 42;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--ranks") && i + 1 < argc) ranks = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--seed") && i + 1 < argc) seed = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--cpu-seconds") && i + 1 < argc) cpu_seconds = atof(argv[++i]);
         else if (!strcmp(argv[i], "--describe")) { describe_columns(); return EXIT_SUCCESS; }
         else if (positional == 0) { n_samples = atoll(argv[i]); ++positional; }
         else if (positional == 1) { n_vals = atoll(argv[i]); ++positional; }
@@ -179,6 +326,7 @@ int main(int argc, char** argv) {
         close(id_pipe[1]);
         if (STORM_hip_comm_init(id) != 0) { fprintf(stderr, "rank %d: %s\n", rank, STORM_hip_error()); return EXIT_FAILURE; }
         gpus = ranks;  // the rows report the GPUs the job ran on
+        g_ranks = ranks;
         if (rank != 0 && !freopen("/dev/null", "w", stdout)) return EXIT_FAILURE;  // rank 0 prints
     } else {
         const int visible = storm_hip_device_count();
@@ -192,7 +340,7 @@ int main(int argc, char** argv) {
     // the reference's header line as it stands (benchmark.cpp:506, :671; it does not match its own rows),
     // then the names of the columns actually printed
     printf("Samples\tAlts\tMethod\tTime(ms)\tCPUCycles\tCount\tThroughput(MB/s)\tInts/s(1e6)\tIntersect/s(1e6)\tActualThroughput(MB/s)\tCycles/int\tCycles/intersect\n");
-    printf("#Method\tAlts\t%stotal\tinstructions_cycle\tcycles_word\tinstructions_word\tcycles\tinstructions\tMinBranchMiss\tMinCacheRef\tMinCacheMiss\tthroughput(MiB/s)\ttime_ms\tGPUs\twords_per_s\tGB_per_s_algorithmic\thbm_frac_algorithmic\tfp4_mfma_frac\n",
+    printf("#Method\tAlts\t%stotal\tinstructions_cycle\tcycles_word\tinstructions_word\tcycles\tinstructions\tMinBranchMiss\tMinCacheRef\tMinCacheMiss\tthroughput(MiB/s)\ttime_ms\tfirst_call_ms\tsteady_ms\tGPUs\twords_per_s\tGB_per_s_algorithmic\thbm_frac_algorithmic\tkernel\troof\troof_frac\tlookups_per_s\trows_per_lookup\tnote\n",
            n_samples >= 256000 ? "size\t" : "");
     const uint32_t n_ints = (uint32_t)std::ceil(M / 64.0);
     uint32_t optimal_b = (uint32_t)(STORM_CACHE_BLOCK_SIZE / (n_ints * 8));  // :823-824
@@ -214,24 +362,32 @@ int main(int argc, char** argv) {
         if (large) {
             char extra[64];
             snprintf(extra, sizeof(extra), "%llu\t", (unsigned long long)storm_size);
-            const Row r = timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps);
-            print_row("storm-blocked", loads[a], extra, r, N, n_ints, gpus);  // :605-613
+            print_row("storm-blocked", loads[a], extra,
+                      timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps, gpus), N, n_ints);  // :605-613
+            if (cpu_seconds > 0 && rank == 0) {  // the dense leaf on the host beside it: a row sample of the same shape
+                const uint64_t rows = N < 512 ? N : 512;
+                std::vector<uint64_t> sample((size_t)n_ints * rows);
+                storm_synth_fill_dense(sample.data(), n_ints, M, 0, rows, loads[a], seed);
+                cpu_rows(sample.data(), rows, N, n_ints, loads[a], optimal_b, cpu_seconds, extra);
+            }
             continue;
         }
         STORM_contig_clear(twk_cont);
         storm_synth_fill_contig(twk_cont, M, 0, N, loads[a], seed);
         storm_synth_fill_dense(vals.data(), n_ints, M, 0, N, loads[a], seed);
         if (n_samples >= 65536) {  // :832-852
-            print_row("storm", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality(twk2); }, reps), N, n_ints, gpus);
-            print_row("storm-blocked", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps), N, n_ints, gpus);
+            print_row("storm", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality(twk2); }, reps, gpus), N, n_ints);
+            print_row("storm-blocked", loads[a], "", timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps, gpus), N, n_ints);
         }
-        print_row("STORM-contig", loads[a], "", timed([&] { return STORM_contig_pairw_intersect_cardinality(twk_cont); }, reps), N, n_ints, gpus);  // :896-904
+        print_row("STORM-contig", loads[a], "", timed([&] { return STORM_contig_pairw_intersect_cardinality(twk_cont); }, reps, gpus), N, n_ints);  // :896-904
         print_row("STORM-contig-" + std::to_string(optimal_b), loads[a], "",
-                  timed([&] { return STORM_contig_pairw_intersect_cardinality_blocked(twk_cont, optimal_b); }, reps), N, n_ints, gpus);  // :906-918
+                  timed([&] { return STORM_contig_pairw_intersect_cardinality_blocked(twk_cont, optimal_b); }, reps, gpus), N, n_ints);  // :906-918
         // the reference's fwrapper_blocked<leaf> rows (:961,:1013,:1031) on the raw buffer: here the
-        // raw-buffer wrapper, which copies `vals` to the device on every call
+        // raw-buffer wrapper, which copies `vals` to the device on every call ...
         print_row("bitmap-hip-blocked-" + std::to_string(optimal_b), loads[a], "",
-                  timed([&] { return STORM_wrapper_diag_blocked((uint32_t)N, vals.data(), n_ints, nullptr, optimal_b); }, reps), N, n_ints, gpus);
+                  timed([&] { return STORM_wrapper_diag_blocked((uint32_t)N, vals.data(), n_ints, nullptr, optimal_b); }, reps, gpus), N, n_ints);
+        // ... and the same loop on the host over the library's SIMD leaves (one thread, row sample, extrapolated)
+        if (cpu_seconds > 0 && rank == 0) cpu_rows(vals.data(), N, N, n_ints, loads[a], optimal_b, cpu_seconds, "");
     }
     STORM_free(twk2);
     if (twk_cont) STORM_contig_free(twk_cont);
