@@ -319,6 +319,14 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
 /* the same arena from a serialized STORM_t (STORM_serialize, storm.h; sizes as reference
  * storm.c:372-394): the host walks the headers only, the payload bytes go up as they are and both
  * block kinds are unpacked on the device. `buf` 2-byte aligned. */
+/* The same from per-block POINTERS into the caller's own containers (what storm.h's STORM_t handles use: nothing
+ * is flattened on the host): block_ptr[b] = the block's sorted uint16 list (block_n[b] entries, kind 0; 2-byte
+ * aligned) or its 1024 words (kind 1; any alignment). The library walks the block headers, ships the raw lists
+ * and bitmaps through a pinned staging ring and lays the list elements out on the device. */
+int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                   const uint64_t* row_block_offset, const uint32_t* block_id,
+                                   const uint8_t* block_kind, const uint32_t* block_n,
+                                   const void* const* block_ptr, storm_hip_sparse_t** out);
 int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
                                        storm_hip_sparse_t** out);
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "storm_hip_sparse_destroy": (None, [vp, vp]),
     "storm_hip_pairw_sparse": (C.c_int, [vp, vp, u32, u32, P(u64)]),
     "storm_hip_sparse_create_serialized": (C.c_int, [vp, vp, u64, P(vp)]),
+    "storm_hip_sparse_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_sparse_last_census": (C.c_int, [vp, P(u64 * 4)]),

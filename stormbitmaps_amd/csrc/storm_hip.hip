@@ -585,6 +585,7 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
     if (ctx->d_positions) (void)hipFree(ctx->d_positions);
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
+    if (ctx->h_stage_ring) (void)hipHostFree(ctx->h_stage_ring);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
     for (hipEvent_t ev : ctx->kernel_events) (void)hipEventDestroy(ev);

@@ -82,6 +82,7 @@ struct storm_hip_ctx_s {
     unsigned long long* d_slots = nullptr;   // kSlots partial sums
     unsigned long long* d_scalar = nullptr;  // one uint64 result
     unsigned long long* h_scalar = nullptr;  // pinned host word the result is read back through
+    void* h_stage_ring = nullptr;            // pinned staging ring of the sparse arena builder (storm_hip_sparse.hip: Stager), allocated on first use
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
     size_t segs_capacity = 0;
     // cache key of d_segs

@@ -80,30 +80,6 @@ __global__ __launch_bounds__(kThreads) void expand_lists_kernel(
     }
 }
 
-// bitmap-kind block -> pool row: one workgroup per block, 16 B per lane
-__global__ __launch_bounds__(kThreads) void place_bitmaps_kernel(
-    uint64_t* __restrict__ pool, const uint32_t* __restrict__ pool_row,
-    const uint64_t* __restrict__ staged) {
-    const uint32_t b = blockIdx.x;
-    const uint4* src = reinterpret_cast<const uint4*>(staged + (uint64_t)b * kBlockWords);
-    uint4* dst = reinterpret_cast<uint4*>(pool + (uint64_t)pool_row[b] * kBlockWords);
-    for (uint32_t k = threadIdx.x; k < kBlockWords / 2; k += kThreads) dst[k] = src[k];
-}
-
-// bitmap-kind block whose 1024 words sit in a byte stream at 2-byte alignment only (a serialized
-// STORM_t, see STORM_serialize): assembled from uint16 loads
-__global__ __launch_bounds__(kThreads) void place_bitmaps_u16_kernel(
-    uint64_t* __restrict__ pool, const uint32_t* __restrict__ pool_row,
-    const uint64_t* __restrict__ src_off_u16, const uint16_t* __restrict__ stream) {
-    const uint32_t b = blockIdx.x;
-    const uint16_t* src = stream + src_off_u16[b];
-    uint64_t* dst = pool + (uint64_t)pool_row[b] * kBlockWords;
-    for (uint32_t k = threadIdx.x; k < kBlockWords; k += kThreads) {
-        const uint16_t* q = src + 4u * k;
-        dst[k] = (uint64_t)q[0] | ((uint64_t)q[1] << 16) | ((uint64_t)q[2] << 32) | ((uint64_t)q[3] << 48);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // K4 — list probe kernel for block columns whose blocks are all sorted lists (the reference's "extremely
 // fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached through the kind
@@ -238,6 +214,171 @@ __global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __rest
     }
 }
 
+
+// ---- arena construction on the device (round 4) ------------------------------------------------------------
+// A first all-pairs call on a fresh STORM_t used to cost 0.6 - 0.9 s at c4's 20971 draws per row: the host laid
+// out 210 M list elements (0.35 s on four threads), after flattening the container (0.1 s) and in front of 1.7 GB of
+// uploads from pageable memory. Now the host only WALKS THE BLOCK HEADERS (where every run of a list begins and
+// where it goes: 8 binary searches per block) and ships the raw lists and bitmaps through a small pinned ring;
+// the elements are laid out here.
+
+// One workgroup per list block of a probe column: element k of the list goes to run_dst[octant] + (k - start of
+// the octant's run) as (row in column) << 16 | position in octant, and as a byte offset (2 x position) for the far
+// stream. meta[b] = {list offset (uint16 units), length, tag = row in column << 16, pad}; run_end / run_dst: 8 per block.
+// A list that is not strictly ascending sets *bad (the probe kernel counts every listed element: none may repeat).
+__global__ __launch_bounds__(kThreads) void probe_fill_kernel(const uint16_t* __restrict__ lists,
+                                                              const uint64_t* __restrict__ list_off,
+                                                              const uint32_t* __restrict__ list_len,
+                                                              const uint32_t* __restrict__ tags,
+                                                              const uint32_t* __restrict__ run_end,
+                                                              const uint32_t* __restrict__ run_dst,
+                                                              uint32_t* __restrict__ elems, uint16_t* __restrict__ pos16,
+                                                              uint32_t* __restrict__ bad) {
+    const uint32_t b = blockIdx.x;
+    const uint16_t* l = lists + list_off[b];
+    const uint32_t n = list_len[b], tag = tags[b];
+    uint32_t end[kProbeOctants], dst[kProbeOctants];
+#pragma unroll
+    for (uint32_t o = 0; o < kProbeOctants; ++o) {
+        end[o] = run_end[(uint64_t)b * kProbeOctants + o];
+        dst[o] = run_dst[(uint64_t)b * kProbeOctants + o];
+    }
+    bool ok = true;
+    for (uint32_t k = threadIdx.x; k < n; k += kThreads) {
+        const uint32_t v = l[k];
+        if (k && l[k - 1] >= v) ok = false;
+        uint32_t o = 0, from = 0;
+#pragma unroll
+        for (uint32_t q = 0; q + 1 < kProbeOctants; ++q)
+            if (k >= end[q]) { o = q + 1; from = end[q]; }
+        // (the host's run ends are lower bounds of the octant limits: a list that is not ascending may disagree
+        //  with them, and is refused below)
+        const uint32_t at = dst[o] + (k - from);
+        const uint32_t pos = v & ((1u << kProbeOctBits) - 1u);
+        elems[at] = tag | pos;
+        pos16[at] = (uint16_t)(pos << 1);
+        if ((v >> kProbeOctBits) != o) ok = false;
+    }
+    if (!ok) atomicOr(bad, 1u);
+}
+
+// The far stream in an order of its own (see build_arena): inside every atom — the elements of one group of
+// kProbeRows rows in one octant — the positions are dealt by LDS bank, eight of bank 0, eight of bank 1, ... round
+// after round. One workgroup per atom {first element, end}: bank counts, then every element's slot from its bank,
+// its rank inside the bank (an LDS counter: any order will do, the positions of an atom may stand in any order)
+// and the counts: all of the earlier rounds, the banks in front of it in its own round. Atoms of fewer than 256
+// elements keep their row order.
+__global__ __launch_bounds__(kThreads) void probe_deal_kernel(const uint32_t* __restrict__ atoms,
+                                                              const uint16_t* __restrict__ src, uint16_t* __restrict__ dst) {
+    __shared__ uint32_t cnt[32], cur[32];
+    const uint32_t s0 = atoms[blockIdx.x * 2u], s1 = atoms[blockIdx.x * 2u + 1u];
+    const uint32_t n = s1 - s0;
+    if (n < 256u) {
+        for (uint32_t j = s0 + threadIdx.x; j < s1; j += kThreads) dst[j] = src[j];
+        return;
+    }
+    if (threadIdx.x < 32) cnt[threadIdx.x] = cur[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = s0 + threadIdx.x; j < s1; j += kThreads) atomicAdd(&cnt[(src[j] >> 2) & 31u], 1u);
+    __syncthreads();
+    for (uint32_t j = s0 + threadIdx.x; j < s1; j += kThreads) {
+        const uint16_t v = src[j];
+        const uint32_t bank = (v >> 2) & 31u;
+        const uint32_t k = atomicAdd(&cur[bank], 1u);
+        const uint32_t round8 = (k >> 3) * 8u;
+        uint32_t before = k & 7u;
+#pragma unroll 8
+        for (uint32_t q = 0; q < 32; ++q) {
+            const uint32_t c = cnt[q];
+            before += min(c, round8);                                       // all earlier rounds
+            before += q < bank ? min(8u, c > round8 ? c - round8 : 0u) : 0u;  // this round, the banks in front
+        }
+        dst[s0 + before] = v;
+    }
+}
+
+// Host data -> device through a small ring of pinned buffers: the pieces of a chunk are packed by a few threads
+// while the previous chunk's copy is in flight (pageable uploads of 1.7 GB were 0.15 s of c4's first call).
+struct Piece { const void* src; size_t bytes; size_t dst_off; };  // dst_off: byte offset from the chunk's device base
+struct Stager {
+    static constexpr size_t kBuf = 8u << 20;  // 8 MiB per buffer: 0.16 ms of PCIe time each
+    static constexpr int kBufs = 3;
+    storm_hip_ctx_t* ctx;
+    hipEvent_t ev[kBufs] = {nullptr, nullptr, nullptr};
+    bool used[kBufs] = {false, false, false};
+    int next = 0;
+    explicit Stager(storm_hip_ctx_t* c) : ctx(c) {}
+    ~Stager() {
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    int init() {
+        if (!ctx->h_stage_ring) {
+            if (hipHostMalloc(&ctx->h_stage_ring, kBuf * kBufs, hipHostMallocDefault) != hipSuccess) {
+                ctx->h_stage_ring = nullptr;
+                set_error("sparse_create: hipHostMalloc of the %zu-byte staging ring failed", kBuf * kBufs);
+                return STORM_HIP_ENOMEM;
+            }
+        }
+        for (int i = 0; i < kBufs; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return STORM_HIP_EHIP;
+        return STORM_HIP_OK;
+    }
+    // pieces[p0, p1): consecutive in the device destination (dst_off ascending from 0, no gaps beyond `span`)
+    int send(uint8_t* d_base, const Piece* pieces, size_t n, size_t span) {
+        uint8_t* buf = static_cast<uint8_t*>(ctx->h_stage_ring) + (size_t)next * kBuf;
+        if (used[next] && hipEventSynchronize(ev[next]) != hipSuccess) return STORM_HIP_EHIP;
+        const unsigned parts = span >= (1u << 20) ? 4u : 1u;
+        auto pack = [&](unsigned part) {
+            for (size_t i = n * part / parts; i < n * (part + 1) / parts; ++i)
+                memcpy(buf + pieces[i].dst_off, pieces[i].src, pieces[i].bytes);
+        };
+        if (parts > 1) {
+            std::thread helpers[3];
+            for (unsigned t = 1; t < parts; ++t) helpers[t - 1] = std::thread(pack, t);
+            pack(0);
+            for (unsigned t = 1; t < parts; ++t) helpers[t - 1].join();
+        } else {
+            pack(0);
+        }
+        if (hipMemcpyAsync(d_base, buf, span, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(ev[next], ctx->stream) != hipSuccess)
+            return STORM_HIP_EHIP;
+        used[next] = true;
+        next = (next + 1) % kBufs;
+        return STORM_HIP_OK;
+    }
+    // A run of pieces that is contiguous on the device from d_base (piece i starts where piece i - 1 ended),
+    // cut into chunks of at most one buffer. A single piece larger than a buffer is cut as well.
+    int send_run(uint8_t* d_base, const std::vector<std::pair<const void*, size_t>>& run) {
+        std::vector<Piece> chunk;
+        size_t chunk_base = 0, at = 0, fill = 0;
+        auto flush = [&]() -> int {
+            if (chunk.empty()) return STORM_HIP_OK;
+            const int rc = send(d_base + chunk_base, chunk.data(), chunk.size(), fill);
+            chunk.clear();
+            chunk_base = at;
+            fill = 0;
+            return rc;
+        };
+        for (const auto& pc : run) {
+            const uint8_t* src = static_cast<const uint8_t*>(pc.first);
+            size_t left = pc.second;
+            while (left) {
+                if (fill == kBuf)
+                    if (int rc = flush()) return rc;
+                const size_t take = std::min(left, kBuf - fill);
+                chunk.push_back({src, take, fill});
+                src += take;
+                left -= take;
+                fill += take;
+                at += take;
+            }
+        }
+        return flush();
+    }
+};
+
 template <typename T>
 int upload(T** d, const T* h, size_t n, hipStream_t stream) {
     *d = nullptr;
@@ -255,18 +396,14 @@ int upload(T** d, const T* h, size_t n, hipStream_t stream) {
 // is uploaded once and both block kinds are unpacked from it on the device.
 static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                        const uint64_t* row_block_offset, const uint32_t* block_id,
-                       const uint8_t* block_kind, const uint64_t* block_data_offset,
-                       const uint32_t* block_n, const uint16_t* list_pool,
-                       uint64_t list_pool_len, const uint64_t* bitmap_pool,
-                       uint64_t bitmap_pool_words, bool bitmaps_in_stream,
-                       storm_hip_sparse_t** out) {
+                       const uint8_t* block_kind, const uint32_t* block_n,
+                       const void* const* block_ptr, storm_hip_sparse_t** out) {
     if (!ctx || !out) {
         set_error("sparse_create: NULL context or output");
         return STORM_HIP_EINVAL;
     }
     *out = nullptr;
-    if (n_blocks > 0 && (!row_block_offset || !block_id || !block_kind || !block_data_offset ||
-                         !block_n)) {
+    if (n_blocks > 0 && (!row_block_offset || !block_id || !block_kind || !block_ptr || !block_n)) {
         set_error("sparse_create: NULL descriptor array");
         return STORM_HIP_EINVAL;
     }
@@ -315,19 +452,10 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 set_error("sparse_create: block kind %u", block_kind[b]);
                 return STORM_HIP_EINVAL;
             }
-            if (block_kind[b] == 0) {
-                if (block_data_offset[b] + block_n[b] > list_pool_len ||
-                    (block_n[b] && !list_pool)) {
-                    set_error("sparse_create: list block outside the list pool");
-                    return STORM_HIP_EINVAL;
-                }
-            } else if (bitmaps_in_stream) {
-                if (block_data_offset[b] + 4ull * kBlockWords > list_pool_len || !list_pool) {
-                    set_error("sparse_create: bitmap block outside the serialized stream");
-                    return STORM_HIP_EINVAL;
-                }
-            } else if (block_data_offset[b] + kBlockWords > bitmap_pool_words || !bitmap_pool) {
-                set_error("sparse_create: bitmap block outside the bitmap pool");
+            if (block_kind[b] == 0 ? (block_n[b] > 65536u || (block_n[b] && (!block_ptr[b] || ((uintptr_t)block_ptr[b] & 1))))
+                                   : !block_ptr[b]) {
+                set_error("sparse_create: block %llu has no data (or a list that is too long or not 2-byte aligned)",
+                          (unsigned long long)b);
                 return STORM_HIP_EINVAL;
             }
             max_id = std::max(max_id, block_id[b]);
@@ -403,7 +531,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     lap("validate");
     // ---- pool row of every block (rows are visited in order => row order inside a column)
     std::vector<uint32_t> list_row, dense_row, list_len;
-    std::vector<uint64_t> list_off, dense_src;
+    std::vector<uint64_t> list_blk, dense_blk;   // the blocks behind those rows
     {
         std::vector<uint64_t> next_bitmap(start), next_list(list0);
         for (uint64_t b = 0; b < n_blocks; ++b) {
@@ -411,12 +539,12 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             if (block_kind[b] == 0) {
                 if (block_n[b] && pr < s->pool_rows_ready) {
                     list_row.push_back(pr);
-                    list_off.push_back(block_data_offset[b]);
+                    list_blk.push_back(b);
                     list_len.push_back(block_n[b]);
                 }
             } else {
                 dense_row.push_back(pr);
-                dense_src.push_back(block_data_offset[b]);
+                dense_blk.push_back(b);
             }
         }
     }
@@ -424,11 +552,27 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     lap("pool rows");
     // ---- probe data (K4): columns whose blocks are all lists and that have at most 65535 rows. Per column
     //      and octant (8192 positions of the block) the listed positions in row order.
-    // (plain arrays, not vectors: the threads that fill them touch their pages first — a zero fill of 1.3 GB on one
-    //  thread was 0.3 s of c4's first call)
-    std::unique_ptr<uint32_t[]> probe_elems;
-    std::unique_ptr<uint16_t[]> probe_pos16;  // the far stream's copy of the positions, in its own order (below)
+    // The host only decides WHERE every run of a list goes (a walk over the block records); the elements are laid
+    // out by the device from the raw lists (probe_fill_kernel, probe_deal_kernel).
     size_t n_probe_elems = 0;
+    constexpr uint32_t kNoBlock = 0xffffffffu;
+    std::vector<uint64_t> probe_blocks;  // the list blocks of probe columns, in row order
+    std::vector<uint32_t> run_end;       // per probe block and octant: end of the octant's run inside the list
+    std::vector<uint32_t> run_dst;       // ... and where the run starts in the element arrays
+    std::vector<uint32_t> block_local;   // the block's row inside its column's list rows
+    std::vector<uint32_t> atoms;         // {first element, end} of every atom of the far stream
+    const unsigned n_host_threads = n_blocks >= 4096 ? 4u : 1u;
+    auto on_threads = [&](auto&& body) {  // body(part, parts); exceptions of a helper end up in `failed`
+        std::atomic<bool> failed{false};
+        std::vector<std::thread> helpers;
+        for (unsigned t = 1; t < n_host_threads; ++t)
+            helpers.emplace_back([&, t] {
+                try { body(t, n_host_threads); } catch (...) { failed = true; }
+            });
+        try { body(0u, n_host_threads); } catch (...) { failed = true; }
+        for (std::thread& h : helpers) h.join();
+        return !failed.load();
+    };
     {
         std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
         s->col_probe.assign(s->cols.size(), 0);
@@ -450,29 +594,37 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             // 16-byte boundary of the uint16 position array
             const size_t n_e = s->cols.size();
             std::vector<uint64_t> oct_count(n_e * kProbeOctants, 0), oct_base(n_e * kProbeOctants, 0);
-            // A list is sorted, so its elements of one octant are one run: the runs' ends per block (binary search),
-            // then where every run goes, then the copy — the first two are a walk over the block records, the copy
-            // (c4 at 20971 draws: 210 M elements, 0.39 s on one thread) is split over helper threads by block range.
-            constexpr uint32_t kNoBlock = 0xffffffffu;
-            std::vector<uint32_t> probe_blocks;  // the list blocks of probe columns, in row order
+            // A list is sorted, so its elements of one octant are one run: the runs' ends per block (binary search, on
+            // a few threads: 8 searches in each of c4's 80000 lists), then where every run goes.
             for (uint64_t b = 0; b < n_blocks; ++b) {
                 const int64_t e = col_entry[block_id[b]];
-                if (e >= 0 && s->col_probe[(size_t)e] && block_kind[b] == 0) probe_blocks.push_back((uint32_t)b);
+                if (e >= 0 && s->col_probe[(size_t)e] && block_kind[b] == 0) probe_blocks.push_back(b);
             }
-            std::vector<uint32_t> run_end(probe_blocks.size() * kProbeOctants);   // end of octant o's run inside the list
-            std::vector<uint32_t> run_dst(probe_blocks.size() * kProbeOctants);   // where the run starts in the element arrays
-            std::vector<uint32_t> block_local(probe_blocks.size(), kNoBlock);     // the block's row inside its column's list rows
+            run_end.assign(probe_blocks.size() * kProbeOctants, 0);
+            run_dst.assign(probe_blocks.size() * kProbeOctants, 0);
+            block_local.assign(probe_blocks.size(), kNoBlock);
+            if (!on_threads([&](unsigned part, unsigned parts) {
+                    for (size_t pb = probe_blocks.size() * part / parts; pb < probe_blocks.size() * (part + 1) / parts; ++pb) {
+                        const uint64_t b = probe_blocks[pb];
+                        const uint16_t* l = static_cast<const uint16_t*>(block_ptr[b]);
+                        uint32_t from = 0;
+                        for (uint32_t o = 0; o < kProbeOctants; ++o) {
+                            const uint32_t end = (uint32_t)(std::lower_bound(l + from, l + block_n[b], (o + 1u) << kProbeOctBits,
+                                                                             [](uint16_t x, uint32_t lim) { return (uint32_t)x < lim; }) - l);
+                            run_end[pb * kProbeOctants + o] = end;
+                            from = end;
+                        }
+                    }
+                })) {
+                set_error("sparse_create: out of memory while walking the lists");
+                return STORM_HIP_ENOMEM;
+            }
             for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
-                const uint64_t b = probe_blocks[pb];
-                const size_t e = (size_t)col_entry[block_id[b]];
-                const uint16_t* l = list_pool + block_data_offset[b];
+                const size_t e = (size_t)col_entry[block_id[probe_blocks[pb]]];
                 uint32_t from = 0;
                 for (uint32_t o = 0; o < kProbeOctants; ++o) {
-                    const uint32_t end = (uint32_t)(std::lower_bound(l + from, l + block_n[b], (o + 1u) << kProbeOctBits,
-                                                                     [](uint16_t x, uint32_t lim) { return (uint32_t)x < lim; }) - l);
-                    run_end[pb * kProbeOctants + o] = end;
-                    oct_count[e * kProbeOctants + o] += end - from;
-                    from = end;
+                    oct_count[e * kProbeOctants + o] += run_end[pb * kProbeOctants + o] - from;
+                    from = run_end[pb * kProbeOctants + o];
                 }
             }
             uint64_t at = 0;
@@ -482,16 +634,6 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 at += oct_count[i];
             }
             n_probe_elems = (size_t)at + 8;
-            probe_elems.reset(new uint32_t[n_probe_elems]);
-            probe_pos16.reset(new uint16_t[n_probe_elems]);
-            for (size_t i = 0; i < oct_count.size(); ++i) {  // the alignment gaps behind every octant
-                const size_t g0 = (size_t)(oct_base[i] + oct_count[i]);
-                const size_t g1 = i + 1 < oct_count.size() ? (size_t)oct_base[i + 1] : n_probe_elems;
-                for (size_t j = g0; j < g1; ++j) {
-                    probe_elems[j] = 0;
-                    probe_pos16[j] = 0;
-                }
-            }
             for (size_t i = 0; i < oct_count.size(); ++i)
                 if (oct_count[i])
                     s->probe_regions.push_back({(uint32_t)oct_base[i], (uint32_t)(oct_base[i] + oct_count[i]),
@@ -524,88 +666,17 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     ++pb;
                 }
             }
-            const unsigned n_threads = at >= (1u << 22) ? 4u : 1u;
-            auto on_threads = [&](auto&& body) {  // body(part, parts); exceptions of a helper end up in `failed`
-                std::atomic<bool> failed{false};
-                std::vector<std::thread> helpers;
-                for (unsigned t = 1; t < n_threads; ++t)
-                    helpers.emplace_back([&, t] {
-                        try { body(t, n_threads); } catch (...) { failed = true; }
-                    });
-                try { body(0u, n_threads); } catch (...) { failed = true; }
-                for (std::thread& h : helpers) h.join();
-                return !failed.load();
-            };
-            std::atomic<uint32_t> bad_block{kNoBlock};  // the probe kernel counts every listed element: none may repeat
-            if (!on_threads([&](unsigned part, unsigned parts) {
-                    const size_t p0 = probe_blocks.size() * part / parts, p1 = probe_blocks.size() * (part + 1) / parts;
-                    for (size_t pb = p0; pb < p1; ++pb) {
-                        const uint64_t b = probe_blocks[pb];
-                        const uint16_t* l = list_pool + block_data_offset[b];
-                        const uint32_t tag = block_local[pb] << 16;
-                        bool ascending = true;
-                        uint32_t from = 0;
-                        for (uint32_t o = 0; o < kProbeOctants; ++o) {
-                            const uint32_t end = run_end[pb * kProbeOctants + o];
-                            uint32_t dst = run_dst[pb * kProbeOctants + o];
-                            for (uint32_t k = from; k < end; ++k, ++dst) {
-                                const uint32_t pos = l[k] & ((1u << kProbeOctBits) - 1u);
-                                probe_elems[dst] = tag | pos;
-                                probe_pos16[dst] = (uint16_t)(pos << 1);  // the byte offset of the position's count
-                                ascending &= k == 0 || l[k] > l[k - 1];
-                            }
-                            from = end;
-                        }
-                        if (!ascending) bad_block = (uint32_t)b;
-                    }
-                })) {
-                set_error("sparse_create: out of memory while laying out the list elements");
-                return STORM_HIP_ENOMEM;
+            lap("list walk + layout");
+            // atoms of the far stream (the elements of one group of kProbeRows rows in one octant): the device deals
+            // the positions of every atom by LDS bank (probe_deal_kernel; why: see there)
+            for (size_t i = 0; i < row_start.size(); ++i) {
+                const std::vector<uint32_t>& rs = row_start[i];
+                const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
+                for (size_t k = 0; k < rs.size(); k += kProbeRows) {
+                    atoms.push_back(rs[k]);
+                    atoms.push_back(k + kProbeRows < rs.size() ? rs[k + kProbeRows] : end);
+                }
             }
-            if (bad_block.load() != kNoBlock) {
-                set_error("sparse_create: a list block of column %u is not strictly ascending", block_id[bad_block.load()]);
-                return STORM_HIP_EINVAL;
-            }
-            lap("probe count+fill");
-            // The far stream (pos16) in an order of its own. A far lookup only needs the POSITION — which row listed
-            // it does not matter — so inside every atom of the stream (the elements of one group of kProbeRows rows in
-            // one octant; items begin and end on atoms) the positions may stand in any order, and the order decides the
-            // LDS bank conflicts: a lookup reads the 2-byte count of its position, count p lies in bank (p / 2) % 32,
-            // and a 2- or 4-byte read is served in two groups of 32 lanes that each want 32 distinct banks. A lane takes
-            // 8 consecutive elements, so at every one of its 8 lookups the lanes of a group read elements 8 apart. In
-            // position order the banks are random (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.68 for the 16-byte
-            // entries the kernel used to read). Dealt by bank — eight positions of bank 0, eight of bank 1, ... round
-            // after round — element i has bank (i / 8) % 32 wherever the atom starts, and the 32 lanes of a group meet
-            // 32 different banks.
-            if (!on_threads([&](unsigned part, unsigned parts) {
-                    std::vector<uint16_t> tmp;
-                    for (size_t i = part; i < row_start.size(); i += parts) {
-                        const std::vector<uint32_t>& rs = row_start[i];
-                        const uint32_t end = (uint32_t)(oct_base[i] + oct_count[i]);
-                        for (size_t k = 0; k < rs.size(); k += kProbeRows) {
-                            const uint32_t s0 = rs[k], s1 = k + kProbeRows < rs.size() ? rs[k + kProbeRows] : end;
-                            const uint32_t n = s1 - s0;
-                            if (n < 256u) continue;
-                            uint32_t cnt[33] = {0};
-                            for (uint32_t j = s0; j < s1; ++j) cnt[((probe_pos16[j] >> 2) & 31u) + 1u]++;
-                            for (int r = 0; r < 32; ++r) cnt[r + 1] += cnt[r];
-                            uint32_t at_r[32], end_r[32], fill[32];
-                            for (int r = 0; r < 32; ++r) { at_r[r] = fill[r] = cnt[r]; end_r[r] = cnt[r + 1]; }
-                            tmp.resize(n);
-                            for (uint32_t j = s0; j < s1; ++j) tmp[fill[(probe_pos16[j] >> 2) & 31u]++] = probe_pos16[j];
-                            uint32_t out = s0;
-                            while (out < s1)
-                                for (int r = 0; r < 32; ++r) {
-                                    const uint32_t take = std::min(8u, end_r[r] - at_r[r]);
-                                    for (uint32_t t = 0; t < take; ++t) probe_pos16[out++] = tmp[at_r[r]++];
-                                }
-                        }
-                    }
-                })) {
-                set_error("sparse_create: out of memory while ordering the far stream");
-                return STORM_HIP_ENOMEM;
-            }
-            lap("pos16 + deal");
             // far work of all groups -> positions per item: about 4096 items over all probe columns, between
             // 2^15 and 2^21 positions each (an item zeroes and scatters its 128 KiB table first)
             uint64_t far_work = 0;
@@ -701,12 +772,12 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     }
 
     lap("items");
-    // ---- device pool ----
+    // ---- device side: pool rows, raw lists through the pinned ring, element layout by kernels ----
     int rc = STORM_HIP_OK;
-    uint32_t *d_lrow = nullptr, *d_llen = nullptr, *d_drow = nullptr;
-    uint64_t *d_loff = nullptr, *d_stage = nullptr;
-    uint16_t* d_lists = nullptr;
-    uint64_t* h_stage = nullptr;
+    uint32_t *d_lrow = nullptr, *d_llen = nullptr, *d_tags = nullptr, *d_rend = nullptr, *d_rdst = nullptr;
+    uint32_t *d_atoms = nullptr, *d_bad = nullptr, *d_pllen = nullptr;
+    uint64_t *d_loff = nullptr, *d_ploff = nullptr;
+    uint16_t *d_lists = nullptr, *d_pos_tmp = nullptr;
     do {
         if (hipSetDevice(ctx->device) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         const size_t pool_bytes = (s->pool_rows_ready + 512) * kBlockWords * sizeof(uint64_t);
@@ -720,18 +791,64 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             rc = STORM_HIP_EHIP;
             break;
         }
-        if (n_probe_elems) {
-            if ((rc = upload(&s->d_probe_elems, probe_elems.get(), n_probe_elems, ctx->stream))) break;
-            if ((rc = upload(&s->d_probe_pos16, probe_pos16.get(), n_probe_elems, ctx->stream))) break;
-            if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = STORM_HIP_EHIP; break; }  // pos16 leaves scope
+        Stager stager(ctx);
+        if ((rc = stager.init())) break;
+        // bitmap-kind blocks: straight into their pool rows — in pool-row order the blocks of a column are
+        // consecutive 8 KiB rows, so a run of them is ONE contiguous destination (no staging copy on the device,
+        // no placement kernel; the words may sit at any alignment on the host: a serialized stream)
+        if (!dense_row.empty()) {
+            std::vector<uint32_t> order(dense_row.size());
+            for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dense_row[x] < dense_row[y]; });
+            std::vector<std::pair<const void*, size_t>> run;
+            size_t i = 0;
+            while (i < order.size() && rc == STORM_HIP_OK) {
+                const uint32_t row0 = dense_row[order[i]];
+                run.clear();
+                size_t j = i;
+                while (j < order.size() && dense_row[order[j]] == row0 + (j - i)) {
+                    run.emplace_back(block_ptr[dense_blk[order[j]]], (size_t)kBlockWords * sizeof(uint64_t));
+                    ++j;
+                }
+                rc = stager.send_run(reinterpret_cast<uint8_t*>(s->d_pool) + (size_t)row0 * kBlockWords * sizeof(uint64_t), run);
+                i = j;
+            }
+            if (rc != STORM_HIP_OK) break;
         }
-        // the list pool (or the whole serialized stream) goes up once
-        if (!list_row.empty() || (bitmaps_in_stream && !dense_row.empty()))
-            if ((rc = upload(&d_lists, list_pool, (size_t)list_pool_len, ctx->stream))) break;
-        // list-kind blocks: expand on the device
+        lap("bitmaps -> pool rows");
+        // the raw lists the device needs — of the probe columns (element layout) and of the list blocks that own a
+        // pool row (expanded there) — go up once, block after block
+        std::vector<uint64_t> dev_off(n_blocks + 1, ~0ull);
+        uint64_t n_list_elems = 0;
+        {
+            std::vector<uint8_t> wanted(n_blocks, 0);
+            for (uint64_t b : probe_blocks) wanted[b] = 1;
+            for (uint64_t b : list_blk) wanted[b] = 1;
+            std::vector<std::pair<const void*, size_t>> run;
+            for (uint64_t b = 0; b < n_blocks; ++b)
+                if (wanted[b] && block_n[b]) {
+                    dev_off[b] = n_list_elems;
+                    n_list_elems += block_n[b];
+                    run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
+                }
+            if (n_list_elems) {
+                if (hipMalloc(reinterpret_cast<void**>(&d_lists), n_list_elems * sizeof(uint16_t)) != hipSuccess) {
+                    set_error("sparse_create: hipMalloc of %llu bytes for the lists failed",
+                              (unsigned long long)(n_list_elems * sizeof(uint16_t)));
+                    rc = STORM_HIP_ENOMEM;
+                    break;
+                }
+                if ((rc = stager.send_run(reinterpret_cast<uint8_t*>(d_lists), run))) break;
+            }
+        }
+        lap("lists -> device");
+        // list-kind blocks that own a pool row (mixed columns, columns the probe kernel cannot take): expanded there
+        std::vector<uint64_t> loff;
         if (!list_row.empty()) {
+            loff.reserve(list_blk.size());
+            for (uint64_t b : list_blk) loff.push_back(dev_off[b]);
             if ((rc = upload(&d_lrow, list_row.data(), list_row.size(), ctx->stream)) ||
-                (rc = upload(&d_loff, list_off.data(), list_off.size(), ctx->stream)) ||
+                (rc = upload(&d_loff, loff.data(), loff.size(), ctx->stream)) ||
                 (rc = upload(&d_llen, list_len.data(), list_len.size(), ctx->stream)))
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
@@ -739,61 +856,66 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                                d_lists);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
-        // bitmap-kind blocks of a serialized stream: unpacked where they lie in the uploaded bytes
-        if (!dense_row.empty() && bitmaps_in_stream) {
-            uint64_t* d_doff = nullptr;
-            if ((rc = upload(&d_drow, dense_row.data(), dense_row.size(), ctx->stream)) ||
-                (rc = upload(&d_doff, dense_src.data(), dense_src.size(), ctx->stream))) {
-                (void)hipFree(d_doff);
-                break;
-            }
-            hipLaunchKernelGGL(place_bitmaps_u16_kernel, dim3((uint32_t)dense_row.size()),
-                               dim3(kThreads), 0, ctx->stream, s->d_pool, d_drow, d_doff, d_lists);
-            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-                rc = STORM_HIP_EHIP;
-            (void)hipFree(d_doff);
-            if (rc != STORM_HIP_OK) break;
-        }
-        // bitmap-kind blocks: staged through a bounded buffer (<= 64 MiB per round)
-        if (!dense_row.empty() && !bitmaps_in_stream) {
-            const size_t round = std::min<size_t>(dense_row.size(), 8192);
-            h_stage = static_cast<uint64_t*>(malloc(round * kBlockWords * sizeof(uint64_t)));
-            if (!h_stage) { rc = STORM_HIP_ENOMEM; break; }
-            if (hipMalloc(reinterpret_cast<void**>(&d_stage),
-                          round * kBlockWords * sizeof(uint64_t)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&d_drow), round * sizeof(uint32_t)) !=
-                    hipSuccess) {
+        // probe columns: element layout on the device
+        std::vector<uint64_t> ploff;
+        std::vector<uint32_t> pllen, tags;
+        uint32_t bad = 0;
+        if (n_probe_elems) {
+            if (hipMalloc(reinterpret_cast<void**>(&s->d_probe_elems), n_probe_elems * sizeof(uint32_t)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&s->d_probe_pos16), n_probe_elems * sizeof(uint16_t)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&d_pos_tmp), n_probe_elems * sizeof(uint16_t)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(uint32_t)) != hipSuccess) {
+                set_error("sparse_create: hipMalloc of the probe element arrays (%zu elements) failed", n_probe_elems);
                 rc = STORM_HIP_ENOMEM;
                 break;
             }
-            for (size_t base = 0; base < dense_row.size() && rc == STORM_HIP_OK; base += round) {
-                const size_t n = std::min(round, dense_row.size() - base);
-                for (size_t k = 0; k < n; ++k)
-                    memcpy(h_stage + k * kBlockWords, bitmap_pool + dense_src[base + k],
-                           kBlockWords * sizeof(uint64_t));
-                if (hipMemcpyAsync(d_stage, h_stage, n * kBlockWords * sizeof(uint64_t),
-                                   hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                    hipMemcpyAsync(d_drow, dense_row.data() + base, n * sizeof(uint32_t),
-                                   hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-                    rc = STORM_HIP_EHIP;
-                    break;
-                }
-                hipLaunchKernelGGL(place_bitmaps_kernel, dim3((uint32_t)n), dim3(kThreads), 0,
-                                   ctx->stream, s->d_pool, d_drow, d_stage);
-                // the staging buffers are reused next round
-                if (hipGetLastError() != hipSuccess ||
-                    hipStreamSynchronize(ctx->stream) != hipSuccess)
-                    rc = STORM_HIP_EHIP;
+            // (the alignment gaps behind every octant read as zero)
+            if (hipMemsetAsync(s->d_probe_elems, 0, n_probe_elems * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+                hipMemsetAsync(s->d_probe_pos16, 0, n_probe_elems * sizeof(uint16_t), ctx->stream) != hipSuccess ||
+                hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream) != hipSuccess) {
+                rc = STORM_HIP_EHIP;
+                break;
+            }
+            ploff.reserve(probe_blocks.size());
+            pllen.reserve(probe_blocks.size());
+            tags.reserve(probe_blocks.size());
+            for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
+                const uint64_t b = probe_blocks[pb];
+                ploff.push_back(block_n[b] ? dev_off[b] : 0);
+                pllen.push_back(block_n[b]);
+                tags.push_back(block_local[pb] << 16);
+            }
+            if ((rc = upload(&d_ploff, ploff.data(), ploff.size(), ctx->stream)) ||
+                (rc = upload(&d_pllen, pllen.data(), pllen.size(), ctx->stream)) ||
+                (rc = upload(&d_tags, tags.data(), tags.size(), ctx->stream)) ||
+                (rc = upload(&d_rend, run_end.data(), run_end.size(), ctx->stream)) ||
+                (rc = upload(&d_rdst, run_dst.data(), run_dst.size(), ctx->stream)) ||
+                (rc = upload(&d_atoms, atoms.data(), atoms.size(), ctx->stream)))
+                break;
+            if (!probe_blocks.empty())
+                hipLaunchKernelGGL(probe_fill_kernel, dim3((uint32_t)probe_blocks.size()), dim3(kThreads), 0, ctx->stream,
+                                   d_lists, d_ploff, d_pllen, d_tags, d_rend, d_rdst, s->d_probe_elems, d_pos_tmp, d_bad);
+            if (!atoms.empty())
+                hipLaunchKernelGGL(probe_deal_kernel, dim3((uint32_t)(atoms.size() / 2)), dim3(kThreads), 0, ctx->stream,
+                                   d_atoms, d_pos_tmp, s->d_probe_pos16);
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+                rc = STORM_HIP_EHIP;
+                break;
             }
         }
-        if (rc == STORM_HIP_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
-            rc = STORM_HIP_EHIP;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
+        if (bad) {
+            set_error("sparse_create: a list block is not strictly ascending");
+            rc = STORM_HIP_EINVAL;
+        }
+        lap("element layout on the device");
     } while (0);
     if (rc == STORM_HIP_EHIP) set_error("sparse_create: HIP failure: %s",
                                         hipGetErrorString(hipGetLastError()));
     (void)hipFree(d_lrow); (void)hipFree(d_loff); (void)hipFree(d_llen); (void)hipFree(d_lists);
-    (void)hipFree(d_stage); (void)hipFree(d_drow);
-    free(h_stage);
+    (void)hipFree(d_tags); (void)hipFree(d_rend); (void)hipFree(d_rdst); (void)hipFree(d_atoms);
+    (void)hipFree(d_bad); (void)hipFree(d_pllen); (void)hipFree(d_ploff); (void)hipFree(d_pos_tmp);
     if (rc != STORM_HIP_OK) return rc;
     *out = owner.release();
     return STORM_HIP_OK;
@@ -850,11 +972,46 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
                             uint64_t list_pool_len, const uint64_t* bitmap_pool,
                             uint64_t bitmap_pool_words, storm_hip_sparse_t** out) {
     try {
-        return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind,
-                           block_data_offset, block_n, list_pool, list_pool_len, bitmap_pool,
-                           bitmap_pool_words, false, out);
+        if (n_blocks > 0 && (!block_kind || !block_data_offset || !block_n)) {
+            set_error("sparse_create: NULL descriptor array");
+            return STORM_HIP_EINVAL;
+        }
+        // the flat pools as per-block pointers (storm_hip_sparse_create_blocks does the work)
+        std::vector<const void*> ptr(n_blocks, nullptr);
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            if (block_kind[b] == 0) {
+                if (block_data_offset[b] + block_n[b] > list_pool_len || (block_n[b] && !list_pool)) {
+                    set_error("sparse_create: list block outside the list pool");
+                    return STORM_HIP_EINVAL;
+                }
+                ptr[b] = list_pool ? list_pool + block_data_offset[b] : nullptr;
+            } else {
+                if (block_data_offset[b] + kBlockWords > bitmap_pool_words || !bitmap_pool) {
+                    set_error("sparse_create: bitmap block outside the bitmap pool");
+                    return STORM_HIP_EINVAL;
+                }
+                ptr[b] = bitmap_pool + block_data_offset[b];
+            }
+        }
+        return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, ptr.data(), out);
     } catch (const std::exception& e) {
         set_error("sparse_create: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+}
+
+// The same from per-block pointers into the caller's own containers: block_ptr[b] = the block's sorted uint16 list
+// (block_n[b] entries, kind 0) or its 1024 words (kind 1, any alignment). Nothing is flattened on the host: the
+// library walks the block headers, ships the raw lists and bitmaps through a pinned ring and lays the elements
+// out on the device.
+int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                   const uint64_t* row_block_offset, const uint32_t* block_id,
+                                   const uint8_t* block_kind, const uint32_t* block_n,
+                                   const void* const* block_ptr, storm_hip_sparse_t** out) {
+    try {
+        return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out);
+    } catch (const std::exception& e) {
+        set_error("sparse_create_blocks: %s", e.what());
         return STORM_HIP_ENOMEM;
     }
 }
@@ -878,7 +1035,8 @@ int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, ui
         // (same validity rules as STORM_deserialize, storm_host.c) a row costs at least its 12 header bytes:
         // the row count is bounded by the stream before it sizes anything
         if (n_rows > (n_bytes - 8) / 12) { set_error("%s", bad); return STORM_HIP_EINVAL; }
-        std::vector<uint64_t> row_off(n_rows + 1, 0), offs;
+        std::vector<uint64_t> row_off(n_rows + 1, 0);
+        std::vector<const void*> ptrs;
         std::vector<uint32_t> ids, lens;
         std::vector<uint8_t> kinds;
         uint64_t at = 8;
@@ -912,18 +1070,19 @@ int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, ui
                 }
                 ids.push_back(id);
                 if (n_bitmap) {  // bitmap kind (storm.c:745-749: a block is one kind or the other)
-                    kinds.push_back(1); offs.push_back(at / 2); lens.push_back(0);
+                    kinds.push_back(1); ptrs.push_back(p + at); lens.push_back(0);
                 } else {
-                    kinds.push_back(0); offs.push_back((at + words) / 2); lens.push_back(has_list ? n_scalar : 0);
+                    kinds.push_back(0); ptrs.push_back(p + at + words); lens.push_back(has_list ? n_scalar : 0);
                 }
                 at += words + list;
             }
             row_off[r + 1] = ids.size();
         }
         if (at != n_bytes) { set_error("%s", bad); return STORM_HIP_EINVAL; }
-        return build_arena(ctx, n_rows, ids.size(), row_off.data(), ids.data(), kinds.data(), offs.data(),
-                           lens.data(), reinterpret_cast<const uint16_t*>(p), n_bytes / 2, nullptr, 0,
-                           true, out);
+        // (the stream is 2-byte aligned, so is every list in it; the bitmap words are copied bytewise)
+        if ((uintptr_t)p & 1) { set_error("sparse_create_serialized: the stream must be 2-byte aligned"); return STORM_HIP_EINVAL; }
+        return build_arena(ctx, n_rows, ids.size(), row_off.data(), ids.data(), kinds.data(), lens.data(),
+                           ptrs.data(), out);
     } catch (const std::exception& e) {
         set_error("sparse_create_serialized: %s", e.what());
         return STORM_HIP_ENOMEM;

@@ -141,6 +141,32 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     (*out)->set_bits = bits;
     return STORM_HIP_OK;
 }
+/* reads every list entry and bitmap word through the pointers handed over (ASan checks their extents) */
+int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                   const uint64_t* row_block_offset, const uint32_t* block_id,
+                                   const uint8_t* block_kind, const uint32_t* block_n,
+                                   const void* const* block_ptr, storm_hip_sparse_t** out) {
+    (void)ctx;
+    if (row_block_offset[0] != 0 || row_block_offset[n_rows] != n_blocks) return STORM_HIP_EINVAL;
+    uint64_t bits = 0;
+    for (uint64_t r = 0; r < n_rows; ++r)
+        for (uint64_t b = row_block_offset[r]; b < row_block_offset[r + 1]; ++b) {
+            if (b > row_block_offset[r] && block_id[b] <= block_id[b - 1]) return STORM_HIP_EINVAL;
+            if (block_kind[b] == 0) {
+                const uint16_t* l = (const uint16_t*)block_ptr[b];
+                for (uint32_t k = 0; k < block_n[b]; ++k)
+                    if (k && l[k] <= l[k - 1]) return STORM_HIP_EINVAL;
+                bits += block_n[b];
+            } else {
+                const uint64_t* w = (const uint64_t*)block_ptr[b];
+                for (int k = 0; k < 1024; ++k) bits += (uint64_t)__builtin_popcountll(w[k]);
+            }
+        }
+    *out = (storm_hip_sparse_t*)calloc(1, sizeof(**out));
+    if (!*out) return STORM_HIP_ENOMEM;
+    (*out)->set_bits = bits;
+    return STORM_HIP_OK;
+}
 int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
                                        storm_hip_sparse_t** out) {
     (void)ctx;

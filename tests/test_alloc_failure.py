@@ -49,7 +49,8 @@ def test_every_failing_allocation_of_the_host_side_is_survived(tmp_path):
     exe = tmp_path / "alloc_inject"
     inc = os.path.join(ROOT, "tests", "host_sanitize", "alloc_inject.h")
     srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
-            os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c")]
+            os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c"),
+                os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_leaves.c")]
     common = ["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
               "-fno-omit-frame-pointer", "-Wall", "-I" + os.path.join(ROOT, "include")]
     objs = []

@@ -139,3 +139,32 @@ def test_default_path_through_the_storm_h_containers(orc):
     assert c.pairw_intersect_cardinality() == want
     assert sb.wrapper_diag_blocked(mat, 31) == want
     c.free()
+
+
+def test_first_call_on_a_fresh_sparse_container_equals_the_steady_calls(orc):
+    """The reference's harness times ONE call right after construction (benchmark.cpp:605-613). Here that call
+    builds the device arena — since round 4 from POINTERS to the blocks where they lie in the containers
+    (storm_hip_sparse_create_blocks: no host flattening; raw lists and bitmaps through a pinned ring; element
+    layout by probe_fill_kernel / probe_deal_kernel on the device). First-call total == steady totals == the
+    oracle's STORM_t restatement, on lists only, bitmaps only and mixed kinds, incl. empty rows, one-element
+    rows, a list that fills an octant and row counts that are not multiples of 128."""
+    rng = np.random.default_rng(11)
+    M = 3 * 65536 + 777
+    for n_rows, draws in ((300, 40), (1000, 700), (517, 3000), (260, 20000), (700, 9000)):
+        rows = []
+        for r in range(n_rows):
+            d = draws if r % 7 else (0 if r % 14 == 0 else 1)
+            if draws == 9000 and r % 3 == 0:
+                d = 60000                                            # mixed kinds: some blocks become bitmaps
+            v = np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32)
+            if r == 5:
+                v = np.unique(np.concatenate([v, np.arange(8192, 16384, 2, dtype=np.uint32)]))   # a full octant
+            rows.append(v)
+        want = orc.storm(rows).pairw_blocked(0)
+        s = sb.Storm()
+        for v in rows:
+            s.add(v)
+        first = s.pairw_intersect_cardinality_blocked(0)
+        again = [s.pairw_intersect_cardinality_blocked(0), s.pairw_intersect_cardinality()]
+        assert first == want and again == [want, want], (n_rows, draws, first, again, want)
+        s.free()

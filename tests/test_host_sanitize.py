@@ -16,6 +16,7 @@ def test_host_containers_under_asan_ubsan(tmp_path):
     exe = tmp_path / "host_sanitize"
     srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
             os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c"),
+                os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_leaves.c"),
             os.path.join(ROOT, "tests", "host_sanitize", "device_stub.c"),
             os.path.join(ROOT, "tests", "host_sanitize", "driver.c")]
     build = subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined",
@@ -39,6 +40,7 @@ def test_host_side_with_three_caller_threads_under_tsan(tmp_path):
     exe = tmp_path / "host_threads"
     srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
             os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c"),
+                os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_leaves.c"),
             os.path.join(ROOT, "tests", "host_sanitize", "device_stub.c"),
             os.path.join(ROOT, "tests", "host_sanitize", "threads.c")]
     build = subprocess.run(["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=thread", "-pthread",
