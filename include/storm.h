@@ -131,6 +131,7 @@ struct STORM_s {
     uint64_t hip_fingerprint; /* rows / blocks / set-bit counts the arena was built from */
     uint32_t hip_private;     /* a container the library keeps for itself (the list mirror of a
                                  STORM_contiguous_t): nobody edits its members, no fingerprint per call */
+    uint64_t hip_epoch;       /* the mutation epoch (storm_host.c) the device arena was last verified at */
 };
 
 /* one row of the dense container (reference storm.h:181-186) */

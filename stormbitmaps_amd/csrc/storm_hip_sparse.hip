@@ -81,25 +81,30 @@ __global__ __launch_bounds__(kThreads) void expand_lists_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// K4 — list probe kernel for block columns whose blocks are all sorted lists (the reference's "extremely
-// fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached through the kind
-// dispatch :618-656). The dense path multiplies 8 KiB per present block whatever its density; here the work
-// is proportional to the listed positions.
-//   data  : per column AND per OCTANT of the block (8192 positions), the listed positions of its rows in row
-//           order: one uint32 per position, (row in column) << 16 | position in octant — and the positions
-//           alone as uint16;
-//   item  : 128 consecutive A rows of a column x one octant x (first item of the group: the A rows' own
-//           elements, each against the rows before it, +) a chunk of the positions of the rows BEHIND the group;
-//   LDS   : the 128 A rows as a TRANSPOSED bitmap — T[position] = 128-bit mask of the A rows that have that
-//           position set (8192 x 16 B = 128 KiB) — zeroed and scattered per item;
-//   stream: every element of the later rows is ONE 16-byte LDS read: popcount(T[pos] & rows_before(j)) is its
-//           contribution against all 128 A rows at once (rows behind the group: no mask, no tag); 16-byte
-//           coalesced loads (8 positions); 1024 threads per workgroup.
-// [r3] Round 2's table held 16 rows x 65536 positions (one 2-byte read per element and 16 rows): it sat at
-// ~7 lookups per clock and CU, an eighth of what the LDS moves, and re-read a column's elements from L2 once
-// per 16 rows. Eight times the rows per lookup and per pass over the elements moved the crossover with the
-// dense path from ~1000 listed positions per block to beyond the longest list a block can hold (4095).
-// Pairs i < j: an A row's own elements mask off the A rows that are not before it.
+// K4 — list probe kernel (probe_lists_kernel): the list blocks of a block column among themselves (the reference's
+// "extremely fast when sparse" regime: STORM_intersect_vector16_cardinality, storm.c:4-73, reached through the kind
+// dispatch :618-656). The dense path multiplies 8 KiB per present block whatever its density; here the work is
+// proportional to the listed positions.
+//   data  : per column AND per OCTANT of the block (8192 positions) the listed positions of its rows, twice:
+//           `elems`: uint32 (row in column) << 16 | position in octant, in row order (what a group's count
+//           table is built from; also the source of ensure_full_pool);
+//           `pos16`: the positions alone as byte offsets (2 x position, uint16) — the FAR STREAM: inside every atom
+//           (the elements of one group of 128 rows in one octant) dealt by LDS bank (probe_deal_kernel);
+//   item  : one group of kProbeRows = 128 consecutive rows of a column x one octant x a chunk of the far stream
+//           behind the group (items begin and end on atoms; the chunk grid is the same for all groups of a stream,
+//           the items that read one chunk — a family — run on one XCD);
+//   LDS   : Cn[position] = how many of the group's rows list the position: a histogram of the group's elements,
+//           8192 x 2 B = 16 KiB per workgroup;
+//   work  : the group's first item adds C(Cn[p], 2) per position (the pairs inside the group); every item adds
+//           Cn[p] per streamed far position p — ONE 2-byte LDS read and one add per lookup, the contribution of that
+//           listed position against all 128 rows of the group at once. A lookup therefore stands for 128 of the
+//           reference's per-pair list tests; the work still grows with N^2 / 128 x density (with the whole column as
+//           one group this would be the column identity sum_c C(n_c, 2), which stays the verification path).
+//   roofs : LDS 32 two-byte lookups per clock and CU; VALU ~2 instructions per lookup (unpack the position, add):
+//           both ~2e13 lookups/s per chip. Measured: profiles/r03_b_sparse_probe_roofline.txt, r04_* .
+// History (rounds 2 / 3, profiles/r03_b_sparse_probe_ab.txt): a table of 16 rows x 65536 positions; then the group
+// as a transposed BITMAP (128-bit masks per position, 128 KiB, popcounts per lookup — v_bcnt_u32_b32 is half rate);
+// the counts are what those popcounts add up to.
 // ------------------------------------------------------------------------------------------
 struct ProbeItem {
     uint32_t a_begin, a_end;  // elements of the A rows [a0, a0 + 128) in this octant
@@ -123,7 +128,8 @@ constexpr uint32_t kProbeOctants = 1u << (16 - kProbeOctBits);
 // (Rounds 2 / 3 kept the group as a transposed BITMAP — 128-bit masks per position, 128 KiB — and took
 //  popcount(mask & rows_before) per own element and popcount(mask) per later element; the counts are what those
 //  popcounts add up to, and v_bcnt_u32_b32 is half rate: profiles/r03_b_sparse_probe_ab.txt has every step.)
-__global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
+template <int kT>
+__global__ __launch_bounds__(kT) void probe_lists_kernel(
     const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
     unsigned long long* __restrict__ slots) {
@@ -133,17 +139,17 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kPosMask = (1u << kProbeOctBits) - 1u;
     static_assert(kProbeRows <= 0xffffu, "16-bit counts");
-    for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads * 4u)
+    for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += (uint32_t)kT * 4u)
         *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
     // (eight loads per lane in flight: one per trip is a chain of ~40 memory latencies per item)
-    for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += kProbeThreads * 8u) {
+    for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += (uint32_t)kT * 8u) {
         uint32_t v[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * kProbeThreads, it.a_end - 1u)];
+        for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * (uint32_t)kT, it.a_end - 1u)];
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k)
-            if (e0 + k * kProbeThreads < it.a_end) {
+            if (e0 + k * (uint32_t)kT < it.a_end) {
                 const uint32_t pos = v[k] & kPosMask;
                 atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
             }
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     __syncthreads();
     uint32_t count = 0;
     if (it.n_end > it.n_begin) {  // the group's own rows among themselves
-        for (uint32_t w = tid; w < (1u << kProbeOctBits) / 2u; w += kProbeThreads) {
+        for (uint32_t w = tid; w < (1u << kProbeOctBits) / 2u; w += (uint32_t)kT) {
             const uint32_t c2 = Cn32[w], lo = c2 & 0xffffu, hi = c2 >> 16;
             count += (lo * (lo - 1u) + hi * (hi - 1u)) >> 1;  // both products are even
         }
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(kProbeThreads) void probe_lists_kernel(
     // hand does not survive hipcc (register rotation by copies makes it wait for the youngest load; without copies
     // it sinks the loads to their uses).
     if (body_end > e) {
-        constexpr uint32_t kStep = kProbeThreads * 8u;
+        constexpr uint32_t kStep = (uint32_t)kT * 8u;
         const uint32_t last = body_end - 8u;
         for (uint32_t q = e + tid * 8u; q < body_end; q += 4u * kStep) {
             uint4 v[4];
@@ -1193,9 +1199,17 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             ctx->pass_report[0] |= STORM_HIP_RAN_LIST_PROBE;
             ctx->pass_report[2] += s->probe_lookups_launch;
             ctx->pass_report[3] = kProbeRows;
-            hipLaunchKernelGGL(probe_lists_kernel, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
-                               s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
-                               shard_rank, ctx->d_slots);
+            // Short items (sparse loads: a few hundred lookups each) are all fixed cost — the item record, the group's
+            // elements and the far positions are three dependent trips to memory — and what covers that is workgroups
+            // per CU: 256 threads each, eight per CU instead of two (c4 at 104 draws per row: 38 -> ~15 us per launch).
+            if (s->probe_lookups_launch / s->n_probe_launch < 16384u)
+                hipLaunchKernelGGL(probe_lists_kernel<256>, dim3(s->n_probe_launch), dim3(256), 0, ctx->stream,
+                                   s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
+                                   shard_rank, ctx->d_slots);
+            else
+                hipLaunchKernelGGL(probe_lists_kernel<kProbeThreads>, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
+                                   s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
+                                   shard_rank, ctx->d_slots);
             STORM_HIP_TRY(hipGetLastError());
         }
         std::vector<RowRange> ranges;

@@ -1205,7 +1205,17 @@ uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_
 /* ------------------------------------------------------------------------------------------
  * STORM_bitmap_t — one 65536-bit block (reference storm.c:372-380, :398-656)
  * ---------------------------------------------------------------------------------------- */
+/* Every public function that changes a STORM_t, a row or a block (they are public, storm.h:203-222, and a block
+ * does not know the container it belongs to) bumps this process-wide epoch. A handle remembers the epoch its
+ * device arena was last verified at: while no mutator has run since, an all-pairs call skips the O(blocks)
+ * fingerprint walk. Members edited in place, without any of these functions: STORM_hip_invalidate (storm.h).
+ * STORM_HIP_ALWAYS_FINGERPRINT=1 walks the fingerprint on every call, as rounds 2 - 3 did. */
+static uint64_t g_mutation_epoch = 1;
+static inline void storm_mutated(void) { __atomic_add_fetch(&g_mutation_epoch, 1, __ATOMIC_RELAXED); }
+static inline uint64_t storm_epoch(void) { return __atomic_load_n(&g_mutation_epoch, __ATOMIC_RELAXED); }
+
 void STORM_bitmap_init(STORM_bitmap_t* b) {
+    storm_mutated();
     if (!b) return;
     memset(b, 0, sizeof(*b));
     b->own_data = 1;
@@ -1226,6 +1236,7 @@ static void bitmap_release_buffers(STORM_bitmap_t* b) {
 }
 
 void STORM_bitmap_free(STORM_bitmap_t* b) {
+    storm_mutated();
     if (!b) return;
     bitmap_release_buffers(b);
     STORM_aligned_free(b);
@@ -1256,6 +1267,7 @@ static int bitmap_ensure_list(STORM_bitmap_t* b, uint32_t extra) {
 
 /* bitmap kind: reference storm.c:442-465 (-1 / -2 / -3 for NULL handle / NULL values / empty) */
 int STORM_bitmap_add(STORM_bitmap_t* b, const uint32_t* values, const uint32_t n_values) {
+    storm_mutated();
     if (!b) return -1;
     if (!values) return -2;
     if (n_values == 0) return -3;
@@ -1273,6 +1285,7 @@ int STORM_bitmap_add(STORM_bitmap_t* b, const uint32_t* values, const uint32_t n
 /* both representations: reference storm.c:468-518 (-1 / -3 / -4) */
 int STORM_bitmap_add_with_scalar(STORM_bitmap_t* b, const uint32_t* values,
                                  const uint32_t n_values) {
+    storm_mutated();
     if (!b) return -1;
     if (!values) return -3;
     if (n_values == 0) return -4;
@@ -1296,6 +1309,7 @@ int STORM_bitmap_add_with_scalar(STORM_bitmap_t* b, const uint32_t* values,
  * list stays duplicate-free, which the list intersections require */
 int STORM_bitmap_add_scalar_only(STORM_bitmap_t* b, const uint32_t* values,
                                  const uint32_t n_values) {
+    storm_mutated();
     if (!b) return -1;
     if (!values) return -3;
     if (n_values == 0) return -4;
@@ -1314,6 +1328,7 @@ int STORM_bitmap_add_scalar_only(STORM_bitmap_t* b, const uint32_t* values,
 }
 
 int STORM_bitmap_clear(STORM_bitmap_t* b) { /* storm.c:561-569: buffers are kept */
+    storm_mutated();
     if (!b) return -1;
     if (b->data) memset(b->data, 0, sizeof(uint64_t) * BLOCK_WORDS);
     b->n_scalar = 0;
@@ -1355,6 +1370,7 @@ uint64_t STORM_bitmap_intersect_cardinality(STORM_bitmap_t* STORM_RESTRICT b1,
  * STORM_bitmap_cont_t — one row (reference storm.c:383-394, :659-824)
  * ---------------------------------------------------------------------------------------- */
 void STORM_bitmap_cont_init(STORM_bitmap_cont_t* r) {
+    storm_mutated();
     if (r) memset(r, 0, sizeof(*r));
 }
 
@@ -1370,6 +1386,7 @@ static void cont_release(STORM_bitmap_cont_t* r) {
 }
 
 void STORM_bitmap_cont_free(STORM_bitmap_cont_t* r) {
+    storm_mutated();
     if (!r) return;
     cont_release(r);
     free(r);
@@ -1397,6 +1414,7 @@ static int cont_reserve(STORM_bitmap_cont_t* r) {
  * values -> list kind, else bitmap kind (reference storm.c:692-758) */
 int STORM_bitmap_cont_add(STORM_bitmap_cont_t* r, const uint32_t* values,
                           const uint32_t n_values) {
+    storm_mutated();
     if (!r) return -1;
     if (!values) return -2;
     if (n_values == 0) return 0;
@@ -1424,6 +1442,7 @@ int STORM_bitmap_cont_add(STORM_bitmap_cont_t* r, const uint32_t* values,
 }
 
 int STORM_bitmap_cont_clear(STORM_bitmap_cont_t* r) { /* storm.c:816-824 */
+    storm_mutated();
     if (!r) return -1;
     for (uint32_t b = 0; b < r->n_bitmaps; ++b) STORM_bitmap_clear(&r->bitmaps[b]);
     r->n_bitmaps = 0;
@@ -1495,6 +1514,7 @@ void STORM_free(STORM_t* h) {
 }
 
 int STORM_add(STORM_t* h, const uint32_t* values, const uint32_t n_values) { /* :844-866 */
+    storm_mutated();
     if (!h) return -1;
     if (h->n_conts == h->m_conts) {
         const uint32_t new_m = h->m_conts + 1024;
@@ -1517,6 +1537,7 @@ int STORM_add(STORM_t* h, const uint32_t* values, const uint32_t n_values) { /* 
 }
 
 int STORM_clear(STORM_t* h) { /* storm.c:868-875 */
+    storm_mutated();
     if (!h) return -1;
     for (uint32_t i = 0; i < h->n_conts; ++i) STORM_bitmap_cont_clear(&h->conts[i]);
     h->n_conts = 0;
@@ -1880,6 +1901,16 @@ static uint64_t storm_pairw_device(STORM_t* h) {
     device_unlock();
     return total;
 }
+static int always_fingerprint(void) {
+    static int v = -1;
+    int x = __atomic_load_n(&v, __ATOMIC_RELAXED);
+    if (x < 0) {
+        const char* e = getenv("STORM_HIP_ALWAYS_FINGERPRINT");
+        x = e && e[0] == '1';
+        __atomic_store_n(&v, x, __ATOMIC_RELAXED);
+    }
+    return x;
+}
 static uint64_t storm_pairw_device_locked(STORM_t* h) {
     if (h->n_conts < 2) return 0;
     configure_from_env();
@@ -1896,7 +1927,8 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
     for (;;) {
         sparse_job_t j;
         j.st = (sparse_state_t*)h->hip_arena;
-        j.check = (!verified && !h->hip_private) ? h : NULL;
+        const uint64_t epoch = storm_epoch(); /* read before the pass: a mutator running meanwhile makes the next call check again */
+        j.check = (!verified && !h->hip_private && (h->hip_epoch != epoch || always_fingerprint())) ? h : NULL;
         j.fingerprint = 0;
         memset(j.part, 0, sizeof(j.part));
         if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return across_ranks(ALL_PAIRS_FAILED);
@@ -1906,6 +1938,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
             verified = 1;
             continue;
         }
+        h->hip_epoch = epoch; /* verified (or just built) at this epoch */
         uint64_t total = 0;
         for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
         return across_ranks(total);

@@ -91,11 +91,10 @@ def test_wrapper_diag_list_refuses_lists_that_contradict_the_bitmaps(lib):
     assert lib.STORM_wrapper_diag_list(*args(n_alts, junk)) == ok
 
 
-@pytest.mark.parametrize("draws", (524, 5242, 20971, 52428, 262144))   # (131072 runs in tools/bench_sparse.py)
+@pytest.mark.parametrize("draws", (524, 5242, 20971, 52428, 131072, 262144))
 def test_sparse_container_at_full_c4_size(hip_ctx, orc, draws):
-    """BASELINE config 4 at its real size: STORM_t, N = 10000 rows x M = 524288 bits, at five of the six
-    README loads (README.md:70-77; benchmark.cpp:605-613; the sixth, 131072, is covered by tools/bench_sparse.py,
-    whose totals are checked the same way), through STORM_add + both all-pairs entry
+    """BASELINE config 4 at its real size: STORM_t, N = 10000 rows x M = 524288 bits, at all six
+    README loads (README.md:70-77; benchmark.cpp:605-613), through STORM_add + both all-pairs entry
     points. A CPU pairwise oracle needs 30 s .. 1 h here, so the full-size total is checked
     against the column identity of the same bits on the device, and a 600-row subset (rows
     4700..5299 of the same matrix) is checked pairwise against the oracle's STORM_t restatement."""
@@ -522,10 +521,11 @@ def test_sparse_contiguous_containers_take_the_list_path(lib, orc):
         oc.add(r)
     want = oc.pairw()
     assert c.pairw_intersect_cardinality() == want == c.pairw_intersect_cardinality_blocked(31)
-    t0 = time.perf_counter()
+    t_lists = 1e9     # best of 5 (a mean lets one hiccup of the box decide: 1.05 ms was measured once where 0.03 is the rule)
     for _ in range(5):
+        t0 = time.perf_counter()
         assert c.pairw_intersect_cardinality() == want
-    t_lists = (time.perf_counter() - t0) / 5
+        t_lists = min(t_lists, time.perf_counter() - t0)
     # a dense row: back to the dense mirror (filled in on demand: nothing was streamed while all rows were lists)
     c.add(dense_row)
     oc.add(dense_row)
@@ -535,10 +535,11 @@ def test_sparse_contiguous_containers_take_the_list_path(lib, orc):
     oc.add(rows[N])
     want3 = oc.pairw()
     assert c.pairw_intersect_cardinality() == want3
-    t0 = time.perf_counter()
+    t_dense = 1e9
     for _ in range(5):
+        t0 = time.perf_counter()
         assert c.pairw_intersect_cardinality() == want3
-    t_dense = (time.perf_counter() - t0) / 5
+        t_dense = min(t_dense, time.perf_counter() - t0)
     assert t_lists * 3 < t_dense, (t_lists, t_dense)
     # clear: a fresh start
     c.clear()
