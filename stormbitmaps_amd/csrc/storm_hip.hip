@@ -652,8 +652,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
-        if (value != 1 && value != 2 && value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 1 (bit operands), 16 or 32 (FP4 shadow)");
+        if (value != 1 && value != 2 && value != 3 && value != 4 && value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 1, 2 (bit operands inflated in registers), 3 / 4 (bit operands, FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES

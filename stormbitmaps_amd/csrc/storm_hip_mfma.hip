@@ -1369,6 +1369,61 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K2tb: the materialised-output kernel in K2b's form (option k2_tile_shape = 3) [r4].
+//
+// tilebits8_kernel inflates every operand it multiplies in registers: 3.75 vector operations per 32x32x64 MFMA,
+// the matrix pipe 79 % busy at the 2.0 GHz that body holds: 0.68 of the FP4 peak. What K2b showed for the totals
+// holds here: an operand that several waves multiply should be inflated ONCE, into an FP4 image in the LDS, and
+// the 16x16x128 shape holds more clock.
+//   workgroup : 4 waves, one 256 x 128 half of a 256 x 256 tile item over all of its k (two workgroups per
+//               item, the two B halves; 80 KiB of LDS each: two workgroups per CU, from two barrier domains);
+//               wave w owns A rows 64 w .. + 63 against the half's 128 B rows: 4 x 8 blocks of 16 x 16
+//               (128 accumulator registers), 32 MFMAs per class of a 512-bit chunk, 128 per chunk.
+//   B operand : the half's bits (128 rows x 64 B = 8 KiB per chunk) arrive by LDS-DMA, 2 pieces per wave, in a
+//               2-deep ring in which a wave touches only its own pieces; one chunk ahead the wave reads its pieces
+//               back, inflates them into all four classes and writes them into the images of the next chunk
+//               (2 slots x 2 class pairs x 16 KiB, K2b's layout and swizzle). ONE barrier per chunk (128 MFMAs).
+//   A operand : nobody shares a wave's A rows: their bits come straight from global memory (4 x 16 B per lane
+//               and chunk, one chunk ahead) and are inflated in registers, the next class beside the MFMAs of
+//               the current one.
+//   classes   : class c = bits 4 n + c of every dword as E2M1 code 1 << c (c = 3: shifted down once), undone by
+//               the block scales 128 / 127 / 126 / 126 on both operands (tilebits8_kernel's scheme): one
+//               vector operation per operand dword and class instead of two. Per MFMA: 0.94 vector operations
+//               (A 80 + B 40 per 128 MFMAs) against 3.75.
+//   body      : generated (tools/gen_tile16_body.py -> tile16_bits_chunk.inc): 32 steps of 4 MFMAs per chunk,
+//               fragments read two steps ahead into a rotation of three registers, the lgkmcnt values computed by
+//               walking the wave's in-order LDS queue.
+// Items, output conventions (triangle / band / rectangle, AND / OR / XOR through row_counts, k-split items that
+// add into a cleared window) are tilebits8_kernel's. Extends the reference (README.md:165-167: per-pair counts
+// for LD); the loop it stands for is storm.c:1199-1238 with the leaf's result kept per pair.
+// ------------------------------------------------------------------------------------------
+constexpr int kTiThreads = 256;
+constexpr uint32_t kTiImgBytes = 128u * 128u;                 // one class pair of a 128-row half: 16 KiB
+constexpr uint32_t kTiImgSlot = 2u * kTiImgBytes;             // both pairs of a chunk
+constexpr uint32_t kTiBits0 = 2u * kTiImgSlot;                // the bits ring behind the images
+constexpr uint32_t kTiBitsSlot = 128u * 64u;                  // 8 KiB
+constexpr uint32_t kTiLdsBytes = kTiBits0 + 2u * kTiBitsSlot; // 80 KiB
+
+#include "tile16_bits_chunk.inc"
+
+template <int C>
+__device__ __forceinline__ int ti_infl1(int w) {
+    if constexpr (C == 3) return (int)(((uint32_t)w >> 1) & 0x44444444u);
+    else return w & (int)(0x11111111u << C);
+}
+
+#define STORM_TI_SHAPE 16
+#define STORM_TI_NAME tile16_bits_kernel
+#include "tile_bits_kernel.inc"
+#undef STORM_TI_SHAPE
+#undef STORM_TI_NAME
+#define STORM_TI_SHAPE 32
+#define STORM_TI_NAME tile32_bits_kernel
+#include "tile_bits_kernel.inc"
+#undef STORM_TI_SHAPE
+#undef STORM_TI_NAME
+
+// ------------------------------------------------------------------------------------------
 // K2sb: the strips on BIT operands (option k2_strip_operands = 1; the default stays the FP4 shadow).
 //
 // Same work items, ring protocol and accumulator handling as strip_fp4_kernel, but the rows travel as
@@ -2519,7 +2574,20 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     if (plan.n_full < plan.n_items)
         hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
                            ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
-    if (bits && ctx->k2_tile_shape == 2)
+    if (bits && ctx->k2_tile_shape == 3 && getenv("STORM_HIP_TIMING")) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile16_bits_kernel, kTiThreads, kTiLdsBytes);
+        fprintf(stderr, "[tile16_bits_kernel] workgroups per CU by the runtime's occupancy query: %d (LDS %u B)\n", nb, kTiLdsBytes);
+    }
+    if (bits && ctx->k2_tile_shape == 3)
+        hipLaunchKernelGGL(tile16_bits_kernel, dim3((plan.n_items + 7u) / 8u * 16u), dim3(kTiThreads), kTiLdsBytes, ctx->stream,
+                           *bits, d_items, plan.n_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.n_full, i_lo, n_cols);
+    else if (bits && ctx->k2_tile_shape == 4)
+        hipLaunchKernelGGL(tile32_bits_kernel, dim3((plan.n_items + 7u) / 8u * 16u), dim3(kTiThreads), kTiLdsBytes, ctx->stream,
+                           *bits, d_items, plan.n_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.n_full, i_lo, n_cols);
+    else if (bits && ctx->k2_tile_shape == 2)
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
@@ -2583,7 +2651,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
     // bit-operand kernel: the operands are the matrix rows themselves (no shadow, no expansion)
-    const bool bits = ctx->k2_tile_shape <= 2;
+    const bool bits = ctx->k2_tile_shape <= 4;
     const uint64_t pitch = bits ? m->stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const size_t x4_bytes = bits ? 0 : (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
@@ -2627,7 +2695,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // 8 block pairs per SIMD; a ragged one ceil(columns / 64) of 4 blocks per wave, but not below the
     // inflation work of its A operands (measured: 0.3)
     std::vector<float> cost;
-    if (ctx->k2_tile_shape == 2) {
+    if (ctx->k2_tile_shape >= 2 && ctx->k2_tile_shape <= 4) {
         const float ragged_cost =
             std::max(ctx->k2_tile_cost_ragged / 100.0f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
         for (const auto& t : tiles) {
@@ -2666,7 +2734,7 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
-    const bool bits = ctx->k2_tile_shape <= 2 && b->stride_words == stride_words;
+    const bool bits = ctx->k2_tile_shape <= 4 && b->stride_words == stride_words;
     const uint64_t pitch = bits ? stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const uint64_t rows_a = (a->n_rows + kTile - 1) / kTile * kTile;
     const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;

@@ -417,7 +417,9 @@ def test_list_probe_kernel_for_columns_of_short_lists(hip_ctx, orc, M, N, d):
                                    (3000, 662, 1000), (2048, 968, 600)])
 def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d):
     """Option k2_tile_shape: the bit-operand kernels (2 = two waves per SIMD, the default; 1 = one wave per
-    SIMD: rows DMA'd as bits, inflated to FP4 in registers, per-class block scales) and the FP4-shadow
+    SIMD: rows DMA'd as bits, inflated to FP4 in registers, per-class block scales; 3 / 4 = round 4's K2tb:
+    the B half's FP4 images built once per workgroup in the LDS, 16x16x128 / 32x32x64 MFMAs, two workgroups
+    per tile item, every block range its loop is instantiated for) and the FP4-shadow
     kernels (16, 32) write the same triangle, for every op. Shapes with interior tiles (stored through
     the LDS, 16 bytes per lane) and with none, row counts that are and are not multiples of 4 (the
     host entry point's ld = N decides whether the wide stores may be used), rows shorter than one stage,
@@ -430,7 +432,7 @@ def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d
     for code, name in ((1, "or"), (2, "xor")):
         want[name] = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, code), k=1)
     try:
-        for shape in shipped(hip_ctx, "k2_tile_shape", (2, 1, 16, 32)):
+        for shape in shipped(hip_ctx, "k2_tile_shape", (2, 3, 4, 1, 16, 32)):
             hip_ctx.set_option("k2_tile_shape", shape)
             for name in ("and", "or", "xor"):
                 assert np.array_equal(m.pairw_matrix(name), want[name]), (shape, name)
@@ -464,7 +466,7 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
         ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
         want = orc.tile_counts(mat, 0, na, na, na + nbr)
         try:
-            for shape in shipped(hip_ctx, "k2_tile_shape", (2, 1, 16)):
+            for shape in shipped(hip_ctx, "k2_tile_shape", (2, 3, 4, 1, 16)):
                 hip_ctx.set_option("k2_tile_shape", shape)
                 assert np.array_equal(ma.square_matrix(mb, "and"), want), (na, nbr, shape)
             want_x = orc.tile_counts_op(mat, 0, na, na, na + nbr, 2)
