@@ -625,8 +625,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         ctx->k2_stages_per_item = (int)value;
     } else if (!strcmp(key, "k2_max_run")) {
-        if (value < 1 || value > 4096) {
-            set_error("k2_max_run out of range");
+        if (value < 0 || value > 4096) {
+            set_error("k2_max_run out of range (0 = chosen by the list-scheduling estimate, 1..4096)");
             return STORM_HIP_EINVAL;
         }
         ctx->k2_max_run = (int)value;

@@ -116,7 +116,7 @@ struct storm_hip_ctx_s {
     uint64_t strip_key[4] = {0, 0, 0, 0};
     uint32_t n_strip_items = 0;
     int k2_stages_per_item = 32;
-    int k2_max_run = 128;   // K2s: B stages per strip item
+    int k2_max_run = 0;     // strips: B stages per item at most; 0 = 64 / 96 / 128, whichever list schedules shortest (ensure_strip_items)
     int k2_ring = 4;        // K2s: LDS ring depth (3, 4 or 5)
     int k2_shadow_budget_mb = 96 * 1024;  // K2s: FP4 shadow above this many MiB -> k-chunked passes (0 = never)
     int k2_strip_operands = 0;  // strips: 0 = K2b; 5 = bit operands, FP4 image of every B stage built in the LDS (strip16_bits_kernel, K2b); 2 = bit operands, one stage stream per workgroup, one launch (bitstream_kernel, K2q); 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel); 1 = bit operands, one item per workgroup (stripbits_kernel)

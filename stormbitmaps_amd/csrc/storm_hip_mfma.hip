@@ -1959,7 +1959,8 @@ struct StripShaping {  // work-list shaping knobs (context options of the same n
 static void build_strip_items(const StripShaping& sh, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
                               uint32_t a_tile, std::vector<StripItem>& items,
-                              uint32_t queue_base[8], uint32_t queue_count[8]) {
+                              uint32_t queue_base[8], uint32_t queue_count[8], double* makespan = nullptr,
+                              uint32_t slots_per_xcd = 128) {
     // stages per item: <= 4096 keeps the f32 accumulators exact; shorter runs trade one more A
     // load per run for a shorter tail at the end of the launch
     const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, sh.max_run));
@@ -2071,6 +2072,23 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
                                  return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
                              });
     }
+    if (makespan) {
+        // List-scheduling estimate of the launch, in stage times: an XCD hands its list, in order, to its workgroup
+        // slots (4 per CU); an item costs its stages + ~5 for the prologue (A rows, two images) + 3 more for the
+        // non-pipelined diagonal phase. Used to choose the run length (k2_max_run = 0).
+        double worst = 0;
+        for (int x = 0; x < 8; ++x) {
+            std::vector<double> slot(std::max<uint32_t>(1, slots_per_xcd), 0.0);  // a min-heap of the slots' free times
+            auto later = [](double p, double q) { return p > q; };
+            for (const StripItem& it : per_xcd[x]) {
+                std::pop_heap(slot.begin(), slot.end(), later);
+                slot.back() += (double)(it.j1 - it.j0) + (it.diag ? kPerTile + 3.0 : 0.0) + 5.0;
+                std::push_heap(slot.begin(), slot.end(), later);
+            }
+            worst = std::max(worst, *std::max_element(slot.begin(), slot.end()));
+        }
+        *makespan = worst;
+    }
     items.clear();
     if (sh.persistent) {  // one contiguous queue per XCD
         for (int x = 0; x < 8; ++x) {
@@ -2101,6 +2119,30 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
     StripShaping sh;
     sh.max_run = ctx->k2_max_run;
+    if (ctx->k2_max_run == 0) {
+        // auto: the run length whose list schedules shortest (the tail of the launch decides between them: N = 6144 is
+        // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/sweep_maxrun.py)
+        StripShaping trial;
+        trial.tail_run = ctx->k2_tail_run;
+        trial.tail_slices = ctx->k2_tail_slices;
+        trial.lpt_rounds = ctx->k2_lpt_rounds;
+        trial.xcd_group = xcd_group;
+        trial.pair_space = ctx->k2_shard_pairs != 0;
+        double best = 0;
+        for (int cand : {96, 64, 128}) {
+            trial.max_run = cand;
+            std::vector<StripItem> tmp;
+            uint32_t qb[8], qc[8];
+            double ms = 0;
+            build_strip_items(trial, ranges, n_kslices, shard_rank, shard_count, a_tile, tmp, qb, qc, &ms,
+                              (uint32_t)std::max(1, ctx->n_cus / 8 * 4));
+            if (getenv("STORM_HIP_TIMING")) fprintf(stderr, "[strip plan] max_run %3d: %zu items, predicted makespan %.0f stages\n", cand, tmp.size(), ms);
+            if (sh.max_run == 0 || ms < best * 0.995) {   // (ties and near-ties go to the earlier candidate)
+                sh.max_run = cand;
+                best = ms;
+            }
+        }
+    }
     sh.tail_run = ctx->k2_tail_run;
     sh.tail_slices = ctx->k2_tail_slices;
     sh.lpt_rounds = ctx->k2_lpt_rounds;
@@ -2374,7 +2416,7 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     }
     memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // the shadow is about to hold [A ; B]
     const uint32_t n_kslices = (uint32_t)(row_bytes / kStripRowBytes);
-    const uint32_t kMaxRun = (uint32_t)std::min(4096, std::max(1, ctx->k2_max_run));
+    const uint32_t kMaxRun = (uint32_t)std::min(4096, ctx->k2_max_run > 0 ? ctx->k2_max_run : 128);   // (0 = auto: the rectangle has no tail problem)
     const uint32_t jb0 = (uint32_t)(rows_a / kStripBRows);
     const uint32_t jb1 = jb0 + (uint32_t)((b->n_rows + kStripBRows - 1) / kStripBRows);
     std::vector<StripItem> items;

@@ -35,7 +35,7 @@ def main():
         seed = int(rng.integers(1, 1 << 30))
         probes = ctx.get_option("probes_build") == 1   # the alternative kernel forms exist in the tools build only
         opts = {"variant": int(rng.choice([-1, -1, 4, 5 if probes else 4, 3, 2])),
-                "k2_max_run": int(rng.choice([128, 128, 1, 7, 64, 4096])),
+                "k2_max_run": int(rng.choice([0, 0, 128, 1, 7, 64, 4096])),
                 "k2_tail_slices": int(rng.choice([3, 0, 1, 8])),
                 "k2_tail_run": int(rng.choice([32, 1, 5, 64])),
                 "k2_persistent": int(rng.choice([0, 0, 1 if probes else 0])),
@@ -120,7 +120,7 @@ def main():
                     lib.storm_hip_sparse_destroy(ctx._h, h)
                 s.free()
         finally:
-            for k, v in {"variant": -1, "k2_max_run": 128, "k2_tail_slices": 3, "k2_tail_run": 32,
+            for k, v in {"variant": -1, "k2_max_run": 0, "k2_tail_slices": 3, "k2_tail_run": 32,
                          "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():

@@ -27,7 +27,7 @@ def main():
     m = ctx.matrix(rows, 1024)
     m.fill_synthetic(65536, 32768, seed=42)
     want = m.column_identity()
-    base = {"k2_max_run": 128, "k2_tail_run": 32, "k2_tail_slices": 3, "k2_lpt_rounds": 6}
+    base = {"k2_max_run": 0, "k2_tail_run": 32, "k2_tail_slices": 3, "k2_lpt_rounds": 6}
     trials = [dict(base)]
     for k, vals in (("k2_max_run", (64, 96, 160, 192, 256, 512)), ("k2_tail_run", (8, 16, 24, 48, 64)),
                     ("k2_tail_slices", (1, 2, 4, 6, 8)), ("k2_lpt_rounds", (0, 2, 12, 20))):
