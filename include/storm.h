@@ -265,6 +265,13 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids);
  * next all-pairs call answers for the rows as they were. Returns 0, -1 for a NULL handle. */
 int STORM_hip_invalidate(STORM_t* bitmap);
 int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
+/* Caller threads on distinct GPUs: after STORM_hip_set_devices(n, ids), a thread that calls
+ * STORM_hip_set_thread_devices(first_slot, n_slots) drives only the device slots [first_slot, first_slot + n_slots)
+ * with its all-pairs calls (n_slots = 0: all slots again) — the handles it uses keep their device mirrors there — and
+ * only those slots are locked, so threads on distinct slots run side by side (one lock per device slot; the raw-buffer
+ * STORM_wrapper_* calls keep one set of device matrices per process and lock all slots). Returns 0, -1 if the run of
+ * slots is not inside the configuration. A handle is still for one thread at a time, as in the reference. */
+int STORM_hip_set_thread_devices(int first_slot, int n_slots);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
 /* What the last all-pairs call ran, over this process's devices (storm_hip.h: storm_hip_last_pass_report):
  * out[0] mask of STORM_HIP_RAN_*, out[1] dense 64-bit word pairs, out[2] list-probe lookups, out[3] rows a
@@ -284,9 +291,11 @@ int STORM_hip_comm_finalize(void);
 /* Threading. Like the reference (no locks anywhere in storm.c), a HANDLE is not thread-safe: one thread at a
  * time per STORM_t / STORM_contiguous_t. Different handles may be used from different threads: every entry point
  * that touches a device (the all-pairs calls, STORM_contig_pairw_matrix, the raw-buffer wrappers, the streaming of
- * STORM_contig_add) takes one process-wide lock — the device contexts behind the handles are shared — so
- * concurrent passes are safe and run one after the other. The device selection (the two setters above, the
- * environment) is read on first use: change it only while no other thread is inside the library.
+ * STORM_contig_add) locks the device slots it drives — one lock per configured device, the contexts behind the
+ * handles are shared — so concurrent passes are safe; threads whose views (STORM_hip_set_thread_devices) are
+ * disjoint slots run side by side, threads on the same slots one after the other. The device selection
+ * (STORM_hip_set_devices / _set_shard, the environment) is read on first use: change it only while no other
+ * thread is inside the library.
  * STORM_hip_shutdown(): releases the wrappers' cached device matrices and every device context (handles that
  * still hold device copies re-create them on their next all-pairs call). Returns 0. */
 int STORM_hip_shutdown(void);

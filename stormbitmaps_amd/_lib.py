@@ -128,6 +128,7 @@ SIGNATURES = {
     "STORM_contig_hip_invalidate": (C.c_int, [vp]),
     "STORM_hip_set_devices": (C.c_int, [C.c_int, vp]),
     "STORM_hip_set_shard": (C.c_int, [u32, u32]),
+    "STORM_hip_set_thread_devices": (C.c_int, [C.c_int, C.c_int]),
     "STORM_hip_error": (cp, []),
     "STORM_hip_shutdown": (C.c_int, []),
     "STORM_hip_comm_unique_id": (C.c_int, [vp]),

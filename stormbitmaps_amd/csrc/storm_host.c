@@ -34,7 +34,18 @@ static uint32_t g_config_generation = 1; /* bumped by STORM_hip_set_devices */
 static int g_device_ids[MAX_DEVICES];
 static storm_hip_ctx_t* g_ctx[MAX_DEVICES];
 static uint32_t g_shard_rank = 0, g_shard_count = 1;
-static char g_host_error[256] = "";
+/* A caller thread may narrow what ITS all-pairs calls use to a run of the configured device slots
+ * (STORM_hip_set_thread_devices): handles driven from that thread keep their device mirrors there, and only those
+ * slots are locked — threads on distinct slots (GPUs) overlap. 0 slots = all of them (the default). */
+static __thread int tl_view_first = 0, tl_view_count = 0;
+static pthread_mutex_t g_config_mu = PTHREAD_MUTEX_INITIALIZER; /* guards the device configuration itself */
+static void configure_from_env(void);
+#define V0 (tl_view_count ? tl_view_first : 0)
+#define VN (tl_view_count ? tl_view_count : g_n_devices)
+#define V1 (V0 + VN)
+/* what a handle's device state was built for: the device configuration AND the caller's slots */
+#define VIEW_GENERATION (g_config_generation * 4096u + (uint32_t)V0 * 64u + (uint32_t)VN)
+static __thread char g_host_error[256] = ""; /* per calling thread, like the device library's last error */
 
 const char* STORM_hip_error(void) {
     return g_host_error[0] ? g_host_error : storm_hip_last_error();
@@ -62,6 +73,8 @@ int STORM_hip_comm_unique_id(uint8_t id[128]) {
     return 0;
 }
 
+/* (not to be called while another thread is inside an all-pairs call; a thread's view that no longer fits the new
+ * configuration is reset by its next STORM_hip_set_thread_devices) */
 int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     if (n_devices < 1 || n_devices > MAX_DEVICES || !device_ids) return -1;
     wrapper_states_release(); /* their matrices live on the contexts that go away here */
@@ -69,9 +82,12 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids) {
         if (g_ctx[d]) storm_hip_ctx_destroy(g_ctx[d]);
         g_ctx[d] = NULL;
     }
+    pthread_mutex_lock(&g_config_mu);
     for (int d = 0; d < n_devices; ++d) g_device_ids[d] = device_ids[d];
-    g_n_devices = n_devices;
+    __atomic_store_n(&g_n_devices, n_devices, __ATOMIC_RELEASE);
     ++g_config_generation; /* device mirrors cached in handles are rebuilt on their next use */
+    pthread_mutex_unlock(&g_config_mu);
+    if (tl_view_first + tl_view_count > n_devices) tl_view_first = tl_view_count = 0;
     return 0;
 }
 
@@ -80,7 +96,7 @@ int STORM_hip_set_devices(int n_devices, const int* device_ids) {
 int STORM_hip_last_pass(uint64_t out[4]) {
     if (!out) return -1;
     memset(out, 0, 4 * sizeof(uint64_t));
-    for (int d = 0; d < g_n_devices; ++d) {
+    for (int d = V0; d < V1; ++d) {
         uint64_t r[4];
         if (!g_ctx[d] || storm_hip_last_pass_report(g_ctx[d], r) != STORM_HIP_OK) continue;
         out[0] |= r[0];
@@ -88,6 +104,20 @@ int STORM_hip_last_pass(uint64_t out[4]) {
         out[2] += r[2];
         if (r[3]) out[3] = r[3];
     }
+    return 0;
+}
+
+/* The calling thread's all-pairs calls use the device slots [first_slot, first_slot + n_slots) of the configured
+ * devices from now on (n_slots = 0: all of them again). -1 if the run is not inside the configuration. */
+int STORM_hip_set_thread_devices(int first_slot, int n_slots) {
+    configure_from_env();
+    if (n_slots == 0) {
+        tl_view_first = tl_view_count = 0;
+        return 0;
+    }
+    if (first_slot < 0 || n_slots < 1 || first_slot + n_slots > g_n_devices) return -1;
+    tl_view_first = first_slot;
+    tl_view_count = n_slots;
     return 0;
 }
 
@@ -99,14 +129,22 @@ int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count) {
 }
 
 /* STORM_HIP_DEVICES = "all" | "0,2,3";  STORM_HIP_SHARD = "rank/count" */
+static void configure_from_env_locked(void);
 static void configure_from_env(void) {
+    if (__atomic_load_n(&g_n_devices, __ATOMIC_ACQUIRE) != 0) return;
+    pthread_mutex_lock(&g_config_mu);
+    configure_from_env_locked();
+    pthread_mutex_unlock(&g_config_mu);
+}
+static void configure_from_env_locked(void) {
     if (g_n_devices != 0) return;
+    int n_devices = 0;
     const char* devs = getenv("STORM_HIP_DEVICES");
     if (devs && !strcmp(devs, "all")) {
         int n = storm_hip_device_count();
         if (n > MAX_DEVICES) n = MAX_DEVICES;
         for (int d = 0; d < n; ++d) g_device_ids[d] = d;
-        g_n_devices = n > 0 ? n : 1;
+        n_devices = n > 0 ? n : 1;
     } else if (devs && devs[0]) {
         int n = 0;
         const char* p = devs;
@@ -114,10 +152,10 @@ static void configure_from_env(void) {
             g_device_ids[n++] = (int)strtol(p, (char**)&p, 10);
             if (*p == ',') ++p;
         }
-        g_n_devices = n > 0 ? n : 1;
+        n_devices = n > 0 ? n : 1;
     } else {
         g_device_ids[0] = 0;
-        g_n_devices = 1;
+        n_devices = 1;
     }
     const char* shard = getenv("STORM_HIP_SHARD");
     unsigned r = 0, c = 1;
@@ -125,9 +163,10 @@ static void configure_from_env(void) {
         g_shard_rank = r;
         g_shard_count = c;
     }
+    __atomic_store_n(&g_n_devices, n_devices, __ATOMIC_RELEASE); /* last: readers take the fast path from here on */
 }
 
-static int g_quiet_ctx = 0; /* 1 while a best-effort caller (row streaming) asks for a context */
+static __thread int g_quiet_ctx = 0; /* 1 while a best-effort caller (row streaming) asks for a context */
 
 static storm_hip_ctx_t* device_ctx(int slot) {
     configure_from_env();
@@ -203,8 +242,10 @@ static int use_host_threads(void) {
 
 /* fn(slot, launch) then fn(slot, fetch) on every configured device; 0 if all returned 0 */
 static int run_on_devices(slot_fn fn, void* arg, const char* what) {
-    const int n = g_n_devices;
-    int rc0 = 0, threads = n > 1 && use_host_threads();
+    const int lo = V0, n = VN;
+    /* the worker pool serves one job at a time and drives slots 1 .. n - 1: only for the full configuration (a thread
+     * with a narrower view drives its slots itself, typically one) */
+    int rc0 = 0, threads = n > 1 && lo == 0 && n == g_n_devices && use_host_threads();
     for (int d = 1; threads && d < n; ++d)
         if (!g_pool.started[d]) {
             if (pthread_create(&g_pool.th[d], NULL, pool_main, (void*)(intptr_t)d) != 0) {
@@ -217,11 +258,11 @@ static int run_on_devices(slot_fn fn, void* arg, const char* what) {
     if (!threads) { /* one thread: every device launched before the first result is waited for */
         int launched = 0;
         for (int k = 0; k < n && !rc0; ++k) {
-            rc0 = fn(k, 0, arg);
+            rc0 = fn(lo + k, 0, arg);
             if (!rc0) launched = k + 1;
         }
         for (int k = 0; k < launched; ++k) {
-            const int r = fn(k, 1, arg);
+            const int r = fn(lo + k, 1, arg);
             if (r && !rc0) rc0 = r;
         }
         if (rc0) device_error(what);
@@ -410,12 +451,13 @@ static void dense_state_release(dense_state_t* st) {
 typedef struct {
     dense_state_t* st;
     uint64_t part[MAX_DEVICES];
+    int first, count; /* the caller's device slots (worker threads do not share its thread-local view) */
 } dense_job_t;
 
 static int dense_job(int d, int phase, void* arg) {
     dense_job_t* j = (dense_job_t*)arg;
-    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
-    const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+    const uint32_t world = g_shard_count * (uint32_t)j->count;
+    const uint32_t rank = g_shard_rank * (uint32_t)j->count + (uint32_t)(d - j->first);
     return phase == 0 ? storm_hip_pairw_dense_begin(g_ctx[d], j->st->m[d], rank, world)
                       : storm_hip_pairw_dense_end(g_ctx[d], &j->part[d]);
 }
@@ -423,10 +465,12 @@ static int dense_job(int d, int phase, void* arg) {
 static uint64_t dense_state_pairw(dense_state_t* st) {
     dense_job_t j;
     j.st = st;
+    j.first = V0;
+    j.count = VN;
     memset(j.part, 0, sizeof(j.part));
     if (run_on_devices(dense_job, &j, "all-pairs pass (dense)")) return across_ranks(ALL_PAIRS_FAILED);
     uint64_t total = 0;
-    for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
+    for (int d = V0; d < V1; ++d) total += j.part[d];
     return across_ranks(total);
 }
 
@@ -438,20 +482,45 @@ static uint32_t g_wrapper_words = 0;
 /* ONE pass at a time per process: the device contexts behind every handle are shared (stream, partial-sum slots,
  * item tables), and so are the wrappers' cached matrices. Every entry point that touches a device takes this lock
  * (recursive: a STORM_contiguous_t's list mirror is a STORM_t of its own); concurrent callers run one after the other. */
-static pthread_mutex_t g_wrapper_mu;
-static pthread_once_t g_wrapper_mu_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t g_slot_mu[MAX_DEVICES];
+static pthread_once_t g_slot_mu_once = PTHREAD_ONCE_INIT;
 static void device_lock_init(void) {
     pthread_mutexattr_t at;
     pthread_mutexattr_init(&at);
     pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
-    pthread_mutex_init(&g_wrapper_mu, &at);
+    for (int d = 0; d < MAX_DEVICES; ++d) pthread_mutex_init(&g_slot_mu[d], &at);
     pthread_mutexattr_destroy(&at);
 }
-static void device_lock(void) {
-    pthread_once(&g_wrapper_mu_once, device_lock_init);
-    pthread_mutex_lock(&g_wrapper_mu);
+/* One lock PER DEVICE SLOT (round 4; rounds 2 - 3: one for the process): a call locks the slots of its thread's view,
+ * in ascending order, so caller threads that drive distinct slots (STORM_hip_set_thread_devices) run side by side.
+ * The raw-buffer wrappers and everything that reconfigures the devices take all of them. */
+static void device_lock_range(int lo, int hi) {
+    pthread_once(&g_slot_mu_once, device_lock_init);
+    for (int d = lo; d < hi; ++d) pthread_mutex_lock(&g_slot_mu[d]);
 }
-static void device_unlock(void) { pthread_mutex_unlock(&g_wrapper_mu); }
+static void device_unlock_range(int lo, int hi) {
+    for (int d = hi - 1; d >= lo; --d) pthread_mutex_unlock(&g_slot_mu[d]);
+}
+static void device_lock(void) {
+    configure_from_env();
+    device_lock_range(V0, V1);
+}
+static void device_unlock(void) { device_unlock_range(V0, V1); }
+/* the raw-buffer wrappers keep ONE set of device matrices per process, over the whole configuration: they lock every
+ * slot and see every slot, whatever the calling thread's view (saved in *saved, restored by device_unlock_all) */
+typedef struct { int first, count; } saved_view_t;
+static void device_lock_all(saved_view_t* saved) {
+    pthread_once(&g_slot_mu_once, device_lock_init);
+    device_lock_range(0, MAX_DEVICES);
+    saved->first = tl_view_first;
+    saved->count = tl_view_count;
+    tl_view_first = tl_view_count = 0;
+}
+static void device_unlock_all(const saved_view_t* saved) {
+    tl_view_first = saved->first;
+    tl_view_count = saved->count;
+    device_unlock_range(0, MAX_DEVICES);
+}
 
 static uint64_t raw_pairw_locked(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints);
 
@@ -461,9 +530,10 @@ static uint64_t raw_pairw(uint32_t n_vectors, const uint64_t* vals, uint32_t n_i
         host_error("all-pairs wrapper: NULL buffer");
         return ALL_PAIRS_FAILED;
     }
-    device_lock();
+    saved_view_t sv;
+    device_lock_all(&sv);
     const uint64_t total = raw_pairw_locked(n_vectors, vals, n_ints);
-    device_unlock();
+    device_unlock_all(&sv);
     return total;
 }
 
@@ -619,7 +689,8 @@ uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_R
         host_error("STORM_wrapper_square: NULL buffer");
         return ALL_PAIRS_FAILED;
     }
-    device_lock();
+    saved_view_t sv;
+    device_lock_all(&sv);
     configure_from_env();
     if (g_square_a.config_generation != g_config_generation || g_square_words != n_ints) {
         dense_state_release(&g_square_a);
@@ -629,7 +700,7 @@ uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_R
     }
     for (int d = 0; d < g_n_devices; ++d)
         if (!device_ctx(d)) {
-            device_unlock();
+            device_unlock_all(&sv);
             return ALL_PAIRS_FAILED;
         }
     square_job_t j;
@@ -647,16 +718,17 @@ uint64_t STORM_wrapper_square(const uint32_t n_vectors1, const uint64_t* STORM_R
     } else {
         for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
     }
-    device_unlock();
+    device_unlock_all(&sv);
     return total;
 }
 
 static void wrapper_states_release(void) {
-    device_lock();
+    saved_view_t sv;
+    device_lock_all(&sv);
     dense_state_release(&g_wrapper_state);
     dense_state_release(&g_square_a);
     dense_state_release(&g_square_b);
-    device_unlock();
+    device_unlock_all(&sv);
 }
 
 int STORM_hip_shutdown(void) {
@@ -1016,18 +1088,18 @@ static int contig_send_rows(STORM_contiguous_t* h, storm_hip_ctx_t* ctx, storm_h
 static int contig_upload_rows(STORM_contiguous_t* h, uint64_t upto) {
     configure_from_env();
     dense_state_t* st = (dense_state_t*)h->hip_matrix;
-    if (st && st->config_generation != g_config_generation) {
+    if (st && st->config_generation != VIEW_GENERATION) { /* other devices, or another thread's slots */
         contig_drop_device(h);
         st = NULL;
     }
     if (!st) {
         st = (dense_state_t*)calloc(1, sizeof(*st));
         if (!st) return -1;
-        st->config_generation = g_config_generation;
+        st->config_generation = VIEW_GENERATION;
         h->hip_matrix = st;
         h->hip_rows_synced = 0;
     }
-    for (int d = 0; d < g_n_devices; ++d) {
+    for (int d = V0; d < V1; ++d) {
         storm_hip_ctx_t* ctx = device_ctx(d);
         if (!ctx) return -1;
         if (!st->m[d] &&
@@ -1063,12 +1135,15 @@ static void contig_stream_rows(STORM_contiguous_t* h) {
     device_unlock();
 }
 static void contig_stream_rows_locked(STORM_contiguous_t* h) {
-    if (g_stream_state == 0) {
+    /* (threads on different device slots get here side by side: the switch is read and written atomically) */
+    int stream_state = __atomic_load_n(&g_stream_state, __ATOMIC_RELAXED);
+    if (stream_state == 0) {
         const char* e = getenv("STORM_HIP_STREAM_ROWS");
-        g_stream_state = (e && e[0] == '0') ? -1 : (e && e[0] == '1') ? 1 : 2;
+        stream_state = (e && e[0] == '0') ? -1 : (e && e[0] == '1') ? 1 : 2;
+        __atomic_store_n(&g_stream_state, stream_state, __ATOMIC_RELAXED);
     }
-    if (g_stream_state < 0) return;
-    if (g_stream_state == 2 && !g_ctx[0]) return;
+    if (stream_state < 0) return;
+    if (stream_state == 2 && !g_ctx[V0]) return;
     /* a container that is all lists so far needs no dense mirror (N x M bits over PCIe for a handful of
      * positions per row): contig_mirror() uploads whatever is missing the day a dense row or the per-pair
      * matrix asks for it */
@@ -1078,14 +1153,14 @@ static void contig_stream_rows_locked(STORM_contiguous_t* h) {
     g_quiet_ctx = 0;
     if (rc != 0) {
         contig_drop_device(h);
-        g_stream_state = -1;
+        __atomic_store_n(&g_stream_state, -1, __ATOMIC_RELAXED);
     }
 }
 
 /* make sure the device mirror of `h` is current; NULL on failure */
 static dense_state_t* contig_mirror(STORM_contiguous_t* h) {
     dense_state_t* st = (dense_state_t*)h->hip_matrix;
-    if (!st || h->hip_rows_synced != h->n_data || st->config_generation != g_config_generation) {
+    if (!st || h->hip_rows_synced != h->n_data || st->config_generation != VIEW_GENERATION) {
         if (h->hip_rows_synced > h->n_data) contig_drop_device(h);
         if (contig_upload_rows(h, h->n_data) != 0) {
             device_error("dense upload");
@@ -1150,10 +1225,10 @@ static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* o
     const uint64_t pairs = n * (n - 1) / 2;
     uint64_t row0 = 0;
     int launched = 0, rc = 0;
-    for (int d = 0; d < g_n_devices; ++d) {
+    for (int d = V0; d < V1; ++d) {
         uint64_t row1 = n;
-        if (d + 1 < g_n_devices) { /* first row r (multiple of 256) with pairs above r >= share */
-            const uint64_t share = pairs / (uint64_t)g_n_devices * (uint64_t)(d + 1);
+        if (d + 1 < V1) { /* first row r (multiple of 256) with pairs above r >= share */
+            const uint64_t share = pairs / (uint64_t)VN * (uint64_t)(d - V0 + 1);
             row1 = row0;
             while (row1 < n && row1 * (n - 1) - row1 * (row1 - 1) / 2 < share) row1 += 256;
             if (row1 > n) row1 = n;
@@ -1169,7 +1244,7 @@ static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* o
         launched = d + 1;
         row0 = row1;
     }
-    for (int d = 0; d < launched; ++d)
+    for (int d = V0; d < launched; ++d)
         if (storm_hip_pairw_matrix_band_end(g_ctx[d]) != STORM_HIP_OK) {
             device_error("storm_hip_pairw_matrix_band_end");
             rc = -3;
@@ -1702,11 +1777,11 @@ static uint64_t serialized_pairw_locked(const void* buf, uint64_t n_bytes) {
     storm_hip_sparse_t* arena[MAX_DEVICES] = {0};
     uint64_t total = 0;
     int ok = 1, launched = 0;
-    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
-    for (int d = 0; ok && d < g_n_devices; ++d) {
+    const uint32_t world = g_shard_count * (uint32_t)VN;
+    for (int d = V0; ok && d < V1; ++d) {
         storm_hip_ctx_t* ctx = device_ctx(d);
         if (!ctx || storm_hip_sparse_create_serialized(ctx, buf, n_bytes, &arena[d]) != STORM_HIP_OK ||
-            storm_hip_pairw_sparse_begin(ctx, arena[d], g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d,
+            storm_hip_pairw_sparse_begin(ctx, arena[d], g_shard_rank * (uint32_t)VN + (uint32_t)(d - V0),
                                          world) != STORM_HIP_OK) {
             device_error("serialized all-pairs");
             ok = 0;
@@ -1714,7 +1789,7 @@ static uint64_t serialized_pairw_locked(const void* buf, uint64_t n_bytes) {
             launched = d + 1;
         }
     }
-    for (int d = 0; d < launched; ++d) {
+    for (int d = V0; d < launched; ++d) {
         uint64_t part = 0;
         if (storm_hip_pairw_sparse_end(g_ctx[d], &part) != STORM_HIP_OK) ok = 0;
         total += part;
@@ -1756,13 +1831,17 @@ static uint64_t storm_fingerprint_rows(const STORM_t* h, uint32_t r0, uint32_t r
 static struct {
     pthread_t th[FP_PARTS];
     int started;
+    pthread_mutex_t job; /* the helpers serve one caller at a time (callers on different device slots run side by side) */
     pthread_mutex_t mu;
     pthread_cond_t go, done;
     uint64_t generation;
     int pending;
     const STORM_t* h;
     uint64_t part[FP_PARTS];
-} g_fp = {.mu = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER};
+} g_fp = {.job = PTHREAD_MUTEX_INITIALIZER,
+          .mu = PTHREAD_MUTEX_INITIALIZER,
+          .go = PTHREAD_COND_INITIALIZER,
+          .done = PTHREAD_COND_INITIALIZER};
 
 static void fp_bounds(const STORM_t* h, int q, uint32_t* r0, uint32_t* r1) {
     *r0 = (uint32_t)((uint64_t)h->n_conts * (uint64_t)q / FP_PARTS);
@@ -1789,7 +1868,8 @@ static void* fp_main(void* p) {
 }
 static uint64_t storm_fingerprint(const STORM_t* h) {
     uint64_t part[FP_PARTS];
-    int threaded = h->n_conts >= 4096;
+    /* a second caller that finds the helpers busy walks its rows itself rather than wait for them */
+    int threaded = h->n_conts >= 4096 && pthread_mutex_trylock(&g_fp.job) == 0;
     if (threaded && !g_fp.started) {
         int ok = 1;
         for (int q = 1; q < FP_PARTS && ok; ++q) {
@@ -1819,6 +1899,7 @@ static uint64_t storm_fingerprint(const STORM_t* h) {
             part[q] = storm_fingerprint_rows(h, r0, r1);
         }
     }
+    if (threaded) pthread_mutex_unlock(&g_fp.job);
     uint64_t f = 0x9e3779b97f4a7c15ull ^ h->n_conts;
     for (int q = 0; q < FP_PARTS; ++q) f = (f ^ part[q]) * 1099511628211ull;
     return f;
@@ -1854,7 +1935,7 @@ static int storm_build_arena(STORM_t* h) {
         }
         row_off[h->n_conts] = nb;
         rc = 0;
-        for (int d = 0; d < g_n_devices && rc == 0; ++d) {
+        for (int d = V0; d < V1 && rc == 0; ++d) {
             storm_hip_ctx_t* ctx = device_ctx(d);
             if (!ctx || storm_hip_sparse_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds, lens, ptrs,
                                                        &st->a[d]) != STORM_HIP_OK) {
@@ -1867,7 +1948,7 @@ static int storm_build_arena(STORM_t* h) {
     if (rc == 0) {
         h->hip_arena = st;
         h->hip_dirty = 0;
-        h->hip_generation = g_config_generation;
+        h->hip_generation = VIEW_GENERATION;
         h->hip_fingerprint = storm_fingerprint(h);
     } else if (st) {
         for (int d = 0; d < MAX_DEVICES; ++d)
@@ -1881,16 +1962,17 @@ static int storm_build_arena(STORM_t* h) {
 typedef struct {
     sparse_state_t* st;
     uint64_t part[MAX_DEVICES];
-    const STORM_t* check; /* fingerprint this container while the devices work (slot 0's thread) */
+    const STORM_t* check; /* fingerprint this container while the devices work (the first slot's thread) */
     uint64_t fingerprint;
+    int first, count; /* the caller's device slots */
 } sparse_job_t;
 
 static int sparse_job(int d, int phase, void* arg) {
     sparse_job_t* j = (sparse_job_t*)arg;
-    const uint32_t world = g_shard_count * (uint32_t)g_n_devices;
-    const uint32_t rank = g_shard_rank * (uint32_t)g_n_devices + (uint32_t)d;
+    const uint32_t world = g_shard_count * (uint32_t)j->count;
+    const uint32_t rank = g_shard_rank * (uint32_t)j->count + (uint32_t)(d - j->first);
     if (phase == 0) return storm_hip_pairw_sparse_begin(g_ctx[d], j->st->a[d], rank, world);
-    if (d == 0 && j->check) j->fingerprint = storm_fingerprint(j->check); /* every device has been launched */
+    if (d == j->first && j->check) j->fingerprint = storm_fingerprint(j->check); /* every device has been launched */
     return storm_hip_pairw_sparse_end(g_ctx[d], &j->part[d]);
 }
 
@@ -1919,7 +2001,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
      * launches, and only a mismatch — a caller edited rows through the public adders — throws the total away,
      * rebuilds the arena and runs again. */
     int verified = 0;
-    if (!h->hip_arena || h->hip_dirty || h->hip_generation != g_config_generation) {
+    if (!h->hip_arena || h->hip_dirty || h->hip_generation != VIEW_GENERATION) { /* (also: another thread's slots) */
         storm_drop_device(h);
         if (storm_build_arena(h)) return across_ranks(ALL_PAIRS_FAILED);
         verified = 1; /* built from the container as it is now */
@@ -1930,6 +2012,8 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         const uint64_t epoch = storm_epoch(); /* read before the pass: a mutator running meanwhile makes the next call check again */
         j.check = (!verified && !h->hip_private && (h->hip_epoch != epoch || always_fingerprint())) ? h : NULL;
         j.fingerprint = 0;
+        j.first = V0;
+        j.count = VN;
         memset(j.part, 0, sizeof(j.part));
         if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return across_ranks(ALL_PAIRS_FAILED);
         if (j.check && j.fingerprint != h->hip_fingerprint) {
@@ -1940,7 +2024,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         }
         h->hip_epoch = epoch; /* verified (or just built) at this epoch */
         uint64_t total = 0;
-        for (int d = 0; d < g_n_devices; ++d) total += j.part[d];
+        for (int d = V0; d < V1; ++d) total += j.part[d];
         return across_ranks(total);
     }
 }

@@ -168,3 +168,52 @@ def test_first_call_on_a_fresh_sparse_container_equals_the_steady_calls(orc):
         again = [s.pairw_intersect_cardinality_blocked(0), s.pairw_intersect_cardinality()]
         assert first == want and again == [want, want], (n_rows, draws, first, again, want)
         s.free()
+
+
+def test_caller_threads_on_their_own_device_slots_run_side_by_side(orc):
+    """STORM_hip_set_thread_devices (storm.h): two device slots configured (the one card of the box twice), two
+    caller threads each narrowed to ITS slot — one lock per slot, so neither waits for the other — each with a
+    STORM_t and a STORM_contiguous_t of its own, against the oracle; then one thread widened to both slots again."""
+    import ctypes as C
+    import threading
+    lib = sb._lib.load()
+    M = 2 * 65536
+    data = []
+    for t in range(2):
+        rows = synth.positions(M, 500, 300 + 2500 * t, seed=90 + t)
+        mat = synth.dense_matrix_c(M, 700, 9000, seed=95 + t)
+        data.append((rows, orc.storm(rows).pairw_blocked(0), mat, orc.wrapper_diag_blocked(mat, 0)))
+    ids = (C.c_int * 2)(0, 0)
+    bad = []
+
+    def work(t):
+        try:
+            assert lib.STORM_hip_set_thread_devices(t, 1) == 0
+            rows, want_s, mat, want_c = data[t]
+            s, c = sb.Storm(), sb.StormContig(M)
+            for r in rows:
+                s.add(r)
+            for r in synth.positions_from_dense(mat):
+                c.add(r)
+            for _ in range(6):
+                assert s.pairw_intersect_cardinality() == want_s
+                assert c.pairw_intersect_cardinality() == want_c
+            assert lib.STORM_hip_set_thread_devices(0, 0) == 0       # both slots: the mirrors follow the view
+            assert c.pairw_intersect_cardinality() == want_c and s.pairw_intersect_cardinality() == want_s
+            s.free()
+            c.free()
+        except BaseException as e:     # noqa: BLE001 — handed to the main thread
+            bad.append((t, repr(e)))
+
+    try:
+        assert lib.STORM_hip_set_devices(2, ids) == 0
+        assert lib.STORM_hip_set_thread_devices(1, 2) == -1
+        th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not bad, bad
+    finally:
+        one_dev = (C.c_int * 1)(0)
+        assert lib.STORM_hip_set_devices(1, one_dev) == 0

@@ -36,7 +36,9 @@ def test_host_containers_under_asan_ubsan(tmp_path):
 def test_host_side_with_three_caller_threads_under_tsan(tmp_path):
     """storm.h promises that different handles may be used from different threads: three threads, each with a
     STORM_t of 4500 rows (the arena fingerprint then runs on its helper threads) and a STORM_contiguous_t of its own,
-    twenty all-pairs calls each, under ThreadSanitizer on the device stub."""
+    twenty all-pairs calls each, under ThreadSanitizer on the device stub — first behind ONE device slot, then with
+    three slots configured and every thread narrowed to its own (STORM_hip_set_thread_devices: one lock per slot, the
+    threads run side by side) while a fourth thread calls a raw-buffer wrapper (all slots locked)."""
     exe = tmp_path / "host_threads"
     srcs = [os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_host.c"),
             os.path.join(ROOT, "stormbitmaps_amd", "csrc", "storm_synth.c"),
