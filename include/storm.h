@@ -248,6 +248,12 @@ uint64_t STORM_contig_pairw_intersect_cardinality_blocked_list(STORM_contiguous_
 uint64_t STORM_contig_n_rows(const STORM_contiguous_t* bitmap);
 int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out, uint64_t out_rows,
                               uint64_t out_ld);
+/* The same for a STORM_t: entry (i, j), i < j, is what STORM_bitmap_cont_intersect_cardinality(&conts[i], &conts[j])
+ * returns (storm.c:790-814; the LD use case of README.md:165-167 on the sparse container), or the union / symmetric
+ * difference count for op 1 / 2. The device keeps the rows as a dense bit matrix for this (65536 x (largest block
+ * id + 1) bits per row; rows beyond 2^25 bits are refused with -3). Same return codes; STORM_n_rows: rows added. */
+uint64_t STORM_n_rows(const STORM_t* bitmap);
+int STORM_pairw_matrix(STORM_t* bitmap, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld);
 
 /* ------------------------------------------------------------- extensions (not in ref) ---
  * Device selection for the entry points above. By default device 0 computes everything.

@@ -329,6 +329,15 @@ int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64
                                    const void* const* block_ptr, storm_hip_sparse_t** out);
 int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
                                        storm_hip_sparse_t** out);
+/* The rows of such a container as a DENSE bit matrix on the device (row width = 65536 x (largest block id + 1) bits,
+ * at most 2^25): what the per-pair output of a STORM_t runs on (storm.h: STORM_pairw_matrix) — a row pair of the
+ * reference (block-id merge + 4-way kind dispatch, storm.c:790-814, :618-656) is popcount(row_i & row_j) over
+ * exactly these bits. Same block description as storm_hip_sparse_create_blocks; blocks travel through the pinned
+ * ring as they lie in the containers and are unpacked by the device. Destroy with storm_hip_matrix_destroy. */
+int storm_hip_matrix_create_from_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                        const uint64_t* row_block_offset, const uint32_t* block_id,
+                                        const uint8_t* block_kind, const uint32_t* block_n,
+                                        const void* const* block_ptr, storm_hip_matrix_t** out);
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
                            uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);

@@ -675,6 +675,20 @@ static uint64_t storm_pair(const void* c, uint64_t i, uint64_t j) {
     return total;
 }
 
+/* The per-pair values themselves — what STORM_bitmap_cont_intersect_cardinality[_premade] (storm.c:790-814) returns
+ * for rows i < j — for rows [i0, i1) against every later row: out[(i - i0) * ld + j], other entries untouched.
+ * (The all-pairs functions below only sum them; the product's STORM_pairw_matrix is checked against this.) */
+int orc_storm_pair_counts(orc_storm_t* h, uint64_t i0, uint64_t i1, uint32_t* out, uint64_t ld) {
+    if (!h || !out || i1 > h->n_rows || i0 > i1 || ld < h->n_rows) return -1;
+    storm_ctx c = {h, orc_get_intersect_count_func(ORC_BLOCK_WORDS),
+                   (uint32_t*)malloc(sizeof(uint32_t) * 2 * ORC_SCALAR_THRESHOLD)};
+    if (!c.scratch) return -3;
+    for (uint64_t i = i0; i < i1; ++i)
+        for (uint64_t j = i + 1; j < h->n_rows; ++j) out[(i - i0) * ld + j] = (uint32_t)storm_pair(&c, i, j);
+    free(c.scratch);
+    return 0;
+}
+
 /* storm.c:877-895 */
 uint64_t orc_storm_pairw_intersect_cardinality(orc_storm_t* h) {
     if (!h) return (uint64_t)-1;

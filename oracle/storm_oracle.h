@@ -103,6 +103,8 @@ int orc_storm_add(orc_storm_t* h, const uint32_t* values, uint32_t n_values);
 int orc_storm_clear(orc_storm_t* h);
 uint64_t orc_storm_n_rows(const orc_storm_t* h);
 uint64_t orc_storm_serialized_size(const orc_storm_t* h);
+/* per-pair values (storm.c:790-814) of rows [i0, i1) against every later row: out[(i - i0) * ld + j] */
+int orc_storm_pair_counts(orc_storm_t* h, uint64_t i0, uint64_t i1, uint32_t* out, uint64_t ld);
 uint64_t orc_storm_pairw_intersect_cardinality(orc_storm_t* h);
 uint64_t orc_storm_pairw_intersect_cardinality_blocked(orc_storm_t* h, uint32_t bsize);
 /* census of block kinds, for tests: out[0]=#scalar blocks, out[1]=#bitmap blocks */

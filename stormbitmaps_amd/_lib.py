@@ -82,6 +82,7 @@ SIGNATURES = {
     "storm_hip_pairw_sparse": (C.c_int, [vp, vp, u32, u32, P(u64)]),
     "storm_hip_sparse_create_serialized": (C.c_int, [vp, vp, u64, P(vp)]),
     "storm_hip_sparse_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
+    "storm_hip_matrix_create_from_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_sparse_last_census": (C.c_int, [vp, P(u64 * 4)]),
@@ -121,6 +122,8 @@ SIGNATURES = {
     "STORM_get_cpuid": (C.c_int, []),
     "STORM_contig_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
     "STORM_contig_n_rows": (u64, [vp]),
+    "STORM_n_rows": (u64, [vp]),
+    "STORM_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
     "STORM_serialize": (u64, [vp, vp, u64]),
     "STORM_deserialize": (vp, [vp, u64]),
     "STORM_serialized_pairw_intersect_cardinality": (u64, [vp, u64]),

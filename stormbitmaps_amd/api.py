@@ -133,6 +133,22 @@ class Storm:
     def clear(self) -> int:
         return int(self._lib.STORM_clear(self._h))  # storm.c:868
 
+    @property
+    def n_rows(self) -> int:
+        """Rows added so far (STORM_n_rows)."""
+        return int(self._lib.STORM_n_rows(self._h))
+
+    def pairw_matrix(self, op: str = "and") -> np.ndarray:
+        """STORM_pairw_matrix (extension): [n_rows, n_rows] uint32, entry (i, j), i < j = what
+        STORM_bitmap_cont_intersect_cardinality gives for rows i and j (storm.c:790-814); "or" / "xor": the union /
+        symmetric-difference counts."""
+        n = self.n_rows
+        out = np.zeros((n, n), dtype=np.uint32)
+        rc = int(self._lib.STORM_pairw_matrix(self._h, {"and": 0, "or": 1, "xor": 2}[op], _ptr(out), n, n))
+        if rc != 0:
+            raise RuntimeError(f"STORM_pairw_matrix -> {rc}: {self._lib.STORM_hip_error().decode()}")
+        return out
+
     def serialized_size(self) -> int:
         return int(self._lib.STORM_serialized_size(self._h))  # storm.c:963
 

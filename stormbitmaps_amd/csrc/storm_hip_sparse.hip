@@ -969,6 +969,38 @@ static int ensure_full_pool(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
     return STORM_HIP_OK;
 }
 
+// The rows of a STORM_t as a dense bit matrix on the device (what the per-pair output runs on: the tile kernels
+// write popcount(row_i OP row_j) for every pair, and a row pair of the reference — the block-id merge and the 4-way
+// kind dispatch of storm.c:790-814, :618-656 — is exactly that over the rows' bits). Blocks travel as they lie in
+// the containers: packed into the pinned ring with a table of pieces, unpacked by one kernel per chunk (bitmap
+// blocks copied to word 1024 * id of their row, list blocks OR-ed in bit by bit).
+struct DensePiece {
+    uint32_t src;       // byte offset inside the chunk (16-byte aligned)
+    uint32_t n;         // list length, or kDenseBitmap
+    uint64_t dst_word;  // first word of the block inside the matrix
+};
+constexpr uint32_t kDenseBitmap = 0xffffffffu;
+
+__global__ __launch_bounds__(kThreads) void densify_kernel(const uint8_t* __restrict__ chunk,
+                                                           const DensePiece* __restrict__ pieces, uint32_t n_pieces,
+                                                           uint64_t* __restrict__ matrix) {
+    for (uint32_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
+        const DensePiece pc = pieces[p];
+        if (pc.n == kDenseBitmap) {
+            const uint4* src = reinterpret_cast<const uint4*>(chunk + pc.src);
+            uint4* dst = reinterpret_cast<uint4*>(matrix + pc.dst_word);   // rows and blocks are multiples of 16 bytes
+            for (uint32_t i = threadIdx.x; i < kBlockWords / 2; i += kThreads) dst[i] = src[i];
+        } else {
+            const uint16_t* list = reinterpret_cast<const uint16_t*>(chunk + pc.src);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(matrix + pc.dst_word);
+            for (uint32_t i = threadIdx.x; i < pc.n; i += kThreads) {
+                const uint32_t v = list[i];
+                atomicOr(dst + (v >> 5), 1u << (v & 31u));
+            }
+        }
+    }
+}
+
 extern "C" {
 
 int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
@@ -1020,6 +1052,98 @@ int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64
         set_error("sparse_create_blocks: %s", e.what());
         return STORM_HIP_ENOMEM;
     }
+}
+
+int storm_hip_matrix_create_from_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                                   const uint64_t* row_block_offset, const uint32_t* block_id,
+                                                   const uint8_t* block_kind, const uint32_t* block_n,
+                                                   const void* const* block_ptr, storm_hip_matrix_t** out) {
+    return guarded("storm_hip_matrix_create_from_blocks", [&]() -> int {
+        if (!ctx || !out) {
+            set_error("matrix_create_from_blocks: NULL context or output");
+            return STORM_HIP_EINVAL;
+        }
+        *out = nullptr;
+        if (n_rows == 0 || !row_block_offset || row_block_offset[0] != 0 || row_block_offset[n_rows] != n_blocks ||
+            (n_blocks > 0 && (!block_id || !block_kind || !block_n || !block_ptr))) {
+            set_error("matrix_create_from_blocks: no rows, NULL descriptor array or a CSR that does not end at n_blocks");
+            return STORM_HIP_EINVAL;
+        }
+        uint32_t max_id = 0;
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            if (row_block_offset[r] > row_block_offset[r + 1] || row_block_offset[r + 1] > n_blocks) {
+                set_error("matrix_create_from_blocks: row_block_offset is not a CSR over %llu blocks",
+                          (unsigned long long)n_blocks);
+                return STORM_HIP_EINVAL;
+            }
+            for (uint64_t b = row_block_offset[r]; b < row_block_offset[r + 1]; ++b) {
+                if ((b > row_block_offset[r] && block_id[b] <= block_id[b - 1]) || block_kind[b] > 1 ||
+                    (block_kind[b] == 0 ? (block_n[b] > 65536u || (block_n[b] && (!block_ptr[b] || ((uintptr_t)block_ptr[b] & 1))))
+                                        : !block_ptr[b])) {
+                    set_error("matrix_create_from_blocks: block %llu of row %llu: ids not ascending, unknown kind or no data",
+                              (unsigned long long)b, (unsigned long long)r);
+                    return STORM_HIP_EINVAL;
+                }
+                max_id = std::max(max_id, block_id[b]);
+            }
+        }
+        // the tile kernels address a row with 32-bit DMA offsets: 2^25 bits (storm_hip_pairw_matrix)
+        if (n_blocks > 0 && max_id >= (1u << 25) / 65536u) {
+            set_error("matrix_create_from_blocks: block id %u: rows of the dense form stop at 2^25 bits", max_id);
+            return STORM_HIP_EINVAL;
+        }
+        storm_hip_matrix_t* m = nullptr;
+        if (int rc = storm_hip_matrix_create(ctx, n_rows, (max_id + 1u) * kBlockWords, &m)) return rc;
+        struct MatrixDeleter {
+            storm_hip_ctx_t* ctx;
+            void operator()(storm_hip_matrix_t* x) const { storm_hip_matrix_destroy(ctx, x); }
+        };
+        std::unique_ptr<storm_hip_matrix_t, MatrixDeleter> owner(m, MatrixDeleter{ctx});
+        Stager stager(ctx);
+        if (int rc = stager.init()) return rc;
+        // chunk = [data | piece table]: up to 7 MiB of blocks and 64 Ki pieces per buffer of the ring
+        constexpr size_t kData = Stager::kBuf - (1u << 20), kMaxPieces = (1u << 20) / sizeof(DensePiece);
+        uint8_t* d_chunks = nullptr;
+        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_chunks), Stager::kBuf * Stager::kBufs));
+        std::unique_ptr<uint8_t, void (*)(uint8_t*)> chunks_owner(d_chunks, [](uint8_t* p) { (void)hipFree(p); });
+        std::vector<DensePiece> table;
+        std::vector<Piece> pieces;
+        table.reserve(kMaxPieces);
+        pieces.reserve(kMaxPieces + 1);
+        size_t fill = 0;
+        int slot = 0;
+        auto flush = [&]() -> int {
+            if (table.empty()) return STORM_HIP_OK;
+            pieces.push_back({table.data(), table.size() * sizeof(DensePiece), fill});  // (fill is 16-byte aligned)
+            uint8_t* d_base = d_chunks + (size_t)slot * Stager::kBuf;
+            if (int rc = stager.send(d_base, pieces.data(), pieces.size(), fill + table.size() * sizeof(DensePiece))) return rc;
+            const uint32_t n = (uint32_t)table.size();
+            densify_kernel<<<std::min<uint32_t>(n, 4096u), kThreads, 0, ctx->stream>>>(
+                d_base, reinterpret_cast<const DensePiece*>(d_base + fill), n, m->d);
+            STORM_HIP_TRY(hipGetLastError());
+            slot = (slot + 1) % Stager::kBufs;
+            table.clear();
+            pieces.clear();
+            fill = 0;
+            return STORM_HIP_OK;
+        };
+        for (uint64_t r = 0; r < n_rows; ++r)
+            for (uint64_t b = row_block_offset[r]; b < row_block_offset[r + 1]; ++b) {
+                const bool bitmap = block_kind[b] != 0;
+                if (!bitmap && block_n[b] == 0) continue;
+                const size_t bytes = bitmap ? kBlockWords * sizeof(uint64_t) : (size_t)block_n[b] * sizeof(uint16_t);
+                if (fill + bytes > kData || table.size() == kMaxPieces)
+                    if (int rc = flush()) return rc;
+                table.push_back({(uint32_t)fill, bitmap ? kDenseBitmap : block_n[b],
+                                 r * m->stride_words + (uint64_t)block_id[b] * kBlockWords});
+                pieces.push_back({block_ptr[b], bytes, fill});
+                fill = (fill + bytes + 15) & ~(size_t)15;
+            }
+        if (int rc = flush()) return rc;
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // the ring and the chunk buffers go away here
+        *out = owner.release();
+        return STORM_HIP_OK;
+    });
 }
 
 // Arena straight from a serialized STORM_t (byte layout: STORM_serialize in storm.h / storm_host.c;

@@ -1213,18 +1213,12 @@ int STORM_contig_pairw_matrix(STORM_contiguous_t* h, int op, uint32_t* out, uint
     device_unlock();
     return rc;
 }
-static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* out, uint64_t out_rows,
-                                      uint64_t out_ld) {
-    if (!h) return -1;
-    if (!out) return -2;
-    const uint64_t n = h->n_data;
-    if (out_rows < n || out_ld < n) return -4;
-    if (n == 0) return 0;
-    dense_state_t* st = contig_mirror(h);
-    if (!st) return -3;
+/* The strict upper triangle of an n-row device matrix (one replica per slot of the caller) into host memory: every
+ * device writes one band of rows, the bands cut so that each holds about the same number of pairs. 0 or -3. */
+static int pairw_matrix_bands(storm_hip_matrix_t* const* m, uint64_t n, int op, uint32_t* out, uint64_t out_ld) {
     const uint64_t pairs = n * (n - 1) / 2;
     uint64_t row0 = 0;
-    int launched = 0, rc = 0;
+    int launched = V0, rc = 0;
     for (int d = V0; d < V1; ++d) {
         uint64_t row1 = n;
         if (d + 1 < V1) { /* first row r (multiple of 256) with pairs above r >= share */
@@ -1234,8 +1228,8 @@ static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* o
             if (row1 > n) row1 = n;
         }
         if (row1 > row0) {
-            if (storm_hip_pairw_matrix_band_begin(g_ctx[d], st->m[d], op, row0, row1 - row0,
-                                                  out + row0 * out_ld, out_ld) != STORM_HIP_OK) {
+            if (storm_hip_pairw_matrix_band_begin(g_ctx[d], m[d], op, row0, row1 - row0, out + row0 * out_ld,
+                                                  out_ld) != STORM_HIP_OK) {
                 device_error("storm_hip_pairw_matrix_band_begin");
                 rc = -3;
                 break;
@@ -1250,6 +1244,18 @@ static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* o
             rc = -3;
         }
     return rc;
+}
+
+static int contig_pairw_matrix_locked(STORM_contiguous_t* h, int op, uint32_t* out, uint64_t out_rows,
+                                      uint64_t out_ld) {
+    if (!h) return -1;
+    if (!out) return -2;
+    const uint64_t n = h->n_data;
+    if (out_rows < n || out_ld < n) return -4;
+    if (n == 0) return 0;
+    dense_state_t* st = contig_mirror(h);
+    if (!st) return -3;
+    return pairw_matrix_bands(st->m, n, op, out, out_ld);
 }
 
 uint64_t STORM_contig_pairw_intersect_cardinality(STORM_contiguous_t* h) { /* :1149-1173 */
@@ -1564,16 +1570,21 @@ uint64_t STORM_bitmap_cont_intersect_cardinality(
  * ---------------------------------------------------------------------------------------- */
 STORM_t* STORM_new() { return (STORM_t*)calloc(1, sizeof(STORM_t)); }
 
-/* device state of a STORM_t handle: one replica of the flattened arena per configured GPU */
+/* device state of a STORM_t handle, per configured GPU: a replica of the block arena (what the all-pairs totals run
+ * on) and/or of the rows as a dense bit matrix (what STORM_pairw_matrix runs on); each is built by its first user */
 typedef struct {
     storm_hip_sparse_t* a[MAX_DEVICES];
+    storm_hip_matrix_t* m[MAX_DEVICES];
+    int have_arena, have_dense;
 } sparse_state_t;
 
 static void storm_drop_device(STORM_t* h) {
     if (h->hip_arena) {
         sparse_state_t* st = (sparse_state_t*)h->hip_arena;
-        for (int d = 0; d < MAX_DEVICES; ++d)
+        for (int d = 0; d < MAX_DEVICES; ++d) {
             if (st->a[d]) storm_hip_sparse_destroy(g_ctx[d], st->a[d]);
+            if (st->m[d]) storm_hip_matrix_destroy(g_ctx[d], st->m[d]);
+        }
         free(st);
         h->hip_arena = NULL;
     }
@@ -1905,23 +1916,42 @@ static uint64_t storm_fingerprint(const STORM_t* h) {
     return f;
 }
 
-/* Flatten rows -> blocks into the arrays storm_hip_sparse_create() takes (storm_hip.h), once, and
- * build one arena replica per configured device. */
-static int storm_build_arena(STORM_t* h) {
-    /* Nothing is flattened here: the device library gets the block headers and a POINTER to every block's list or
-     * bitmap where it lies in the containers, ships the raw data through its pinned ring and lays it out on the
-     * device (storm_hip_sparse_create_blocks). A first call at c4's 20971 draws per row cost 0.6 - 0.9 s with the
-     * host-side flattening and element layout of rounds 2 - 3. */
+/* The device state of a handle: thrown away and started afresh (empty, fingerprinted) when the handle is marked
+ * dirty or was built for another device configuration / another thread's slots. *fresh = 1 then: what is built into
+ * it next comes from the container as it is now. NULL: out of memory. */
+static sparse_state_t* storm_state(STORM_t* h, int* fresh) {
+    *fresh = 0;
+    if (!h->hip_arena || h->hip_dirty || h->hip_generation != VIEW_GENERATION) {
+        storm_drop_device(h);
+        sparse_state_t* st = (sparse_state_t*)calloc(1, sizeof(*st));
+        if (!st) {
+            host_error("STORM_t device state: out of host memory");
+            return NULL;
+        }
+        h->hip_arena = st;
+        h->hip_dirty = 0;
+        h->hip_generation = VIEW_GENERATION;
+        h->hip_fingerprint = storm_fingerprint(h);
+        *fresh = 1;
+    }
+    return (sparse_state_t*)h->hip_arena;
+}
+
+/* One replica per device slot of the caller of (dense = 0) the block arena or (dense = 1) the dense row matrix.
+ * Nothing is flattened here: the device library gets the block headers and a POINTER to every block's list or
+ * bitmap where it lies in the containers, ships the raw data through its pinned ring and lays it out on the
+ * device (storm_hip_sparse_create_blocks / storm_hip_matrix_create_from_blocks). A first call at c4's 20971 draws
+ * per row cost 0.6 - 0.9 s with the host-side flattening and element layout of rounds 2 - 3. */
+static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
     uint64_t n_blocks = 0;
     for (uint32_t i = 0; i < h->n_conts; ++i) n_blocks += h->conts[i].n_bitmaps;
-    sparse_state_t* st = (sparse_state_t*)calloc(1, sizeof(*st));
     uint64_t* row_off = (uint64_t*)malloc((h->n_conts + 1ull) * sizeof(uint64_t));
     uint32_t* ids = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
     uint8_t* kinds = (uint8_t*)malloc(n_blocks + 1);
     uint32_t* lens = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
     const void** ptrs = (const void**)malloc((n_blocks + 1) * sizeof(void*));
     int rc = -1;
-    if (st && row_off && ids && kinds && lens && ptrs) {
+    if (row_off && ids && kinds && lens && ptrs) {
         uint64_t nb = 0;
         for (uint32_t i = 0; i < h->n_conts; ++i) {
             row_off[i] = nb;
@@ -1937,23 +1967,28 @@ static int storm_build_arena(STORM_t* h) {
         rc = 0;
         for (int d = V0; d < V1 && rc == 0; ++d) {
             storm_hip_ctx_t* ctx = device_ctx(d);
-            if (!ctx || storm_hip_sparse_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds, lens, ptrs,
-                                                       &st->a[d]) != STORM_HIP_OK) {
-                device_error("storm_hip_sparse_create_blocks");
+            const int r = !ctx ? -1
+                          : dense ? storm_hip_matrix_create_from_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
+                                                                        lens, ptrs, &st->m[d])
+                                  : storm_hip_sparse_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds, lens,
+                                                                   ptrs, &st->a[d]);
+            if (r != STORM_HIP_OK) {
+                device_error(dense ? "storm_hip_matrix_create_from_blocks" : "storm_hip_sparse_create_blocks");
                 rc = -1;
             }
         }
+    } else {
+        host_error("STORM_t device state: out of host memory");
     }
     free(row_off); free(ids); free(kinds); free(lens); free((void*)ptrs);
     if (rc == 0) {
-        h->hip_arena = st;
-        h->hip_dirty = 0;
-        h->hip_generation = VIEW_GENERATION;
-        h->hip_fingerprint = storm_fingerprint(h);
-    } else if (st) {
-        for (int d = 0; d < MAX_DEVICES; ++d)
-            if (st->a[d]) storm_hip_sparse_destroy(g_ctx[d], st->a[d]);
-        free(st);
+        if (dense) st->have_dense = 1;
+        else st->have_arena = 1;
+    } else {
+        for (int d = 0; d < MAX_DEVICES; ++d) {
+            if (!dense && st->a[d]) { storm_hip_sparse_destroy(g_ctx[d], st->a[d]); st->a[d] = NULL; }
+            if (dense && st->m[d]) { storm_hip_matrix_destroy(g_ctx[d], st->m[d]); st->m[d] = NULL; }
+        }
     }
     return rc;
 }
@@ -2000,15 +2035,16 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
      * pass runs on it: the pass is launched first, the fingerprint is computed on the caller's thread behind the
      * launches, and only a mismatch — a caller edited rows through the public adders — throws the total away,
      * rebuilds the arena and runs again. */
-    int verified = 0;
-    if (!h->hip_arena || h->hip_dirty || h->hip_generation != VIEW_GENERATION) { /* (also: another thread's slots) */
-        storm_drop_device(h);
-        if (storm_build_arena(h)) return across_ranks(ALL_PAIRS_FAILED);
-        verified = 1; /* built from the container as it is now */
-    }
+    int verified = 0; /* 1: the state was started from the container as it is now */
+    sparse_state_t* st = storm_state(h, &verified);
+    if (!st) return across_ranks(ALL_PAIRS_FAILED);
     for (;;) {
+        if (!st->have_arena && storm_build_device(h, st, 0)) {
+            storm_drop_device(h);
+            return across_ranks(ALL_PAIRS_FAILED);
+        }
         sparse_job_t j;
-        j.st = (sparse_state_t*)h->hip_arena;
+        j.st = st;
         const uint64_t epoch = storm_epoch(); /* read before the pass: a mutator running meanwhile makes the next call check again */
         j.check = (!verified && !h->hip_private && (h->hip_epoch != epoch || always_fingerprint())) ? h : NULL;
         j.fingerprint = 0;
@@ -2018,8 +2054,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return across_ranks(ALL_PAIRS_FAILED);
         if (j.check && j.fingerprint != h->hip_fingerprint) {
             storm_drop_device(h);
-            if (storm_build_arena(h)) return across_ranks(ALL_PAIRS_FAILED);
-            verified = 1;
+            if (!(st = storm_state(h, &verified))) return across_ranks(ALL_PAIRS_FAILED);
             continue;
         }
         h->hip_epoch = epoch; /* verified (or just built) at this epoch */
@@ -2028,6 +2063,40 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         return across_ranks(total);
     }
 }
+
+/* Extension (storm.h): the per-pair matrix of a STORM_t — what STORM_bitmap_cont_intersect_cardinality (storm.c:790-814)
+ * returns for rows i < j, for every pair at once. The rows are laid out as a dense bit matrix on the device (built
+ * on the first call, kept with the handle like the arena, checked against the container's fingerprint) and the tile
+ * kernels of STORM_contig_pairw_matrix write the triangle. */
+static int storm_pairw_matrix_locked(STORM_t* h, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld) {
+    if (!h) return -1;
+    if (!out) return -2;
+    const uint64_t n = h->n_conts;
+    if (out_rows < n || out_ld < n) return -4;
+    if (n == 0) return 0;
+    configure_from_env();
+    int fresh = 0;
+    sparse_state_t* st = storm_state(h, &fresh);
+    if (!st) return -3;
+    const uint64_t epoch = storm_epoch();
+    if (!fresh && !h->hip_private && (h->hip_epoch != epoch || always_fingerprint()) &&
+        storm_fingerprint(h) != h->hip_fingerprint) { /* rows edited through the public adders behind STORM_add */
+        storm_drop_device(h);
+        if (!(st = storm_state(h, &fresh))) return -3;
+    }
+    h->hip_epoch = epoch;
+    if (!st->have_dense && storm_build_device(h, st, 1)) return -3;
+    return pairw_matrix_bands(st->m, n, op, out, out_ld);
+}
+
+int STORM_pairw_matrix(STORM_t* h, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld) {
+    device_lock();
+    const int rc = storm_pairw_matrix_locked(h, op, out, out_rows, out_ld);
+    device_unlock();
+    return rc;
+}
+
+uint64_t STORM_n_rows(const STORM_t* h) { return h ? h->n_conts : 0; }
 
 /* Extensions (storm.h): forget the device copy of a handle whose public members were edited
  * in place (the reference structs are not opaque, storm.h:157-200); the next all-pairs call

@@ -58,6 +58,7 @@ class Oracle:
             "orc_tile_counts": (None, [vp, u64, u64, u64, u64, u64, vp]),
             "orc_tile_counts_op": (None, [vp, u64, u64, u64, u64, u64, C.c_int, vp]),
             "orc_truth_naive_dense_op": (u64, [vp, u64, u64, C.c_int]),
+            "orc_storm_pair_counts": (C.c_int, [vp, u64, u64, vp, u64]),
             "orc_wrapper_diag": (u64, [u32, vp, u32, vp]),
             "orc_wrapper_diag_blocked": (u64, [u32, vp, u32, vp, u32]),
             "orc_wrapper_square": (u64, [u32, vp, u32, vp, u32, vp]),
@@ -194,6 +195,14 @@ class OrcStorm:
     def pairw(self): return int(self.lib.orc_storm_pairw_intersect_cardinality(self.h))
     def pairw_blocked(self, b=0): return int(self.lib.orc_storm_pairw_intersect_cardinality_blocked(self.h, b))
     def serialized_size(self): return int(self.lib.orc_storm_serialized_size(self.h))
+
+    def pair_counts(self, i0=0, i1=None) -> np.ndarray:
+        """[i1 - i0, n_rows] uint32: the row-pair function of storm.c:790-814 for rows i0 <= i < i1, i < j."""
+        n = int(self.lib.orc_storm_n_rows(self.h))
+        i1 = n if i1 is None else i1
+        out = np.zeros((i1 - i0, n), dtype=np.uint32)
+        assert self.lib.orc_storm_pair_counts(self.h, i0, i1, _p(out), n) == 0
+        return out
 
     def census(self):
         out = np.zeros(2, dtype=np.uint64)

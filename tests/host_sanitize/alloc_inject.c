@@ -52,6 +52,12 @@ static int scenario(void) {
     }
     if (s) {
         (void)STORM_pairw_intersect_cardinality(s);
+        uint32_t* tri = (uint32_t*)(malloc)((size_t)STORM_n_rows(s) * STORM_n_rows(s) * 4 + 4);
+        if (tri) {
+            const int rc = STORM_pairw_matrix(s, 0, tri, STORM_n_rows(s), STORM_n_rows(s));
+            if (rc != 0 && rc != -3) bad = 1;
+            (free)(tri);
+        }
         const uint64_t n = STORM_serialized_size(s);
         uint8_t* buf = (uint8_t*)(malloc)(n + 2);
         if (buf) {

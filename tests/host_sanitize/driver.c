@@ -74,7 +74,15 @@ static int scenario(uint32_t n_rows, uint32_t width, uint32_t draws, int with_em
     if (sparse->n_conts >= 2) {
         CHECK(STORM_pairw_intersect_cardinality(sparse) == distinct_sparse);
         CHECK(STORM_pairw_intersect_cardinality_blocked(sparse, 0) == distinct_sparse);
+        const uint64_t n = STORM_n_rows(sparse);
+        CHECK(n == sparse->n_conts);
+        uint32_t* out = (uint32_t*)malloc((size_t)n * n * sizeof(uint32_t));
+        CHECK(out && STORM_pairw_matrix(sparse, 0, out, n, n) == 0);   /* dense replica built beside the arena */
+        CHECK(STORM_pairw_matrix(sparse, 0, out, n - 1, n) == -4 && STORM_pairw_matrix(sparse, 0, NULL, n, n) == -2);
+        CHECK(STORM_pairw_intersect_cardinality(sparse) == distinct_sparse);
+        free(out);
     }
+    CHECK(STORM_pairw_matrix(NULL, 0, NULL, 0, 0) == -1);
     CHECK(STORM_serialized_size(sparse) >= 8);
     { /* serialized form: exact size, round trip, truncations rejected, nothing leaked */
         const uint64_t n = STORM_serialized_size(sparse);

@@ -217,3 +217,43 @@ def test_caller_threads_on_their_own_device_slots_run_side_by_side(orc):
     finally:
         one_dev = (C.c_int * 1)(0)
         assert lib.STORM_hip_set_devices(1, one_dev) == 0
+
+
+def test_per_pair_matrix_of_a_sparse_container_against_the_row_pair_function(orc):
+    """STORM_pairw_matrix (storm.h extension; the LD use case of README.md:165-167 on STORM_t): entry (i, j) is what
+    STORM_bitmap_cont_intersect_cardinality returns for rows i, j (storm.c:790-814 — oracle: orc_storm_pair_counts),
+    on list-only rows, bitmap rows, mixed kinds, empty and one-element rows; union / xor through the rows' own
+    cardinalities; its sum is the all-pairs total of the same handle; the dense replica follows STORM_add."""
+    rng = np.random.default_rng(17)
+    M = 5 * 65536 + 300
+    for n_rows, draws in ((130, 60), (300, 4000), (257, 30000), (200, None)):
+        rows = []
+        for r in range(n_rows):
+            d = draws if draws is not None else (20, 2500, 50000, 120000)[r % 4]
+            d = d if r % 9 else (0 if r % 18 == 0 else 1)
+            rows.append(np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32))
+        want = orc.storm(rows).pair_counts()
+        s = sb.Storm()
+        for v in rows:
+            s.add(v)
+        assert s.n_rows == n_rows
+        got = s.pairw_matrix()
+        assert np.array_equal(got, want), (n_rows, draws)
+        assert int(got.sum(dtype=np.uint64)) == s.pairw_intersect_cardinality()
+        card = np.array([len(v) for v in rows], dtype=np.int64)
+        union = np.triu(card[:, None] + card[None, :], k=1) - want
+        assert np.array_equal(s.pairw_matrix("or"), union)
+        assert np.array_equal(s.pairw_matrix("xor"), union - want)
+        extra = np.unique(rng.integers(0, M, size=700, dtype=np.uint64)).astype(np.uint32)
+        s.add(extra)                                                  # the replica is rebuilt for the new row
+        rows.append(extra)
+        assert np.array_equal(s.pairw_matrix(), orc.storm(rows).pair_counts())
+        s.free()
+    # rows beyond 2^25 bits: refused with the reason, nothing written
+    wide = sb.Storm()
+    wide.add(np.array([5, (1 << 25) + 3], dtype=np.uint32))
+    wide.add(np.array([5], dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="2\\^25"):
+        wide.pairw_matrix()
+    assert wide.pairw_intersect_cardinality() == 1
+    wide.free()

@@ -202,3 +202,21 @@ def test_container_conventions(orc):
     s.add([3, 70000])
     # two list blocks of one value each: (2 + 16) * 2 + 4 * 2 + 12
     assert s.serialized_size() == 20 + (2 + 16) * 2 + 8 + 12
+
+
+def test_storm_pair_counts_are_the_dense_and_counts(orc):
+    """orc_storm_pair_counts (the row-pair function of storm.c:790-814, every pair written out) against the dense
+    tile truth over the same bits, on list blocks, bitmap blocks and both mixed kinds; its sum is the all-pairs total."""
+    rng = np.random.default_rng(5)
+    M = 3 * 65536
+    rows = []
+    for r in range(60):
+        d = (30, 900, 9000, 60000)[r % 4]
+        rows.append(np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32))
+    rows[7] = np.zeros(0, dtype=np.uint32)
+    s = orc.storm(rows)
+    got = s.pair_counts()
+    want = np.triu(orc.tile_counts(_dense_from_rows(M, rows), 0, 60, 0, 60), k=1)
+    assert np.array_equal(got, want)
+    assert int(got.sum(dtype=np.uint64)) == s.pairw() == s.pairw_blocked(0)
+    assert np.array_equal(s.pair_counts(10, 20), want[10:20])

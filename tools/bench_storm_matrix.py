@@ -1,0 +1,43 @@
+"""Per-pair output of a STORM_t (STORM_pairw_matrix): first call (dense replica built from the containers) and steady
+calls at BASELINE c4's shape, with the all-pairs total of the same handle beside it as the check.
+    python tools/bench_storm_matrix.py [--rows 10000] [--bits 524288] [--draws 524,20971,262144] > out.jsonl"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stormbitmaps_amd as sb  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=10000)
+    ap.add_argument("--bits", type=int, default=524288)
+    ap.add_argument("--draws", default="524,20971,262144")
+    a = ap.parse_args()
+    for d in [int(x) for x in a.draws.split(",")]:
+        s = sb.Storm()
+        assert s.add_synthetic(a.bits, a.rows, d, seed=42) == a.rows
+        out = np.zeros((a.rows, a.rows), dtype=np.uint32)
+        lib, ptr = s._lib, out.ctypes.data
+        t0 = time.perf_counter()
+        assert lib.STORM_pairw_matrix(s._h, 0, ptr, a.rows, a.rows) == 0
+        first = time.perf_counter() - t0
+        steady = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            assert lib.STORM_pairw_matrix(s._h, 0, ptr, a.rows, a.rows) == 0
+            steady.append(time.perf_counter() - t0)
+        total = s.pairw_intersect_cardinality()
+        print(json.dumps({"rows": a.rows, "bits": a.bits, "draws": d, "first_call_ms": round(first * 1e3, 2),
+                          "steady_ms": round(min(steady) * 1e3, 2), "output_mb": out.nbytes / 1e6,
+                          "sum_equals_all_pairs_total": int(out.sum(dtype=np.uint64)) == total}), flush=True)
+        s.free()
+
+
+if __name__ == "__main__":
+    main()
