@@ -1406,10 +1406,21 @@ constexpr uint32_t kTiLdsBytes = kTiBits0 + 2u * kTiBitsSlot; // 80 KiB
 
 #include "tile16_bits_chunk.inc"
 
+// Class c of a dword (bits 4 n + c) as E2M1 codes with ONE set bit per nibble: bit 0 = 0.5, bit 1 = 1.0, bit 2 = 2.0.
+// The A side keeps its bit where it is (one operation; class 3 moves down to 2.0): values 0.5, 1, 2, 2. The B side —
+// inflated once per workgroup into the LDS image — takes the reciprocal: 2, 1, 0.5, 0.5. Every product is 1.0, so the
+// multiplies need no block scales: the compiler emits the plain v_mfma_f32_*_f8f6f4 (the scaled form costs ~6 % in
+// these loops: a 16-byte encoding and two more register reads, measured on K2b, LAB_NOTES.md).
 template <int C>
 __device__ __forceinline__ int ti_infl1(int w) {
     if constexpr (C == 3) return (int)(((uint32_t)w >> 1) & 0x44444444u);
     else return w & (int)(0x11111111u << C);
+}
+template <int C>
+__device__ __forceinline__ int ti_inflb(int w) {
+    if constexpr (C == 0) return (int)(((uint32_t)w << 2) & 0x44444444u);
+    else if constexpr (C == 1) return w & 0x22222222;
+    else return (int)(((uint32_t)w >> (C == 2 ? 2 : 3)) & 0x11111111u);
 }
 
 #define STORM_TI_SHAPE 16
