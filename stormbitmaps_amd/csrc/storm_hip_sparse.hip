@@ -129,7 +129,7 @@ constexpr uint32_t kProbeOctants = 1u << (16 - kProbeOctBits);
 //  popcount(mask & rows_before) per own element and popcount(mask) per later element; the counts are what those
 //  popcounts add up to, and v_bcnt_u32_b32 is half rate: profiles/r03_b_sparse_probe_ab.txt has every step.)
 template <int kT>
-__global__ __launch_bounds__(kT) void probe_lists_kernel(
+__global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SIMD: two workgroups of 1024 per CU)
     const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
     unsigned long long* __restrict__ slots) {
@@ -142,17 +142,31 @@ __global__ __launch_bounds__(kT) void probe_lists_kernel(
     for (uint32_t w = tid * 4u; w < (1u << kProbeOctBits) / 2u; w += (uint32_t)kT * 4u)
         *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
     __syncthreads();
-    // (eight loads per lane in flight: one per trip is a chain of ~40 memory latencies per item)
-    for (uint32_t e0 = it.a_begin + tid; e0 < it.a_end; e0 += (uint32_t)kT * 8u) {
-        uint32_t v[8];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) v[k] = elems[min(e0 + k * (uint32_t)kT, it.a_end - 1u)];
-#pragma unroll
-        for (uint32_t k = 0; k < 8; ++k)
-            if (e0 + k * (uint32_t)kT < it.a_end) {
-                const uint32_t pos = v[k] & kPosMask;
-                atomicAdd(&Cn32[pos >> 1], 1u << (16u * (pos & 1u)));
+    // The group's histogram, from the 2-byte positions of its atom (pos16 holds every atom in an order of its own —
+    // dealt by LDS bank — and a histogram takes any order): 8 positions per 16-byte load, and the 64 adds of an
+    // instruction fall on different banks. (Until round 4 it was built from the row-tagged 4-byte elements, one
+    // per load in row order: with the far stream switched off a launch at c4's 20971 draws still took 0.23 of its
+    // 0.93 ms — 30 us per item for 42 000 adds, profiles/r04_h_*.)
+    {
+        auto bump = [&](uint32_t p2) { atomicAdd(&Cn32[p2 >> 2], 1u << (8u * (p2 & 2u))); };   // p2 = 2 x position
+        const uint32_t h_end = min(it.a_end, (it.a_begin + 7u) & ~7u);
+        if (it.a_begin + tid < h_end) bump(pos16[it.a_begin + tid]);
+        const uint32_t hb_end = h_end + ((it.a_end - h_end) & ~7u);
+        if (hb_end > h_end) {
+            const uint32_t h_last = hb_end - 8u;
+            for (uint32_t q = h_end + tid * 8u; q < hb_end; q += 2u * (uint32_t)kT * 8u) {
+                const uint32_t q1 = q + (uint32_t)kT * 8u;
+                const uint4 v0 = *reinterpret_cast<const uint4*>(&pos16[q]);
+                const uint4 v1 = *reinterpret_cast<const uint4*>(&pos16[min(q1, h_last)]);
+                bump(v0.x & 0xffffu); bump(v0.x >> 16); bump(v0.y & 0xffffu); bump(v0.y >> 16);
+                bump(v0.z & 0xffffu); bump(v0.z >> 16); bump(v0.w & 0xffffu); bump(v0.w >> 16);
+                if (q1 < hb_end) {
+                    bump(v1.x & 0xffffu); bump(v1.x >> 16); bump(v1.y & 0xffffu); bump(v1.y >> 16);
+                    bump(v1.z & 0xffffu); bump(v1.z >> 16); bump(v1.w & 0xffffu); bump(v1.w >> 16);
+                }
             }
+        }
+        if (hb_end + tid < it.a_end) bump(pos16[hb_end + tid]);
     }
     __syncthreads();
     uint32_t count = 0;
@@ -173,11 +187,12 @@ __global__ __launch_bounds__(kT) void probe_lists_kernel(
     const uint32_t body_end = e + ((it.b_end - e) & ~7u);
     // Body: FOUR 16-byte pieces per lane and trip, loaded together and looked up whether or not they lie inside the
     // item (the address is clamped to the item's last piece, whose positions are valid ones; a piece outside counts
-    // for nothing): behind a branch hipcc sinks the load to its use and waits for it with vmcnt(0). The eight
-    // lookups of a piece are issued together before the first of them is added. With one piece per trip the stream
-    // was latency-bound — 16 KiB in flight per CU, 5.1 TB/s whatever the L2 hit rate — and software-pipelining it by
-    // hand does not survive hipcc (register rotation by copies makes it wait for the youngest load; without copies
-    // it sinks the loads to their uses).
+    // for nothing): behind a branch hipcc sinks the load to its use and waits for it with vmcnt(0). With one piece
+    // per trip the stream was latency-bound (16 KiB in flight per CU). Fetching the NEXT trip's pieces under this
+    // trip's lookups — inline-asm loads, counted waits that name the registers they release — was built in round 4
+    // and is 2 - 15 % SLOWER (0.696 against 0.679 ms at 20971 draws, 0.093 against 0.079 at 524, same box,
+    // profiles/r04_h_sparse_probe.txt): eight waves per SIMD already cover the round trip, and the stream runs at
+    // 0.8 of what the LDS delivers for conflict-free 2-byte gathers (tools/probes/lds_gather_roof.hip).
     if (body_end > e) {
         constexpr uint32_t kStep = (uint32_t)kT * 8u;
         const uint32_t last = body_end - 8u;
@@ -493,7 +508,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         uint64_t total = 0;
         for (uint32_t c = 0; c <= max_id; ++c) {
             const uint64_t n_l = n_list_col[c];
-            if (n_l >= 2 && n_l <= 65535 && col_elems[c] > 0 && total + col_elems[c] + 64 < (1ull << 32) - 8) {
+            if (n_l >= 2 && n_l <= 65535 && col_elems[c] > 0 && total + col_elems[c] + 64 < (1ull << 32) - (1u << 20)) {  // (the probe kernel's element indices run up to 12 x 8192 past an item's end)
                 probe_c[c] = 1;
                 total += col_elems[c] + 64;
             }

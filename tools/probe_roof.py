@@ -19,6 +19,9 @@ import sys
 
 N, BLOCKS, ROWS_PER_ITEM = 10000, 8, 128
 LDS_LOOKUPS_PER_CLK_CU, CUS, CLK = 32, 256, 2.4e9
+# what the chip delivers for conflict-free 2-byte gathers from a 16 KiB table, 1024-thread workgroups, two per CU
+# (tools/probes/lds_gather_roof.hip, profiles/r04_h_lds_gather_roof.jsonl); uniformly random positions: 5.5e12
+MEASURED_GATHER_PEAK = 1.665e13
 
 
 def counters(path):
@@ -63,7 +66,7 @@ def main():
         line = f"{load:6d} {u:8.0f} {w['dense_ms']:9.3f} {w['probe_ms']:9.3f}  |"
         if us:
             rate = lookups / (us * 1e-6)
-            line += f" {us:9.1f}  {lookups:11.3e}  {rate:10.3e}  {rate / roof:8.3f}        |"
+            line += f" {us:9.1f}  {lookups:11.3e}  {rate:10.3e}  {rate / roof:8.3f} ({rate / MEASURED_GATHER_PEAK:5.3f})  |"
             sq = counters(os.path.join(out, f"sq_{load}"))
             tcc = counters(os.path.join(out, f"tcc_{load}"))
             fetch = counters(os.path.join(out, f"fetch_{load}"))
@@ -76,6 +79,7 @@ def main():
                 line += (f" {sq.get('SQ_INSTS_LDS', 0):9.3e}  {sq.get('SQ_LDS_BANK_CONFLICT', 0) / max(sq.get('SQ_LDS_IDX_ACTIVE', 1), 1):8.3f}"
                          f"  {sq.get('SQ_WAIT_INST_LDS', 0) / max(sq.get('SQ_WAVE_CYCLES', 1), 1):8.3f}")
         print(line)
+    print(f"# measured conflict-free 2-byte gather peak (tools/probes/lds_gather_roof.hip): {MEASURED_GATHER_PEAK:.3e} lookups/s; uniformly random positions: 5.5e12")
     print(f"# LDS roof: {LDS_LOOKUPS_PER_CLK_CU} two-byte lookups/clk/CU x {CUS} CUs x {CLK / 1e9} GHz = {roof:.3e} lookups/s; VALU roof (2 instructions per lookup): {64 / 2 * CUS * CLK:.3e}")
 
 
