@@ -712,14 +712,16 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 }
             }
             // Chunks of the far stream are the SAME for every group of a (column, octant) stream: a fixed grid of runs
-            // of atoms, ~far_work / 4096 positions each and at most 2^19 (1 MiB of positions: a quarter of an XCD's
-            // L2). A group needs the rest of the chunk its own atom lies in and every later chunk. The items that read
-            // one chunk are a FAMILY; a family goes to one XCD, its items one after the other, so that the XCD's 32 CUs
-            // work through the same MiB at the same time and HBM delivers it once (the kernel fetched 16 GB per launch
-            // at c4's 20971 draws — every group streaming its own 4 MiB chunks through an L2 that hit 9 % of the time —
-            // and ran at the HBM rate with the LDS half idle).
+            // of atoms, ~far_work / 2048 positions each and at most 2^23. A group needs the rest of the chunk its own
+            // atom lies in and every later chunk. The items that read one chunk are a FAMILY; a family goes to one XCD,
+            // its items one after the other, so that the XCD's 32 CUs work through the same positions at the same time
+            // and HBM delivers them once (the kernel fetched 16 GB per launch at c4's 20971 draws — every group
+            // streaming its own 4 MiB chunks through an L2 that hit 9 % of the time — and ran at the HBM rate with the
+            // LDS half idle). Every item pays for its group's histogram, so fewer, longer items win as long as the
+            // 512 workgroup slots stay filled: / 4096 and 2^21 until round 4; / 2048 is 8 - 18 % faster at every c4
+            // load and 2^23 another 7 % at 30000 draws (profiles/r04_h_sparse_probe.txt).
             const uint64_t kProbeChunk =
-                std::min<uint64_t>(1u << 21, std::max<uint64_t>(1u << 15, far_work / 4096)) & ~7ull;
+                std::min<uint64_t>(1u << 23, std::max<uint64_t>(1u << 15, far_work / 2048)) & ~7ull;
             struct Family {
                 uint64_t work = 0;
                 std::vector<storm_hip_sparse_s::ProbeItemHost> items;
