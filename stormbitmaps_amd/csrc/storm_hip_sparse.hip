@@ -1340,17 +1340,23 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             ctx->pass_report[0] |= STORM_HIP_RAN_LIST_PROBE;
             ctx->pass_report[2] += s->probe_lookups_launch;
             ctx->pass_report[3] = kProbeRows;
-            // Short items (sparse loads: a few hundred lookups each) are all fixed cost — the item record, the group's
-            // elements and the far positions are three dependent trips to memory — and what covers that is workgroups
-            // per CU: 256 threads each, eight per CU instead of two (c4 at 104 draws per row: 38 -> ~15 us per launch).
-            if (s->probe_lookups_launch / s->n_probe_launch < 16384u)
-                hipLaunchKernelGGL(probe_lists_kernel<256>, dim3(s->n_probe_launch), dim3(256), 0, ctx->stream,
-                                   s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
-                                   shard_rank, ctx->d_slots);
-            else
-                hipLaunchKernelGGL(probe_lists_kernel<kProbeThreads>, dim3(s->n_probe_launch), dim3(kProbeThreads), 0, ctx->stream,
-                                   s->d_probe_elems, s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count,
-                                   shard_rank, ctx->d_slots);
+            // Threads per workgroup by the length of the items (c4, ms per call at 104 / 524 / 1048 / 2097 / 5242 / 10485 /
+            // 20971 draws per row, one box, profiles/r04_h_sparse_probe.txt):
+            //     256 threads, 8 workgroups per CU   0.034 0.047 0.063 0.095 0.193 0.495 1.554
+            //     512, 4                             0.039 0.051 0.064 0.096 0.183 0.341 0.917
+            //    1024, 2                             0.055 0.065 0.078 0.106 0.189 0.328 0.664
+            // Short items are all fixed cost — the item record, the group's positions and the far positions are three
+            // dependent trips to memory, then the histogram — and what covers that is workgroups per CU; long ones want
+            // the workgroups of a CU in step on the same chunk of the stream (its L2 lines are read once per XCD).
+            const uint64_t per_item = s->probe_lookups_launch / s->n_probe_launch;
+            const int threads = per_item < 400000u ? 256 : per_item < 1500000u ? 512 : kProbeThreads;
+#define STORM_PROBE_LAUNCH(T)                                                                                          \
+    hipLaunchKernelGGL(probe_lists_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_elems,       \
+                       s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots)
+            if (threads == 256) STORM_PROBE_LAUNCH(256);
+            else if (threads == 512) STORM_PROBE_LAUNCH(512);
+            else STORM_PROBE_LAUNCH(kProbeThreads);
+#undef STORM_PROBE_LAUNCH
             STORM_HIP_TRY(hipGetLastError());
         }
         std::vector<RowRange> ranges;
