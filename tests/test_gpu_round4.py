@@ -249,6 +249,22 @@ def test_per_pair_matrix_of_a_sparse_container_against_the_row_pair_function(orc
         rows.append(extra)
         assert np.array_equal(s.pairw_matrix(), orc.storm(rows).pair_counts())
         s.free()
+    # three device slots (the one card three times): each writes one band of rows of the same triangle
+    import ctypes as C
+    lib = sb._lib.load()
+    rows = [np.unique(rng.integers(0, M, size=(40, 3000, 70000)[r % 3], dtype=np.uint64)).astype(np.uint32) for r in range(700)]
+    want = orc.storm(rows).pair_counts()
+    s = sb.Storm()
+    for v in rows:
+        s.add(v)
+    try:
+        assert lib.STORM_hip_set_devices(3, (C.c_int * 3)(0, 0, 0)) == 0
+        assert np.array_equal(s.pairw_matrix(), want)
+        assert s.pairw_intersect_cardinality() == int(want.sum(dtype=np.uint64))
+    finally:
+        assert lib.STORM_hip_set_devices(1, (C.c_int * 1)(0)) == 0
+    assert np.array_equal(s.pairw_matrix("and"), want)                # rebuilt for the one-device configuration
+    s.free()
     # rows beyond 2^25 bits: refused with the reason, nothing written
     wide = sb.Storm()
     wide.add(np.array([5, (1 << 25) + 3], dtype=np.uint32))
