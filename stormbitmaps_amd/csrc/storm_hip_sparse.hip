@@ -246,6 +246,27 @@ __global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __rest
 // One workgroup per list block of a probe column: element k of the list goes to run_dst[octant] + (k - start of
 // the octant's run) as (row in column) << 16 | position in octant, and as a byte offset (2 x position) for the far
 // stream. meta[b] = {list offset (uint16 units), length, tag = row in column << 16, pad}; run_end / run_dst: 8 per block.
+// Where the runs of a sorted list end: run_end[8 b + o] = the first index of list b whose value is >= (o + 1) * 8192
+// (one thread per list and octant; the host did these 640 000 binary searches over cold lists in 65 of the 89 ms a
+// first call took at c4's 20971 draws per row — the lists have to travel to the device anyway).
+__global__ __launch_bounds__(kThreads) void probe_run_end_kernel(const uint16_t* __restrict__ lists,
+                                                                 const uint64_t* __restrict__ list_off,
+                                                                 const uint32_t* __restrict__ list_len, uint32_t n_lists,
+                                                                 uint32_t* __restrict__ run_end) {
+    const uint32_t idx = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t b = idx / kProbeOctants, o = idx % kProbeOctants;
+    if (b >= n_lists) return;
+    const uint16_t* l = lists + list_off[b];
+    const uint32_t lim = (o + 1u) << kProbeOctBits;
+    uint32_t lo = 0, hi = list_len[b];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint32_t)l[mid] < lim) lo = mid + 1u;
+        else hi = mid;
+    }
+    run_end[idx] = lo;
+}
+
 // A list that is not strictly ascending sets *bad (the probe kernel counts every listed element: none may repeat).
 __global__ __launch_bounds__(kThreads) void probe_fill_kernel(const uint16_t* __restrict__ lists,
                                                               const uint64_t* __restrict__ list_off,
@@ -349,7 +370,7 @@ struct Stager {
     int send(uint8_t* d_base, const Piece* pieces, size_t n, size_t span) {
         uint8_t* buf = static_cast<uint8_t*>(ctx->h_stage_ring) + (size_t)next * kBuf;
         if (used[next] && hipEventSynchronize(ev[next]) != hipSuccess) return STORM_HIP_EHIP;
-        const unsigned parts = span >= (1u << 20) ? 4u : 1u;
+        const unsigned parts = span >= (1u << 20) ? 4u : 1u;   // (2 / 4 / 8 / 12 packers: 31 / 24 / 28 / 32 ms for c4's 420 MB of lists)
         auto pack = [&](unsigned part) {
             for (size_t i = n * part / parts; i < n * (part + 1) / parts; ++i)
                 memcpy(buf + pieces[i].dst_off, pieces[i].src, pieces[i].bytes);
@@ -582,18 +603,83 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     std::vector<uint32_t> run_dst;       // ... and where the run starts in the element arrays
     std::vector<uint32_t> block_local;   // the block's row inside its column's list rows
     std::vector<uint32_t> atoms;         // {first element, end} of every atom of the far stream
-    const unsigned n_host_threads = n_blocks >= 4096 ? 4u : 1u;
-    auto on_threads = [&](auto&& body) {  // body(part, parts); exceptions of a helper end up in `failed`
-        std::atomic<bool> failed{false};
-        std::vector<std::thread> helpers;
-        for (unsigned t = 1; t < n_host_threads; ++t)
-            helpers.emplace_back([&, t] {
-                try { body(t, n_host_threads); } catch (...) { failed = true; }
-            });
-        try { body(0u, n_host_threads); } catch (...) { failed = true; }
-        for (std::thread& h : helpers) h.join();
-        return !failed.load();
-    };
+    // device temporaries of the build: released on every way out
+    struct DevTemps {
+        uint32_t *lrow = nullptr, *llen = nullptr, *tags = nullptr, *rend = nullptr, *rdst = nullptr;
+        uint32_t *atoms = nullptr, *bad = nullptr, *pllen = nullptr;
+        uint64_t *loff = nullptr, *ploff = nullptr;
+        uint16_t *lists = nullptr, *pos_tmp = nullptr;
+        ~DevTemps() {
+            (void)hipFree(lrow); (void)hipFree(loff); (void)hipFree(llen); (void)hipFree(lists);
+            (void)hipFree(tags); (void)hipFree(rend); (void)hipFree(rdst); (void)hipFree(atoms);
+            (void)hipFree(bad); (void)hipFree(pllen); (void)hipFree(ploff); (void)hipFree(pos_tmp);
+        }
+    } dt;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    Stager stager(ctx);
+    if (int rc0 = stager.init()) return rc0;
+    // ---- the raw lists the device needs — of the probe columns (element layout) and of the list blocks that own a
+    //      pool row (expanded there) — go up FIRST, block after block: the device then finds where the octants' runs
+    //      end inside every list of a probe column, which is all the host's layout below needs to know of them
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (block_kind[b] == 0 && probe_c[block_id[b]]) probe_blocks.push_back(b);
+    std::vector<uint64_t> dev_off(n_blocks + 1, ~0ull);
+    uint64_t n_list_elems = 0;
+    {
+        std::vector<uint8_t> wanted(n_blocks, 0);
+        for (uint64_t b : probe_blocks) wanted[b] = 1;
+        for (uint64_t b : list_blk) wanted[b] = 1;
+        std::vector<std::pair<const void*, size_t>> run;
+        for (uint64_t b = 0; b < n_blocks; ++b)
+            if (wanted[b] && block_n[b]) {
+                dev_off[b] = n_list_elems;
+                n_list_elems += block_n[b];
+                run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
+            }
+        if (n_list_elems) {
+            if (hipMalloc(reinterpret_cast<void**>(&dt.lists), n_list_elems * sizeof(uint16_t)) != hipSuccess) {
+                set_error("sparse_create: hipMalloc of %llu bytes for the lists failed",
+                          (unsigned long long)(n_list_elems * sizeof(uint16_t)));
+                return STORM_HIP_ENOMEM;
+            }
+            if (int rc0 = stager.send_run(reinterpret_cast<uint8_t*>(dt.lists), run)) return rc0;
+        }
+    }
+    lap("lists -> device");
+    std::vector<uint64_t> ploff;
+    std::vector<uint32_t> pllen;
+    if (!probe_blocks.empty()) {
+        ploff.reserve(probe_blocks.size());
+        pllen.reserve(probe_blocks.size());
+        for (uint64_t b : probe_blocks) {
+            ploff.push_back(block_n[b] ? dev_off[b] : 0);
+            pllen.push_back(block_n[b]);
+        }
+        run_end.assign(probe_blocks.size() * kProbeOctants, 0);
+        if (int rc0 = upload(&dt.ploff, ploff.data(), ploff.size(), ctx->stream)) return rc0;
+        if (int rc0 = upload(&dt.pllen, pllen.data(), pllen.size(), ctx->stream)) return rc0;
+        STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dt.rend), run_end.size() * sizeof(uint32_t)));
+        const uint32_t n_threads = (uint32_t)run_end.size();
+        hipLaunchKernelGGL(probe_run_end_kernel, dim3((n_threads + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
+                           dt.lists, dt.ploff, dt.pllen, (uint32_t)probe_blocks.size(), dt.rend);
+        STORM_HIP_TRY(hipGetLastError());
+        STORM_HIP_TRY(hipMemcpyAsync(run_end.data(), dt.rend, run_end.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // a list that is not ascending may give ends that run backwards: refused here, before they are laid out
+        // (ascending ends that disagree with the values are caught by probe_fill_kernel)
+        for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
+            uint32_t from = 0;
+            for (uint32_t o = 0; o < kProbeOctants; ++o) {
+                const uint32_t end = run_end[pb * kProbeOctants + o];
+                if (end < from || end > pllen[pb]) {
+                    set_error("sparse_create: a list block is not strictly ascending");
+                    return STORM_HIP_EINVAL;
+                }
+                from = end;
+            }
+        }
+        lap("run ends on the device");
+    }
     {
         std::vector<int64_t> col_entry((size_t)max_id + 2, -1);  // column id -> index into s->cols
         s->col_probe.assign(s->cols.size(), 0);
@@ -615,31 +701,8 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             // 16-byte boundary of the uint16 position array
             const size_t n_e = s->cols.size();
             std::vector<uint64_t> oct_count(n_e * kProbeOctants, 0), oct_base(n_e * kProbeOctants, 0);
-            // A list is sorted, so its elements of one octant are one run: the runs' ends per block (binary search, on
-            // a few threads: 8 searches in each of c4's 80000 lists), then where every run goes.
-            for (uint64_t b = 0; b < n_blocks; ++b) {
-                const int64_t e = col_entry[block_id[b]];
-                if (e >= 0 && s->col_probe[(size_t)e] && block_kind[b] == 0) probe_blocks.push_back(b);
-            }
-            run_end.assign(probe_blocks.size() * kProbeOctants, 0);
             run_dst.assign(probe_blocks.size() * kProbeOctants, 0);
             block_local.assign(probe_blocks.size(), kNoBlock);
-            if (!on_threads([&](unsigned part, unsigned parts) {
-                    for (size_t pb = probe_blocks.size() * part / parts; pb < probe_blocks.size() * (part + 1) / parts; ++pb) {
-                        const uint64_t b = probe_blocks[pb];
-                        const uint16_t* l = static_cast<const uint16_t*>(block_ptr[b]);
-                        uint32_t from = 0;
-                        for (uint32_t o = 0; o < kProbeOctants; ++o) {
-                            const uint32_t end = (uint32_t)(std::lower_bound(l + from, l + block_n[b], (o + 1u) << kProbeOctBits,
-                                                                             [](uint16_t x, uint32_t lim) { return (uint32_t)x < lim; }) - l);
-                            run_end[pb * kProbeOctants + o] = end;
-                            from = end;
-                        }
-                    }
-                })) {
-                set_error("sparse_create: out of memory while walking the lists");
-                return STORM_HIP_ENOMEM;
-            }
             for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
                 const size_t e = (size_t)col_entry[block_id[probe_blocks[pb]]];
                 uint32_t from = 0;
@@ -687,7 +750,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                     ++pb;
                 }
             }
-            lap("list walk + layout");
+            lap("layout (prefix sums, row starts)");
             // atoms of the far stream (the elements of one group of kProbeRows rows in one octant): the device deals
             // the positions of every atom by LDS bank (probe_deal_kernel; why: see there)
             for (size_t i = 0; i < row_start.size(); ++i) {
@@ -797,12 +860,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     lap("items");
     // ---- device side: pool rows, raw lists through the pinned ring, element layout by kernels ----
     int rc = STORM_HIP_OK;
-    uint32_t *d_lrow = nullptr, *d_llen = nullptr, *d_tags = nullptr, *d_rend = nullptr, *d_rdst = nullptr;
-    uint32_t *d_atoms = nullptr, *d_bad = nullptr, *d_pllen = nullptr;
-    uint64_t *d_loff = nullptr, *d_ploff = nullptr;
-    uint16_t *d_lists = nullptr, *d_pos_tmp = nullptr;
     do {
-        if (hipSetDevice(ctx->device) != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         const size_t pool_bytes = (s->pool_rows_ready + 512) * kBlockWords * sizeof(uint64_t);
         if (hipMalloc(reinterpret_cast<void**>(&s->d_pool), pool_bytes) != hipSuccess) {
             set_error("sparse_create: hipMalloc of %zu bytes for the block pool failed",
@@ -814,8 +872,6 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             rc = STORM_HIP_EHIP;
             break;
         }
-        Stager stager(ctx);
-        if ((rc = stager.init())) break;
         // bitmap-kind blocks: straight into their pool rows — in pool-row order the blocks of a column are
         // consecutive 8 KiB rows, so a run of them is ONE contiguous destination (no staging copy on the device,
         // no placement kernel; the words may sit at any alignment on the host: a serialized stream)
@@ -839,55 +895,28 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             if (rc != STORM_HIP_OK) break;
         }
         lap("bitmaps -> pool rows");
-        // the raw lists the device needs — of the probe columns (element layout) and of the list blocks that own a
-        // pool row (expanded there) — go up once, block after block
-        std::vector<uint64_t> dev_off(n_blocks + 1, ~0ull);
-        uint64_t n_list_elems = 0;
-        {
-            std::vector<uint8_t> wanted(n_blocks, 0);
-            for (uint64_t b : probe_blocks) wanted[b] = 1;
-            for (uint64_t b : list_blk) wanted[b] = 1;
-            std::vector<std::pair<const void*, size_t>> run;
-            for (uint64_t b = 0; b < n_blocks; ++b)
-                if (wanted[b] && block_n[b]) {
-                    dev_off[b] = n_list_elems;
-                    n_list_elems += block_n[b];
-                    run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
-                }
-            if (n_list_elems) {
-                if (hipMalloc(reinterpret_cast<void**>(&d_lists), n_list_elems * sizeof(uint16_t)) != hipSuccess) {
-                    set_error("sparse_create: hipMalloc of %llu bytes for the lists failed",
-                              (unsigned long long)(n_list_elems * sizeof(uint16_t)));
-                    rc = STORM_HIP_ENOMEM;
-                    break;
-                }
-                if ((rc = stager.send_run(reinterpret_cast<uint8_t*>(d_lists), run))) break;
-            }
-        }
-        lap("lists -> device");
         // list-kind blocks that own a pool row (mixed columns, columns the probe kernel cannot take): expanded there
         std::vector<uint64_t> loff;
         if (!list_row.empty()) {
             loff.reserve(list_blk.size());
             for (uint64_t b : list_blk) loff.push_back(dev_off[b]);
-            if ((rc = upload(&d_lrow, list_row.data(), list_row.size(), ctx->stream)) ||
-                (rc = upload(&d_loff, loff.data(), loff.size(), ctx->stream)) ||
-                (rc = upload(&d_llen, list_len.data(), list_len.size(), ctx->stream)))
+            if ((rc = upload(&dt.lrow, list_row.data(), list_row.size(), ctx->stream)) ||
+                (rc = upload(&dt.loff, loff.data(), loff.size(), ctx->stream)) ||
+                (rc = upload(&dt.llen, list_len.data(), list_len.size(), ctx->stream)))
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
-                               dim3(kThreads), 0, ctx->stream, s->d_pool, d_lrow, d_loff, d_llen,
-                               d_lists);
+                               dim3(kThreads), 0, ctx->stream, s->d_pool, dt.lrow, dt.loff, dt.llen,
+                               dt.lists);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
         // probe columns: element layout on the device
-        std::vector<uint64_t> ploff;
-        std::vector<uint32_t> pllen, tags;
+        std::vector<uint32_t> tags;
         uint32_t bad = 0;
         if (n_probe_elems) {
             if (hipMalloc(reinterpret_cast<void**>(&s->d_probe_elems), n_probe_elems * sizeof(uint32_t)) != hipSuccess ||
                 hipMalloc(reinterpret_cast<void**>(&s->d_probe_pos16), n_probe_elems * sizeof(uint16_t)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&d_pos_tmp), n_probe_elems * sizeof(uint16_t)) != hipSuccess ||
-                hipMalloc(reinterpret_cast<void**>(&d_bad), sizeof(uint32_t)) != hipSuccess) {
+                hipMalloc(reinterpret_cast<void**>(&dt.pos_tmp), n_probe_elems * sizeof(uint16_t)) != hipSuccess ||
+                hipMalloc(reinterpret_cast<void**>(&dt.bad), sizeof(uint32_t)) != hipSuccess) {
                 set_error("sparse_create: hipMalloc of the probe element arrays (%zu elements) failed", n_probe_elems);
                 rc = STORM_HIP_ENOMEM;
                 break;
@@ -895,34 +924,25 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             // (the alignment gaps behind every octant read as zero)
             if (hipMemsetAsync(s->d_probe_elems, 0, n_probe_elems * sizeof(uint32_t), ctx->stream) != hipSuccess ||
                 hipMemsetAsync(s->d_probe_pos16, 0, n_probe_elems * sizeof(uint16_t), ctx->stream) != hipSuccess ||
-                hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream) != hipSuccess) {
+                hipMemsetAsync(dt.bad, 0, sizeof(uint32_t), ctx->stream) != hipSuccess) {
                 rc = STORM_HIP_EHIP;
                 break;
             }
-            ploff.reserve(probe_blocks.size());
-            pllen.reserve(probe_blocks.size());
             tags.reserve(probe_blocks.size());
-            for (size_t pb = 0; pb < probe_blocks.size(); ++pb) {
-                const uint64_t b = probe_blocks[pb];
-                ploff.push_back(block_n[b] ? dev_off[b] : 0);
-                pllen.push_back(block_n[b]);
-                tags.push_back(block_local[pb] << 16);
-            }
-            if ((rc = upload(&d_ploff, ploff.data(), ploff.size(), ctx->stream)) ||
-                (rc = upload(&d_pllen, pllen.data(), pllen.size(), ctx->stream)) ||
-                (rc = upload(&d_tags, tags.data(), tags.size(), ctx->stream)) ||
-                (rc = upload(&d_rend, run_end.data(), run_end.size(), ctx->stream)) ||
-                (rc = upload(&d_rdst, run_dst.data(), run_dst.size(), ctx->stream)) ||
-                (rc = upload(&d_atoms, atoms.data(), atoms.size(), ctx->stream)))
+            for (size_t pb = 0; pb < probe_blocks.size(); ++pb) tags.push_back(block_local[pb] << 16);
+            // (the lists' offsets, their lengths and the run ends are on the device since the start)
+            if ((rc = upload(&dt.tags, tags.data(), tags.size(), ctx->stream)) ||
+                (rc = upload(&dt.rdst, run_dst.data(), run_dst.size(), ctx->stream)) ||
+                (rc = upload(&dt.atoms, atoms.data(), atoms.size(), ctx->stream)))
                 break;
             if (!probe_blocks.empty())
                 hipLaunchKernelGGL(probe_fill_kernel, dim3((uint32_t)probe_blocks.size()), dim3(kThreads), 0, ctx->stream,
-                                   d_lists, d_ploff, d_pllen, d_tags, d_rend, d_rdst, s->d_probe_elems, d_pos_tmp, d_bad);
+                                   dt.lists, dt.ploff, dt.pllen, dt.tags, dt.rend, dt.rdst, s->d_probe_elems, dt.pos_tmp, dt.bad);
             if (!atoms.empty())
                 hipLaunchKernelGGL(probe_deal_kernel, dim3((uint32_t)(atoms.size() / 2)), dim3(kThreads), 0, ctx->stream,
-                                   d_atoms, d_pos_tmp, s->d_probe_pos16);
+                                   dt.atoms, dt.pos_tmp, s->d_probe_pos16);
             if (hipGetLastError() != hipSuccess ||
-                hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+                hipMemcpyAsync(&bad, dt.bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
                 rc = STORM_HIP_EHIP;
                 break;
             }
@@ -936,9 +956,6 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     } while (0);
     if (rc == STORM_HIP_EHIP) set_error("sparse_create: HIP failure: %s",
                                         hipGetErrorString(hipGetLastError()));
-    (void)hipFree(d_lrow); (void)hipFree(d_loff); (void)hipFree(d_llen); (void)hipFree(d_lists);
-    (void)hipFree(d_tags); (void)hipFree(d_rend); (void)hipFree(d_rdst); (void)hipFree(d_atoms);
-    (void)hipFree(d_bad); (void)hipFree(d_pllen); (void)hipFree(d_ploff); (void)hipFree(d_pos_tmp);
     if (rc != STORM_HIP_OK) return rc;
     *out = owner.release();
     return STORM_HIP_OK;
