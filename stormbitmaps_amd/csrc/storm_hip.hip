@@ -684,7 +684,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
     } else if (!strcmp(key, "k2_shard_pairs")) {
         ctx->k2_shard_pairs = value != 0;
     } else if (!strcmp(key, "k2_matrix_pad")) {
-        ctx->k2_matrix_pad = value < 0 ? -1 : value != 0;
+        ctx->k2_matrix_pad = value < 0 ? -1 : (int)std::min<int64_t>(value, 64);   // chunks of 512 bytes
     } else if (!strcmp(key, "k2_fold_inline")) {
         ctx->k2_fold_inline = value != 0;
     } else if (!strcmp(key, "k2_wave_ring")) {
@@ -919,10 +919,11 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
     // The bit-operand strips read 64-byte pieces of 64 consecutive rows straight from this buffer: rows whose
     // byte length is a multiple of 1 KiB would put the rows of a k-slice into a handful of L2 sets and memory
-    // channels, so one more chunk of zero words per row breaks the pattern (same finding as shadow_pitch,
-    // storm_hip_mfma.hip; K2b at the headline shape 769 -> 758 us, at M = 524288 6.69 -> 6.40 ms,
-    // profiles/r04_a_pitch_pad.txt). Option k2_matrix_pad = 0 keeps the dense pitch.
-    if (ctx->k2_matrix_pad != 0 && m->stride_words % 128 == 0) m->stride_words += kChunkWords;
+    // channels, so two more chunks of zero words per row break the pattern (same finding as shadow_pitch,
+    // storm_hip_mfma.hip). K2b per pass, pitch + 0 / 512 / 1024 / 1536 / 2048 bytes (profiles/r04_a_pitch_pad.txt,
+    // r04_k_pitch_pad.jsonl): headline shape 0.766 / 0.756 / 0.758 / 0.758 / 0.758 ms, M = 524288 6.57 / 6.22 /
+    // 5.97 / 6.00 / 5.99 ms. Option k2_matrix_pad = number of chunks (0 keeps the dense pitch).
+    if (ctx->k2_matrix_pad != 0 && m->stride_words % 128 == 0) m->stride_words += (uint64_t)std::abs(ctx->k2_matrix_pad) * kChunkWords;
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

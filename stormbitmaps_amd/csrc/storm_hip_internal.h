@@ -122,7 +122,7 @@ struct storm_hip_ctx_s {
     int k2_strip_operands = 0;  // strips: 0 = K2b; 5 = bit operands, FP4 image of every B stage built in the LDS (strip16_bits_kernel, K2b); 2 = bit operands, one stage stream per workgroup, one launch (bitstream_kernel, K2q); 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel); 1 = bit operands, one item per workgroup (stripbits_kernel)
     int k2_stream_max_rows = 8192;  // auto: matrices up to this many rows take K2q
     int k2_shard_pairs = 0;         // ownership among shards: 0 = whole k-slices first (leftover slices along the pair space), 1 = every slice along the pair space
-    int k2_matrix_pad = 1;          // matrices created from now on: rows that are a multiple of 1 KiB get 512 more bytes of pitch (0: dense pitch)
+    int k2_matrix_pad = 2;          // matrices created from now on: rows that are a multiple of 1 KiB get this many 512-byte chunks more of pitch (0: dense pitch)
     int k2_fold_inline = 0;         // K2b: the last workgroup to arrive folds the partial sums (0: a fold launch behind the strips)
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel

@@ -43,7 +43,7 @@ def main():
                 "k2_shape": int(rng.choice([16, 16, 32 if probes else 16])),
                 "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32] if probes else [2, 2, 32])),
                 "k2_strip_operands": int(rng.choice([0, 0, 5, 4, 1 if probes else 2, 2])),
-                "k2_matrix_pad": int(rng.choice([1, 1, 0])),
+                "k2_matrix_pad": int(rng.choice([2, 2, 1, 0, 3])),
                 "k2_fold_inline": int(rng.choice([0, 0, 1])),
                 "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
                 "k2_stream_min_piece": int(rng.choice([6, 6, 1, 30])),
