@@ -29,8 +29,11 @@
 
 using namespace storm;
 
+constexpr uint64_t kPoolPitchDefault = 1024;
+
 struct storm_hip_sparse_s {
-    uint64_t* d_pool = nullptr;      // pool rows: [pool_rows_ready + 512][1024] words
+    uint64_t* d_pool = nullptr;      // pool rows: [pool_rows_ready + 512][pitch] words, 1024 of them used
+    uint64_t pitch = kPoolPitchDefault;  // words per pool row (see build_arena: the row pitch and the memory channels)
     uint64_t n_pool_rows = 0;        // rows of the whole layout: columns the list-probe kernel cannot take first, ...
     uint64_t pool_rows_ready = 0;    // ... and only those exist until a dense pass over a probe column is asked for
     struct ProbeRegion { uint32_t e_begin, e_end, pool_row0, octant; };
@@ -67,12 +70,12 @@ constexpr uint32_t kSerialMagic = 0x314d5453u;  // "STM1": second header word of
 
 // list-kind block -> pool row: one workgroup per block
 __global__ __launch_bounds__(kThreads) void expand_lists_kernel(
-    uint64_t* __restrict__ pool, const uint32_t* __restrict__ pool_row,
+    uint64_t* __restrict__ pool, uint64_t pitch, const uint32_t* __restrict__ pool_row,
     const uint64_t* __restrict__ list_off, const uint32_t* __restrict__ list_len,
     const uint16_t* __restrict__ lists) {
     const uint32_t b = blockIdx.x;
     unsigned long long* row =
-        reinterpret_cast<unsigned long long*>(pool + (uint64_t)pool_row[b] * kBlockWords);
+        reinterpret_cast<unsigned long long*>(pool + (uint64_t)pool_row[b] * pitch);
     const uint16_t* l = lists + list_off[b];
     for (uint32_t k = threadIdx.x; k < list_len[b]; k += kThreads) {
         const uint32_t v = l[k];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SI
 
 // Pool rows of a probe column from its probe elements (ensure_full_pool): one workgroup per (column, octant)
 // region {first element, end, first pool row of the column, octant}
-__global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __restrict__ pool,
+__global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __restrict__ pool, uint64_t pitch,
                                                                 const uint32_t* __restrict__ elems,
                                                                 const uint32_t* __restrict__ regions) {
     const uint32_t e0 = regions[blockIdx.x * 4u + 0], e1 = regions[blockIdx.x * 4u + 1];
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void expand_probe_kernel(uint64_t* __rest
     for (uint32_t e = e0 + threadIdx.x; e < e1; e += kThreads) {
         const uint32_t v = elems[e];
         const uint32_t pos = (oct << kProbeOctBits) | (v & ((1u << kProbeOctBits) - 1u));
-        unsigned long long* row = reinterpret_cast<unsigned long long*>(pool + (uint64_t)(row0 + (v >> 16)) * kBlockWords);
+        unsigned long long* row = reinterpret_cast<unsigned long long*>(pool + (uint64_t)(row0 + (v >> 16)) * pitch);
         atomicOr(&row[pos >> 6], 1ull << (pos & 63u));
     }
 }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void probe_deal_kernel(const uint32_t* __
 
 // Host data -> device through a small ring of pinned buffers: the pieces of a chunk are packed by a few threads
 // while the previous chunk's copy is in flight (pageable uploads of 1.7 GB were 0.15 s of c4's first call).
-struct Piece { const void* src; size_t bytes; size_t dst_off; };  // dst_off: byte offset from the chunk's device base
+struct Piece { const void* src; size_t bytes; size_t dst_off; size_t zero_after = 0; };  // dst_off: byte offset from the chunk's device base; zero_after: bytes of zeros behind the piece
 struct Stager {
     static constexpr size_t kBuf = 8u << 20;  // 8 MiB per buffer: 0.16 ms of PCIe time each
     static constexpr int kBufs = 3;
@@ -372,8 +375,10 @@ struct Stager {
         if (used[next] && hipEventSynchronize(ev[next]) != hipSuccess) return STORM_HIP_EHIP;
         const unsigned parts = span >= (1u << 20) ? 4u : 1u;   // (2 / 4 / 8 / 12 packers: 31 / 24 / 28 / 32 ms for c4's 420 MB of lists)
         auto pack = [&](unsigned part) {
-            for (size_t i = n * part / parts; i < n * (part + 1) / parts; ++i)
+            for (size_t i = n * part / parts; i < n * (part + 1) / parts; ++i) {
                 memcpy(buf + pieces[i].dst_off, pieces[i].src, pieces[i].bytes);
+                if (pieces[i].zero_after) memset(buf + pieces[i].dst_off + pieces[i].bytes, 0, pieces[i].zero_after);
+            }
         };
         if (parts > 1) {
             std::thread helpers[3];
@@ -388,6 +393,19 @@ struct Stager {
             return STORM_HIP_EHIP;
         used[next] = true;
         next = (next + 1) % kBufs;
+        return STORM_HIP_OK;
+    }
+    // Rows of `stride` bytes from d_base, the first `bytes` of each from one host piece, zeros behind (whole rows per
+    // chunk: stride <= kBuf).
+    int send_rows(uint8_t* d_base, const std::vector<const void*>& rows, size_t bytes, size_t stride) {
+        const size_t per_chunk = kBuf / stride;
+        std::vector<Piece> chunk;
+        for (size_t r0 = 0; r0 < rows.size(); r0 += per_chunk) {
+            const size_t n = std::min(per_chunk, rows.size() - r0);
+            chunk.clear();
+            for (size_t i = 0; i < n; ++i) chunk.push_back({rows[r0 + i], bytes, i * stride, stride - bytes});
+            if (int rc = send(d_base + r0 * stride, chunk.data(), n, n * stride)) return rc;
+        }
         return STORM_HIP_OK;
     }
     // A run of pieces that is contiguous on the device from d_base (piece i starts where piece i - 1 ended),
@@ -861,7 +879,13 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
     // ---- device side: pool rows, raw lists through the pinned ring, element layout by kernels ----
     int rc = STORM_HIP_OK;
     do {
-        const size_t pool_bytes = (s->pool_rows_ready + 512) * kBlockWords * sizeof(uint64_t);
+        // Pool rows are 8 KiB of bits; their PITCH gets two 512-byte chunks more when the strips on bit operands will
+        // read them (K2b fetches 64-byte pieces of 64 consecutive rows: at a power-of-two pitch they fall into a
+        // handful of memory channels — the dense matrix's finding, storm_hip_matrix_create; option k2_matrix_pad).
+        // The pad words stay zero: the kernels that take the pitch for the row length multiply zeros there.
+        s->pitch = kBlockWords + (uint64_t)std::abs(ctx->k2_matrix_pad) * kChunkWords;
+        const size_t row_bytes = s->pitch * sizeof(uint64_t);
+        const size_t pool_bytes = (s->pool_rows_ready + 512) * row_bytes;
         if (hipMalloc(reinterpret_cast<void**>(&s->d_pool), pool_bytes) != hipSuccess) {
             set_error("sparse_create: hipMalloc of %zu bytes for the block pool failed",
                       pool_bytes);
@@ -873,23 +897,24 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             break;
         }
         // bitmap-kind blocks: straight into their pool rows — in pool-row order the blocks of a column are
-        // consecutive 8 KiB rows, so a run of them is ONE contiguous destination (no staging copy on the device,
-        // no placement kernel; the words may sit at any alignment on the host: a serialized stream)
+        // consecutive rows, so a run of them is ONE contiguous destination (no staging copy on the device, no
+        // placement kernel; the words may sit at any alignment on the host: a serialized stream)
         if (!dense_row.empty()) {
             std::vector<uint32_t> order(dense_row.size());
             for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
             std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dense_row[x] < dense_row[y]; });
-            std::vector<std::pair<const void*, size_t>> run;
+            std::vector<const void*> run;
             size_t i = 0;
             while (i < order.size() && rc == STORM_HIP_OK) {
                 const uint32_t row0 = dense_row[order[i]];
                 run.clear();
                 size_t j = i;
                 while (j < order.size() && dense_row[order[j]] == row0 + (j - i)) {
-                    run.emplace_back(block_ptr[dense_blk[order[j]]], (size_t)kBlockWords * sizeof(uint64_t));
+                    run.push_back(block_ptr[dense_blk[order[j]]]);
                     ++j;
                 }
-                rc = stager.send_run(reinterpret_cast<uint8_t*>(s->d_pool) + (size_t)row0 * kBlockWords * sizeof(uint64_t), run);
+                rc = stager.send_rows(reinterpret_cast<uint8_t*>(s->d_pool) + (size_t)row0 * row_bytes, run,
+                                      (size_t)kBlockWords * sizeof(uint64_t), row_bytes);
                 i = j;
             }
             if (rc != STORM_HIP_OK) break;
@@ -905,7 +930,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 (rc = upload(&dt.llen, list_len.data(), list_len.size(), ctx->stream)))
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
-                               dim3(kThreads), 0, ctx->stream, s->d_pool, dt.lrow, dt.loff, dt.llen,
+                               dim3(kThreads), 0, ctx->stream, s->d_pool, s->pitch, dt.lrow, dt.loff, dt.llen,
                                dt.lists);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
@@ -965,8 +990,8 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
 // exist copied over, the lists of the probe columns expanded from their probe elements.
 static int ensure_full_pool(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
     if (s->pool_rows_ready >= s->n_pool_rows) return STORM_HIP_OK;
-    const size_t old_bytes = (size_t)s->pool_rows_ready * kBlockWords * sizeof(uint64_t);
-    const size_t new_bytes = (size_t)(s->n_pool_rows + 512) * kBlockWords * sizeof(uint64_t);
+    const size_t old_bytes = (size_t)s->pool_rows_ready * s->pitch * sizeof(uint64_t);
+    const size_t new_bytes = (size_t)(s->n_pool_rows + 512) * s->pitch * sizeof(uint64_t);
     uint64_t* np = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&np), new_bytes) != hipSuccess) {
         set_error("sparse: hipMalloc of %zu bytes for the pool rows of the list columns failed", new_bytes);
@@ -986,7 +1011,7 @@ static int ensure_full_pool(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
                              s->probe_regions.size() * 4, ctx->stream)))
                 break;
             hipLaunchKernelGGL(expand_probe_kernel, dim3((uint32_t)s->probe_regions.size()), dim3(kThreads), 0,
-                               ctx->stream, np, s->d_probe_elems, d_regions);
+                               ctx->stream, np, s->pitch, s->d_probe_elems, d_regions);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = STORM_HIP_EHIP;
@@ -1400,14 +1425,14 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         // in the pool (columns start on multiples of 512 and nothing writes between them).
         if (variant == 4 && (ctx->k2_strip_operands == 0 || ctx->k2_strip_operands == 5) && ctx->k2_debug == 0 &&
             !ctx->k2_persistent && ctx->k2_shape == 16 && rows_dst <= s->pool_rows_ready + 512) {
-            if (int rc = launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(s->d_pool), kBlockWords * 8ull,
+            if (int rc = launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(s->d_pool), s->pitch * 8ull,
                                                   ranges, kBlockWords / 4u, shard_rank, shard_count,
                                                   reinterpret_cast<uint64_t*>(ctx->d_scalar)))
                 return rc;
             ctx->last_info[3] = s->n_probe_cols_launch;
             return STORM_HIP_OK;
         }
-        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, kBlockWords, s->pool_rows_ready + 512,
+        if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, s->pitch, s->pool_rows_ready + 512,
                                               std::max<uint64_t>(rows_dst, 512), ranges,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
                                               reinterpret_cast<uint64_t*>(ctx->d_scalar)))
@@ -1449,7 +1474,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         s->seg_count = shard_count;
         s->seg_len = seg_len;
     }
-    if (int rc = launch_pairw_segments(ctx, s->d_pool, kBlockWords, s->d_segs, s->n_segs,
+    if (int rc = launch_pairw_segments(ctx, s->d_pool, s->pitch, s->d_segs, s->n_segs,
                                        s->seg_row_sum,
                                        reinterpret_cast<uint64_t*>(ctx->d_scalar)))
         return rc;
