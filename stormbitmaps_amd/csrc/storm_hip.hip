@@ -917,13 +917,7 @@ int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_wo
     m->generation = next_matrix_generation();
     m->n_rows_pad = std::max<uint64_t>(kRowPad, (n_rows + kRowPad - 1) / kRowPad * kRowPad);
     m->stride_words = ((uint64_t)n_words + kChunkWords - 1) / kChunkWords * kChunkWords;
-    // The bit-operand strips read 64-byte pieces of 64 consecutive rows straight from this buffer: rows whose
-    // byte length is a multiple of 1 KiB would put the rows of a k-slice into a handful of L2 sets and memory
-    // channels, so two more chunks of zero words per row break the pattern (same finding as shadow_pitch,
-    // storm_hip_mfma.hip). K2b per pass, pitch + 0 / 512 / 1024 / 1536 / 2048 bytes (profiles/r04_a_pitch_pad.txt,
-    // r04_k_pitch_pad.jsonl): headline shape 0.766 / 0.756 / 0.758 / 0.758 / 0.758 ms, M = 524288 6.57 / 6.22 /
-    // 5.97 / 6.00 / 5.99 ms. Option k2_matrix_pad = number of chunks (0 keeps the dense pitch).
-    if (ctx->k2_matrix_pad != 0 && m->stride_words % 128 == 0) m->stride_words += (uint64_t)std::abs(ctx->k2_matrix_pad) * kChunkWords;
+    m->stride_words += pitch_pad_chunks(ctx->k2_matrix_pad, m->stride_words) * kChunkWords;   // (why: storm_hip_internal.h)
     const size_t bytes = m->n_rows_pad * m->stride_words * sizeof(uint64_t);
     if (hipMalloc(reinterpret_cast<void**>(&m->d), bytes) != hipSuccess) {
         set_error("hipMalloc of %zu bytes for the dense matrix failed", bytes);

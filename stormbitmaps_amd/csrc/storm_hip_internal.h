@@ -122,7 +122,7 @@ struct storm_hip_ctx_s {
     int k2_strip_operands = 0;  // strips: 0 = K2b; 5 = bit operands, FP4 image of every B stage built in the LDS (strip16_bits_kernel, K2b); 2 = bit operands, one stage stream per workgroup, one launch (bitstream_kernel, K2q); 4 = FP4 shadow (strip16_fp4_kernel / strip_fp4_kernel); 1 = bit operands, one item per workgroup (stripbits_kernel)
     int k2_stream_max_rows = 8192;  // auto: matrices up to this many rows take K2q
     int k2_shard_pairs = 0;         // ownership among shards: 0 = whole k-slices first (leftover slices along the pair space), 1 = every slice along the pair space
-    int k2_matrix_pad = 2;          // matrices created from now on: rows that are a multiple of 1 KiB get this many 512-byte chunks more of pitch (0: dense pitch)
+    int k2_matrix_pad = -1;         // matrices created from now on: rows that are a multiple of 1 KiB get this many 512-byte chunks more of pitch (0: dense pitch; -1: by the pitch, pitch_pad_chunks)
     int k2_fold_inline = 0;         // K2b: the last workgroup to arrive folds the partial sums (0: a fold launch behind the strips)
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
@@ -219,6 +219,18 @@ int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
 void kernel_time_mark(storm_hip_ctx_t* ctx);
 uint64_t next_matrix_generation();
 }  // namespace storm
+
+// Pad of a row pitch that is a multiple of 1 KiB, in 512-byte chunks. The bit-operand strips (K2b) read 64-byte
+// pieces of 64 consecutive rows: at a power-of-two pitch they fall into a handful of L2 sets and memory channels.
+// Measured per pass (profiles/r04_a_pitch_pad.txt, r04_k_pitch_pad.jsonl), pad 0 / 1 / 2 / 4 chunks:
+//   10000 rows x  8 KiB (the headline shape)   0.766 / 0.756 / 0.758 / 0.758 ms    (16 and 32 KiB rows: all the same)
+//   10000 rows x 64 KiB                        6.57  / 6.22  / 5.97  / 5.99
+//   20000 rows x 128 KiB                          -  / 46.1  / 57.9  / 46.0       (2^k + 2^(k-7) bytes is the bad pitch)
+// so: one chunk below 64 KiB of pitch (6 % of memory at the headline shape), four from there on.
+static inline uint64_t pitch_pad_chunks(int option, uint64_t stride_words) {
+    if (option == 0 || stride_words % 128 != 0) return 0;
+    return option > 0 ? (uint64_t)option : stride_words >= 8192 ? 4u : 1u;
+}
 
 struct storm_hip_matrix_s {
     uint64_t* d = nullptr;

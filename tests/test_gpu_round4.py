@@ -25,7 +25,7 @@ def orc():
 
 
 def _reset(ctx):
-    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", 0), ("k2_matrix_pad", 2), ("variant", -1)):
+    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", 0), ("k2_matrix_pad", -1), ("variant", -1)):
         ctx.set_option(k, v)
 
 
@@ -68,12 +68,13 @@ def test_bit_operand_strips_with_and_without_the_pitch_pad_and_with_the_in_kerne
     (the last workgroup to arrive folds the partial sums and leaves slots and ticket zeroed; slower, kept as an
     option) do not change the total; repeated passes see clean slots."""
     try:
-        for pad in (0, 1, 2, 3):
+        for pad in (0, 1, 2, 3, -1):
             hip_ctx.set_option("k2_matrix_pad", pad)
-            for M, N in ((65536, 1024), (8192, 3000), (20000, 2300), (1024, 5000)):
+            for M, N in ((65536, 1024), (8192, 3000), (20000, 2300), (1024, 5000), (524288, 300)):
                 m = hip_ctx.matrix(N, (M + 63) // 64)
                 dense = ((M + 63) // 64 + 63) // 64 * 64                  # words, padded to whole 512-byte chunks
-                assert m.stride_words == dense + (64 * pad if dense % 128 == 0 else 0)
+                chunks = pad if pad >= 0 else (4 if dense >= 8192 else 1)   # -1 (default): by the pitch
+                assert m.stride_words == dense + (64 * chunks if dense % 128 == 0 else 0)
                 m.fill_synthetic(M, M // 3, seed=9)
                 want = m.column_identity()
                 for fold in (0, 1, 0):
