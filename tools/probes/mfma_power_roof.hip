@@ -1,0 +1,81 @@
+// mfma_power_roof.hip — what an MFMA-ONLY loop of v_mfma_f32_16x16x128_f8f6f4 (FP4, the instruction of K2b) reaches on
+// this chip as a function of the OPERAND DATA. Four waves per SIMD, 64 accumulators per wave, A fixed per wave (as in
+// K2b), B cycling through eight register quads. Nothing else runs: whatever is lost against 10 PFLOP/s here is clock.
+//   data 0: all operands zero            2: one-hot nibbles (0 or 0x2), density 0.39 (the headline matrix's)
+//        1: one-hot nibbles, density 0.05     3: one-hot, density 1.0       4: random nibbles (raw bits as FP4 codes)
+// Build + run through gpurun:  hipcc -O3 --offload-arch=gfx950 -o /tmp/mfma_power_roof tools/probes/mfma_power_roof.hip
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 4) void mfma_loop(const uint32_t* __restrict__ data, uint32_t iters, float* out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    v8i a[4], b[8];
+    for (int m = 0; m < 4; ++m) {
+        a[m] = v8i{};
+        for (int i = 0; i < 4; ++i) a[m][i] = (int)data[(t * 48u + m * 4 + i) % (1u << 22)];
+    }
+    for (int q = 0; q < 8; ++q) {
+        b[q] = v8i{};
+        for (int i = 0; i < 4; ++i) b[q][i] = (int)data[(t * 48u + 16 + q * 4 + i) % (1u << 22)];
+    }
+    v4f acc[4][4];
+    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 4; ++n) acc[m][n] = v4f{};
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                acc[m][q & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[m], b[q], acc[m][q & 3], 4, 4, 0, 0, 0, 0);
+    }
+    float s = 0;
+    for (int m = 0; m < 4; ++m)
+        for (int n = 0; n < 4; ++n)
+            for (int r = 0; r < 4; ++r) s += acc[m][n][r];
+    if (s == -1.0f) out[0] = s;
+}
+
+int main() {
+    const uint32_t blocks = 256 * 4 * 4, iters = 4000;   // 4 workgroups of 4 waves per CU, four rounds
+    std::vector<uint32_t> h(1u << 22);
+    uint32_t* d;
+    float* o;
+    (void)hipMalloc(&d, h.size() * 4);
+    (void)hipMalloc(&o, 4);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    uint64_t rng = 0x9e3779b97f4a7c15ull;
+    auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 16); };
+    const double dens[4] = {0.0, 0.05, 0.39, 1.0};
+    for (int mode = 0; mode < 5; ++mode) {
+        for (auto& w : h) {
+            uint32_t v = 0;
+            if (mode == 4) v = next();
+            else
+                for (int n = 0; n < 8; ++n)
+                    if ((next() & 0xffff) < (uint32_t)(dens[mode] * 65536.0)) v |= 0x2u << (4 * n);
+            w = v;
+        }
+        (void)hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            (void)hipEventRecord(e0);
+            mfma_loop<<<blocks, 256>>>(d, iters, o);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < best) best = ms;   // (the first run ramps the clock)
+        }
+        const double flop = (double)blocks * 4 * iters * 32 * 65536.0;   // 32 MFMAs x 2 * 16 * 16 * 128 per iteration and wave
+        printf("{\"data\": %d, \"ms\": %.3f, \"pflops\": %.3f, \"frac_of_10_pflops\": %.4f}\n", mode, best, flop / (best * 1e-3) / 1e15,
+               flop / (best * 1e-3) / 1e16);
+    }
+    return 0;
+}
