@@ -101,8 +101,19 @@ def main():
                 s = sb.Storm()
                 for r in rows:
                     s.add(r)
-                want = orc.storm(rows).pairw()
+                # (mixed kinds in a third of the cases: every seventh row forty times as dense)
+                if seed % 3 == 0:
+                    rows = [synth.positions(M, 1, min(M // 2, d * 40), seed=seed + i)[0] if i % 7 == 0 else r for i, r in enumerate(rows)]
+                    s.free()
+                    s = sb.Storm()
+                    for r in rows:
+                        s.add(r)
+                o = orc.storm(rows)
+                want = o.pairw()
                 ok = s.pairw_intersect_cardinality() == want == s.pairw_intersect_cardinality_blocked(0)
+                # the per-pair matrix of the handle against the oracle's row-pair function (rows up to 2^25 bits)
+                if ok and N <= 400:
+                    ok = np.array_equal(s.pairw_matrix(), o.pair_counts())
                 # the same container as a serialized stream on THIS context (random sparse_probe / shards)
                 import ctypes as C
                 data = s.serialize()
@@ -121,7 +132,7 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 0, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
