@@ -11,6 +11,7 @@
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256, 4) void mfma_loop(const uint32_t* __restrict__ data, uint32_t iters, float* out) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -40,6 +41,35 @@ __global__ __launch_bounds__(256, 4) void mfma_loop(const uint32_t* __restrict__
     if (s == -1.0f) out[0] = s;
 }
 
+// the 32x32x64 form (the output kernels'): 2 x 4 blocks of 32 x 32 per wave = 128 accumulators, two waves per SIMD
+__global__ __launch_bounds__(256, 2) void mfma_loop32(const uint32_t* __restrict__ data, uint32_t iters, float* out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    v8i a[2], b[8];
+    for (int m = 0; m < 2; ++m) {
+        a[m] = v8i{};
+        for (int i = 0; i < 4; ++i) a[m][i] = (int)data[(t * 48u + m * 4 + i) % (1u << 22)];
+    }
+    for (int q = 0; q < 8; ++q) {
+        b[q] = v8i{};
+        for (int i = 0; i < 4; ++i) b[q][i] = (int)data[(t * 48u + 16 + q * 4 + i) % (1u << 22)];
+    }
+    v16f acc[2][4];
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 4; ++n) acc[m][n] = v16f{};
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc[m][q & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[m], b[q], acc[m][q & 3], 4, 4, 0, 0, 0, 0);
+    }
+    float s = 0;
+    for (int m = 0; m < 2; ++m)
+        for (int n = 0; n < 4; ++n)
+            for (int r = 0; r < 16; ++r) s += acc[m][n][r];
+    if (s == -1.0f) out[0] = s;
+}
+
 int main() {
     const uint32_t blocks = 256 * 4 * 4, iters = 4000;   // 4 workgroups of 4 waves per CU, four rounds
     std::vector<uint32_t> h(1u << 22);
@@ -52,30 +82,38 @@ int main() {
     (void)hipEventCreate(&e1);
     uint64_t rng = 0x9e3779b97f4a7c15ull;
     auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (uint32_t)(rng >> 16); };
-    const double dens[4] = {0.0, 0.05, 0.39, 1.0};
-    for (int mode = 0; mode < 5; ++mode) {
+    // modes 5, 6: density 0.39 with the set code 0.5 / 2.0 (bit 0 / bit 2 of the nibble); 7: the code drawn per dword from
+    // 0.5 / 1.0 / 2.0 (the class codes of the output kernels)
+    const double dens[8] = {0.0, 0.05, 0.39, 1.0, 0.0, 0.39, 0.39, 0.39};
+    for (int mode = 0; mode < 8; ++mode) {
         for (auto& w : h) {
             uint32_t v = 0;
+            const uint32_t code = mode == 5 ? 0x1u : mode == 6 ? 0x4u : mode == 7 ? (0x1u << (next() % 3u)) : 0x2u;
             if (mode == 4) v = next();
             else
                 for (int n = 0; n < 8; ++n)
-                    if ((next() & 0xffff) < (uint32_t)(dens[mode] * 65536.0)) v |= 0x2u << (4 * n);
+                    if ((next() & 0xffff) < (uint32_t)(dens[mode] * 65536.0)) v |= code << (4 * n);
             w = v;
         }
         (void)hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        float best = 1e30f;
-        for (int rep = 0; rep < 4; ++rep) {
-            (void)hipEventRecord(e0);
-            mfma_loop<<<blocks, 256>>>(d, iters, o);
-            (void)hipEventRecord(e1);
-            (void)hipEventSynchronize(e1);
-            float ms;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            if (rep > 0 && ms < best) best = ms;   // (the first run ramps the clock)
+        for (int shape = 16; shape <= 32; shape += 16) {
+            float best = 1e30f;
+            const uint32_t nb = shape == 16 ? blocks : blocks / 2;   // two waves per SIMD in the 32 x 32 x 64 form
+            for (int rep = 0; rep < 4; ++rep) {
+                (void)hipEventRecord(e0);
+                if (shape == 16) mfma_loop<<<nb, 256>>>(d, iters, o);
+                else mfma_loop32<<<nb, 256>>>(d, iters, o);
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                float ms;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;   // (the first run ramps the clock)
+            }
+            // per iteration and wave: 32 MFMAs of 2 * 16 * 16 * 128 flop, or 16 of 2 * 32 * 32 * 64
+            const double flop = (double)nb * 4 * iters * (shape == 16 ? 32 * 65536.0 : 16 * 131072.0);
+            printf("{\"data\": %d, \"shape\": %d, \"ms\": %.3f, \"pflops\": %.3f, \"frac_of_10_pflops\": %.4f}\n", mode, shape, best,
+                   flop / (best * 1e-3) / 1e15, flop / (best * 1e-3) / 1e16);
         }
-        const double flop = (double)blocks * 4 * iters * 32 * 65536.0;   // 32 MFMAs x 2 * 16 * 16 * 128 per iteration and wave
-        printf("{\"data\": %d, \"ms\": %.3f, \"pflops\": %.3f, \"frac_of_10_pflops\": %.4f}\n", mode, best, flop / (best * 1e-3) / 1e15,
-               flop / (best * 1e-3) / 1e16);
     }
     return 0;
 }
