@@ -74,7 +74,7 @@ int STORM_hip_comm_unique_id(uint8_t id[128]) {
 }
 
 /* (not to be called while another thread is inside an all-pairs call; a thread's view that no longer fits the new
- * configuration is reset by its next STORM_hip_set_thread_devices) */
+ * configuration falls back to all slots at that thread's next call) */
 int STORM_hip_set_devices(int n_devices, const int* device_ids) {
     if (n_devices < 1 || n_devices > MAX_DEVICES || !device_ids) return -1;
     wrapper_states_release(); /* their matrices live on the contexts that go away here */
@@ -131,7 +131,12 @@ int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count) {
 /* STORM_HIP_DEVICES = "all" | "0,2,3";  STORM_HIP_SHARD = "rank/count" */
 static void configure_from_env_locked(void);
 static void configure_from_env(void) {
-    if (__atomic_load_n(&g_n_devices, __ATOMIC_ACQUIRE) != 0) return;
+    const int n = __atomic_load_n(&g_n_devices, __ATOMIC_ACQUIRE);
+    if (n != 0) {
+        /* a view made for an earlier, larger configuration (STORM_hip_set_devices since): back to all slots */
+        if (tl_view_count && tl_view_first + tl_view_count > n) tl_view_first = tl_view_count = 0;
+        return;
+    }
     pthread_mutex_lock(&g_config_mu);
     configure_from_env_locked();
     pthread_mutex_unlock(&g_config_mu);

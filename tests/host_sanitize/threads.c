@@ -59,6 +59,17 @@ int main(void) {
     for (int i = 0; i < 3; ++i) pthread_create(&t[i], NULL, worker, (void*)(uintptr_t)(i + 1));
     pthread_create(&t[3], NULL, wrapper_caller, NULL);
     for (int i = 0; i < 4; ++i) pthread_join(t[i], NULL);
+    /* a view made for three slots outlives a reconfiguration to one: the next call falls back to all (= the one) slot */
+    if (STORM_hip_set_thread_devices(2, 1) != 0) return 1;
+    const int one[1] = {0};
+    if (STORM_hip_set_devices(1, one) != 0) return 1;
+    {
+        STORM_contiguous_t* c = STORM_contig_new(4096);
+        storm_synth_fill_contig(c, 4096, 0, 300, 700, 5);
+        const uint64_t a = STORM_contig_pairw_intersect_cardinality(c), b = STORM_contig_pairw_intersect_cardinality(c);
+        if (a != b || a == (uint64_t)-1) { fprintf(stderr, "STALE VIEW\n"); return 1; }
+        STORM_contig_free(c);
+    }
     puts("mt ok");
     return 0;
 }
