@@ -246,6 +246,17 @@ int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
  *           from slice to slice). */
 int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,
                           int form, int pair_space, uint32_t* out, uint64_t capacity_items, uint64_t* n_items);
+/* The same with the work-list options spelled out — the context options of the same names, and the device's
+ * compute-unit count (context option "n_cus", read-only) — i.e. EXACTLY the list a context with these options
+ * launches for this shard: one function derives the shaping for the device path and for this planner. max_run = 0
+ * selects the run length automatically (64 / 96 / 128, whichever schedules the SLOWEST of the shard_count ranks
+ * shortest: the choice never depends on shard_rank, so that all ranks cut the slices they deal among themselves at
+ * the same length); *run_chosen (may be NULL) receives the run length used. storm_hip_strip_plan2 = the defaults
+ * (max_run 0, tail_run 32, tail_slices 3, lpt_rounds 6, 256 compute units). */
+int storm_hip_strip_plan3(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank, uint32_t shard_count,
+                          int form, int pair_space, int max_run, int tail_run, int tail_slices, int lpt_rounds,
+                          uint32_t n_cus, uint32_t* out, uint64_t capacity_items, uint64_t* n_items,
+                          int* run_chosen);
 
 /* The same for the one-launch stage stream on bit operands (K2q, the default for matrices of up to 8192
  * rows on one device): the segments shard `shard_rank` of `shard_count` walks on a device of

@@ -37,6 +37,29 @@
 
 namespace storm {
 
+// In-kernel clock witness (tools build only — in the shipped library no stamp executes): a workgroup reads the shader
+// clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) when it starts and when it ends and adds both
+// differences to a device array that nothing else reads; sum(dt) / sum(dr) x 100 MHz is the clock the kernel's
+// workgroups ran at, weighted by their lifetimes (MI355X_MICROARCH.md, "DVFS give-back" (6)). Read and cleared by
+// storm_hip_probe_clock (tools/clock_power.py).
+#ifdef STORM_HIP_PROBES
+__device__ unsigned long long g_clock_probe[4];
+#define STORM_CLOCK_BEGIN()                                  \
+    const uint64_t ck_t0 = __builtin_amdgcn_s_memtime();     \
+    const uint64_t ck_r0 = __builtin_amdgcn_s_memrealtime()
+#define STORM_CLOCK_END()                                                                           \
+    do {                                                                                            \
+        if (threadIdx.x == 0) {                                                                     \
+            atomicAdd(&g_clock_probe[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - ck_t0)); \
+            atomicAdd(&g_clock_probe[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ck_r0)); \
+            atomicAdd(&g_clock_probe[2], 1ull);                                                     \
+        }                                                                                           \
+    } while (0)
+#else
+#define STORM_CLOCK_BEGIN() do {} while (0)
+#define STORM_CLOCK_END() do {} while (0)
+#endif
+
 constexpr int kTile = 256;           // rows per tile side
 constexpr int kStageBytes = 64;      // bytes of one row per stage = 128 nibbles = 128 bits of k
 constexpr int kMfmaThreads = 512;
@@ -687,6 +710,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSb16ImgBytes + kSb16BitRing * kSb16BitStage];
 
+    STORM_CLOCK_BEGIN();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -911,6 +935,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
 #undef STORM_MUL16
 #undef STORM_LGKM
 
+    STORM_CLOCK_END();
     uint64_t mine = 0;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {  // 16 x 64 entries below 2^24 each: a uint32 cannot overflow
@@ -1139,6 +1164,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
     uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbRing][kTbStageBytes];
 
+    STORM_CLOCK_BEGIN();
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1284,6 +1310,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
             asm volatile("" : "+v"(aop[0][0]), "+v"(aop[0][1]), "+v"(bop[0]));
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the empty pieces of the tail, too
+        STORM_CLOCK_END();
 
         // ---- epilogue: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of a 32 x 32 block
         if constexpr (NB == 4) {
@@ -2116,6 +2143,67 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
     }
 }
 
+// The shaping a pass runs with, from the options alone — NEVER from the calling rank. Where ownership is dealt along
+// the pair space (k2_shard_pairs, and the leftover slices of the default mode) every rank replays the same deal of
+// the same items, so every rank must cut the slices at the same run length: a choice made from one rank's own list
+// gave ranks [64, 96, 96] at N = 6144 / world 3 and pairs were dropped or counted twice. The automatic
+// run length (max_run = 0) is therefore the candidate whose SLOWEST rank schedules shortest; every rank evaluates
+// all ranks' lists and arrives at the same answer. Shared by the device path (ensure_strip_items) and the host-only
+// planner (storm_hip_strip_plan3), so that the plan the CPU tests partition is the plan the GPU launches.
+struct StripOptions {
+    int max_run = 0, tail_run = 32, tail_slices = 3, lpt_rounds = 6;   // the context's defaults (storm_hip_internal.h)
+    int shard_pairs = 0;
+    int n_cus = 256;
+};
+static StripShaping choose_strip_shaping(const StripOptions& o, const std::vector<RowRange>& ranges, uint32_t n_kslices,
+                                         uint32_t shard_count, uint32_t a_tile, int xcd_group) {
+    StripShaping sh;
+    sh.tail_run = o.tail_run;
+    sh.tail_slices = o.tail_slices;
+    sh.lpt_rounds = o.lpt_rounds;
+    sh.xcd_group = xcd_group;
+    sh.pair_space = o.shard_pairs != 0;
+    sh.max_run = o.max_run;
+    if (o.max_run != 0) return sh;
+    // auto: the run length whose list schedules shortest (the tail of the launch decides between them: N = 6144 is
+    // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/sweep_maxrun.py)
+    const uint32_t slots = (uint32_t)std::max(1, o.n_cus / 8 * 4);
+    const bool timing = getenv("STORM_HIP_TIMING") != nullptr;
+    double best = 0;
+    for (int cand : {96, 64, 128}) {
+        StripShaping trial = sh;
+        trial.max_run = cand;
+        double worst = 0;
+        size_t n_items = 0;
+        for (uint32_t r = 0; r < shard_count; ++r) {
+            std::vector<StripItem> tmp;
+            uint32_t qb[8], qc[8];
+            double ms = 0;
+            build_strip_items(trial, ranges, n_kslices, r, shard_count, a_tile, tmp, qb, qc, &ms, slots);
+            worst = std::max(worst, ms);
+            n_items += tmp.size();
+        }
+        if (timing)
+            fprintf(stderr, "[strip plan] max_run %3d: %zu items over %u rank(s), predicted makespan %.0f stages\n", cand,
+                    n_items, shard_count, worst);
+        if (sh.max_run == 0 || worst < best * 0.995) {   // (ties and near-ties go to the earlier candidate)
+            sh.max_run = cand;
+            best = worst;
+        }
+    }
+    return sh;
+}
+static StripOptions strip_options_of(const storm_hip_ctx_t* ctx) {
+    StripOptions o;
+    o.max_run = ctx->k2_max_run;
+    o.tail_run = ctx->k2_tail_run;
+    o.tail_slices = ctx->k2_tail_slices;
+    o.lpt_rounds = ctx->k2_lpt_rounds;
+    o.shard_pairs = ctx->k2_shard_pairs;
+    o.n_cus = ctx->n_cus;
+    return o;
+}
+
 static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>& ranges,
                               uint32_t n_kslices, uint32_t shard_rank, uint32_t shard_count,
                               uint32_t a_tile, int xcd_group = 1) {
@@ -2128,37 +2216,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
                                  ((uint64_t)(ctx->k2_tail_run & 0xffff) << 16) |
                                  (uint64_t)(ctx->k2_max_run & 0xffff)};
     if (ctx->d_strip_items && !memcmp(key, ctx->strip_key, sizeof(key))) return STORM_HIP_OK;
-    StripShaping sh;
-    sh.max_run = ctx->k2_max_run;
-    if (ctx->k2_max_run == 0) {
-        // auto: the run length whose list schedules shortest (the tail of the launch decides between them: N = 6144 is
-        // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/sweep_maxrun.py)
-        StripShaping trial;
-        trial.tail_run = ctx->k2_tail_run;
-        trial.tail_slices = ctx->k2_tail_slices;
-        trial.lpt_rounds = ctx->k2_lpt_rounds;
-        trial.xcd_group = xcd_group;
-        trial.pair_space = ctx->k2_shard_pairs != 0;
-        double best = 0;
-        for (int cand : {96, 64, 128}) {
-            trial.max_run = cand;
-            std::vector<StripItem> tmp;
-            uint32_t qb[8], qc[8];
-            double ms = 0;
-            build_strip_items(trial, ranges, n_kslices, shard_rank, shard_count, a_tile, tmp, qb, qc, &ms,
-                              (uint32_t)std::max(1, ctx->n_cus / 8 * 4));
-            if (getenv("STORM_HIP_TIMING")) fprintf(stderr, "[strip plan] max_run %3d: %zu items, predicted makespan %.0f stages\n", cand, tmp.size(), ms);
-            if (sh.max_run == 0 || ms < best * 0.995) {   // (ties and near-ties go to the earlier candidate)
-                sh.max_run = cand;
-                best = ms;
-            }
-        }
-    }
-    sh.tail_run = ctx->k2_tail_run;
-    sh.tail_slices = ctx->k2_tail_slices;
-    sh.lpt_rounds = ctx->k2_lpt_rounds;
-    sh.xcd_group = xcd_group;
-    sh.pair_space = ctx->k2_shard_pairs != 0;
+    StripShaping sh = choose_strip_shaping(strip_options_of(ctx), ranges, n_kslices, shard_count, a_tile, xcd_group);
     sh.persistent = ctx->k2_persistent != 0;
     sh.one_slice_probe = (ctx->k2_debug & 16) != 0;
     std::vector<StripItem> items;
@@ -3280,11 +3338,14 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 // Host-only view of the default path's work decomposition (no device is touched): what a shard
 // of a multi-GPU run multiplies, so that the partition of the pair space can be checked — and
 // rehearsed with CPU partials — without a GPU (tests/test_dist_cpu.py).
-extern "C" int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
-                                     uint32_t shard_count, int form, int pair_space, uint32_t* out,
-                                     uint64_t capacity_items, uint64_t* n_items) {
+extern "C" int storm_hip_strip_plan3(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                                     uint32_t shard_count, int form, int pair_space, int max_run, int tail_run,
+                                     int tail_slices, int lpt_rounds, uint32_t n_cus, uint32_t* out,
+                                     uint64_t capacity_items, uint64_t* n_items, int* run_chosen) {
     using namespace storm;
-    if (!n_items || shard_count == 0 || shard_rank >= shard_count || n_words == 0 || (form != 0 && form != 1)) {
+    if (!n_items || shard_count == 0 || shard_rank >= shard_count || n_words == 0 || (form != 0 && form != 1) ||
+        max_run < 0 || max_run > 4096 || tail_run < 1 || tail_run > 4096 || tail_slices < 0 || tail_slices > 255 ||
+        lpt_rounds < 0 || lpt_rounds > 63 || n_cus == 0) {
         set_error("strip_plan: bad arguments");
         return STORM_HIP_EINVAL;
     }
@@ -3296,9 +3357,16 @@ extern "C" int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t
         if (n_rows > 1) ranges.push_back({0, n_rows});
         std::vector<StripItem> items;
         uint32_t qb[8], qc[8];
-        StripShaping sh;
-        sh.xcd_group = form == 0 ? 1 : 2;
-        sh.pair_space = pair_space != 0;
+        StripOptions o;
+        o.max_run = max_run;
+        o.tail_run = tail_run;
+        o.tail_slices = tail_slices;
+        o.lpt_rounds = lpt_rounds;
+        o.shard_pairs = pair_space != 0;
+        o.n_cus = (int)n_cus;
+        // exactly what ensure_strip_items launches for these options (one function derives the shaping)
+        const StripShaping sh = choose_strip_shaping(o, ranges, n_kslices, shard_count, (uint32_t)kStripATile, form == 0 ? 1 : 2);
+        if (run_chosen) *run_chosen = sh.max_run;
         build_strip_items(sh, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile, items, qb, qc);
         *n_items = items.size();
         if (out)
@@ -3314,6 +3382,15 @@ extern "C" int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t
         return STORM_HIP_ENOMEM;
     }
     return STORM_HIP_OK;
+}
+
+// The context's default options on a 256-CU device (what a fresh context launches on an MI355X).
+extern "C" int storm_hip_strip_plan2(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
+                                     uint32_t shard_count, int form, int pair_space, uint32_t* out,
+                                     uint64_t capacity_items, uint64_t* n_items) {
+    const storm::StripOptions d;
+    return storm_hip_strip_plan3(n_rows, n_words, shard_rank, shard_count, form, pair_space, d.max_run, d.tail_run,
+                                 d.tail_slices, d.lpt_rounds, (uint32_t)d.n_cus, out, capacity_items, n_items, nullptr);
 }
 
 extern "C" int storm_hip_strip_plan(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
@@ -3361,3 +3438,19 @@ extern "C" int storm_hip_stream_plan(uint64_t n_rows, uint32_t n_words, uint32_t
     }
     return STORM_HIP_OK;
 }
+
+#ifdef STORM_HIP_PROBES
+// Tools build only: the in-kernel clock witness of the stamped kernels (STORM_CLOCK_BEGIN / _END above) since the last
+// call: out = {sum of shader-clock ticks, sum of 100 MHz ticks, workgroups}; clears the counters. Current device.
+extern "C" int storm_hip_probe_clock(uint64_t out[3]) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return STORM_HIP_EINVAL;
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(storm::g_clock_probe), sizeof(v)) != hipSuccess) return STORM_HIP_EINVAL;
+    out[0] = v[0];
+    out[1] = v[1];
+    out[2] = v[2];
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(storm::g_clock_probe), z, sizeof(z)) != hipSuccess) return STORM_HIP_EINVAL;
+    return STORM_HIP_OK;
+}
+#endif

@@ -52,11 +52,16 @@ def init_process_group(backend: str):
     return dist
 
 
-def strip_plan(n_rows: int, n_words: int, rank: int, world: int, form: int = 1, pair_space: int = 0):
+def strip_plan(n_rows: int, n_words: int, rank: int, world: int, form: int = 1, pair_space: int = 0, *,
+               max_run: int = 0, tail_run: int = 32, tail_slices: int = 3, lpt_rounds: int = 6, n_cus: int = 256,
+               return_run: bool = False):
     """The work items rank `rank` of `world` multiplies, as an [n, 5] uint32 array of {a_row0, diag, j0, j1, ks}
-    (see storm_hip_strip_plan2 in include/storm_hip.h). form 1 = the default path (K2b: slice ks = class pair
+    (see storm_hip_strip_plan3 in include/storm_hip.h). form 1 = the default path (K2b: slice ks = class pair
     ks & 1 of the 512-bit chunk ks / 2), form 0 = the FP4-shadow strips (slice ks = 256 consecutive bits);
-    pair_space 1 = every slice cut along the pair space (option k2_shard_pairs).
+    pair_space 1 = every slice cut along the pair space (option k2_shard_pairs). The keyword options are the
+    context options of the same names (defaults = a fresh context on a 256-CU device): the list returned is the
+    list such a context launches — one function derives the shaping for both. max_run 0 = automatic, the same
+    for every rank of a world; return_run=True also returns the run length chosen.
     Host-only: computed by libstorm_hip.so without touching a device."""
     import ctypes as C
 
@@ -65,13 +70,14 @@ def strip_plan(n_rows: int, n_words: int, rank: int, world: int, form: int = 1, 
     from . import _lib
     lib = _lib.load()
     n = C.c_uint64(0)
-    _lib.check(lib.storm_hip_strip_plan2(n_rows, n_words, rank, world, form, pair_space, None, 0, C.byref(n)),
-               "storm_hip_strip_plan2")
+    run = C.c_int(0)
+    args = (n_rows, n_words, rank, world, form, pair_space, max_run, tail_run, tail_slices, lpt_rounds, n_cus)
+    _lib.check(lib.storm_hip_strip_plan3(*args, None, 0, C.byref(n), C.byref(run)), "storm_hip_strip_plan3")
     out = np.zeros((int(n.value), 5), dtype=np.uint32)
     if n.value:
-        _lib.check(lib.storm_hip_strip_plan2(n_rows, n_words, rank, world, form, pair_space,
-                                             out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "storm_hip_strip_plan2")
-    return out
+        _lib.check(lib.storm_hip_strip_plan3(*args, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(run)),
+                   "storm_hip_strip_plan3")
+    return (out, int(run.value)) if return_run else out
 
 
 def slice_columns(mat, ks: int, form: int = 1):

@@ -81,6 +81,57 @@ def test_headline_shape_balances_within_three_percent_for_any_world(form, pair_s
     assert min(cost) > 0 and max(cost) <= 1.03 * (sum(cost) / 8), cost
 
 
+def _block_cover(n_rows, n_words, world, form, pair_space, **opts):
+    """Coverage at (k-slice, A tile, B block) granularity — cheap enough for the shapes where the automatic run
+    length differs from shape to shape: cover[ks, tile, block] and diag[ks, tile] summed over all ranks' lists,
+    and the run length every rank reports."""
+    n_tiles = (n_rows + A_TILE - 1) // A_TILE
+    n_blocks = n_tiles * (A_TILE // B_BLOCK)
+    ks_n = _n_kslices(n_words, form)
+    cover = np.zeros((ks_n, n_tiles, n_blocks), dtype=np.int32)
+    diag = np.zeros((ks_n, n_tiles), dtype=np.int32)
+    runs = []
+    for r in range(world):
+        items, run = sdist.strip_plan(n_rows, n_words, r, world, form, pair_space, return_run=True, **opts)
+        runs.append(run)
+        for a0, dg, j0, j1, ks in items.tolist():
+            cover[ks, a0 // A_TILE, j0:j1] += 1
+            diag[ks, a0 // A_TILE] += dg
+    return cover, diag, runs
+
+
+@pytest.mark.parametrize("n_rows", [6144, 8192])
+@pytest.mark.parametrize("pair_space,opts", [
+    (1, {}),                    # every slice dealt along the pair space, automatic run length
+    (0, {"tail_run": 96}),      # default ownership, leftover slices cut at min(run, tail_run) with a long tail_run
+    (1, {"n_cus": 64}),         # a smaller device: other makespans, same rule
+])
+def test_every_rank_cuts_the_dealt_slices_at_the_same_run_length(n_rows, pair_space, opts):
+    """the automatic run length was chosen from the calling rank's own list — N = 6144 at world 3
+    gave ranks [64, 96, 96], N = 8192 [96, 128, 128] — while the pair-space deal only partitions the work if every rank
+    cuts the slices identically. The choice is now made from all ranks' lists (slowest rank decides)."""
+    world, n_words = 3, 1024 + 8 * (1 - pair_space)   # default mode: 258 slices = 3 x 84 whole + 6 leftover... units of 4
+    cover, diag, runs = _block_cover(n_rows, n_words, world, 1, pair_space, **opts)
+    assert len(set(runs)) == 1 and runs[0] in (64, 96, 128), runs
+    n_tiles = cover.shape[1]
+    per = A_TILE // B_BLOCK
+    want = np.zeros(cover.shape[1:], dtype=np.int32)
+    for t in range(n_tiles):
+        want[t, (t + 1) * per:] = 1
+    assert np.array_equal(diag, np.ones_like(diag))
+    for ks in range(cover.shape[0]):
+        assert np.array_equal(cover[ks], want), ks
+
+
+def test_plan_with_explicit_options_matches_the_defaults_and_a_fixed_run():
+    """storm_hip_strip_plan2 == storm_hip_strip_plan3 with the context's defaults; a fixed max_run is honoured."""
+    a = sdist.strip_plan(3000, 64, 1, 2)
+    b, run = sdist.strip_plan(3000, 64, 1, 2, max_run=0, tail_run=32, tail_slices=3, lpt_rounds=6, n_cus=256, return_run=True)
+    assert np.array_equal(a, b) and run in (64, 96, 128)
+    c, run = sdist.strip_plan(3000, 64, 0, 1, max_run=16, return_run=True)
+    assert run == 16 and int((c[:, 3] - c[:, 2]).max()) <= 16
+
+
 def _item_total(orc, mat, item, form=1):
     """Oracle partial of one strip item: pairs (A tile x B blocks [+ own triangle]) on k-slice ks."""
     a0, diag, j0, j1, ks = (int(x) for x in item)

@@ -1,0 +1,59 @@
+"""Round-5 GPU parity tests. Everything goes through the C-ABI; the oracle is the checker only."""
+import numpy as np
+import pytest
+
+import stormbitmaps_amd as sb
+from stormbitmaps_amd import dist as sdist
+from stormbitmaps_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip_ctx():
+    ctx = sb.HipContext(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from tests._orc import Oracle
+    return Oracle()
+
+
+def _reset(ctx):
+    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", 0), ("k2_matrix_pad", -1), ("variant", -1),
+                 ("k2_shard_pairs", 0), ("k2_max_run", 0), ("k2_tail_run", 32)):
+        ctx.set_option(k, v)
+
+
+def test_pair_space_shards_sum_to_the_total_where_the_automatic_run_length_differs_by_rank(hip_ctx):
+    """with k2_shard_pairs = 1 every rank replays the same longest-first deal of every slice's
+    items, so all ranks must cut the slices at the same run length. The automatic choice (k2_max_run = 0) used to be
+    made from the calling rank's own list — N = 6144 at world 3 chose [64, 96, 96], N = 8192 [96, 128, 128]: pairs
+    dropped or counted twice, silently. The sum of all ranks' partials against the one-device total and the column
+    identity (storm.c:1199-1238 is the loop being sharded); the planner reports ONE run length for the world and the
+    device launches exactly the planner's item count."""
+    try:
+        for N in (6144, 8192):
+            M = 65536
+            m = hip_ctx.matrix(N, M // 64)
+            m.fill_synthetic(M, M // 3, seed=N)
+            want = m.column_identity()
+            assert m.pairw() == want
+            for pairs, tail_run in ((1, 32), (0, 96)):
+                hip_ctx.set_option("k2_shard_pairs", pairs)
+                hip_ctx.set_option("k2_tail_run", tail_run)
+                for world in (3, 5):
+                    parts = []
+                    for r in range(world):
+                        parts.append(m.pairw(r, world))
+                        items, run = sdist.strip_plan(N, M // 64, r, world, 1, pairs, tail_run=tail_run,
+                                                      n_cus=hip_ctx.get_option("n_cus"), return_run=True)
+                        assert hip_ctx.last_launch_info()["items"] == len(items), (N, pairs, world, r, run)
+                    assert sum(parts) == want, (N, pairs, tail_run, world, parts, want)
+            _reset(hip_ctx)
+            m.close()
+    finally:
+        _reset(hip_ctx)
