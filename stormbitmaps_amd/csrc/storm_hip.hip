@@ -652,8 +652,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
-        if (value != 1 && value != 2 && value != 3 && value != 4 && value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 1, 2 (bit operands inflated in registers), 3 / 4 (bit operands, FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
+        if (value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
@@ -663,6 +663,14 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
         ctx->k2_tile_shape = (int)value;
+    } else if (!strcmp(key, "k2_ring_sync")) {
+        ctx->k2_ring_sync = value != 0;
+    } else if (!strcmp(key, "k2_ring_cost_diag") || !strcmp(key, "k2_ring_cost_ragged")) {
+        if (value < 5 || value > 100) {
+            set_error("%s is a percentage of a full tile's time, 5..100", key);
+            return STORM_HIP_EINVAL;
+        }
+        (key[13] == 'd' ? ctx->k2_ring_cost_diag : ctx->k2_ring_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_tile_cost_diag") || !strcmp(key, "k2_tile_cost_ragged")) {
         if (value < 5 || value > 100) {
             set_error("%s is a percentage of a full tile's time, 5..100", key);
@@ -815,6 +823,8 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_fold_inline")) return ctx->k2_fold_inline;
     if (!strcmp(key, "k2_matrix_pad")) return ctx->k2_matrix_pad;
     if (!strcmp(key, "k2_shard_pairs")) return ctx->k2_shard_pairs;
+    if (!strcmp(key, "k2_ring_sync")) return ctx->k2_ring_sync;
+    if (!strcmp(key, "k2_tile_shape")) return ctx->k2_tile_shape;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;

@@ -126,6 +126,8 @@ struct storm_hip_ctx_s {
     int k2_fold_inline = 0;         // K2b: the last workgroup to arrive folds the partial sums (0: a fold launch behind the strips)
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
+    int k2_ring_sync = 0;   // tilering_kernel: 0 = one s_barrier per stage; 1 = arrival counters in the LDS (waves may drift a stage apart; measured 2 % slower)
+    int k2_ring_cost_diag = 78, k2_ring_cost_ragged = 40;  // the same for tilering_kernel (k2_tile_shape = 5)
     int k2_tile_cost_diag = 63, k2_tile_cost_ragged = 30;  // percent of a full tile (tilebits8_kernel): what the planner assumes when it cuts the last round
     int k2_shape = 16;      // K2s: MFMA shape of the default strip kernel: 16 = 16x16x128 (default), 32 = 32x32x64
     int k2_persistent = 0;  // K2s: workgroups pull items from per-XCD queues (0: one item per workgroup)

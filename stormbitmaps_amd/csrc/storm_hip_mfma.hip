@@ -1461,6 +1461,8 @@ __device__ __forceinline__ int ti_inflb(int w) {
 #undef STORM_TI_SHAPE
 #undef STORM_TI_NAME
 
+#include "tile_ring_kernel.inc"
+
 // ------------------------------------------------------------------------------------------
 // K2sb: the strips on BIT operands (option k2_strip_operands = 1; the default stays the FP4 shadow).
 //
@@ -2698,6 +2700,14 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         hipLaunchKernelGGL(tile32_bits_kernel, dim3((plan.n_items + 7u) / 8u * 16u), dim3(kTiThreads), kTiLdsBytes, ctx->stream,
                            *bits, d_items, plan.n_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
+    else if (bits && ctx->k2_tile_shape == 5 && ctx->k2_ring_sync == 0)
+        hipLaunchKernelGGL(tilering_kernel<false>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
+                           *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.n_full, i_lo, n_cols);
+    else if (bits && ctx->k2_tile_shape == 5)
+        hipLaunchKernelGGL(tilering_kernel<true>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
+                           *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
+                           plan.n_full, i_lo, n_cols);
     else if (bits && ctx->k2_tile_shape == 2)
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
@@ -2762,7 +2772,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
     // bit-operand kernel: the operands are the matrix rows themselves (no shadow, no expansion)
-    const bool bits = ctx->k2_tile_shape <= 4;
+    const bool bits = ctx->k2_tile_shape <= 5;
     const uint64_t pitch = bits ? m->stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const size_t x4_bytes = bits ? 0 : (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
@@ -2785,7 +2795,9 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
         ctx->x4_capacity = x4_bytes;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
-    const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
+    // stages of 128 bits; the bit kernels walk whole 512-bit chunks that hold DATA (the pitch's pad chunks — 8 of 136 at
+    // the headline shape since round 4's pitch pad — are never multiplied)
+    const uint32_t total_stages = bits ? (m->n_words + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
     // off-diagonal tiles first; the diagonal ones (half of their window is written) go last,
     // where run_matrix_tiles may cut them along k
@@ -2806,11 +2818,14 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // 8 block pairs per SIMD; a ragged one ceil(columns / 64) of 4 blocks per wave, but not below the
     // inflation work of its A operands (measured: 0.3)
     std::vector<float> cost;
-    if (ctx->k2_tile_shape >= 2 && ctx->k2_tile_shape <= 4) {
-        const float ragged_cost =
-            std::max(ctx->k2_tile_cost_ragged / 100.0f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
+    if (ctx->k2_tile_shape >= 2 && ctx->k2_tile_shape <= 5) {
+        // (tilering_kernel: a diagonal tile keeps its busiest SIMD at 12 of 16 block rows; a ragged column multiplies one
+        //  block column in two of the eight waves but stores all of its images: options k2_ring_cost_*)
+        const bool ring = ctx->k2_tile_shape == 5;
+        const float ragged_cost = ring ? std::max(ctx->k2_ring_cost_ragged / 100.0f, m->n_rows % kTile > 16 ? 1.0f : 0.0f)
+                                       : std::max(ctx->k2_tile_cost_ragged / 100.0f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
         for (const auto& t : tiles) {
-            float c = t.first == t.second ? ctx->k2_tile_cost_diag / 100.0f : 1.0f;
+            float c = t.first == t.second ? (ring ? ctx->k2_ring_cost_diag : ctx->k2_tile_cost_diag) / 100.0f : 1.0f;
             if (ragged && t.second == nT - 1) c *= ragged_cost;
             cost.push_back(c);
         }
@@ -2845,7 +2860,7 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
-    const bool bits = ctx->k2_tile_shape <= 4 && b->stride_words == stride_words;
+    const bool bits = ctx->k2_tile_shape <= 5 && b->stride_words == stride_words;
     const uint64_t pitch = bits ? stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const uint64_t rows_a = (a->n_rows + kTile - 1) / kTile * kTile;
     const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;

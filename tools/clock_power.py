@@ -166,6 +166,8 @@ def main():
                 if os.path.exists(probes_lib) and not k.endswith("_shipped"):
                     env["STORM_HIP_LIB"] = probes_lib
                 cmd = [sys.executable, os.path.abspath(__file__), "--worker", k.split("_")[0], "--seconds", str(args.seconds)]
+            elif k.startswith("ring_"):   # tools/probes/tile_ring, ablation mask behind the underscore
+                cmd = [os.path.join(ROOT, "tools", "probes", "tile_ring"), "10000", "65536", "3", k[5:], str(args.seconds)]
             else:
                 shape, data = k[4:6], {"onehot": "2", "random": "4", "zeros": "0"}[k.split("_")[1]]
                 cmd = [roof, data, shape, str(args.seconds)]
