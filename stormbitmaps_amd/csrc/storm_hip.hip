@@ -694,7 +694,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
     } else if (!strcmp(key, "k2_matrix_pad")) {
         ctx->k2_matrix_pad = value < 0 ? -1 : (int)std::min<int64_t>(value, 64);   // chunks of 512 bytes
     } else if (!strcmp(key, "k2_fold_inline")) {
-        ctx->k2_fold_inline = value != 0;
+        ctx->k2_fold_inline = value < 0 ? -1 : value != 0;
     } else if (!strcmp(key, "k2_wave_ring")) {
         if (value != 0 && value != 3 && value != 4 && value != 6 && value != 8) {
             set_error("k2_wave_ring must be 0 (by occupancy), 3, 4, 6 or 8");

@@ -60,6 +60,11 @@ __device__ unsigned long long g_clock_probe[4];
 #define STORM_CLOCK_END() do {} while (0)
 #endif
 
+static bool timing_env() {
+    static const bool on = getenv("STORM_HIP_TIMING") != nullptr;   // (read once, not per call)
+    return on;
+}
+
 constexpr int kTile = 256;           // rows per tile side
 constexpr int kStageBytes = 64;      // bytes of one row per stage = 128 nibbles = 128 bits of k
 constexpr int kMfmaThreads = 512;
@@ -694,7 +699,6 @@ constexpr int kSb16BitRing = 3;                                   // bit stages 
 constexpr int kSb16BitStage = kStripBRows * 64;                   // 4 KiB of bits per B stage
 constexpr uint32_t kSb16ImgBytes = kSb16ImgRing * kStripStageBytes;
 constexpr uint32_t kSb16Mask = 0x22222222u;
-constexpr int kSb16Ticket = kSlots + 6;                          // arrival counter behind the slots (zero between passes; bitstream_kernel uses the same word)
 
 __device__ __forceinline__ v4i sb16_inflate(v4i w, uint32_t rot) {
     v4i e;
@@ -952,36 +956,54 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     //  the loop does not have — the first build spilled them)
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t tid_e = wave * 64u + lane_e;
-    if (lane_e == 0 && mine != 0)
+    if (out == nullptr) {   // the partial sums stay in the slots: a fold launch follows (fold_slots_kernel)
+        if (lane_e == 0 && mine != 0)
+            atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+                      (unsigned long long)mine);
+        return;
+    }
+    // ---- the fold inside the launch [r5]: a wave's sum and its ARRIVAL travel in ONE fire-and-forget atomic — the slot
+    //      word's low 48 bits take the sum, the high 16 count arrivals (the host checks both fields' ranges,
+    //      launch_pairw_bits_ranges) — so there is nothing to order and nothing to wait for at the end of an item. The
+    //      workgroup dispatched LAST folds: behind its own item it polls the slots until the arrival fields add up to
+    //      every wave of the grid (a snapshot in which they do holds every sum as well: the fields only grow), writes the
+    //      total and leaves the slots zeroed for the next pass. It holds one workgroup slot while it polls, when the list
+    //      has run dry anyway; every other workgroup is running or done by then and needs nothing from it.
+    //      (Round 4's form — a ticket word that every workgroup hits with a RETURNING atomic — cost 1 ms at this grid size:
+    //       atomics on one address serialise at ~14 M/s, and a returning atomic holds the workgroup's slot for ~2 us.)
+    if (lane_e == 0)
         atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
-                  (unsigned long long)mine);
-    if (out == nullptr) return;
-    // ---- the fold, by the last workgroup to arrive: every wave's add is ordered before its
-    //      workgroup's ticket. Slots and ticket are left zeroed for the next pass.
-    //      (One ticket word for tens of thousands of workgroups: 1.8 ms instead of 0.8 at the headline
-    //       shape, profiles/r04_a_*: kept for short launches only, see launch_pairw_bits.)
-    __threadfence();
-    __syncthreads();
-    uint32_t* flag = reinterpret_cast<uint32_t*>(lds_raw);
-    if (tid_e == 0) {
-        const unsigned long long arrived = atomicAdd(&slots[kSb16Ticket], 1ull);
-        flag[0] = (arrived == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (flag[0] == 0u) return;
-    __threadfence();
-    unsigned long long v = 0;
-    for (uint32_t i = tid_e; i < (uint32_t)kSlots; i += (uint32_t)kStripThreads)
-        v += __hip_atomic_exchange(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  (unsigned long long)mine + (1ull << 48));
+    if (blockIdx.x != gridDim.x - 1u) return;
+    const unsigned long long expected = (unsigned long long)gridDim.x * (unsigned long long)kStripWaves;
+    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(lds_raw);   // [0..3] arrivals, [4..7] sums per wave
+    unsigned long long total = 0;
+    for (;;) {
+        unsigned long long cnt = 0, sum = 0;
+        for (uint32_t i = tid_e; i < (uint32_t)kSlots; i += (uint32_t)kStripThreads) {
+            const unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt += v >> 48;
+            sum += v & ((1ull << 48) - 1ull);
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(lds_raw + 64);
-    if (lane_e == 0) wsum[wave] = v;
-    __syncthreads();
-    if (tid_e == 0) {
-        out[0] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __hip_atomic_store(&slots[kSb16Ticket], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_down(cnt, o, 64);
+            sum += __shfl_down(sum, o, 64);
+        }
+        __syncthreads();   // (the previous round's reads of wsum are done)
+        if (lane_e == 0) {
+            wsum[wave] = cnt;
+            wsum[4 + wave] = sum;
+        }
+        __syncthreads();
+        cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        total = wsum[4] + wsum[5] + wsum[6] + wsum[7];
+        if (cnt == expected) break;
+        __builtin_amdgcn_s_sleep(8);
     }
+    for (uint32_t i = tid_e; i < (uint32_t)(kSlots + kSlotsExtra); i += (uint32_t)kStripThreads)
+        __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid_e == 0) out[0] = total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2170,7 +2192,7 @@ static StripShaping choose_strip_shaping(const StripOptions& o, const std::vecto
     // auto: the run length whose list schedules shortest (the tail of the launch decides between them: N = 6144 is
     // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/sweep_maxrun.py)
     const uint32_t slots = (uint32_t)std::max(1, o.n_cus / 8 * 4);
-    const bool timing = getenv("STORM_HIP_TIMING") != nullptr;
+    const bool timing = timing_env();
     double best = 0;
     for (int cand : {96, 64, 128}) {
         StripShaping trial = sh;
@@ -2687,7 +2709,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     if (plan.n_full < plan.n_items)
         hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
                            ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
-    if (bits && ctx->k2_tile_shape == 3 && getenv("STORM_HIP_TIMING")) {
+    if (bits && ctx->k2_tile_shape == 3 && timing_env()) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile16_bits_kernel, kTiThreads, kTiLdsBytes);
         fprintf(stderr, "[tile16_bits_kernel] workgroups per CU by the runtime's occupancy query: %d (LDS %u B)\n", nb, kTiLdsBytes);
@@ -3239,7 +3261,7 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
 // sparse container: the pool rows of its block columns.
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
-                             uint32_t shard_count, uint64_t* d_total) {
+                             uint32_t shard_count, uint64_t* d_total, bool slots_hold_sums) {
     if (pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
         set_error("K2b: rows of %llu bytes are beyond the strips' 32-bit DMA offsets", (unsigned long long)pitch);
         return STORM_HIP_EINVAL;
@@ -3258,7 +3280,14 @@ int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pi
     ctx->last_info[1] = ctx->k2_stages_per_item;
     ctx->last_info[2] = 1;
     ctx->last_info[3] = 0;
-    const bool fold_inline = ctx->k2_fold_inline != 0 && n_strip > 0;
+    // the fold inside the launch (option k2_fold_inline: -1 = whenever the packed slot words cannot overflow, 0 = never:
+    // a fold launch follows): arrivals per slot below 2^16, a slot's sum below 2^48 — a wave adds at most 64 rows x
+    // (run x 64 + 256) rows x 256 bits
+    const uint64_t arrivals_per_slot = (uint64_t)n_strip * (uint64_t)kStripWaves / (uint64_t)kSlots + 1u;
+    const uint64_t wave_sum_max = 64ull * (4096ull * 64ull + 256ull) * 256ull;   // (runs are capped at 4096 stages)
+    // (slots_hold_sums: another kernel of this pass — the list-probe kernel — has added sums of unknown size: fold launch)
+    const bool fold_inline = ctx->k2_fold_inline != 0 && !slots_hold_sums && n_strip > 0 && arrivals_per_slot < 65535u &&
+                             arrivals_per_slot * wave_sum_max < (1ull << 48);
     if (n_strip > 0) {
         kernel_time_mark(ctx);
         hipLaunchKernelGGL(strip16_bits_kernel, dim3(n_strip), dim3(kStripThreads), (size_t)ctx->k2_lds_pad,
@@ -3318,6 +3347,12 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
 #endif
 }
 
+// Which strips an all-pairs pass runs (option k2_strip_operands; 0 = the default: K2b unless a non-default ring or MFMA
+// shape asks for the FP4 strips): ONE rule for the dense matrix and for the pool rows of a sparse container.
+int strip_operands_of(const storm_hip_ctx_t* ctx) {
+    if (ctx->k2_strip_operands != 0) return ctx->k2_strip_operands;
+    return (ctx->k2_ring == kStripRingDefault && ctx->k2_shape == 16) ? 5 : 4;
+}
 int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t shard_rank,
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
@@ -3328,9 +3363,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
     // 8.2 / 9.5 / 14.9 us at N = 256, 17.1 / 20.2 / 31.8 at 1024, 41.9 / 43.4 / 60.4 at 2048, 142 / 143 / 169 at
     // 4096, 537 / 539 / 591 at 8192, 752 / 809 / 817 at 10000 (K2q is ahead around N = 6144 only: 311 against
     // 325) — and for the shards of a multi-GPU pass (an eighth of the headline matrix: 103 against 119 us).
-    int operands = ctx->k2_strip_operands;
-    if (operands == 0)
-        operands = (ctx->k2_ring == kStripRingDefault && ctx->k2_shape == 16) ? 5 : 4;
+    const int operands = strip_operands_of(ctx);
     if (strip_mode == 1 && (operands == 1 || operands == 2 || operands == 3 || operands == 5) && !ctx->k2_persistent && ctx->k2_debug == 0 &&
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
         m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))

@@ -1423,11 +1423,11 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         // The strips on bit operands (K2b) multiply the pool rows as they are: no FP4 shadow of the pool (2.6 GB
         // at c4), no expansion pass. The rows behind a column's last one up to the next multiple of 512 are zero
         // in the pool (columns start on multiples of 512 and nothing writes between them).
-        if (variant == 4 && (ctx->k2_strip_operands == 0 || ctx->k2_strip_operands == 5) && ctx->k2_debug == 0 &&
-            !ctx->k2_persistent && ctx->k2_shape == 16 && rows_dst <= s->pool_rows_ready + 512) {
+        if (variant == 4 && strip_operands_of(ctx) == 5 && ctx->k2_debug == 0 && !ctx->k2_persistent &&
+            rows_dst <= s->pool_rows_ready + 512) {
             if (int rc = launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(s->d_pool), s->pitch * 8ull,
                                                   ranges, kBlockWords / 4u, shard_rank, shard_count,
-                                                  reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+                                                  reinterpret_cast<uint64_t*>(ctx->d_scalar), s->n_probe_launch > 0))
                 return rc;
             ctx->last_info[3] = s->n_probe_cols_launch;
             return STORM_HIP_OK;

@@ -116,6 +116,11 @@ int STORM_hip_set_thread_devices(int first_slot, int n_slots) {
         return 0;
     }
     if (first_slot < 0 || n_slots < 1 || first_slot + n_slots > g_n_devices) return -1;
+    if (g_comm) {   /* the communicator's stream and buffers live on slot 0: a thread that does not hold slot 0's lock must not
+                       drive them: one process per GPU has one slot anyway */
+        host_error("STORM_hip_set_thread_devices: refused while a communicator is attached (STORM_hip_comm_init)");
+        return -1;
+    }
     tl_view_first = first_slot;
     tl_view_count = n_slots;
     return 0;
@@ -302,6 +307,10 @@ int STORM_hip_comm_init(const uint8_t id[128]) {
         host_error("STORM_hip_comm_init: a communicator is already attached (STORM_hip_comm_finalize first)");
         return -1;
     }
+    if (tl_view_count) {
+        host_error("STORM_hip_comm_init: refused on a thread whose view is narrowed (STORM_hip_set_thread_devices(0, 0) first)");
+        return -1;
+    }
     storm_hip_ctx_t* ctx = device_ctx(0);
     if (!ctx || storm_hip_comm_init_rank(ctx, id, g_shard_rank, g_shard_count, &g_comm) != STORM_HIP_OK) {
         device_error("STORM_hip_comm_init");
@@ -326,7 +335,10 @@ int STORM_hip_comm_finalize(void) {
 static uint64_t across_ranks(uint64_t partial) {
     if (!g_comm) return partial;
     uint64_t v[2] = {partial == ALL_PAIRS_FAILED ? 0 : partial, partial == ALL_PAIRS_FAILED ? 1u : 0u};
-    if (!g_ctx[0] || storm_hip_comm_allreduce_u64s(g_ctx[0], g_comm, v, 2) != STORM_HIP_OK) {
+    /* (slot 0's context exists since STORM_hip_comm_init made the communicator on it; the caller's view is the whole
+     *  configuration — narrowed views are refused while a communicator is attached — so it holds slot 0's lock) */
+    storm_hip_ctx_t* ctx = g_ctx[0] ? g_ctx[0] : device_ctx(0);
+    if (!ctx || storm_hip_comm_allreduce_u64s(ctx, g_comm, v, 2) != STORM_HIP_OK) {
         device_error("all-reduce of the shard totals");
         return ALL_PAIRS_FAILED;
     }

@@ -15,17 +15,41 @@
  * identity token and the work runs on the MI355X (no CPU fallback). Each is compiled for its own ISA by a
  * function attribute and must only be called when STORM_get_cpuid() reports the ISA — the reference's rule.
  */
-#include <immintrin.h>
 #include <stddef.h>
 #include <stdint.h>
 
 #include "storm.h"
 
 #if defined(__x86_64__)
+#include <immintrin.h>
+
+/* The reference's rule — call a leaf only when STORM_get_cpuid() reports its ISA — is documented, not enforced by the
+ * STORM_HAVE_* macros (libalgebra.h defines them for every x86-64 compile). So each exported leaf checks the running CPU
+ * once and falls back to the portable loop where the ISA is missing, instead of faulting. */
+static uint64_t count_portable(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n) {
+    uint64_t c = 0;
+    for (size_t k = 0; k < n; ++k) c += (uint64_t)__builtin_popcountll(b1[k] & b2[k]);
+    return c;
+}
+/* 0 = portable loop, 1 = sse4.2 + popcnt, 2 = avx2, 3 = avx512bw, 4 = avx512bw + vpopcntdq (benign race: every thread
+ * computes the same value) */
+static int cpu_level(void) {
+    static int level = -1;
+    int v = __atomic_load_n(&level, __ATOMIC_RELAXED);
+    if (v < 0) {
+        __builtin_cpu_init();
+        v = 0;
+        if (__builtin_cpu_supports("sse4.2") && __builtin_cpu_supports("popcnt")) v = 1;
+        if (v == 1 && __builtin_cpu_supports("avx2")) v = 2;
+        if (v == 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw")) v = 3;
+        if (v == 3 && __builtin_cpu_supports("avx512vpopcntdq")) v = 4;
+        __atomic_store_n(&level, v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
 
 __attribute__((target("sse4.2,popcnt")))
-uint64_t STORM_intersect_count_sse4(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2,
-                                    const size_t n) {
+static uint64_t count_sse4(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n) {
     uint64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     size_t k = 0;
     for (; k + 4 <= n; k += 4) {
@@ -39,8 +63,7 @@ uint64_t STORM_intersect_count_sse4(const uint64_t* STORM_RESTRICT b1, const uin
 }
 
 __attribute__((target("avx2,popcnt")))
-uint64_t STORM_intersect_count_avx2(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2,
-                                    const size_t n) {
+static uint64_t count_avx2(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2, const size_t n) {
     const __m256i lut = _mm256_setr_epi8(0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4,
                                          0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4);
     const __m256i low = _mm256_set1_epi8(0x0f);
@@ -106,16 +129,20 @@ static uint64_t count_avx512_bw(const uint64_t* STORM_RESTRICT b1, const uint64_
     return count;
 }
 
+uint64_t STORM_intersect_count_sse4(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2,
+                                    const size_t n) {
+    return cpu_level() >= 1 ? count_sse4(b1, b2, n) : count_portable(b1, b2, n);
+}
+
+uint64_t STORM_intersect_count_avx2(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2,
+                                    const size_t n) {
+    return cpu_level() >= 2 ? count_avx2(b1, b2, n) : STORM_intersect_count_sse4(b1, b2, n);
+}
+
 uint64_t STORM_intersect_count_avx512(const uint64_t* STORM_RESTRICT b1, const uint64_t* STORM_RESTRICT b2,
                                       const size_t n) {
-    static int has_vpopcnt = -1; /* (benign race: every thread computes the same value) */
-    int v = __atomic_load_n(&has_vpopcnt, __ATOMIC_RELAXED);
-    if (v < 0) {
-        __builtin_cpu_init();
-        v = __builtin_cpu_supports("avx512vpopcntdq") ? 1 : 0;
-        __atomic_store_n(&has_vpopcnt, v, __ATOMIC_RELAXED);
-    }
-    return v ? count_avx512_vpopcnt(b1, b2, n) : count_avx512_bw(b1, b2, n);
+    const int v = cpu_level();
+    return v >= 4 ? count_avx512_vpopcnt(b1, b2, n) : v == 3 ? count_avx512_bw(b1, b2, n) : STORM_intersect_count_avx2(b1, b2, n);
 }
 
 #endif /* __x86_64__ */

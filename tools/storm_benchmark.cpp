@@ -138,7 +138,9 @@ static void describe_columns() {
     fprintf(stderr,
             "columns of a result row (tab separated; reference row = name, load, [size], then bench_t::PrintPretty, benchmark.cpp:74-87):\n"
             "  1 Method                 row name of the reference (storm, storm-blocked, STORM-contig, STORM-contig-<b>); bitmap-hip-blocked-<b> = STORM_wrapper_diag_blocked on the raw buffer;\n"
-            "                           bitmap-<leaf>-blocked-<b>-cpu = the harness's blocked loop over the library's host leaf, one thread, row sample, extrapolated\n"
+            "                           bitmap-<leaf>-blocked-<b>-cpu = the harness's blocked loop over the library's host leaf, one thread, row sample, extrapolated;\n"
+            "                           storm-blocked-cpu = the reference's STORM_t host path (benchmark.cpp:605-613, storm.c:897-961) over the library's one-pair helper, one thread, row sample;\n"
+            "                           bitmap-scalar-skip-list = flwrapper<STORM_intersect_count_scalar_list> (benchmark.cpp:1039-1045, loads <= 300), one thread, row sample\n"
             "  2 Alts                   values drawn per row (the load)\n"
             "  [3 size]                 STORM_serialized_size, only in the M >= 256000 form (benchmark.cpp:609)\n"
             "  + total                  bench_t.total: sum over row pairs of popcount(A & B) (CPU rows: of the row sample)\n"
@@ -232,6 +234,101 @@ static void cpu_rows(const uint64_t* vals, uint64_t have, uint64_t N, uint32_t n
         r.note = note;
         print_row(std::string("bitmap-") + l.name + "-blocked-" + std::to_string(bsize) + "-cpu", load, extra, r, N, n_ints);
     }
+}
+
+// ---- "storm-blocked-cpu": the reference's STORM_t CPU path itself (benchmark_large times STORM_pairw_intersect_cardinality_blocked
+// on the host, benchmark.cpp:605-613; the loop is storm.c:897-961) over the product's OWN exported one-pair helper
+// STORM_bitmap_cont_intersect_cardinality_premade (storm.c:790-814: merge of the two rows' block ids, then the 4-way kind
+// dispatch per matching block): one thread, the first R rows of the container, extrapolated by pair count.
+static uint64_t cpu_storm_blocked(const STORM_t* h, uint64_t rows, uint32_t bsize, uint32_t* scratch) {
+    const STORM_compute_func leaf = STORM_get_intersect_count_func(1024);
+    uint64_t total = 0;
+    for (uint64_t i0 = 0; i0 < rows; i0 += bsize) {
+        const uint64_t i1 = i0 + bsize < rows ? i0 + bsize : rows;
+        for (uint64_t i = i0; i < i1; ++i)
+            for (uint64_t j = i + 1; j < i1; ++j)
+                total += STORM_bitmap_cont_intersect_cardinality_premade(&h->conts[i], &h->conts[j], leaf, scratch);
+        for (uint64_t j0 = i1; j0 < rows; j0 += bsize) {
+            const uint64_t j1 = j0 + bsize < rows ? j0 + bsize : rows;
+            for (uint64_t i = i0; i < i1; ++i)
+                for (uint64_t j = j0; j < j1; ++j)
+                    total += STORM_bitmap_cont_intersect_cardinality_premade(&h->conts[i], &h->conts[j], leaf, scratch);
+        }
+    }
+    return total;
+}
+static void cpu_storm_row(const STORM_t* h, uint64_t N, uint32_t n_ints, uint32_t load, double seconds, const char* extra) {
+    // block size as STORM_pairw_intersect_cardinality_blocked(h, 0) derives it (storm.c:903-914): 256e3 / average serialized row
+    const uint64_t bytes = STORM_serialized_size(h);
+    uint32_t bsize = (uint32_t)std::ceil(256e3 / ((double)bytes / (double)(N ? N : 1) + 1.0));
+    if (bsize < 5) bsize = 5;
+    std::vector<uint32_t> scratch(2 * 4096);   // storm.c:900
+    uint64_t R = N < 64 ? N : 64;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    (void)cpu_storm_blocked(h, R, bsize, scratch.data());
+    double s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    const double per_pair = s / ((double)R * (R - 1) / 2.0 + 1.0);
+    const uint64_t fit = (uint64_t)std::sqrt(2.0 * seconds / (per_pair > 0 ? per_pair : 1e-9));
+    R = fit < 64 ? 64 : fit;
+    if (R > N) R = N;
+    t0 = std::chrono::high_resolution_clock::now();
+    const uint64_t c0 = tsc();
+    const uint64_t total = cpu_storm_blocked(h, R, bsize, scratch.data());
+    const uint64_t c1 = tsc();
+    s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    const double scale = ((double)N * (N - 1) / 2.0) / ((double)R * (R - 1) / 2.0 + 1e-9);
+    Row r;
+    r.gpus = 0;
+    r.total = total;
+    r.first_ms = r.steady_ms = s * 1e3 * scale;
+    r.cycles = (double)(c1 - c0) * scale;
+    char note[360];
+    snprintf(note, sizeof(note), "cpu 1 thread; the STORM_t host path (storm.c:897-961) over the library's one-pair helper STORM_bitmap_cont_intersect_cardinality_premade, bsize %u; first %llu of %llu rows timed (%.3f s), time and cycles extrapolated x%.1f by pair count; total is the sample's",
+             bsize, (unsigned long long)R, (unsigned long long)N, s, scale);
+    r.note = note;
+    print_row("storm-blocked-cpu", load, extra, r, N, n_ints);
+}
+
+// ---- "bitmap-scalar-skip-list" (benchmark.cpp:1039-1045, loads <= 300): flwrapper's plain all-pairs loop (:318-335) over
+// STORM_intersect_count_scalar_list — the shorter row's positions probed in the other row's bitmap — one thread, first R rows.
+static void cpu_skip_list_row(const uint64_t* vals, uint64_t N, uint32_t n_ints, uint32_t load, double seconds) {
+    const uint64_t have = N < 4096 ? N : 4096;
+    std::vector<std::vector<uint32_t>> pos(have);
+    for (uint64_t i = 0; i < have; ++i)
+        for (uint32_t w = 0; w < n_ints; ++w)
+            for (uint64_t x = vals[i * n_ints + w]; x; x &= x - 1) pos[i].push_back(w * 64u + (uint32_t)__builtin_ctzll(x));
+    auto run = [&](uint64_t rows) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < rows; ++i)
+            for (uint64_t j = i + 1; j < rows; ++j)
+                total += STORM_intersect_count_scalar_list(vals + i * n_ints, vals + j * n_ints, pos[i].data(), pos[j].data(),
+                                                           pos[i].size(), pos[j].size());
+        return total;
+    };
+    uint64_t R = have < 64 ? have : 64;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    const bool agrees = run(R) == cpu_blocked(STORM_intersect_count_scalar, vals, R, n_ints, 31);
+    double s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    const double per_pair = s / ((double)R * (R - 1) / 2.0 + 1.0);
+    const uint64_t fit = (uint64_t)std::sqrt(2.0 * seconds / (per_pair > 0 ? per_pair : 1e-9));
+    R = fit < 64 ? 64 : fit;
+    if (R > have) R = have;
+    t0 = std::chrono::high_resolution_clock::now();
+    const uint64_t c0 = tsc();
+    const uint64_t total = run(R);
+    const uint64_t c1 = tsc();
+    s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    const double scale = ((double)N * (N - 1) / 2.0) / ((double)R * (R - 1) / 2.0 + 1e-9);
+    Row r;
+    r.gpus = 0;
+    r.total = total;
+    r.first_ms = r.steady_ms = s * 1e3 * scale;
+    r.cycles = (double)(c1 - c0) * scale;
+    char note[320];
+    snprintf(note, sizeof(note), "cpu 1 thread; flwrapper's all-pairs loop over STORM_intersect_count_scalar_list; first %llu of %llu rows timed (%.3f s), time and cycles extrapolated x%.1f by pair count; total is the sample's; %s the dense scalar leaf on 64 rows",
+             (unsigned long long)R, (unsigned long long)N, s, scale, agrees ? "==" : "!=");
+    r.note = note;
+    print_row("bitmap-scalar-skip-list", load, "", r, N, n_ints);
 }
 
 static std::vector<uint32_t> default_loads(uint32_t M) {
@@ -366,6 +463,7 @@ int main(int argc, char** argv) {
             snprintf(extra, sizeof(extra), "%llu\t", (unsigned long long)storm_size);
             print_row("storm-blocked", loads[a], extra,
                       timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps, gpus), N, n_ints);  // :605-613
+            if (cpu_seconds > 0 && rank == 0) cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, extra);   // what :605-613 times: the host path
             if (cpu_seconds > 0 && rank == 0) {  // the dense leaf on the host beside it: a row sample of the same shape
                 const uint64_t rows = N < 512 ? N : 512;
                 std::vector<uint64_t> sample((size_t)n_ints * rows);
@@ -390,6 +488,9 @@ int main(int argc, char** argv) {
                   timed([&] { return STORM_wrapper_diag_blocked((uint32_t)N, vals.data(), n_ints, nullptr, optimal_b); }, reps, gpus), N, n_ints);
         // ... and the same loop on the host over the library's SIMD leaves (one thread, row sample, extrapolated)
         if (cpu_seconds > 0 && rank == 0) cpu_rows(vals.data(), N, N, n_ints, loads[a], optimal_b, cpu_seconds, "");
+        if (cpu_seconds > 0 && rank == 0 && n_samples >= 65536)   // the STORM_t host path beside the "storm" rows
+            cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, "");
+        if (cpu_seconds > 0 && rank == 0 && loads[a] <= 300) cpu_skip_list_row(vals.data(), N, n_ints, loads[a], cpu_seconds);   // :1039-1045
     }
     STORM_free(twk2);
     if (twk_cont) STORM_contig_free(twk_cont);
