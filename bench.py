@@ -313,8 +313,18 @@ def main():
             dist.all_reduce(scratch, op=dist.ReduceOp.SUM)   # blocking form: latency of one collective
         torch.cuda.synchronize(dev)
         allreduce_us = (time.perf_counter() - t_ar) * 1e6 / n_ar
+        # the same steps WITHOUT their collective (untimed diagnostic; every rank runs the same count): what the
+        # all-reduce adds to a step is wall_ms_per_step - wall_ms_per_step_no_collective, rank by rank
+        fence()
+        t_nc = time.perf_counter()
+        for _ in range(args.steps):
+            launch_pass()
+            state["n"] += 1
+        torch.cuda.synchronize(dev)
+        no_coll_ms = (time.perf_counter() - t_nc) * 1e3 / args.steps
+        fence()
         mine = torch.tensor([kernel_ms, launch_ms, my_elapsed * 1e3 / args.steps, allreduce_us,
-                             float(ctx.last_launch_info()["items"])], dtype=torch.float64,
+                             float(ctx.last_launch_info()["items"]), no_coll_ms], dtype=torch.float64,
                             device=dev if args.backend != "gloo" else "cpu")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
@@ -327,7 +337,8 @@ def main():
         dist.all_gather_object(ident, {"device": local_rank, "pci_bus_id": pci.value.decode(),
                                        "pid": os.getpid()})
         per_rank = [{"rank": r, "kernel_ms": round(float(g[0]), 4), "pass_ms": round(float(g[1]), 4),
-                     "wall_ms_per_step": round(float(g[2]), 4), "allreduce_us": round(float(g[3]), 1),
+                     "wall_ms_per_step": round(float(g[2]), 4),
+                     "wall_ms_per_step_no_collective": round(float(g[5]), 4), "allreduce_us": round(float(g[3]), 1),
                      "work_items": int(g[4]), **ident[r]} for r, g in enumerate(gathered)]
 
     # Secondary figure, never `value`: the same pass when the FP4 re-encoding of the (unchanged)
@@ -421,7 +432,7 @@ def main():
                             "benchmark.cpp:131); on-chip reuse lets it exceed the HBM peak — the binding "
                             "resource is VALU popcount issue (valu_popcount_frac)"}
         out = {
-            "metric": "64-bit bitmap words/s, XX^T upper-tri pairwise AND+popcount (10000x65536)",
+            "metric": f"64-bit bitmap words/s, XX^T upper-tri pairwise AND+popcount ({N}x{M})",
             "value": value, "unit": "words/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

@@ -94,6 +94,13 @@ void* storm_hip_matrix_device_ptr(const storm_hip_matrix_t* m);
  * plain   : synchronous; *h_total on the host. */
 int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                                  uint32_t shard_rank, uint32_t shard_count, uint64_t* d_total);
+/* The same total for rows that are still in the CALLER's memory: `host_rows` (src_stride_words words per row, >= the
+ * matrix's) replace all rows of `m`, travelling in panels of whole 256-row tiles on a second stream while the panel before is
+ * being multiplied (the pairs whose later row lies in a panel are multiplied as soon as it has landed); *h_total on the
+ * host, synchronous. What STORM_wrapper_diag[_blocked] (storm.c:132-150, :222-279) run on one device: those entry points
+ * get the caller's buffer anew on every call. Matrices below 2048 rows: the copy, then the pass. */
+int storm_hip_pairw_dense_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, const uint64_t* host_rows,
+                                 uint64_t src_stride_words, uint64_t* h_total);
 int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                           uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);
 /* split form, so that one host thread can keep several GPUs busy: _begin launches into the

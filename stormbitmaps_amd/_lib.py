@@ -44,6 +44,7 @@ SIGNATURES = {
     "storm_hip_matrix_device_ptr": (vp, [vp]),
     "storm_hip_pairw_dense_launch": (C.c_int, [vp, vp, u32, u32, vp]),
     "storm_hip_pairw_dense": (C.c_int, [vp, vp, u32, u32, P(u64)]),
+    "storm_hip_pairw_dense_upload": (C.c_int, [vp, vp, vp, u64, P(u64)]),
     "storm_hip_pairw_dense_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_dense_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_square_dense": (C.c_int, [vp, vp, vp, P(u64)]),

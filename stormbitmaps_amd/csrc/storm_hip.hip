@@ -1327,6 +1327,31 @@ int storm_hip_pairw_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
     return storm_hip_pairw_dense_end(ctx, h_total);
 }
 
+int storm_hip_pairw_dense_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, const uint64_t* host_rows,
+                                 uint64_t src_stride_words, uint64_t* h_total) {
+    return guarded("storm_hip_pairw_dense_upload", [&]() -> int {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (!m || !host_rows || !h_total || src_stride_words < m->n_words) {
+        set_error("pairw_dense_upload: bad argument");
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    m->generation = next_matrix_generation();
+    const bool strips = (ctx->variant < 0 || ctx->variant == 4) && strip_operands_of(ctx) == 5 && !ctx->k2_persistent &&
+                        ctx->k2_debug == 0 && m->n_rows >= 2048 &&
+                        (m->n_rows + 255) / 256 * 256 <= m->n_rows_pad && m->stride_words * 8 * 64ull < (1ull << 32);
+    if (!strips) {   // small matrices, forced kernel forms: the copy, then the pass
+        if (int rc = storm_hip_matrix_upload(ctx, m, 0, m->n_rows, host_rows, src_stride_words)) return rc;
+        return storm_hip_pairw_dense(ctx, m, 0, 1, h_total);
+    }
+    memset(ctx->pass_report, 0, sizeof(ctx->pass_report));
+    ctx->variant_used = 4;
+    if (int rc = launch_pairw_bits_upload(ctx, m, host_rows, src_stride_words, reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+        return rc;
+    return fetch_result_word(ctx, h_total);
+    });
+}
+
 int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                            const storm_hip_matrix_t* b, uint64_t* h_total) {
     return guarded("storm_hip_square_dense", [&]() -> int {

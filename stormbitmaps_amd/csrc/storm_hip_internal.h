@@ -111,6 +111,8 @@ struct storm_hip_ctx_s {
     size_t items_capacity = 0;
     uint64_t items_key[4] = {0, 0, 0, 0};  // rows, stages, shard rank/count, stages per item
     uint32_t n_items = 0;
+    void* panel_lists = nullptr;     // work lists of the row panels of storm_hip_pairw_dense_upload (std::vector<PanelList>*)
+    hipStream_t copy_stream = nullptr;   // ... its copies travel here while ctx->stream multiplies the panel before
     void* d_strip_items = nullptr;
     size_t strip_capacity = 0;
     uint64_t strip_key[4] = {0, 0, 0, 0};
@@ -186,12 +188,18 @@ struct RowRange {
                          // multiple of the A tile from r0, or >= r1): the rows [r0, a_end) among themselves and
                          // against everything behind them — a block column's bitmap rows, with its list rows,
                          // which the list-probe kernel pairs with each other, behind them
+    uint64_t back_from = ~0ull;  // != ~0: a row PANEL [back_from, r1) that has just arrived (a multiple of the A tile): only the
+                                 // pairs whose LATER row lies in the panel — every A tile of the panel against all the blocks in
+                                 // front of it (from r0) plus its own triangle (popcount(a & b) is symmetric: the new rows are the
+                                 // stationary operand, the rows already there stream past in long runs)
 };
 int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stride_words,
                              uint64_t n_rows_src, uint64_t n_rows_dst,
                              const std::vector<RowRange>& ranges, uint32_t shard_rank,
                              uint32_t shard_count, int strip_mode, uint64_t* d_total,
                              uint64_t shadow_generation = 0, uint32_t n_words_logical = 0);
+int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
+                             uint64_t src_stride_words, uint64_t* d_total);   // storm_hip_mfma.hip
 int strip_operands_of(const storm_hip_ctx_t* ctx);   // 5 = K2b, 4 = FP4 strips, ... (storm_hip_mfma.hip)
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch_bytes,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,

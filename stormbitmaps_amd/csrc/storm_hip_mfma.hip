@@ -1867,9 +1867,31 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
 #include "../../tools/probes/bitwave.hip"
 #endif  // STORM_HIP_PROBES
 
+struct PanelList {   // the work list of one row panel of launch_pairw_bits_upload, kept on the device between calls
+    uint64_t key[4] = {0, 0, 0, 0};
+    void* d = nullptr;
+    size_t cap = 0;
+    uint32_t n = 0;
+    hipEvent_t landed = nullptr;
+};
+static void release_panel_lists(storm_hip_ctx_t* ctx) {
+    auto* lists = static_cast<std::vector<PanelList>*>(ctx->panel_lists);
+    if (lists) {
+        for (PanelList& l : *lists) {
+            if (l.d) (void)hipFree(l.d);
+            if (l.landed) (void)hipEventDestroy(l.landed);
+        }
+        delete lists;
+    }
+    ctx->panel_lists = nullptr;
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    ctx->copy_stream = nullptr;
+}
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
+    release_panel_lists(ctx);
     if (ctx->d_strip_items) (void)hipFree(ctx->d_strip_items);
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -1902,6 +1924,7 @@ static uint64_t ranges_hash(const std::vector<RowRange>& ranges) {
         h = (h ^ r.r0) * 1099511628211ull;
         h = (h ^ r.r1) * 1099511628211ull;
         h = (h ^ r.a_end) * 1099511628211ull;
+        h = (h ^ r.back_from) * 1099511628211ull;
     }
     return h;
 }
@@ -2043,6 +2066,19 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
         // launch as it would run if nothing ever missed in L2
         const uint32_t ks_data = sh.one_slice_probe ? ks % 8u : ks;
         for (const RowRange& rg : ranges) {
+            if (rg.back_from != ~0ull) {   // a row panel that has just arrived: its tiles against everything in front of them
+                const uint32_t blk0 = (uint32_t)(rg.r0 / kStripBRows);
+                for (uint64_t a0 = rg.back_from; a0 < rg.r1; a0 += a_tile) {
+                    const uint32_t a_row0 = (uint32_t)a0, end = (uint32_t)(a0 / kStripBRows);
+                    if (end <= blk0) {
+                        dst.push_back({a_row0, 1, end, end, ks_data});
+                        continue;
+                    }
+                    for (uint32_t j0 = blk0; j0 < end; j0 += max_run)
+                        dst.push_back({a_row0, (uint32_t)(j0 == blk0), j0, std::min(end, j0 + max_run), ks_data});
+                }
+                continue;
+            }
             // A tiles of a_tile rows from the start of the range (the rows between r1 and
             // the end of its last A tile are zero: the caller pads ranges accordingly)
             const uint64_t a_rows = (rg.a_end ? std::min(rg.a_end, rg.r1) : rg.r1) - rg.r0;  // A tiles only below a_end
@@ -3345,6 +3381,97 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
     ctx->last_info[3] = 0;
     return launch_fold_slots(ctx, d_total);
 #endif
+}
+
+// The all-pairs total of a matrix that is still in the CALLER's memory (STORM_wrapper_diag[_blocked], storm.c:132-150,
+// :222-279: the raw-buffer entry points pay the transfer on every call — 82 MB at the headline shape, 1.5 ms in front of
+// a 0.76 ms pass). The rows travel in panels of whole A tiles on a second stream; as soon as a panel has landed, K2b
+// multiplies the pairs whose later row lies in it (RowRange::back_from: the panel's tiles stationary, all rows in front
+// of them streaming past) while the next panel is on the bus. What stays exposed is the first panel's copy and the last
+// panel's pairs. One fold at the end; the work lists of the panels stay on the device between calls.
+int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
+                             uint64_t src_stride_words, uint64_t* d_total) {
+    const uint64_t pitch = m->stride_words * 8;
+    const uint64_t tiles = (m->n_rows + kStripATile - 1) / kStripATile;
+    if (tiles * kStripATile > m->n_rows_pad || pitch * (uint64_t)kStripBRows >= (1ull << 32) || m->n_rows < 2) {
+        set_error("pairw_dense_upload: matrix outside the bit-operand strips' reach");
+        return STORM_HIP_EINVAL;
+    }
+    if (!ctx->copy_stream) STORM_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->panel_lists) ctx->panel_lists = new std::vector<PanelList>();
+    auto& lists = *static_cast<std::vector<PanelList>*>(ctx->panel_lists);
+    // Panels of equal size, at most 8 and at least 4 tiles each: the last panel's pairs (~ 2 / panels of the pass) are what
+    // the copies cannot cover, and short panels cost every item its prologue and every copy its set-up (shrinking the last
+    // panels to 4, 3 and 2 tiles changed nothing at the headline shape — 1.87 ms either way: the pageable copy itself,
+    // 44 - 48 GB/s, is the bound — and cost 6 % at 10000 x 524288).
+    std::vector<uint64_t> first_tile;   // panel p = tiles [first_tile[p], first_tile[p + 1])
+    {
+        const uint64_t n = std::max<uint64_t>(1, std::min<uint64_t>(8, tiles / 4));
+        for (uint64_t p = 0; p <= n; ++p) first_tile.push_back(tiles * p / n);
+    }
+    const uint64_t n_panels = first_tile.size() - 1;
+    const uint32_t n_kslices2 = 2u * ((m->n_words + 7u) / 8u);
+    if (lists.size() < n_panels) lists.resize(n_panels);
+    ctx->pass_report[0] |= STORM_HIP_RAN_BIT_STRIPS;
+    ctx->pass_report[1] += ranges_word_pairs({{0, m->n_rows}}, (uint64_t)n_kslices2 * 4u, 1);
+    ctx->k2_operands_used = 5;
+    uint64_t n_total = 0;
+    for (uint64_t p = 0; p < n_panels; ++p) {
+        const uint64_t t0 = first_tile[p], t1 = first_tile[p + 1];
+        if (t0 >= t1) continue;
+        const uint64_t row0 = t0 * kStripATile, row1 = std::min<uint64_t>(m->n_rows, t1 * kStripATile);
+        PanelList& l = lists[p];
+        if (!l.landed) STORM_HIP_TRY(hipEventCreateWithFlags(&l.landed, hipEventDisableTiming));
+        STORM_HIP_TRY(hipMemcpy2DAsync(m->d + row0 * m->stride_words, pitch, host_rows + row0 * src_stride_words,
+                                       src_stride_words * 8, (size_t)m->n_words * 8, row1 - row0, hipMemcpyHostToDevice,
+                                       ctx->copy_stream));
+        STORM_HIP_TRY(hipEventRecord(l.landed, ctx->copy_stream));
+        const uint64_t key[4] = {m->n_rows, ((uint64_t)n_kslices2 << 32) | (uint64_t)p, (t0 << 48) | (t1 << 32) | (uint64_t)ctx->k2_tail_run,
+                                 ((uint64_t)ctx->k2_tail_slices << 32) | (uint64_t)ctx->k2_lpt_rounds};
+        if (!l.d || memcmp(key, l.key, sizeof(key))) {
+            StripShaping sh;   // (a fixed run length: a panel's list is short and all tail)
+            sh.tail_run = ctx->k2_tail_run;
+            sh.tail_slices = ctx->k2_tail_slices;
+            sh.lpt_rounds = ctx->k2_lpt_rounds;
+            sh.xcd_group = 2;
+            RowRange rg{0, row1};
+            rg.back_from = row0;
+            std::vector<StripItem> items;
+            uint32_t qb[8], qc[8];
+            build_strip_items(sh, {rg}, n_kslices2, 0, 1, (uint32_t)kStripATile, items, qb, qc);
+            if (items.size() >= (1ull << 31)) {
+                set_error("pairw_dense_upload: %zu strip items exceed the grid limit", items.size());
+                return STORM_HIP_EINVAL;
+            }
+            if (items.size() > l.cap) {
+                if (l.d) STORM_HIP_TRY(hipFree(l.d));
+                l.d = nullptr;
+                l.cap = 0;
+                const size_t cap = std::max<size_t>(items.size(), 1024);
+                STORM_HIP_TRY(hipMalloc(&l.d, cap * sizeof(StripItem)));
+                l.cap = cap;
+            }
+            l.n = (uint32_t)items.size();
+            if (l.n) {
+                STORM_HIP_TRY(hipMemcpyAsync(l.d, items.data(), items.size() * sizeof(StripItem), hipMemcpyHostToDevice, ctx->stream));
+                STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `items` leaves scope
+            }
+            memcpy(l.key, key, sizeof(key));
+        }
+        STORM_HIP_TRY(hipStreamWaitEvent(ctx->stream, l.landed, 0));
+        if (l.n) {
+            hipLaunchKernelGGL(strip16_bits_kernel, dim3(l.n), dim3(kStripThreads), (size_t)ctx->k2_lds_pad, ctx->stream,
+                               reinterpret_cast<const uint8_t*>(m->d), pitch, static_cast<const StripItem*>(l.d), ctx->d_slots,
+                               (unsigned long long*)nullptr);
+            STORM_HIP_TRY(hipGetLastError());
+        }
+        n_total += l.n;
+    }
+    ctx->last_info[0] = n_total;
+    ctx->last_info[1] = ctx->k2_stages_per_item;
+    ctx->last_info[2] = 1;
+    ctx->last_info[3] = n_panels;
+    return launch_fold_slots(ctx, d_total);
 }
 
 // Which strips an all-pairs pass runs (option k2_strip_operands; 0 = the default: K2b unless a non-default ring or MFMA

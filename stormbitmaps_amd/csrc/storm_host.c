@@ -562,6 +562,20 @@ static uint64_t raw_pairw_locked(uint32_t n_vectors, const uint64_t* vals, uint3
         st->config_generation = g_config_generation;
         g_wrapper_words = n_ints;
     }
+    if (g_n_devices == 1 && g_shard_count == 1 && !g_comm) {
+        /* one device, the whole pair space: the rows travel in panels while the panels before are multiplied */
+        storm_hip_ctx_t* ctx = device_ctx(0);
+        uint64_t total = 0;
+        if (!ctx ||
+            (!st->m[0] && storm_hip_matrix_create(ctx, n_vectors, n_ints, &st->m[0]) != STORM_HIP_OK) ||
+            storm_hip_matrix_resize(ctx, st->m[0], n_vectors) != STORM_HIP_OK ||
+            storm_hip_pairw_dense_upload(ctx, st->m[0], vals, n_ints, &total) != STORM_HIP_OK) {
+            device_error("all-pairs wrapper: upload + pass");
+            dense_state_release(st);
+            return ALL_PAIRS_FAILED;
+        }
+        return total;
+    }
     for (int d = 0; d < g_n_devices; ++d) {
         storm_hip_ctx_t* ctx = device_ctx(d);
         if (!ctx ||

@@ -95,6 +95,12 @@ int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
     *h_total = ctx->pending;
     return STORM_HIP_OK;
 }
+int storm_hip_pairw_dense_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, const uint64_t* host,
+                                 uint64_t stride_words, uint64_t* h_total) {
+    if (storm_hip_matrix_upload(ctx, m, 0, m->n_rows, host, stride_words) != STORM_HIP_OK) return STORM_HIP_EINVAL;
+    *h_total = set_bits_of(m);
+    return STORM_HIP_OK;
+}
 int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                            const storm_hip_matrix_t* b, uint64_t* h_total) {
     (void)ctx;

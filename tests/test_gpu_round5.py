@@ -57,3 +57,30 @@ def test_pair_space_shards_sum_to_the_total_where_the_automatic_run_length_diffe
             m.close()
     finally:
         _reset(hip_ctx)
+
+
+def test_raw_buffer_wrappers_stream_their_rows_in_panels(hip_ctx, orc):
+    """STORM_wrapper_diag[_blocked] (storm.c:132-150, :222-279) get the caller's matrix anew on every call. On one device the
+    rows travel in panels of whole tiles while the panels before are multiplied (storm_hip_pairw_dense_upload: the pairs
+    whose later row lies in a panel, its tiles stationary). Against the oracle's blocked loop on shapes around the panel
+    edges (rows not a multiple of 256, fewer tiles than panels, one word per row, rows below the streaming threshold), and
+    with the caller's buffer CHANGED between calls — nothing of the previous call may be reused."""
+    for M, N, d in ((4096, 2048, 1500), (4096, 2050, 1500), (1024, 5000, 400), (64, 9000, 20), (8192, 2559, 3000),
+                    (700, 4097, 300), (4096, 300, 1500)):
+        mat = synth.dense_matrix_c(M, N, d, seed=M + N)
+        want = orc.wrapper_diag_blocked(mat, 31)
+        assert sb.wrapper_diag(mat) == want, (M, N)
+        assert sb.wrapper_diag_blocked(mat, 7) == want
+        mat[N // 2] = 0            # the caller edits its buffer in place ...
+        mat[5, :] = mat[N - 1, :]
+        want2 = orc.wrapper_diag_blocked(mat, 31)
+        assert sb.wrapper_diag(mat) == want2, (M, N)
+        smaller = np.ascontiguousarray(mat[: N - 300])   # ... and comes back with fewer rows
+        assert sb.wrapper_diag(smaller) == orc.wrapper_diag_blocked(smaller, 31)
+    # the headline shape: the device-built matrix downloaded, through the wrapper, against the resident pass
+    N, M = 10000, 65536
+    m = hip_ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, M // 2, seed=42)
+    host = m.download()
+    assert sb.wrapper_diag_blocked(host, 31) == m.pairw() == m.column_identity()
+    m.close()
