@@ -254,6 +254,13 @@ int STORM_contig_pairw_matrix(STORM_contiguous_t* bitmap, int op, uint32_t* out,
  * id + 1) bits per row; rows beyond 2^25 bits are refused with -3). Same return codes; STORM_n_rows: rows added. */
 uint64_t STORM_n_rows(const STORM_t* bitmap);
 int STORM_pairw_matrix(STORM_t* bitmap, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld);
+/* Both with the output left in DEVICE memory: `d_out` is a device pointer (hipMalloc) to out_rows x out_ld uint32 on the one
+ * device slot the calling thread drives (-5 when its view spans several: STORM_hip_set_thread_devices). Entries i >= j of
+ * the n x n window are written as 0 only inside the tiles the kernel touches: clear the buffer once if they matter. The
+ * 4 n^2 bytes then never cross the bus (half of a STORM_pairw_matrix call at n = 10000). Same return codes otherwise. */
+int STORM_pairw_matrix_device(STORM_t* bitmap, int op, uint32_t* d_out, uint64_t out_rows, uint64_t out_ld);
+int STORM_contig_pairw_matrix_device(STORM_contiguous_t* bitmap, int op, uint32_t* d_out, uint64_t out_rows,
+                                     uint64_t out_ld);
 
 /* ------------------------------------------------------------- extensions (not in ref) ---
  * Device selection for the entry points above. By default device 0 computes everything.
@@ -278,6 +285,10 @@ int STORM_contig_hip_invalidate(STORM_contiguous_t* bitmap);
  * STORM_wrapper_* calls keep one set of device matrices per process and lock all slots). Returns 0, -1 if the run of
  * slots is not inside the configuration. A handle is still for one thread at a time, as in the reference. */
 int STORM_hip_set_thread_devices(int first_slot, int n_slots);
+/* A context option (include/storm_hip.h: storm_hip_ctx_set_option — kernel forms, work-list shaping) for every device
+ * context behind the handles, existing and future; the environment variable STORM_HIP_OPTIONS="key=value,key=value" does the
+ * same. Tuning and A/B measurements: no option changes a result. 0, or -1 (unknown key / value out of range). */
+int STORM_hip_set_option(const char* key, int64_t value);
 int STORM_hip_set_shard(uint32_t shard_rank, uint32_t shard_count);
 /* What the last all-pairs call ran, over this process's devices (storm_hip.h: storm_hip_last_pass_report):
  * out[0] mask of STORM_HIP_RAN_*, out[1] dense 64-bit word pairs, out[2] list-probe lookups, out[3] rows a

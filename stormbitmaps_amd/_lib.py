@@ -127,6 +127,9 @@ SIGNATURES = {
     "STORM_contig_n_rows": (u64, [vp]),
     "STORM_n_rows": (u64, [vp]),
     "STORM_pairw_matrix": (C.c_int, [vp, C.c_int, vp, u64, u64]),
+    "STORM_pairw_matrix_device": (C.c_int, [vp, C.c_int, vp, u64, u64]),
+    "STORM_hip_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "STORM_contig_pairw_matrix_device": (C.c_int, [vp, C.c_int, vp, u64, u64]),
     "STORM_serialize": (u64, [vp, vp, u64]),
     "STORM_deserialize": (vp, [vp, u64]),
     "STORM_serialized_pairw_intersect_cardinality": (u64, [vp, u64]),

@@ -88,6 +88,13 @@ class StormContig:
                                f"{self._lib.STORM_hip_error().decode()}")
         return out
 
+    def pairw_matrix_device(self, d_out: int, out_rows: int, out_ld: int, op: str = "and") -> None:
+        """STORM_contig_pairw_matrix_device (extension): the same triangle left in device memory at address d_out."""
+        rc = int(self._lib.STORM_contig_pairw_matrix_device(self._h, {"and": 0, "or": 1, "xor": 2}[op], C.c_void_p(d_out),
+                                                            out_rows, out_ld))
+        if rc != 0:
+            raise RuntimeError(f"STORM_contig_pairw_matrix_device -> {rc}: {self._lib.STORM_hip_error().decode()}")
+
     def hip_invalidate(self) -> None:
         """STORM_contig_hip_invalidate: forget the device copy after an in-place edit of the
         handle's public buffers (storm.h extension)."""
@@ -148,6 +155,13 @@ class Storm:
         if rc != 0:
             raise RuntimeError(f"STORM_pairw_matrix -> {rc}: {self._lib.STORM_hip_error().decode()}")
         return out
+
+    def pairw_matrix_device(self, d_out: int, out_rows: int, out_ld: int, op: str = "and") -> None:
+        """STORM_pairw_matrix_device (extension): the same triangle left in device memory at address d_out."""
+        rc = int(self._lib.STORM_pairw_matrix_device(self._h, {"and": 0, "or": 1, "xor": 2}[op], C.c_void_p(d_out),
+                                                     out_rows, out_ld))
+        if rc != 0:
+            raise RuntimeError(f"STORM_pairw_matrix_device -> {rc}: {self._lib.STORM_hip_error().decode()}")
 
     def serialized_size(self) -> int:
         return int(self._lib.STORM_serialized_size(self._h))  # storm.c:963

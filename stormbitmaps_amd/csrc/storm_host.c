@@ -178,6 +178,41 @@ static void configure_from_env_locked(void) {
 
 static __thread int g_quiet_ctx = 0; /* 1 while a best-effort caller (row streaming) asks for a context */
 
+/* Extension (storm.h): context options (include/storm_hip.h: storm_hip_ctx_set_option) for the contexts behind the storm.h
+ * handles — applied to the ones that exist and remembered for the ones still to be made. STORM_HIP_OPTIONS="key=value,..." in
+ * the environment does the same at the first use. Tuning and A/B only: every option keeps the results exact. */
+#define MAX_HOST_OPTIONS 16
+static struct { char key[40]; int64_t value; } g_host_opt[MAX_HOST_OPTIONS];
+static int g_n_host_opt = 0, g_env_opts_read = 0;
+static void apply_host_options(storm_hip_ctx_t* ctx) {
+    for (int i = 0; i < g_n_host_opt; ++i) (void)storm_hip_ctx_set_option(ctx, g_host_opt[i].key, g_host_opt[i].value);
+}
+static int remember_host_option(const char* key, int64_t value) {
+    for (int i = 0; i < g_n_host_opt; ++i)
+        if (!strcmp(g_host_opt[i].key, key)) {
+            g_host_opt[i].value = value;
+            return 0;
+        }
+    if (g_n_host_opt == MAX_HOST_OPTIONS || strlen(key) >= sizeof(g_host_opt[0].key)) return -1;
+    snprintf(g_host_opt[g_n_host_opt].key, sizeof(g_host_opt[0].key), "%s", key);
+    g_host_opt[g_n_host_opt++].value = value;
+    return 0;
+}
+static void read_env_options(void) {
+    if (g_env_opts_read) return;
+    g_env_opts_read = 1;
+    const char* e = getenv("STORM_HIP_OPTIONS");
+    if (!e) return;
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s", e);
+    for (char* tok = strtok(buf, ","); tok; tok = strtok(NULL, ",")) {
+        char* eq = strchr(tok, '=');
+        if (!eq) continue;
+        *eq = '\0';
+        (void)remember_host_option(tok, strtoll(eq + 1, NULL, 10));
+    }
+}
+
 static storm_hip_ctx_t* device_ctx(int slot) {
     configure_from_env();
     if (slot < 0 || slot >= g_n_devices) return NULL;
@@ -189,6 +224,8 @@ static storm_hip_ctx_t* device_ctx(int slot) {
             /* the device mirrors behind the storm.h handles are written by this file only, so a
              * repeated all-pairs call on an unchanged handle may reuse the FP4 shadow */
             (void)storm_hip_ctx_set_option(g_ctx[slot], "keep_shadow", 1);
+            read_env_options();
+            apply_host_options(g_ctx[slot]);
         }
     }
     return g_ctx[slot];
@@ -537,6 +574,21 @@ static void device_unlock_all(const saved_view_t* saved) {
     tl_view_first = saved->first;
     tl_view_count = saved->count;
     device_unlock_range(0, MAX_DEVICES);
+}
+
+int STORM_hip_set_option(const char* key, int64_t value) {
+    if (!key) return -1;
+    saved_view_t sv;
+    device_lock_all(&sv);
+    read_env_options();
+    int rc = remember_host_option(key, value);
+    for (int d = 0; d < MAX_DEVICES && !rc; ++d)
+        if (g_ctx[d] && storm_hip_ctx_set_option(g_ctx[d], key, value) != STORM_HIP_OK) {
+            device_error("STORM_hip_set_option");
+            rc = -1;
+        }
+    device_unlock_all(&sv);
+    return rc;
 }
 
 static uint64_t raw_pairw_locked(uint32_t n_vectors, const uint64_t* vals, uint32_t n_ints);
@@ -2123,6 +2175,66 @@ static int storm_pairw_matrix_locked(STORM_t* h, int op, uint32_t* out, uint64_t
 int STORM_pairw_matrix(STORM_t* h, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld) {
     device_lock();
     const int rc = storm_pairw_matrix_locked(h, op, out, out_rows, out_ld);
+    device_unlock();
+    return rc;
+}
+
+/* The same into DEVICE memory (storm.h: STORM_pairw_matrix_device): the 4 N^2 bytes of output never cross the bus — at the
+ * README's STORM_t shape (N = 10000: 400 MB) the copy to pageable host memory was half of a call. One device slot only:
+ * `d_out` lives on one GPU. */
+static int one_slot_or_refuse(const char* who) {
+    configure_from_env();
+    if (VN == 1) return 0;
+    char msg[160];
+    snprintf(msg, sizeof(msg), "%s: the output lives on ONE device: narrow the thread's view to one slot (STORM_hip_set_thread_devices)", who);
+    host_error(msg);
+    return -5;
+}
+int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_rows, uint64_t out_ld) {
+    if (!h) return -1;
+    if (!d_out) return -2;
+    device_lock();
+    int rc = one_slot_or_refuse("STORM_pairw_matrix_device");
+    const uint64_t n = h->n_conts;
+    if (!rc && (out_rows < n || out_ld < n)) rc = -4;
+    if (!rc && n != 0) {
+        int fresh = 0;
+        sparse_state_t* st = storm_state(h, &fresh);
+        if (!st) rc = -3;
+        if (!rc) {
+            const uint64_t epoch = storm_epoch();
+            if (!fresh && !h->hip_private && (h->hip_epoch != epoch || always_fingerprint()) &&
+                storm_fingerprint(h) != h->hip_fingerprint) {
+                storm_drop_device(h);
+                if (!(st = storm_state(h, &fresh))) rc = -3;
+            }
+            if (!rc) h->hip_epoch = epoch;
+        }
+        if (!rc && !st->have_dense && storm_build_device(h, st, 1)) rc = -3;
+        if (!rc && storm_hip_pairw_matrix_device(g_ctx[V0], st->m[V0], op, d_out, out_ld) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_matrix_device");
+            rc = -3;
+        }
+    }
+    device_unlock();
+    return rc;
+}
+
+int STORM_contig_pairw_matrix_device(STORM_contiguous_t* h, int op, uint32_t* d_out, uint64_t out_rows, uint64_t out_ld) {
+    if (!h) return -1;
+    if (!d_out) return -2;
+    device_lock();
+    int rc = one_slot_or_refuse("STORM_contig_pairw_matrix_device");
+    const uint64_t n = h->n_data;
+    if (!rc && (out_rows < n || out_ld < n)) rc = -4;
+    if (!rc && n != 0) {
+        dense_state_t* st = contig_mirror(h);
+        if (!st) rc = -3;
+        else if (storm_hip_pairw_matrix_device(g_ctx[V0], st->m[V0], op, d_out, out_ld) != STORM_HIP_OK) {
+            device_error("storm_hip_pairw_matrix_device");
+            rc = -3;
+        }
+    }
     device_unlock();
     return rc;
 }

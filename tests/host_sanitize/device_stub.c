@@ -107,6 +107,14 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     *h_total = set_bits_of(a) + set_bits_of(b);
     return STORM_HIP_OK;
 }
+int storm_hip_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op, uint32_t* d_out,
+                                  uint64_t ld) {
+    (void)ctx; (void)op;
+    if (ld < m->n_rows) return STORM_HIP_EINVAL;
+    for (uint64_t i = 0; i < m->n_rows; ++i) /* ("device" memory is host memory here: touches the whole window) */
+        for (uint64_t j = 0; j < m->n_rows; ++j) d_out[i * ld + j] = 0;
+    return STORM_HIP_OK;
+}
 int storm_hip_pairw_matrix_band_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m, int op,
                                       uint64_t row0, uint64_t n_band_rows, uint32_t* h_out, uint64_t ld) {
     (void)ctx; (void)op;

@@ -1,4 +1,6 @@
 """Round-5 GPU parity tests. Everything goes through the C-ABI; the oracle is the checker only."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -84,3 +86,39 @@ def test_raw_buffer_wrappers_stream_their_rows_in_panels(hip_ctx, orc):
     host = m.download()
     assert sb.wrapper_diag_blocked(host, 31) == m.pairw() == m.column_identity()
     m.close()
+
+
+def test_per_pair_matrix_left_in_device_memory(orc):
+    """STORM_pairw_matrix_device / STORM_contig_pairw_matrix_device (extensions): the triangle of STORM_pairw_matrix left in
+    device memory — entry (i, j), i < j, is what STORM_bitmap_cont_intersect_cardinality returns for rows i and j
+    (storm.c:790-814) — against the host-output entry points and the oracle's row-pair function written out, for both
+    tile kernels (STORM_hip_set_option: tilebits8_kernel and tilering_kernel), lists, bitmaps and mixed kinds."""
+    import torch
+    lib = sb.load()
+    try:
+        for M, N, d in ((200000, 300, 40), (131072, 257, 9000), (65536, 600, 5000)):
+            rows = [np.unique(np.random.default_rng(N + i).integers(0, M, size=d if i % 3 else d // 50 + 1)).astype(np.uint32)
+                    for i in range(N)]
+            s, c = sb.Storm(), sb.StormContig(M)
+            for r in rows:
+                s.add(r)
+                c.add(r)
+            want = s.pairw_matrix("and")
+            if N <= 300:
+                assert np.array_equal(want, orc.storm(rows).pair_counts())
+            for shape in (2, 5, 2):
+                assert lib.STORM_hip_set_option(b"k2_tile_shape", shape) == 0
+                dev = torch.zeros((N + 3, N + 8), dtype=torch.int32, device="cuda:0")
+                s.pairw_matrix_device(dev.data_ptr(), N + 3, N + 8)
+                got = np.triu(dev.cpu().numpy().astype(np.uint32)[:N, :N], k=1)
+                assert np.array_equal(got, want), (M, N, shape)
+                dev.zero_()
+                c.pairw_matrix_device(dev.data_ptr(), N + 3, N + 8, "xor")
+                got = np.triu(dev.cpu().numpy().astype(np.uint32)[:N, :N], k=1)
+                assert np.array_equal(got, c.pairw_matrix("xor")), (M, N, shape)
+            assert lib.STORM_pairw_matrix_device(s._h, 0, None, N, N) == -2
+            assert lib.STORM_pairw_matrix_device(s._h, 0, C.c_void_p(dev.data_ptr()), N - 1, N) == -4
+            s.free()
+            c.free()
+    finally:
+        lib.STORM_hip_set_option(b"k2_tile_shape", 2)

@@ -33,9 +33,28 @@ def main():
             assert lib.STORM_pairw_matrix(s._h, 0, ptr, a.rows, a.rows) == 0
             steady.append(time.perf_counter() - t0)
         total = s.pairw_intersect_cardinality()
+        # the same into DEVICE memory (STORM_pairw_matrix_device, round 5), for both tile kernels
+        import torch
+        dev = torch.zeros((a.rows, a.rows), dtype=torch.int32, device="cuda:0")
+        dev_ms = {}
+        same = True
+        for shape in (2, 5):
+            sb.load().STORM_hip_set_option(b"k2_tile_shape", shape)
+            s.pairw_matrix_device(dev.data_ptr(), a.rows, a.rows)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                s.pairw_matrix_device(dev.data_ptr(), a.rows, a.rows)
+                ts.append(time.perf_counter() - t0)
+            dev_ms[shape] = round(min(ts) * 1e3, 2)
+            same = same and int(dev.to(torch.int64).sum().item()) == total
+        sb.load().STORM_hip_set_option(b"k2_tile_shape", 2)
         print(json.dumps({"rows": a.rows, "bits": a.bits, "draws": d, "first_call_ms": round(first * 1e3, 2),
                           "steady_ms": round(min(steady) * 1e3, 2), "output_mb": out.nbytes / 1e6,
+                          "device_output_ms_tilebits8": dev_ms[2], "device_output_ms_tilering": dev_ms[5],
+                          "device_output_sum_equals_total": same,
                           "sum_equals_all_pairs_total": int(out.sum(dtype=np.uint64)) == total}), flush=True)
+        del dev
         s.free()
 
 
