@@ -2943,7 +2943,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
         ctx->x4_capacity = x4_bytes;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     }
-    const uint32_t total_stages = (uint32_t)(row_bytes / kStageBytes);
+    // (bit kernels: whole 512-bit chunks that hold DATA; the pitch's pad chunks are never multiplied)
+    const uint32_t total_stages = bits ? (std::max(a->n_words, b->n_words) + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
     xcd_grouped_tiles(0, ta, ta, ta + tb, false, tiles);

@@ -531,6 +531,12 @@ def test_benchmark_cli_rows_agree_with_golden_totals():
         # the host rows: the library's own SIMD leaves under the harness's blocked loop (a row sample)
         assert {r["#Method"].split("-")[1] for r in cpu_rows} >= {"scalar"}
         assert all("==" in r["note"] and "extrapolated" in r["note"] for r in cpu_rows), cpu_rows
+        # [r5] the reference's STORM_t host path (benchmark.cpp:605-613) and its list-probe row (:1039-1045, loads <= 300),
+        # over the library's own exported one-pair helpers
+        cpu_names = {(r["#Method"], int(r["Alts"])) for r in cpu_rows}
+        for load in (int(x) for x in loads.split(",")):
+            assert (("storm-blocked-cpu", load) in cpu_names) == (M >= 65536), (M, load, cpu_names)
+            assert (("bitmap-scalar-skip-list", load) in cpu_names) == (load <= 300), (M, load, cpu_names)
         for load in (int(x) for x in loads.split(",")):
             totals = {int(r["total"]) for r in gpu_rows if int(r["Alts"]) == load}
             names = [r["#Method"] for r in gpu_rows if int(r["Alts"]) == load]

@@ -257,16 +257,21 @@ static uint64_t cpu_storm_blocked(const STORM_t* h, uint64_t rows, uint32_t bsiz
     }
     return total;
 }
-static void cpu_storm_row(const STORM_t* h, uint64_t N, uint32_t n_ints, uint32_t load, double seconds, const char* extra) {
+static void cpu_storm_row(const STORM_t* h, uint64_t N, uint32_t n_ints, uint32_t load, double seconds, const char* extra,
+                          const uint64_t* dense_rows, uint64_t dense_have) {
     // block size as STORM_pairw_intersect_cardinality_blocked(h, 0) derives it (storm.c:903-914): 256e3 / average serialized row
     const uint64_t bytes = STORM_serialized_size(h);
     uint32_t bsize = (uint32_t)std::ceil(256e3 / ((double)bytes / (double)(N ? N : 1) + 1.0));
     if (bsize < 5) bsize = 5;
     std::vector<uint32_t> scratch(2 * 4096);   // storm.c:900
     uint64_t R = N < 64 ? N : 64;
+    if (dense_rows && dense_have < R) R = dense_have;
     auto t0 = std::chrono::high_resolution_clock::now();
-    (void)cpu_storm_blocked(h, R, bsize, scratch.data());
+    const uint64_t t64 = cpu_storm_blocked(h, R, bsize, scratch.data());
     double s = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    // (the same rows as a dense bit matrix under the scalar leaf: the container path must count the same)
+    const bool agrees = !dense_rows || t64 == cpu_blocked(STORM_intersect_count_scalar, dense_rows, R, n_ints, 31);
+    const uint64_t R0 = R;
     const double per_pair = s / ((double)R * (R - 1) / 2.0 + 1.0);
     const uint64_t fit = (uint64_t)std::sqrt(2.0 * seconds / (per_pair > 0 ? per_pair : 1e-9));
     R = fit < 64 ? 64 : fit;
@@ -283,8 +288,8 @@ static void cpu_storm_row(const STORM_t* h, uint64_t N, uint32_t n_ints, uint32_
     r.first_ms = r.steady_ms = s * 1e3 * scale;
     r.cycles = (double)(c1 - c0) * scale;
     char note[360];
-    snprintf(note, sizeof(note), "cpu 1 thread; the STORM_t host path (storm.c:897-961) over the library's one-pair helper STORM_bitmap_cont_intersect_cardinality_premade, bsize %u; first %llu of %llu rows timed (%.3f s), time and cycles extrapolated x%.1f by pair count; total is the sample's",
-             bsize, (unsigned long long)R, (unsigned long long)N, s, scale);
+    snprintf(note, sizeof(note), "cpu 1 thread; the STORM_t host path (storm.c:897-961) over the library's one-pair helper STORM_bitmap_cont_intersect_cardinality_premade, bsize %u; first %llu of %llu rows timed (%.3f s), time and cycles extrapolated x%.1f by pair count; total is the sample's; %s the dense scalar leaf on the first %llu rows",
+             bsize, (unsigned long long)R, (unsigned long long)N, s, scale, agrees ? "==" : "!=", (unsigned long long)R0);
     r.note = note;
     print_row("storm-blocked-cpu", load, extra, r, N, n_ints);
 }
@@ -463,11 +468,11 @@ int main(int argc, char** argv) {
             snprintf(extra, sizeof(extra), "%llu\t", (unsigned long long)storm_size);
             print_row("storm-blocked", loads[a], extra,
                       timed([&] { return STORM_pairw_intersect_cardinality_blocked(twk2, 0); }, reps, gpus), N, n_ints);  // :605-613
-            if (cpu_seconds > 0 && rank == 0) cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, extra);   // what :605-613 times: the host path
             if (cpu_seconds > 0 && rank == 0) {  // the dense leaf on the host beside it: a row sample of the same shape
                 const uint64_t rows = N < 512 ? N : 512;
                 std::vector<uint64_t> sample((size_t)n_ints * rows);
                 storm_synth_fill_dense(sample.data(), n_ints, M, 0, rows, loads[a], seed);
+                cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, extra, sample.data(), rows);   // what :605-613 times: the host path
                 cpu_rows(sample.data(), rows, N, n_ints, loads[a], optimal_b, cpu_seconds, extra);
             }
             continue;
@@ -489,7 +494,7 @@ int main(int argc, char** argv) {
         // ... and the same loop on the host over the library's SIMD leaves (one thread, row sample, extrapolated)
         if (cpu_seconds > 0 && rank == 0) cpu_rows(vals.data(), N, N, n_ints, loads[a], optimal_b, cpu_seconds, "");
         if (cpu_seconds > 0 && rank == 0 && n_samples >= 65536)   // the STORM_t host path beside the "storm" rows
-            cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, "");
+            cpu_storm_row(twk2, N, n_ints, loads[a], cpu_seconds, "", vals.data(), N);
         if (cpu_seconds > 0 && rank == 0 && loads[a] <= 300) cpu_skip_list_row(vals.data(), N, n_ints, loads[a], cpu_seconds);   // :1039-1045
     }
     STORM_free(twk2);
