@@ -432,7 +432,7 @@ def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d
     for code, name in ((1, "or"), (2, "xor")):
         want[name] = np.triu(orc.tile_counts_op(mat, 0, N, 0, N, code), k=1)
     try:
-        for shape in shipped(hip_ctx, "k2_tile_shape", (2, 3, 4, 1, 16, 32)):
+        for shape in shipped(hip_ctx, "k2_tile_shape", (2, 5, 3, 4, 1, 16, 32)):
             hip_ctx.set_option("k2_tile_shape", shape)
             for name in ("and", "or", "xor"):
                 assert np.array_equal(m.pairw_matrix(name), want[name]), (shape, name)
@@ -466,7 +466,7 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
         ma, mb = hip_ctx.matrix_from_host(a), hip_ctx.matrix_from_host(b)
         want = orc.tile_counts(mat, 0, na, na, na + nbr)
         try:
-            for shape in shipped(hip_ctx, "k2_tile_shape", (2, 3, 4, 1, 16)):
+            for shape in shipped(hip_ctx, "k2_tile_shape", (2, 5, 3, 4, 1, 16)):
                 hip_ctx.set_option("k2_tile_shape", shape)
                 assert np.array_equal(ma.square_matrix(mb, "and"), want), (na, nbr, shape)
             want_x = orc.tile_counts_op(mat, 0, na, na, na + nbr, 2)

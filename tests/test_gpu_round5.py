@@ -122,3 +122,55 @@ def test_per_pair_matrix_left_in_device_memory(orc):
             c.free()
     finally:
         lib.STORM_hip_set_option(b"k2_tile_shape", 2)
+
+
+def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc):
+    """tilering_kernel (k2_tile_shape = 5: both operands as FP4 images in the LDS, 16x16x128 MFMAs, SIMD partners half a stage
+    apart; barrier and counter synchronisation) against the oracle's per-pair counts (storm.c:1199-1238 with the leaf's result
+    kept per pair) and tilebits8_kernel: triangle, AND / OR / XOR, rectangle, bands, rows of zero, ragged row blocks (1 .. 255
+    rows beyond a multiple of 256), row lengths that are not whole 512-bit chunks or whole chunk PAIRS, one tile, k-split last
+    rounds (more tiles than CUs)."""
+    import torch
+    try:
+        for M, N, d in ((4096, 256, 2048), (640, 65, 200), (1000, 257, 300), (9000, 700, 3000), (300, 130, 100), (512, 300, 100),
+                        (520, 300, 100), (70000, 1029, 20000), (1536, 4700, 500)):
+            mat = synth.dense_matrix_c(M, N, d, seed=N + M)
+            mat[N // 3] = 0
+            m = hip_ctx.matrix_from_host(mat)
+            for op in ("and", "or", "xor"):
+                hip_ctx.set_option("k2_tile_shape", 2)
+                ref = m.pairw_matrix(op)
+                hip_ctx.set_option("k2_tile_shape", 5)
+                for sync in (0, 1):
+                    hip_ctx.set_option("k2_ring_sync", sync)
+                    got = m.pairw_matrix(op)
+                    assert np.array_equal(ref, got), (M, N, op, sync, np.argwhere(ref != got)[:3].tolist())
+                hip_ctx.set_option("k2_ring_sync", 0)
+                if N <= 300 and op == "and":
+                    assert np.array_equal(got, np.triu(orc.tile_counts(mat, 0, N, 0, N), k=1).astype(np.uint32))
+            if N >= 600:   # a band of the triangle into device memory, and the rectangle of the two halves
+                hip_ctx.set_option("k2_tile_shape", 5)
+                band = torch.zeros((300, N), dtype=torch.int32, device="cuda:0")
+                m.pairw_matrix_band_device(band.data_ptr(), N, 256, 300)
+                assert np.array_equal(np.triu(band.cpu().numpy().astype(np.uint32), k=257)[:, :],
+                                      np.triu(ref_and(m, hip_ctx)[256:556], k=257))
+                na = N // 2
+                ma, mb = hip_ctx.matrix_from_host(mat[:na]), hip_ctx.matrix_from_host(mat[na:])
+                got = ma.square_matrix(mb, "and")
+                hip_ctx.set_option("k2_tile_shape", 2)
+                assert np.array_equal(got, ma.square_matrix(mb, "and"))
+                if N <= 1100:
+                    assert np.array_equal(got, orc.tile_counts(mat, 0, na, na, N).astype(np.uint32))
+                ma.close()
+                mb.close()
+            m.close()
+    finally:
+        hip_ctx.set_option("k2_tile_shape", 2)
+        hip_ctx.set_option("k2_ring_sync", 0)
+
+
+def ref_and(m, ctx):
+    ctx.set_option("k2_tile_shape", 2)
+    out = m.pairw_matrix("and")
+    ctx.set_option("k2_tile_shape", 5)
+    return out
