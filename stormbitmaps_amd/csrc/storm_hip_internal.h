@@ -125,7 +125,7 @@ struct storm_hip_ctx_s {
     int k2_stream_max_rows = 8192;  // auto: matrices up to this many rows take K2q
     int k2_shard_pairs = 0;         // ownership among shards: 0 = whole k-slices first (leftover slices along the pair space), 1 = every slice along the pair space
     int k2_matrix_pad = -1;         // matrices created from now on: rows that are a multiple of 1 KiB get this many 512-byte chunks more of pitch (0: dense pitch; -1: by the pitch, pitch_pad_chunks)
-    int k2_fold_inline = 0;         // K2b: 0 = a fold launch behind the strips (default: level at N = 10000, 0.8 - 4 us faster at N <= 1024, profiles/r05_c_fold_ab.jsonl); -1 / 1 = the workgroup dispatched last folds inside the launch (whenever the packed slot words cannot overflow)
+    int k2_fold_inline = -1;        // K2b: the workgroup dispatched last folds the partial sums inside the launch: -1 = for short launches (<= 4096 workgroups, where the fold launch and its gaps are a fifth of a pass), 1 = always (level at N = 10000), 0 = never (a fold launch behind the strips); profiles/r05_c_fold_ab.jsonl
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
     int k2_ring_sync = 0;   // tilering_kernel: 0 = one s_barrier per stage; 1 = arrival counters in the LDS (waves may drift a stage apart; measured 2 % slower)

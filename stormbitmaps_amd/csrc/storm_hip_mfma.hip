@@ -711,7 +711,7 @@ __device__ __forceinline__ v4i sb16_inflate(v4i w, uint32_t rot) {
 
 __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     const uint8_t* __restrict__ X, uint64_t row_bytes, const StripItem* __restrict__ items,
-    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out) {
+    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out, uint32_t fold_slots) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSb16ImgBytes + kSb16BitRing * kSb16BitStage];
 
     STORM_CLOCK_BEGIN();
@@ -971,8 +971,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     //      has run dry anyway; every other workgroup is running or done by then and needs nothing from it.
     //      (Round 4's form — a ticket word that every workgroup hits with a RETURNING atomic — cost 1 ms at this grid size:
     //       atomics on one address serialise at ~14 M/s, and a returning atomic holds the workgroup's slot for ~2 us.)
+    // (fold_slots: a power of two <= kSlots — short launches use few slots, one per polling thread)
     if (lane_e == 0)
-        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
+        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (fold_slots - 1u)],
                   (unsigned long long)mine + (1ull << 48));
     if (blockIdx.x != gridDim.x - 1u) return;
     const unsigned long long expected = (unsigned long long)gridDim.x * (unsigned long long)kStripWaves;
@@ -980,7 +981,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     unsigned long long total = 0;
     for (;;) {
         unsigned long long cnt = 0, sum = 0;
-        for (uint32_t i = tid_e; i < (uint32_t)kSlots; i += (uint32_t)kStripThreads) {
+        for (uint32_t i = tid_e; i < fold_slots; i += (uint32_t)kStripThreads) {
             const unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cnt += v >> 48;
             sum += v & ((1ull << 48) - 1ull);
@@ -999,9 +1000,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
         cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         total = wsum[4] + wsum[5] + wsum[6] + wsum[7];
         if (cnt == expected) break;
-        __builtin_amdgcn_s_sleep(8);
+        if (fold_slots > (uint32_t)kStripThreads) __builtin_amdgcn_s_sleep(8);   // (long launches: poll gently)
     }
-    for (uint32_t i = tid_e; i < (uint32_t)(kSlots + kSlotsExtra); i += (uint32_t)kStripThreads)
+    for (uint32_t i = tid_e; i < fold_slots; i += (uint32_t)kStripThreads)
         __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid_e == 0) out[0] = total;
 }
@@ -3320,16 +3321,21 @@ int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pi
     // the fold inside the launch (option k2_fold_inline: -1 = whenever the packed slot words cannot overflow, 0 = never:
     // a fold launch follows): arrivals per slot below 2^16, a slot's sum below 2^48 — a wave adds at most 64 rows x
     // (run x 64 + 256) rows x 256 bits
-    const uint64_t arrivals_per_slot = (uint64_t)n_strip * (uint64_t)kStripWaves / (uint64_t)kSlots + 1u;
+    // ... and what it is worth depends on the launch: a short one (up to 4096 workgroups: N <= ~2000 at M = 65536) spends a
+    // fifth of a pass in the fold launch and its gaps and uses 256 slots, one per polling thread (-1 = on for those); a long
+    // one gains nothing (profiles/r05_c_fold_ab.jsonl) and keeps the fold launch unless the option is 1
+    const uint32_t fold_slots = n_strip <= 4096u ? 256u : (uint32_t)kSlots;
+    const bool fold_wanted = ctx->k2_fold_inline > 0 || (ctx->k2_fold_inline < 0 && n_strip <= 4096u);
+    const uint64_t arrivals_per_slot = (uint64_t)n_strip * (uint64_t)kStripWaves / (uint64_t)fold_slots + 1u;
     const uint64_t wave_sum_max = 64ull * (4096ull * 64ull + 256ull) * 256ull;   // (runs are capped at 4096 stages)
     // (slots_hold_sums: another kernel of this pass — the list-probe kernel — has added sums of unknown size: fold launch)
-    const bool fold_inline = ctx->k2_fold_inline != 0 && !slots_hold_sums && n_strip > 0 && arrivals_per_slot < 65535u &&
+    const bool fold_inline = fold_wanted && !slots_hold_sums && n_strip > 0 && arrivals_per_slot < 65535u &&
                              arrivals_per_slot * wave_sum_max < (1ull << 48);
     if (n_strip > 0) {
         kernel_time_mark(ctx);
         hipLaunchKernelGGL(strip16_bits_kernel, dim3(n_strip), dim3(kStripThreads), (size_t)ctx->k2_lds_pad,
                            ctx->stream, X, pitch, static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots,
-                           fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr);
+                           fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr, fold_slots);
         kernel_time_mark(ctx);
         STORM_HIP_TRY(hipGetLastError());
     }
@@ -3463,7 +3469,7 @@ int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const 
         if (l.n) {
             hipLaunchKernelGGL(strip16_bits_kernel, dim3(l.n), dim3(kStripThreads), (size_t)ctx->k2_lds_pad, ctx->stream,
                                reinterpret_cast<const uint8_t*>(m->d), pitch, static_cast<const StripItem*>(l.d), ctx->d_slots,
-                               (unsigned long long*)nullptr);
+                               (unsigned long long*)nullptr, (uint32_t)kSlots);
             STORM_HIP_TRY(hipGetLastError());
         }
         n_total += l.n;

@@ -25,7 +25,7 @@ def orc():
 
 
 def _reset(ctx):
-    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", 0), ("k2_matrix_pad", -1), ("variant", -1)):
+    for k, v in (("k2_strip_operands", 0), ("k2_fold_inline", -1), ("k2_matrix_pad", -1), ("variant", -1)):
         ctx.set_option(k, v)
 
 
