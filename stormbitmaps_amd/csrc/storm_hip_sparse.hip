@@ -135,9 +135,10 @@ template <int kT>
 __global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SIMD: two workgroups of 1024 per CU)
     const uint32_t* __restrict__ elems, const uint16_t* __restrict__ pos16,
     const ProbeItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
-    unsigned long long* __restrict__ slots) {
+    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out, uint32_t fold_slots) {
     // two 16-bit counts per word: a group has at most kProbeRows = 128 rows
     __shared__ __attribute__((aligned(16))) uint32_t Cn32[(1u << kProbeOctBits) / 2u];
+    __shared__ unsigned long long fold_ws[2 * (kT / 64)];
     const ProbeItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kPosMask = (1u << kProbeOctBits) - 1u;
@@ -219,8 +220,51 @@ __global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SI
     uint64_t mine = count;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    if ((tid & 63u) == 0 && mine != 0)
-        atomicAdd(&slots[(blockIdx.x * 16u + (tid >> 6)) & (kSlots - 1)], (unsigned long long)mine);
+    if (out == nullptr) {   // another kernel of the pass adds into the slots too: a fold launch follows
+        if ((tid & 63u) == 0 && mine != 0)
+            atomicAdd(&slots[(blockIdx.x * 16u + (tid >> 6)) & (kSlots - 1)], (unsigned long long)mine);
+        return;
+    }
+    // ---- [r5] a pass of lists only, short launch: the fold inside the launch, as in strip16_bits_kernel — sum and ARRIVAL
+    //      of a wave in one fire-and-forget atomic (low 48 / high 16 bits of the slot word), the workgroup dispatched last
+    //      polls fold_slots slots (one per thread) until every wave of the grid has arrived, writes the total and leaves
+    //      the slots zeroed. At a few hundred positions per row a call is mostly launches: this removes one of two.
+    if ((tid & 63u) == 0)
+        atomicAdd(&slots[(blockIdx.x * (uint32_t)(kT / 64) + (tid >> 6)) & (fold_slots - 1u)],
+                  (unsigned long long)mine + (1ull << 48));
+    if (blockIdx.x != gridDim.x - 1u) return;
+    const unsigned long long expected = (unsigned long long)gridDim.x * (unsigned long long)(kT / 64);
+    unsigned long long total = 0;
+    for (;;) {
+        unsigned long long cnt = 0, sum = 0;
+        for (uint32_t i = tid; i < fold_slots; i += (uint32_t)kT) {
+            const unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt += v >> 48;
+            sum += v & ((1ull << 48) - 1ull);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_down(cnt, o, 64);
+            sum += __shfl_down(sum, o, 64);
+        }
+        __syncthreads();
+        if ((tid & 63u) == 0) {
+            fold_ws[tid >> 6] = cnt;
+            fold_ws[(kT / 64) + (tid >> 6)] = sum;
+        }
+        __syncthreads();
+        cnt = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kT / 64; ++w) {
+            cnt += fold_ws[w];
+            total += fold_ws[(kT / 64) + w];
+        }
+        if (cnt == expected) break;
+    }
+    for (uint32_t i = tid; i < fold_slots; i += (uint32_t)kT)
+        __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) out[0] = total;
 }
 
 // Pool rows of a probe column from its probe elements (ensure_full_pool): one workgroup per (column, octant)
@@ -1378,29 +1422,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                 s->probe_key = key;
             }
         }
-        if (s->n_probe_launch > 0) {
-            ctx->pass_report[0] |= STORM_HIP_RAN_LIST_PROBE;
-            ctx->pass_report[2] += s->probe_lookups_launch;
-            ctx->pass_report[3] = kProbeRows;
-            // Threads per workgroup by the length of the items (c4, ms per call at 104 / 524 / 1048 / 2097 / 5242 / 10485 /
-            // 20971 draws per row, one box, profiles/r04_h_sparse_probe.txt):
-            //     256 threads, 8 workgroups per CU   0.034 0.047 0.063 0.095 0.193 0.495 1.554
-            //     512, 4                             0.039 0.051 0.064 0.096 0.183 0.341 0.917
-            //    1024, 2                             0.055 0.065 0.078 0.106 0.189 0.328 0.664
-            // Short items are all fixed cost — the item record, the group's positions and the far positions are three
-            // dependent trips to memory, then the histogram — and what covers that is workgroups per CU; long ones want
-            // the workgroups of a CU in step on the same chunk of the stream (its L2 lines are read once per XCD).
-            const uint64_t per_item = s->probe_lookups_launch / s->n_probe_launch;
-            const int threads = per_item < 400000u ? 256 : per_item < 1500000u ? 512 : kProbeThreads;
-#define STORM_PROBE_LAUNCH(T)                                                                                          \
-    hipLaunchKernelGGL(probe_lists_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_elems,       \
-                       s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots)
-            if (threads == 256) STORM_PROBE_LAUNCH(256);
-            else if (threads == 512) STORM_PROBE_LAUNCH(512);
-            else STORM_PROBE_LAUNCH(kProbeThreads);
-#undef STORM_PROBE_LAUNCH
-            STORM_HIP_TRY(hipGetLastError());
-        }
+        bool probe_folds = false;
         std::vector<RowRange> ranges;
         uint64_t rows_needed = 0;
         for (size_t e = 0; e < s->cols.size(); ++e) {
@@ -1415,6 +1437,41 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
                 ranges.push_back(rg);
                 rows_needed = std::max(rows_needed, rg.r1);
             }
+        }
+        if (s->n_probe_launch > 0) {
+            ctx->pass_report[0] |= STORM_HIP_RAN_LIST_PROBE;
+            ctx->pass_report[2] += s->probe_lookups_launch;
+            ctx->pass_report[3] = kProbeRows;
+            // Threads per workgroup by the length of the items (c4, ms per call at 104 / 524 / 1048 / 2097 / 5242 / 10485 /
+            // 20971 draws per row, one box, profiles/r04_h_sparse_probe.txt):
+            //     256 threads, 8 workgroups per CU   0.034 0.047 0.063 0.095 0.193 0.495 1.554
+            //     512, 4                             0.039 0.051 0.064 0.096 0.183 0.341 0.917
+            //    1024, 2                             0.055 0.065 0.078 0.106 0.189 0.328 0.664
+            // Short items are all fixed cost — the item record, the group's positions and the far positions are three
+            // dependent trips to memory, then the histogram — and what covers that is workgroups per CU; long ones want
+            // the workgroups of a CU in step on the same chunk of the stream (its L2 lines are read once per XCD).
+            const uint64_t per_item = s->probe_lookups_launch / s->n_probe_launch;
+            const int threads = per_item < 400000u ? 256 : per_item < 1500000u ? 512 : kProbeThreads;
+            // lists only (no pool rows to multiply) and a short launch: the probe kernel folds inside the launch
+            // (option k2_fold_inline as for the strips; the slot words' 48-bit sums hold any total below 2^47 / 4096 x 256)
+            probe_folds = ranges.empty() && ctx->k2_fold_inline != 0 && s->n_probe_launch <= 16384u &&
+                          s->probe_lookups_launch < (1ull << 38);
+            unsigned long long* fold_out = probe_folds ? reinterpret_cast<unsigned long long*>(ctx->d_scalar) : nullptr;
+#define STORM_PROBE_LAUNCH(T)                                                                                          \
+    hipLaunchKernelGGL(probe_lists_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_elems,       \
+                       s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots, \
+                       fold_out, 256u)
+            if (threads == 256) STORM_PROBE_LAUNCH(256);
+            else if (threads == 512) STORM_PROBE_LAUNCH(512);
+            else STORM_PROBE_LAUNCH(kProbeThreads);
+#undef STORM_PROBE_LAUNCH
+            STORM_HIP_TRY(hipGetLastError());
+        }
+        if (probe_folds) {   // the total is in d_scalar already: nothing to multiply, nothing to fold
+            ctx->last_info[0] = 0;
+            ctx->last_info[3] = s->n_probe_cols_launch;
+            ctx->k2_operands_used = 5;
+            return STORM_HIP_OK;
         }
         if (rows_needed > s->pool_rows_ready)
             if (int rc = ensure_full_pool(ctx, s)) return rc;
