@@ -193,11 +193,16 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *        "k2_pitch_pad" (-1 = auto): extra bytes per shadow row; "k2_lds_pad": cap workgroups per CU;
  *        "k2_matrix_split" (1): cut the last round of matrix-output tiles along k;
  *        "k2_shape" (16): MFMA form of the default strips, 16 = 16x16x128, 32 = 32x32x64;
- *        "k2_strip_operands" (4): operands of the strips: 4 = FP4 shadow (expansion pass + strips), 1 = the
- *        bit matrix itself, inflated to FP4 in registers (no shadow; 6 % slower at the headline shape; set it
- *        before storm_hip_matrix_create so that the row pitch is padded for it);
- *        "k2_tile_shape" (2): materialised-output kernel: 2 / 1 = bit operands inflated to FP4 in
- *        registers (two / one wave per SIMD; no FP4 shadow), 16 / 32 = the FP4-shadow kernels;
+ *        "k2_strip_operands" (0): operands of the strips: 0 / 5 = the bit matrix itself, the FP4 image of every B
+ *        stage built in the LDS by the workgroup (K2b, the default); 4 = FP4 shadow (expansion pass + strips); 2 = one
+ *        stage stream per workgroup on bit operands (K2q); 1 / 3: tools build only;
+ *        "k2_tile_shape" (0): materialised-output kernel: 0 = by the matrix (5 for a dense matrix, 2 for the dense
+ *        replica of a sparse container); 5 = tilering_kernel: both operands as FP4 images built once per workgroup in the
+ *        LDS, 16x16x128 MFMAs, SIMD partners half a stage apart ("k2_ring_sync" (0): 0 = one barrier per stage, 1 = arrival
+ *        counters in the LDS); 2 / 1 = bit operands inflated to FP4 in registers, 32x32x64 MFMAs (two / one wave per SIMD);
+ *        3 / 4 = B as LDS images, A in registers; 16 / 32 = the FP4-shadow kernels (1, 16: tools build only);
+ *        "k2_fold_inline" (-1): the all-pairs total is folded inside the last kernel of the pass by the workgroup dispatched
+ *        last (-1: for short launches, where the fold launch and its gaps are a fifth of a pass; 1: always; 0: never);
  *        "k2_tile_cost_diag" (63), "k2_tile_cost_ragged" (30): percent of a full tile's time the
  *        planner assumes for diagonal / ragged-column tiles when it cuts the last round into k-parts;
  *        "k2_shadow_budget_mb" (98304): when the FP4 shadow (4 x the bits) of a matrix would exceed

@@ -652,8 +652,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
-        if (value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 0 (chosen by the matrix), 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
@@ -825,6 +825,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_shard_pairs")) return ctx->k2_shard_pairs;
     if (!strcmp(key, "k2_ring_sync")) return ctx->k2_ring_sync;
     if (!strcmp(key, "k2_tile_shape")) return ctx->k2_tile_shape;
+    if (!strcmp(key, "k2_tile_shape_used")) return ctx->k2_tile_shape_eff;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;
     if (!strcmp(key, "k2_shadow_budget_mb")) return ctx->k2_shadow_budget_mb;

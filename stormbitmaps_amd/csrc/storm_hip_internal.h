@@ -127,7 +127,8 @@ struct storm_hip_ctx_s {
     int k2_matrix_pad = -1;         // matrices created from now on: rows that are a multiple of 1 KiB get this many 512-byte chunks more of pitch (0: dense pitch; -1: by the pitch, pitch_pad_chunks)
     int k2_fold_inline = -1;        // K2b: the workgroup dispatched last folds the partial sums inside the launch: -1 = for short launches (<= 4096 workgroups, where the fold launch and its gaps are a fifth of a pass), 1 = always (level at N = 10000), 0 = never (a fold launch behind the strips); profiles/r05_c_fold_ab.jsonl
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
-    int k2_tile_shape = 2;  // write-mode tile kernel: 2 = bit operands inflated in registers, two waves per SIMD (tilebits8_kernel); 1 = the same, one wave per SIMD (tilebits_kernel); 16 = FP4 shadow, 16x16x128 MFMAs (tile16_fp4_kernel); 32 = pairw_fp4_kernel
+    int k2_tile_shape = 0;  // write-mode tile kernel: 0 = by the matrix (5 for a dense matrix, 2 for the dense replica of a sparse container: sparse operands let tilebits8_kernel, which sits at the socket's power cap, clock higher; crossover near 20 % density, profiles/r05_g_*); 5 = tilering_kernel (both operands as FP4 images in the LDS, 16x16x128); 2 = tilebits8_kernel (bit operands inflated in registers, 32x32x64); 3 / 4 = K2tb; 1 / 16 / 32: tools build
+    int k2_tile_shape_eff = 2;  // what the call in flight runs (set by launch_pairw_matrix / launch_square_matrix)
     int k2_ring_sync = 0;   // tilering_kernel: 0 = one s_barrier per stage; 1 = arrival counters in the LDS (waves may drift a stage apart; measured 2 % slower)
     int k2_ring_cost_diag = 78, k2_ring_cost_ragged = 40;  // the same for tilering_kernel (k2_tile_shape = 5)
     int k2_tile_cost_diag = 63, k2_tile_cost_ragged = 30;  // percent of a full tile (tilebits8_kernel): what the planner assumes when it cuts the last round
@@ -250,4 +251,5 @@ struct storm_hip_matrix_s {
     uint32_t n_words = 0;       // logical words per row
     uint64_t stride_words = 0;  // allocated words per row (multiple of kChunkWords)
     uint64_t generation = 0;    // changes with every mutation through the library (see "keep_shadow")
+    bool sparse_origin = false; // the dense replica of a sparse container (storm_hip_matrix_create_from_blocks): mostly zeros
 };

@@ -2746,28 +2746,28 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     if (plan.n_full < plan.n_items)
         hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
                            ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
-    if (bits && ctx->k2_tile_shape == 3 && timing_env()) {
+    if (bits && ctx->k2_tile_shape_eff == 3 && timing_env()) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile16_bits_kernel, kTiThreads, kTiLdsBytes);
         fprintf(stderr, "[tile16_bits_kernel] workgroups per CU by the runtime's occupancy query: %d (LDS %u B)\n", nb, kTiLdsBytes);
     }
-    if (bits && ctx->k2_tile_shape == 3)
+    if (bits && ctx->k2_tile_shape_eff == 3)
         hipLaunchKernelGGL(tile16_bits_kernel, dim3((plan.n_items + 7u) / 8u * 16u), dim3(kTiThreads), kTiLdsBytes, ctx->stream,
                            *bits, d_items, plan.n_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
-    else if (bits && ctx->k2_tile_shape == 4)
+    else if (bits && ctx->k2_tile_shape_eff == 4)
         hipLaunchKernelGGL(tile32_bits_kernel, dim3((plan.n_items + 7u) / 8u * 16u), dim3(kTiThreads), kTiLdsBytes, ctx->stream,
                            *bits, d_items, plan.n_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
-    else if (bits && ctx->k2_tile_shape == 5 && ctx->k2_ring_sync == 0)
+    else if (bits && ctx->k2_tile_shape_eff == 5 && ctx->k2_ring_sync == 0)
         hipLaunchKernelGGL(tilering_kernel<false>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
-    else if (bits && ctx->k2_tile_shape == 5)
+    else if (bits && ctx->k2_tile_shape_eff == 5)
         hipLaunchKernelGGL(tilering_kernel<true>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
-    else if (bits && ctx->k2_tile_shape == 2)
+    else if (bits && ctx->k2_tile_shape_eff == 2)
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
@@ -2776,7 +2776,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         hipLaunchKernelGGL(tilebits_kernel, dim3(plan.n_items), dim3(kTbThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
-    else if (ctx->k2_tile_shape == 16)
+    else if (ctx->k2_tile_shape_eff == 16)
         hipLaunchKernelGGL(tile16_fp4_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            ctx->d_x4, pitch, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base,
                            j_count, plan.n_full, i_lo, n_cols);
@@ -2827,11 +2827,12 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // band: only rows [band_row0, band_row0 + band_rows) of the triangle, written from output row 0
     const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
     if (band_row0 >= band_end) return STORM_HIP_OK;
+    ctx->k2_tile_shape_eff = ctx->k2_tile_shape ? ctx->k2_tile_shape : (m->sparse_origin ? 2 : 5);
     if (m->n_rows < 2) return STORM_HIP_OK;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;
     // bit-operand kernel: the operands are the matrix rows themselves (no shadow, no expansion)
-    const bool bits = ctx->k2_tile_shape <= 5;
+    const bool bits = ctx->k2_tile_shape_eff <= 5;
     const uint64_t pitch = bits ? m->stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const size_t x4_bytes = bits ? 0 : (size_t)n_rows4 * pitch;
     if (n_rows4 / kTile >= 65535) {
@@ -2877,10 +2878,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // 8 block pairs per SIMD; a ragged one ceil(columns / 64) of 4 blocks per wave, but not below the
     // inflation work of its A operands (measured: 0.3)
     std::vector<float> cost;
-    if (ctx->k2_tile_shape >= 2 && ctx->k2_tile_shape <= 5) {
+    if (ctx->k2_tile_shape_eff >= 2 && ctx->k2_tile_shape_eff <= 5) {
         // (tilering_kernel: a diagonal tile keeps its busiest SIMD at 12 of 16 block rows; a ragged column multiplies one
         //  block column in two of the eight waves but stores all of its images: options k2_ring_cost_*)
-        const bool ring = ctx->k2_tile_shape == 5;
+        const bool ring = ctx->k2_tile_shape_eff == 5;
         const float ragged_cost = ring ? std::max(ctx->k2_ring_cost_ragged / 100.0f, m->n_rows % kTile > 16 ? 1.0f : 0.0f)
                                        : std::max(ctx->k2_tile_cost_ragged / 100.0f, (float)((m->n_rows % kTile + 63) / 64) / 4.0f);
         for (const auto& t : tiles) {
@@ -2917,9 +2918,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
 int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                          const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld) {
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
+    ctx->k2_tile_shape_eff = ctx->k2_tile_shape ? ctx->k2_tile_shape : ((a->sparse_origin && b->sparse_origin) ? 2 : 5);
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
-    const bool bits = ctx->k2_tile_shape <= 5 && b->stride_words == stride_words;
+    const bool bits = ctx->k2_tile_shape_eff <= 5 && b->stride_words == stride_words;
     const uint64_t pitch = bits ? stride_words * 8 : shadow_pitch(ctx, row_bytes, false);
     const uint64_t rows_a = (a->n_rows + kTile - 1) / kTile * kTile;
     const uint64_t rows_b = (b->n_rows + kTile - 1) / kTile * kTile;
@@ -3407,6 +3409,13 @@ int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const 
     if (!ctx->copy_stream) STORM_HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->panel_lists) ctx->panel_lists = new std::vector<PanelList>();
     auto& lists = *static_cast<std::vector<PanelList>*>(ctx->panel_lists);
+    // The copies must not overtake what the context's stream still has to do to this matrix: storm_hip_matrix_create
+    // zero-fills a fresh allocation ASYNCHRONOUSLY there, storm_hip_matrix_resize clears the rows a shrinking matrix gives
+    // up (a first call on a new shape lost rows to that memset one time in six before this wait was here).
+    if (lists.empty()) lists.resize(1);
+    if (!lists[0].landed) STORM_HIP_TRY(hipEventCreateWithFlags(&lists[0].landed, hipEventDisableTiming));
+    STORM_HIP_TRY(hipEventRecord(lists[0].landed, ctx->stream));
+    STORM_HIP_TRY(hipStreamWaitEvent(ctx->copy_stream, lists[0].landed, 0));
     // Panels of equal size, at most 8 and at least 4 tiles each: the last panel's pairs (~ 2 / panels of the pass) are what
     // the copies cannot cover, and short panels cost every item its prologue and every copy its set-up (shrinking the last
     // panels to 4, 3 and 2 tiles changed nothing at the headline shape — 1.87 ms either way: the pageable copy itself,

@@ -1197,6 +1197,7 @@ int storm_hip_matrix_create_from_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, u
         }
         storm_hip_matrix_t* m = nullptr;
         if (int rc = storm_hip_matrix_create(ctx, n_rows, (max_id + 1u) * kBlockWords, &m)) return rc;
+        m->sparse_origin = true;   // (the output kernel is chosen by this: storm_hip_internal.h, k2_tile_shape)
         struct MatrixDeleter {
             storm_hip_ctx_t* ctx;
             void operator()(storm_hip_matrix_t* x) const { storm_hip_matrix_destroy(ctx, x); }

@@ -451,7 +451,7 @@ def test_materialised_output_kernels_agree_with_the_oracle(hip_ctx, orc, M, N, d
             m.pairw_matrix_band_device(band.data_ptr(), N, r0, nb, "xor")
             assert np.array_equal(band.cpu().numpy().astype(np.uint32), want["xor"][r0:r0 + nb]), shape
     finally:
-        hip_ctx.set_option("k2_tile_shape", 2)
+        hip_ctx.set_option("k2_tile_shape", 0)
         m.close()
 
 
@@ -472,7 +472,7 @@ def test_rectangle_output_on_bit_operands(hip_ctx, orc):
             want_x = orc.tile_counts_op(mat, 0, na, na, na + nbr, 2)
             assert np.array_equal(ma.square_matrix(mb, "xor"), want_x), (na, nbr)
         finally:
-            hip_ctx.set_option("k2_tile_shape", 2)
+            hip_ctx.set_option("k2_tile_shape", 0)
             ma.close()
             mb.close()
 

@@ -121,7 +121,7 @@ def test_per_pair_matrix_left_in_device_memory(orc):
             s.free()
             c.free()
     finally:
-        lib.STORM_hip_set_option(b"k2_tile_shape", 2)
+        lib.STORM_hip_set_option(b"k2_tile_shape", 0)
 
 
 def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc):
@@ -165,7 +165,7 @@ def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc
                 mb.close()
             m.close()
     finally:
-        hip_ctx.set_option("k2_tile_shape", 2)
+        hip_ctx.set_option("k2_tile_shape", 0)
         hip_ctx.set_option("k2_ring_sync", 0)
 
 

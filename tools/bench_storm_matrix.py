@@ -48,7 +48,7 @@ def main():
                 ts.append(time.perf_counter() - t0)
             dev_ms[shape] = round(min(ts) * 1e3, 2)
             same = same and int(dev.to(torch.int64).sum().item()) == total
-        sb.load().STORM_hip_set_option(b"k2_tile_shape", 2)
+        sb.load().STORM_hip_set_option(b"k2_tile_shape", 0)
         print(json.dumps({"rows": a.rows, "bits": a.bits, "draws": d, "first_call_ms": round(first * 1e3, 2),
                           "steady_ms": round(min(steady) * 1e3, 2), "output_mb": out.nbytes / 1e6,
                           "device_output_ms_tilebits8": dev_ms[2], "device_output_ms_tilering": dev_ms[5],
