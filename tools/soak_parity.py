@@ -31,7 +31,7 @@ def main():
     n_cases = 0
     kinds = {}
     while time.time() < t_end and n_cases < args.max_cases:
-        kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "sparse"])
+        kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "matrix_big", "wrapper", "sparse"])
         seed = int(rng.integers(1, 1 << 30))
         probes = ctx.get_option("probes_build") == 1   # the alternative kernel forms exist in the tools build only
         opts = {"variant": int(rng.choice([-1, -1, 4, 5 if probes else 4, 3, 2])),
@@ -41,10 +41,11 @@ def main():
                 "k2_persistent": int(rng.choice([0, 0, 1 if probes else 0])),
                 "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
                 "k2_shape": int(rng.choice([16, 16, 32 if probes else 16])),
-                "k2_tile_shape": int(rng.choice([2, 2, 1, 16, 32] if probes else [2, 2, 32])),
+                "k2_tile_shape": int(rng.choice([0, 5, 5, 2, 2, 1, 16, 32] if probes else [0, 5, 5, 2, 2, 3, 4, 32])),
+                "k2_ring_sync": int(rng.choice([0, 0, 1])),
                 "k2_strip_operands": int(rng.choice([0, 0, 5, 4, 1 if probes else 2, 2])),
                 "k2_matrix_pad": int(rng.choice([2, 2, 1, 0, 3])),
-                "k2_fold_inline": int(rng.choice([0, 0, 1])),
+                "k2_fold_inline": int(rng.choice([-1, -1, 0, 1])),
                 "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
                 "k2_stream_min_piece": int(rng.choice([6, 6, 1, 30])),
                 "k2_stream_min_run": int(rng.choice([2, 2, 1, 9])),
@@ -82,6 +83,39 @@ def main():
                     ma, mb = ctx.matrix_from_host(a), ctx.matrix_from_host(b)
                     ok = ma.square(mb) == orc.wrapper_square(a, b)
                     ma.close(); mb.close()
+            elif kind == "matrix_big":   # more tiles than CUs now and then: k-split last rounds, ragged edges, rectangle, bands
+                import torch
+                N = int(rng.integers(600, 5200))
+                M = int(rng.choice([640, 4096, 9000, 8192 + 512, 65536]))
+                d = int(max(1, M * rng.choice([0.5, 0.1, 0.02]) * rng.random()))
+                m = ctx.matrix(N, (M + 63) // 64)
+                m.fill_synthetic(M, d, seed=seed)
+                op = ["and", "or", "xor"][int(rng.integers(0, 3))]
+                out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+                m.pairw_matrix_device(out.data_ptr(), N, op)
+                got = out.to(torch.int64)
+                ok = int(torch.triu(got, diagonal=1).sum().item()) == m.pairw_op(op)
+                # a random window against the oracle
+                i0 = int(rng.integers(0, N - 40)); j0 = int(rng.integers(i0, N - 40))
+                sub_rows = m.download(0, N)
+                want = orc.tile_counts_op(sub_rows, i0, i0 + 40, j0, j0 + 40, ["and", "or", "xor"].index(op)).astype(np.int64)
+                win = got[i0:i0 + 40, j0:j0 + 40].cpu().numpy()
+                mask = (np.arange(i0, i0 + 40)[:, None] < np.arange(j0, j0 + 40)[None, :])
+                ok = ok and np.array_equal(win[mask], want[mask])
+                del out, got
+                m.close()
+            elif kind == "wrapper":      # the raw-buffer wrappers: rows streamed in panels on one device (storm.h context)
+                N = int(rng.integers(2, 6000))
+                M = int(rng.choice([64, 700, 4096, 20000]))
+                d = int(max(1, M * rng.choice([0.5, 0.05]) * rng.random()))
+                mat = synth.dense_matrix_c(M, N, d, seed=seed)
+                want = orc.wrapper_diag_blocked(mat, 31) if N <= 2500 else None
+                got = sb.wrapper_diag(mat)
+                if want is None:
+                    mm = ctx.matrix_from_host(mat)
+                    want = mm.column_identity()
+                    mm.close()
+                ok = got == want == sb.wrapper_diag_blocked(mat, 5)
             elif kind == "dense_big":
                 N = int(rng.integers(1500, 9000))
                 M = int(rng.choice([4096, 20000, 65536, 131072]))
@@ -132,7 +166,7 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 0, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 2, "k2_strip_operands": 0,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 0, "k2_ring_sync": 0, "k2_fold_inline": -1, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
