@@ -36,6 +36,7 @@ extern "C" {
 typedef struct storm_hip_ctx_s storm_hip_ctx_t;       /* one device + stream + workspace */
 typedef struct storm_hip_matrix_s storm_hip_matrix_t; /* dense bitmap matrix in HBM      */
 typedef struct storm_hip_sparse_s storm_hip_sparse_t; /* flattened STORM_t arena in HBM  */
+typedef struct storm_hip_rowlists_s storm_hip_rowlists_t; /* rows of a list-only STORM_t as window-ordered positions (K5) */
 
 /* ---- library / device ---- */
 const char* storm_hip_last_error(void);
@@ -310,6 +311,8 @@ typedef struct storm_hip_comm_s storm_hip_comm_t;
 #define STORM_HIP_RAN_BITSTREAM 8u  /* bitstream_kernel (K2q), bit operands               roof: FP4 matrix cores */
 #define STORM_HIP_RAN_BIT_STRIPS 16u /* strip16_bits_kernel (K2b), bit operands (default) roof: FP4 matrix cores */
 #define STORM_HIP_RAN_LIST_PROBE 32u /* probe_lists_kernel (K4), list x list blocks       roof: LDS lookups    */
+#define STORM_HIP_RAN_TILES_OUT 128u  /* tilering_kernel / tilebits8_kernel: per-pair output of a dense matrix (or replica) roof: FP4 matrix cores */
+#define STORM_HIP_RAN_LISTS_MATRIX 64u /* lists_matrix_kernel (K5), per-pair output from the lists: out[2] = its table lookups, out[3] = 64 */
 int storm_hip_last_pass_report(storm_hip_ctx_t* ctx, uint64_t out[4]);
 
 int storm_hip_comm_unique_id(uint8_t id[STORM_HIP_COMM_ID_BYTES]);
@@ -362,6 +365,26 @@ int storm_hip_matrix_create_from_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, u
                                         const uint8_t* block_kind, const uint32_t* block_n,
                                         const void* const* block_ptr, storm_hip_matrix_t** out);
 void storm_hip_sparse_destroy(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s);
+/* [r5] K5 — the per-pair matrix of a LIST-ONLY container straight from its lists (replaces, for every pair at once,
+ * STORM_bitmap_cont_intersect_cardinality, storm.c:790-814, with two list blocks meeting in
+ * STORM_intersect_vector16_cardinality, storm.c:4-73). Same block description as storm_hip_sparse_create_blocks.
+ * *out stays NULL (and the call returns STORM_HIP_OK) when the container is not eligible — a bitmap block, a row of
+ * more than 65535 positions, more than 2^26 positions in all: the dense replica (storm_hip_matrix_create_from_blocks)
+ * is the path then. _worthwhile: 1 when the lists are expected to beat the dense replica's multiply (l = NULL: 1 unless the
+ * path is switched off, i.e. whether building the lists is worth a try; option
+ * `matrix_lists`: -1 by density, 0 never, 1 whenever eligible; `matrix_lists_density`: the crossover in 1/10000).
+ * _pairw_matrix_device: out[i * ld + j] = popcount(row_i OP row_j) for i < j, device memory, complete on return;
+ * entries i >= j are not written. */
+int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                     const uint64_t* row_block_offset, const uint32_t* block_id,
+                                     const uint8_t* block_kind, const uint32_t* block_n,
+                                     const void* const* block_ptr, storm_hip_rowlists_t** out);
+void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l);
+int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l);
+int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
+                                           uint32_t* d_out, uint64_t ld);
+uint64_t storm_hip_rowlists_n_elems(const storm_hip_rowlists_t* l);
+
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,
                            uint32_t shard_rank, uint32_t shard_count, uint64_t* h_total);
 /* split form (one host thread, one arena replica per GPU): _begin launches this shard into the

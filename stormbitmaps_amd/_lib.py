@@ -86,6 +86,11 @@ SIGNATURES = {
     "storm_hip_sparse_create_serialized": (C.c_int, [vp, vp, u64, P(vp)]),
     "storm_hip_sparse_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_matrix_create_from_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
+    "storm_hip_rowlists_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
+    "storm_hip_rowlists_destroy": (None, [vp, vp]),
+    "storm_hip_rowlists_worthwhile": (C.c_int, [vp, vp]),
+    "storm_hip_rowlists_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
+    "storm_hip_rowlists_n_elems": (u64, [vp]),
     "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),
     "storm_hip_sparse_last_census": (C.c_int, [vp, P(u64 * 4)]),

@@ -612,6 +612,18 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->sparse_probe = (int)value;
+    } else if (!strcmp(key, "matrix_lists")) {
+        if (value < -1 || value > 1) {
+            set_error("matrix_lists must be -1 (by density), 0 (never) or 1 (whenever eligible)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->matrix_lists = (int)value;
+    } else if (!strcmp(key, "matrix_lists_density")) {
+        if (value < 0 || value > 10000) {
+            set_error("matrix_lists_density: 0 .. 10000 (1/10000 of the dense replica's bits)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->matrix_lists_permille_x10 = (int)value;
     } else if (!strcmp(key, "seg_rows")) {
         if (value < 1 || value > (1 << 20)) {
             set_error("seg_rows out of range");
@@ -813,6 +825,8 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "variant")) return ctx->variant;
     if (!strcmp(key, "variant_used")) return ctx->variant_used;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
+    if (!strcmp(key, "matrix_lists")) return ctx->matrix_lists;
+    if (!strcmp(key, "matrix_lists_density")) return ctx->matrix_lists_permille_x10;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
     if (!strcmp(key, "k2_stages_per_item")) return ctx->k2_stages_per_item;
     if (!strcmp(key, "k2_max_run")) return ctx->k2_max_run;

@@ -94,6 +94,8 @@ struct storm_hip_ctx_s {
     int variant = -1;       // -1 auto, 0/1/2 popcount kernel (B path), 3 MFMA tiles, 4 MFMA strips
     int variant_used = 2;   // what the last dense launch ran
     int sparse_probe = -1;  // sparse container: list-probe kernel for columns of short lists (-1 auto, 0 never, 1 always)
+    int matrix_lists = -1;  // per-pair matrix of a list-only sparse container from its lists (K5, storm_hip_lists.hip): -1 by density, 0 never, 1 whenever eligible
+    int matrix_lists_permille_x10 = 50;  // ... the crossover density in 1/10000 of the dense replica's bits
     int seg_rows = 256;
     int chunks_per_item = 0;
     // info of the last dense launch

@@ -2828,6 +2828,9 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
     if (band_row0 >= band_end) return STORM_HIP_OK;
     ctx->k2_tile_shape_eff = ctx->k2_tile_shape ? ctx->k2_tile_shape : (m->sparse_origin ? 2 : 5);
+    ctx->pass_report[0] = STORM_HIP_RAN_TILES_OUT;   // (a report of its own: the per-pair output is no all-pairs pass)
+    ctx->pass_report[1] = m->n_rows * (m->n_rows - (m->n_rows != 0)) / 2 * m->n_words;
+    ctx->pass_report[2] = ctx->pass_report[3] = 0;
     if (m->n_rows < 2) return STORM_HIP_OK;
     const uint64_t n_rows4 = (m->n_rows + kStripATile - 1) / kStripATile * kStripATile;
     const uint64_t row_bytes = m->stride_words * 32;

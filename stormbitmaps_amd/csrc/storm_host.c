@@ -1658,7 +1658,9 @@ STORM_t* STORM_new() { return (STORM_t*)calloc(1, sizeof(STORM_t)); }
 typedef struct {
     storm_hip_sparse_t* a[MAX_DEVICES];
     storm_hip_matrix_t* m[MAX_DEVICES];
+    storm_hip_rowlists_t* l[MAX_DEVICES]; /* [r5] a list-only container's rows as window-ordered positions (K5) */
     int have_arena, have_dense;
+    int have_lists; /* 0 not tried, 1 built (on every slot of the view), -1 not eligible */
 } sparse_state_t;
 
 static void storm_drop_device(STORM_t* h) {
@@ -1667,6 +1669,7 @@ static void storm_drop_device(STORM_t* h) {
         for (int d = 0; d < MAX_DEVICES; ++d) {
             if (st->a[d]) storm_hip_sparse_destroy(g_ctx[d], st->a[d]);
             if (st->m[d]) storm_hip_matrix_destroy(g_ctx[d], st->m[d]);
+            if (st->l[d]) storm_hip_rowlists_destroy(g_ctx[d], st->l[d]);
         }
         free(st);
         h->hip_arena = NULL;
@@ -2033,7 +2036,7 @@ static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
     uint8_t* kinds = (uint8_t*)malloc(n_blocks + 1);
     uint32_t* lens = (uint32_t*)malloc((n_blocks + 1) * sizeof(uint32_t));
     const void** ptrs = (const void**)malloc((n_blocks + 1) * sizeof(void*));
-    int rc = -1;
+    int rc = -1, not_eligible = 0;
     if (row_off && ids && kinds && lens && ptrs) {
         uint64_t nb = 0;
         for (uint32_t i = 0; i < h->n_conts; ++i) {
@@ -2051,27 +2054,35 @@ static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
         for (int d = V0; d < V1 && rc == 0; ++d) {
             storm_hip_ctx_t* ctx = device_ctx(d);
             const int r = !ctx ? -1
+                          : dense == 2 ? storm_hip_rowlists_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
+                                                                          lens, ptrs, &st->l[d])
                           : dense ? storm_hip_matrix_create_from_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
                                                                         lens, ptrs, &st->m[d])
                                   : storm_hip_sparse_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds, lens,
                                                                    ptrs, &st->a[d]);
             if (r != STORM_HIP_OK) {
-                device_error(dense ? "storm_hip_matrix_create_from_blocks" : "storm_hip_sparse_create_blocks");
+                device_error(dense == 2 ? "storm_hip_rowlists_create_blocks"
+                             : dense    ? "storm_hip_matrix_create_from_blocks"
+                                        : "storm_hip_sparse_create_blocks");
                 rc = -1;
             }
+            if (dense == 2 && rc == 0 && !st->l[d]) not_eligible = 1; /* (the same answer on every slot) */
         }
     } else {
         host_error("STORM_t device state: out of host memory");
     }
     free(row_off); free(ids); free(kinds); free(lens); free((void*)ptrs);
-    if (rc == 0) {
-        if (dense) st->have_dense = 1;
+    if (rc == 0 && !(dense == 2 && not_eligible)) {
+        if (dense == 2) st->have_lists = 1;
+        else if (dense) st->have_dense = 1;
         else st->have_arena = 1;
     } else {
         for (int d = 0; d < MAX_DEVICES; ++d) {
             if (!dense && st->a[d]) { storm_hip_sparse_destroy(g_ctx[d], st->a[d]); st->a[d] = NULL; }
-            if (dense && st->m[d]) { storm_hip_matrix_destroy(g_ctx[d], st->m[d]); st->m[d] = NULL; }
+            if (dense == 1 && st->m[d]) { storm_hip_matrix_destroy(g_ctx[d], st->m[d]); st->m[d] = NULL; }
+            if (dense == 2 && st->l[d]) { storm_hip_rowlists_destroy(g_ctx[d], st->l[d]); st->l[d] = NULL; }
         }
+        if (dense == 2 && rc == 0) st->have_lists = -1;
     }
     return rc;
 }
@@ -2210,10 +2221,24 @@ int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_
             }
             if (!rc) h->hip_epoch = epoch;
         }
-        if (!rc && !st->have_dense && storm_build_device(h, st, 1)) rc = -3;
-        if (!rc && storm_hip_pairw_matrix_device(g_ctx[V0], st->m[V0], op, d_out, out_ld) != STORM_HIP_OK) {
-            device_error("storm_hip_pairw_matrix_device");
-            rc = -3;
+        /* [r5] a list-only container that is sparse enough: straight from the lists (K5, storm_hip_lists.hip) — no dense
+         * replica is built at all then */
+        int from_lists = 0;
+        if (!rc && (op == 0 || op == 1 || op == 2) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL)) { /* (NULL: are the lists switched on at all) */
+            if (st->have_lists == 0 && storm_build_device(h, st, 2)) rc = -3;
+            from_lists = !rc && st->have_lists == 1 && storm_hip_rowlists_worthwhile(g_ctx[V0], st->l[V0]);
+        }
+        if (!rc && from_lists) {
+            if (storm_hip_rowlists_pairw_matrix_device(g_ctx[V0], st->l[V0], op, d_out, out_ld) != STORM_HIP_OK) {
+                device_error("storm_hip_rowlists_pairw_matrix_device");
+                rc = -3;
+            }
+        } else {
+            if (!rc && !st->have_dense && storm_build_device(h, st, 1)) rc = -3;
+            if (!rc && storm_hip_pairw_matrix_device(g_ctx[V0], st->m[V0], op, d_out, out_ld) != STORM_HIP_OK) {
+                device_error("storm_hip_pairw_matrix_device");
+                rc = -3;
+            }
         }
     }
     device_unlock();

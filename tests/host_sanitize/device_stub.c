@@ -256,3 +256,19 @@ int storm_hip_comm_allreduce_u64s(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm, 
     return STORM_HIP_OK;
 }
 void storm_hip_comm_destroy(storm_hip_comm_t* comm) { free(comm); }
+
+/* K5 (storm_hip_lists.hip): the stub never finds a container eligible, so the host takes the dense replica's path */
+int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                     const uint64_t* row_block_offset, const uint32_t* block_id,
+                                     const uint8_t* block_kind, const uint32_t* block_n,
+                                     const void* const* block_ptr, storm_hip_rowlists_t** out) {
+    (void)ctx; (void)n_rows; (void)n_blocks; (void)row_block_offset; (void)block_id; (void)block_kind; (void)block_n; (void)block_ptr;
+    *out = NULL;
+    return STORM_HIP_OK;
+}
+void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l) { (void)ctx; (void)l; }
+int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l) { (void)ctx; return l == NULL; }
+int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* d_out, uint64_t ld) {
+    (void)ctx; (void)l; (void)op; (void)d_out; (void)ld;
+    return STORM_HIP_EINVAL;
+}
