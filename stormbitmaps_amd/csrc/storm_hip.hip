@@ -618,6 +618,20 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->matrix_lists = (int)value;
+    } else if (!strcmp(key, "matrix_lists_kernel")) {
+        if (value < 0 || value > 2) {
+            set_error("matrix_lists_kernel: 0 (by the row length), 1 (window kernel) or 2 (hash kernel)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->matrix_lists_kernel = (int)value;
+    } else if (!strcmp(key, "matrix_lists_hash_min_log2")) {
+        if (value < 3 || value > 7) {
+            set_error("matrix_lists_hash_min_log2: 3 .. 7");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->matrix_lists_hash_min_log2 = (int)value;
+    } else if (!strcmp(key, "matrix_lists_debug")) {
+        ctx->matrix_lists_debug = (int)value;
     } else if (!strcmp(key, "matrix_lists_density")) {
         if (value < 0 || value > 10000) {
             set_error("matrix_lists_density: 0 .. 10000 (1/10000 of the dense replica's bits)");

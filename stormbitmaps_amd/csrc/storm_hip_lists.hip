@@ -74,11 +74,12 @@ struct LmWin { uint32_t ab, ae, fb, fe; bool ok; };
 __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     const uint32_t* __restrict__ elems, const uint32_t* __restrict__ off, uint32_t n_windows,
     const uint32_t* __restrict__ rowlen, const LmItem* __restrict__ items, uint32_t n_rows, int op,
-    uint32_t* __restrict__ out, uint64_t ld) {
+    uint32_t* __restrict__ out, uint64_t ld, uint32_t dbg) {
     __shared__ __attribute__((aligned(16))) uint32_t table[kLmTableBytes / 4u];   // [position][plane][2 words]
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kLmCountBytes / 4u];     // [a][j / 2]: two 16-bit counters per word
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const LmItem it = items[blockIdx.x];
+    if (it.gi == 0xffffffffu) return;   // (a filler: see the item order)
     for (uint32_t w = tid * 4u; w < kLmTableBytes / 4u; w += (uint32_t)kLmThreads * 4u)
         *reinterpret_cast<uint4*>(&table[w]) = uint4{0u, 0u, 0u, 0u};
     for (uint32_t w = tid * 4u; w < kLmCountBytes / 4u; w += (uint32_t)kLmThreads * 4u)
@@ -115,45 +116,244 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
             load_windows();
         }
     };
-    auto toggle = [&](uint32_t b, uint32_t e, uint32_t plane) {
-        for (uint32_t i = b + tid; i < e; i += (uint32_t)kLmThreads) {
-            const uint32_t v = elems[i];
+    // Elements travel in registers: the far elements of a step (the first kFarRegs per thread) are loaded one step before
+    // they are looked up, the A elements (kARegs per thread) two steps before they are toggled in, and stay until they have
+    // been toggled out; kInvalid beyond a range. History (profiles/r05_j_lists_matrix_ablation.jsonl): loads where they
+    // are used, 1024 threads: 1.34 ms at 524 positions per row (a round trip to the L2 per step, every wave waiting);
+    // loads a step early: 1.10 — the step loop WITHOUT any element, barrier or store still takes 0.71 ms (195 000 steps of
+    // ~130 vector instructions on sixteen waves: the CU's instruction issue), and four waves that carry four times as much
+    // each are slower still (3.1 ms: one wave per SIMD covers no latency). The steps are the cost of this formulation:
+    // lists_hash_kernel below has none and takes over where the rows are short.
+    constexpr uint32_t kInvalid = 0xffffffffu;
+    constexpr uint32_t kFarRegs = 4u;
+    constexpr uint32_t kARegs = 1u;
+    constexpr uint32_t kBatch = 8u;      // loads in flight per thread in the remainder loops
+    constexpr uint32_t kT = (uint32_t)kLmThreads;
+    auto toggle1 = [&](uint32_t v, uint32_t plane) {
+        if (v != kInvalid) {
             const uint32_t a = (v >> kLmWinBits) & (kLmGroup - 1u), p = v & (kLmWin - 1u);
             atomicXor(&table[p * 4u + plane * 2u + (a >> 5)], 1u << (a & 31u));
         }
     };
-    auto lookup = [&](uint32_t b, uint32_t e, uint32_t plane) {
-        for (uint32_t i = b + tid; i < e; i += (uint32_t)kLmThreads) {
-            const uint32_t v = elems[i];
-            const uint32_t j = (v >> kLmWinBits) & (kLmChunk - 1u), p = v & (kLmWin - 1u);
-            const uint2 m = *reinterpret_cast<const uint2*>(&table[p * 4u + plane * 2u]);
-            const uint32_t inc = 1u << (16u * (j & 1u));
-            for (uint32_t x = m.x; x; x &= x - 1u)
-                atomicAdd(&cnt[((uint32_t)__builtin_ctz(x) * kLmChunk + j) >> 1], inc);
-            for (uint32_t x = m.y; x; x &= x - 1u)
-                atomicAdd(&cnt[((32u + (uint32_t)__builtin_ctz(x)) * kLmChunk + j) >> 1], inc);
+    auto count_bits = [&](uint32_t v, uint2 m) {
+        const uint32_t j = (v >> kLmWinBits) & (kLmChunk - 1u);
+        const uint32_t inc = 1u << (16u * (j & 1u));
+        for (uint32_t x = m.x; x; x &= x - 1u)
+            atomicAdd(&cnt[((uint32_t)__builtin_ctz(x) * kLmChunk + j) >> 1], inc);
+        for (uint32_t x = m.y; x; x &= x - 1u)
+            atomicAdd(&cnt[((32u + (uint32_t)__builtin_ctz(x)) * kLmChunk + j) >> 1], inc);
+    };
+    // the masks of a batch are read together (one LDS round trip per batch, not per element); an invalid element reads
+    // entry 0 and drops what it gets
+    auto lookup_batch = [&](const uint32_t* v, uint32_t n, uint32_t plane) {
+        uint2 m[kFarRegs];
+#pragma unroll
+        for (uint32_t q = 0; q < kFarRegs; ++q)
+            if (q < n) m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 4u + plane * 2u]);
+#pragma unroll
+        for (uint32_t q = 0; q < kFarRegs; ++q)
+            if (q < n && v[q] != kInvalid && (m[q].x | m[q].y)) count_bits(v[q], m[q]);
+    };
+    auto load_at = [&](uint32_t i, uint32_t e) -> uint32_t { return (i < e && !(dbg & 1u)) ? elems[i] : kInvalid; };
+    // the elements of [b, e) from the `skip`-th per thread on, kBatch loads in flight
+    auto toggle_rest = [&](uint32_t b, uint32_t e, uint32_t skip, uint32_t plane) {
+        for (uint32_t i = b + tid + skip * kT; i < e; i += kBatch * kT) {
+            uint32_t v[kBatch];
+#pragma unroll
+            for (uint32_t q = 0; q < kBatch; ++q) v[q] = load_at(i + q * kT, e);
+#pragma unroll
+            for (uint32_t q = 0; q < kBatch; ++q) toggle1(v[q], plane);
         }
     };
+    auto lookup_rest = [&](uint32_t b, uint32_t e, uint32_t skip, uint32_t plane) {
+        for (uint32_t i = b + tid + skip * kT; i < e; i += kFarRegs * kT) {
+            uint32_t v[kFarRegs];
+#pragma unroll
+            for (uint32_t q = 0; q < kFarRegs; ++q) v[q] = load_at(i + q * kT, e);
+            lookup_batch(v, kFarRegs, plane);
+        }
+    };
+    // (a barrier for the LDS alone: __syncthreads() also waits for every global load in flight — the loads that were
+    //  issued a step early precisely so that nobody waits for them)
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(dbg & 4u)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
 
+    // Step k multiplies window w[k]: its far elements and the A elements of w[k + 1] were loaded during step k - 1, the A
+    // elements of w[k - 1] are still in their registers from when they were toggled in; the step itself loads the far
+    // elements of w[k + 1] and the A elements of w[k + 2].
     load_windows();
-    LmWin nxt = next_window();
-    __syncthreads();   // the zeroed table
-    if (nxt.ok) toggle(nxt.ab, nxt.ae, 0u);
-    __syncthreads();
-    LmWin prv{0u, 0u, 0u, 0u, false};
-    for (uint32_t k = 0; nxt.ok; ++k) {
-        const LmWin cur = nxt;
-        nxt = next_window();
-        lookup(cur.fb, cur.fe, k & 1u);
-        if (prv.ok) toggle(prv.ab, prv.ae, (k + 1u) & 1u);   // out of the plane the next window takes ...
-        if (nxt.ok) toggle(nxt.ab, nxt.ae, (k + 1u) & 1u);   // ... and the next window in (XOR both: any order)
-        __syncthreads();
-        prv = cur;
+    LmWin w0 = next_window(), w1 = next_window(), w2 = next_window();
+    uint32_t a_prev[kARegs], a_cur[kARegs], a_next[kARegs], a_next2[kARegs];
+    uint32_t f_cur[kFarRegs], f_next[kFarRegs];
+#pragma unroll
+    for (uint32_t q = 0; q < kARegs; ++q) {
+        a_prev[q] = kInvalid;
+        a_next2[q] = kInvalid;
+        a_cur[q] = w0.ok ? load_at(w0.ab + tid + q * kT, w0.ae) : kInvalid;
+        a_next[q] = w1.ok ? load_at(w1.ab + tid + q * kT, w1.ae) : kInvalid;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < kFarRegs; ++q) {
+        f_cur[q] = w0.ok ? load_at(w0.fb + tid + q * kT, w0.fe) : kInvalid;
+        f_next[q] = kInvalid;
+    }
+    lds_barrier();   // the zeroed table
+#pragma unroll
+    for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_cur[q], 0u);
+    if (w0.ok && w0.ae - w0.ab > kARegs * kT) toggle_rest(w0.ab, w0.ae, kARegs, 0u);
+    lds_barrier();
+    LmWin wp{0u, 0u, 0u, 0u, false};
+    uint32_t k = 0;
+    // One step. The registers a step LOADS and the ones it CONSUMES swap roles from step to step: the loop below is unrolled
+    // twice over the two namings, so that no register is ever copied while its load is in flight (a copy is a use: a version
+    // that rotated the names with v_mov at the end of a step waited there for every load it had just issued).
+    auto step = [&](uint32_t (&fc)[kFarRegs], uint32_t (&fn)[kFarRegs], uint32_t (&an)[kARegs], uint32_t (&an2)[kARegs]) {
+        const uint32_t plane = k & 1u, other = plane ^ 1u;
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) an2[q] = w2.ok ? load_at(w2.ab + tid + q * kT, w2.ae) : kInvalid;
+#pragma unroll
+        for (uint32_t q = 0; q < kFarRegs; ++q) fn[q] = w1.ok ? load_at(w1.fb + tid + q * kT, w1.fe) : kInvalid;
+        lookup_batch(fc, kFarRegs, plane);
+        if (w0.fe - w0.fb > kFarRegs * kT) lookup_rest(w0.fb, w0.fe, kFarRegs, plane);
+        // window k - 1 out of the plane window k + 1 takes, window k + 1 in: both XOR, any order
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_prev[q], other);
+        if (wp.ok && wp.ae - wp.ab > kARegs * kT) toggle_rest(wp.ab, wp.ae, kARegs, other);
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) toggle1(an[q], other);
+        if (w1.ok && w1.ae - w1.ab > kARegs * kT) toggle_rest(w1.ab, w1.ae, kARegs, other);
+        lds_barrier();
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) {   // (all long since loaded)
+            a_prev[q] = a_cur[q];
+            a_cur[q] = an[q];
+        }
+        wp = w0; w0 = w1; w1 = w2;
+        w2 = next_window();
+        ++k;
+    };
+    while (w0.ok && !(dbg & 16u)) {
+        step(f_cur, f_next, a_next, a_next2);
+        if (!w0.ok) break;
+        step(f_next, f_cur, a_next2, a_next);
     }
     // the tile: rows gi * 64 + a, columns cj * 256 + j, strict upper part
     const uint32_t row0 = it.gi * kLmGroup, col0 = it.cj * kLmChunk;
     for (uint32_t idx = tid; idx < kLmGroup * kLmChunk; idx += (uint32_t)kLmThreads) {
         const uint32_t a = idx / kLmChunk, j = idx % kLmChunk;
+        const uint32_t row = row0 + a, col = col0 + j;
+        if (row < n_rows && col < n_rows && col > row && !(dbg & 8u)) {
+            uint32_t c = (cnt[idx >> 1] >> (16u * (j & 1u))) & 0xffffu;
+            if (op == STORM_HIP_OP_OR) c = rowlen[row] + rowlen[col] - c;
+            else if (op == STORM_HIP_OP_XOR) c = rowlen[row] + rowlen[col] - 2u * c;
+            out[(uint64_t)row * ld + col] = c;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// K5h — the same join with a HASH table instead of a direct-indexed one: no windows, no steps.
+//   data   : the rows as they are — `pos`: every row's positions, row after row (CSR, `row_off`); `rtag`: row & 2047 per
+//            element, so that a flat stream of elements knows its rows.
+//   item   : group gi of G rows (G = 64 / 32 / 16 / 8: the largest whose every group lists at most kLhFill positions) x
+//            chunk cj of F = 16384 / G rows. One workgroup of 1024 threads.
+//   LDS    : open-addressing table of 8192 buckets of four 32-bit entries, position << 6 | row in group (128 KiB;
+//            multiplicative hash, overflow into the next bucket; at most 0.375 full); counters[G][F] of 16 bits (32 KiB).
+//   work   : build the table from the group's elements (LDS compare-and-swap), then stream the chunk's elements —
+//            contiguous in memory, eight loads in flight per thread — and read every element's home bucket (one
+//            ds_read_b128): an entry with the same position is one intersecting position of one row pair.
+//            Lookups = N / G x elements / 2; G falls with the row length, so the work grows with
+//            the SQUARE of the density: this is the kernel of the sparse end, the window kernel above that of the middle.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kLhThreads = 1024;
+constexpr uint32_t kLhSlots = 32768u;
+constexpr uint32_t kLhEmpty = 0xffffffffu;
+constexpr uint32_t kLhCounters = 16384u;     // G x F
+constexpr uint32_t kLhFill = 12288u;         // elements of a group at most
+constexpr uint32_t kLhRowBits = 6u;          // row in group: G <= 64
+constexpr uint32_t kLhMaxPos = (1u << (32u - kLhRowBits)) - 2u;
+
+constexpr uint32_t kLhBuckets = kLhSlots / 4u;   // of four entries
+__device__ __forceinline__ uint32_t lh_hash(uint32_t pos) { return (pos * 0x9E3779B1u) >> 19; }   // home bucket: 13 bits
+
+__global__ __launch_bounds__(kLhThreads, 1) void lists_hash_kernel(
+    const uint32_t* __restrict__ pos, const uint16_t* __restrict__ rtag, const uint32_t* __restrict__ row_off,
+    const uint32_t* __restrict__ rowlen, const LmItem* __restrict__ items, uint32_t n_rows, uint32_t g_log2, int op,
+    uint32_t* __restrict__ out, uint64_t ld, uint32_t dbg) {
+    __shared__ __attribute__((aligned(16))) uint32_t table[kLhSlots];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[kLhCounters / 2u];
+    const uint32_t tid = threadIdx.x;
+    const LmItem it = items[blockIdx.x];
+    if (it.gi == 0xffffffffu) return;
+    const uint32_t G = 1u << g_log2, f_log2 = 14u - g_log2, F = 1u << f_log2;
+    for (uint32_t w = tid * 4u; w < kLhSlots; w += (uint32_t)kLhThreads * 4u)
+        *reinterpret_cast<uint4*>(&table[w]) = uint4{kLhEmpty, kLhEmpty, kLhEmpty, kLhEmpty};
+    for (uint32_t w = tid * 4u; w < kLhCounters / 2u; w += (uint32_t)kLhThreads * 4u)
+        *reinterpret_cast<uint4*>(&cnt[w]) = uint4{0u, 0u, 0u, 0u};
+    const uint32_t row0 = it.gi << g_log2, row1 = min(n_rows, row0 + G);
+    const uint32_t col0 = it.cj << f_log2, col1 = min(n_rows, col0 + F);
+    const uint32_t a_b = row_off[row0], a_e = row_off[row1], f_b = row_off[col0], f_e = row_off[col1];
+    __syncthreads();
+    // Buckets of four entries (16 bytes): an element goes into the first free slot of its home bucket, or of the next
+    // one that has any; entries are never removed, so the used slots of a bucket are a prefix and the first empty slot
+    // ends a search. At most 0.375 full, a lookup reads ONE bucket in 97 % of the cases. (The first version probed slot
+    // by slot: a wave walks until the longest of its 64 chains ends — 0.83 ms at 190 positions per row where this
+    // takes 0.3, profiles/r05_j_*.)
+    for (uint32_t e = a_b + tid; e < a_e; e += (uint32_t)kLhThreads) {
+        const uint32_t p = pos[e];
+        const uint32_t entry = (p << kLhRowBits) | ((uint32_t)rtag[e] & (G - 1u));
+        uint32_t b = lh_hash(p);
+        for (bool placed = false; !placed; b = (b + 1u) & (kLhBuckets - 1u))
+#pragma unroll
+            for (uint32_t s4 = 0; s4 < 4u && !placed; ++s4)
+                placed = atomicCAS(&table[b * 4u + s4], kLhEmpty, entry) == kLhEmpty;
+    }
+    __syncthreads();
+    constexpr uint32_t kBatch = 8u;
+    for (uint32_t e = f_b + tid; e < f_e; e += kBatch * (uint32_t)kLhThreads) {
+        uint32_t p[kBatch], j[kBatch];
+#pragma unroll
+        for (uint32_t q = 0; q < kBatch; ++q) {
+            const uint32_t i = e + q * (uint32_t)kLhThreads;
+            p[q] = (i < f_e && !(dbg & 1u)) ? pos[i] : kLhEmpty;
+            j[q] = (i < f_e && !(dbg & 1u)) ? (uint32_t)rtag[i] & (F - 1u) : 0u;
+        }
+        if (dbg & 2u) {   // (timing: the stream alone)
+            uint32_t acc = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < kBatch; ++q) acc += p[q] + j[q];
+            if (acc == 0x12345u) cnt[0] = acc;
+            continue;
+        }
+        uint4 v[kBatch];
+#pragma unroll
+        for (uint32_t q = 0; q < kBatch; ++q)   // (an element beyond the stream reads bucket 0 and matches nothing: no key is kLhEmpty >> 6)
+            v[q] = *reinterpret_cast<const uint4*>(&table[(p[q] == kLhEmpty ? 0u : lh_hash(p[q])) * 4u]);
+#pragma unroll
+        for (uint32_t q = 0; q < kBatch; ++q) {
+            const uint32_t inc = 1u << (16u * (j[q] & 1u));
+            const uint32_t key = p[q];
+            auto hit = [&](uint32_t entry) {
+                if ((entry >> kLhRowBits) == key && entry != kLhEmpty)
+                    atomicAdd(&cnt[(((entry & (G - 1u)) << f_log2) + j[q]) >> 1], inc);
+            };
+            hit(v[q].x); hit(v[q].y); hit(v[q].z); hit(v[q].w);
+            if (v[q].w != kLhEmpty && key != kLhEmpty) {   // a full bucket: the search goes on (rare)
+                for (uint32_t b = (lh_hash(key) + 1u) & (kLhBuckets - 1u);; b = (b + 1u) & (kLhBuckets - 1u)) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(&table[b * 4u]);
+                    hit(u.x); hit(u.y); hit(u.z); hit(u.w);
+                    if (u.w == kLhEmpty) break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < kLhCounters; idx += (uint32_t)kLhThreads) {
+        const uint32_t a = idx >> f_log2, j = idx & (F - 1u);
         const uint32_t row = row0 + a, col = col0 + j;
         if (row < n_rows && col < n_rows && col > row) {
             uint32_t c = (cnt[idx >> 1] >> (16u * (j & 1u))) & 0xffffu;
@@ -162,6 +362,31 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
             out[(uint64_t)row * ld + col] = c;
         }
     }
+}
+
+// the tiles of a (group, chunk) grid in the order the kernels want them: all tiles of a chunk on ONE XCD (workgroup b runs
+// on XCD b % 8), one after the other, so that the chunk's far stream stays in that L2; chunks dealt longest first, lists
+// that come out shorter filled with empty items
+static std::vector<LmItem> tile_order(uint64_t n_rows, uint32_t group_rows, uint32_t chunk_rows) {
+    constexpr uint32_t kXcds = 8;
+    const uint32_t n_group = (uint32_t)((n_rows + group_rows - 1u) / group_rows);
+    const uint32_t n_chunk = (uint32_t)((n_rows + chunk_rows - 1u) / chunk_rows);
+    const uint32_t per = chunk_rows / group_rows;
+    std::vector<std::vector<LmItem>> per_xcd(kXcds);
+    for (uint32_t c = n_chunk; c-- > 0;) {   // (the last chunks have the most tiles)
+        size_t best = 0;
+        for (size_t x = 1; x < kXcds; ++x)
+            if (per_xcd[x].size() < per_xcd[best].size()) best = x;
+        for (uint32_t gi = 0; gi < n_group && gi <= c * per + (per - 1u); ++gi) per_xcd[best].push_back({gi, c});
+    }
+    size_t longest = 0;
+    for (const auto& v : per_xcd) longest = std::max(longest, v.size());
+    std::vector<LmItem> items;
+    for (size_t i = 0; i < longest; ++i)
+        for (uint32_t x = 0; x < kXcds; ++x)
+            items.push_back(i < per_xcd[x].size() ? per_xcd[x][i] : LmItem{0xffffffffu, 0u});
+    while (!items.empty() && items.back().gi == 0xffffffffu) items.pop_back();
+    return items;
 }
 
 }  // namespace
@@ -175,6 +400,13 @@ struct storm_hip_rowlists_s {
     uint32_t* d_rowlen = nullptr;
     LmItem* d_items = nullptr;
     uint32_t n_items = 0;
+    // K5h: the rows as they are
+    uint32_t* d_pos = nullptr;
+    uint16_t* d_rtag = nullptr;
+    uint32_t* d_row_off = nullptr;
+    LmItem* d_hash_items = nullptr;
+    uint32_t n_hash_items = 0;
+    uint32_t hash_g_log2 = 0;   // 0: no group size fits the table (rows too long): the window kernel only
 };
 
 extern "C" {
@@ -189,6 +421,10 @@ void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l) {
     (void)hipFree(l->d_off);
     (void)hipFree(l->d_rowlen);
     (void)hipFree(l->d_items);
+    (void)hipFree(l->d_pos);
+    (void)hipFree(l->d_rtag);
+    (void)hipFree(l->d_row_off);
+    (void)hipFree(l->d_hash_items);
     delete l;
 }
 
@@ -255,6 +491,7 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
 
         // ---- rows as global positions (checked: strictly ascending — a repeated position would toggle itself away)
         std::vector<uint32_t> pos(n_elems), row_off(n_rows + 1), rowlen(n_rows);
+        std::vector<uint16_t> rtag(n_elems);
         {
             uint64_t e = 0;
             for (uint64_t r = 0; r < n_rows; ++r) {
@@ -267,6 +504,7 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
                             set_error("rowlists_create: list of block %llu is not strictly ascending", (unsigned long long)b);
                             return STORM_HIP_EINVAL;
                         }
+                        rtag[e] = (uint16_t)(r & 2047u);
                         pos[e++] = base + v[k];
                     }
                 }
@@ -276,12 +514,16 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         }
         STORM_HIP_TRY(hipSetDevice(ctx->device));
         struct Temps {
-            uint32_t *pos = nullptr, *row_off = nullptr, *cursor = nullptr;
-            ~Temps() { (void)hipFree(pos); (void)hipFree(row_off); (void)hipFree(cursor); }
+            uint32_t *pos = nullptr, *row_off = nullptr, *cursor = nullptr;   // (pos and row_off: the arena's own, see below)
+            ~Temps() { (void)hipFree(cursor); }
         } t;
         const size_t n_cells = (size_t)(n_groups + 1u) * n_windows;
-        STORM_HIP_TRY(hipMalloc(&t.pos, n_elems * sizeof(uint32_t)));
-        STORM_HIP_TRY(hipMalloc(&t.row_off, (n_rows + 1) * sizeof(uint32_t)));
+        STORM_HIP_TRY(hipMalloc(&l->d_pos, n_elems * sizeof(uint32_t)));
+        STORM_HIP_TRY(hipMalloc(&l->d_row_off, (n_rows + 1) * sizeof(uint32_t)));
+        STORM_HIP_TRY(hipMalloc(&l->d_rtag, n_elems * sizeof(uint16_t)));
+        t.pos = l->d_pos;
+        t.row_off = l->d_row_off;
+        STORM_HIP_TRY(hipMemcpyAsync(l->d_rtag, rtag.data(), n_elems * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
         STORM_HIP_TRY(hipMalloc(&t.cursor, n_cells * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_elems, n_elems * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_off, n_cells * sizeof(uint32_t)));
@@ -316,15 +558,26 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         hipLaunchKernelGGL(lists_place_kernel, dim3((uint32_t)n_rows), dim3(256), 0, ctx->stream, t.pos, t.row_off,
                            (uint32_t)n_rows, n_windows, t.cursor, l->d_elems);
         STORM_HIP_TRY(hipGetLastError());
-        // ---- the tiles: chunk after chunk (the far stream of a chunk is shared by its tiles)
-        std::vector<LmItem> items;
-        const uint32_t groups_used = (uint32_t)((n_rows + kLmGroup - 1u) / kLmGroup);
-        for (uint32_t cj = 0; cj < n_groups / kLmChunkGroups; ++cj)
-            for (uint32_t gi = 0; gi < groups_used && gi <= cj * kLmChunkGroups + (kLmChunkGroups - 1u); ++gi)
-                items.push_back({gi, cj});
+        const std::vector<LmItem> items = tile_order(n_rows, kLmGroup, kLmChunk);
         l->n_items = (uint32_t)items.size();
         STORM_HIP_TRY(hipMalloc(&l->d_items, items.size() * sizeof(LmItem)));
         STORM_HIP_TRY(hipMemcpyAsync(l->d_items, items.data(), items.size() * sizeof(LmItem), hipMemcpyHostToDevice, ctx->stream));
+        // ---- K5h: the largest group size whose every group fits the hash table
+        if (max_pos <= kLhMaxPos) {
+            for (uint32_t g_log2 = 6; g_log2 >= 3 && !l->hash_g_log2; --g_log2) {
+                const uint64_t G = 1ull << g_log2;
+                uint64_t worst = 0;
+                for (uint64_t r = 0; r < n_rows; r += G)
+                    worst = std::max<uint64_t>(worst, row_off[std::min<uint64_t>(n_rows, r + G)] - row_off[r]);
+                if (worst <= kLhFill) l->hash_g_log2 = g_log2;
+            }
+        }
+        if (l->hash_g_log2) {
+            const std::vector<LmItem> hitems = tile_order(n_rows, 1u << l->hash_g_log2, kLhCounters >> l->hash_g_log2);
+            l->n_hash_items = (uint32_t)hitems.size();
+            STORM_HIP_TRY(hipMalloc(&l->d_hash_items, hitems.size() * sizeof(LmItem)));
+            STORM_HIP_TRY(hipMemcpyAsync(l->d_hash_items, hitems.data(), hitems.size() * sizeof(LmItem), hipMemcpyHostToDevice, ctx->stream));
+        }
         STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
         *out = owner.release();
         return STORM_HIP_OK;
@@ -357,16 +610,25 @@ int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    // which of the two: the hash kernel where the rows are short (its work grows with the square of the row length, the
+    // window kernel's with the row length on top of a fixed cost per step); option matrix_lists_kernel forces one
+    const bool hash = l->hash_g_log2 != 0 && ctx->matrix_lists_kernel != 1 &&
+                      (ctx->matrix_lists_kernel == 2 || l->hash_g_log2 >= (uint32_t)ctx->matrix_lists_hash_min_log2);
     kernel_time_mark(ctx);
-    hipLaunchKernelGGL(lists_matrix_kernel, dim3(l->n_items), dim3(kLmThreads), 0, ctx->stream, l->d_elems, l->d_off,
-                       l->n_windows, l->d_rowlen, l->d_items, (uint32_t)l->n_rows, op, d_out, ld);
+    if (hash)
+        hipLaunchKernelGGL(lists_hash_kernel, dim3(l->n_hash_items), dim3(kLhThreads), 0, ctx->stream, l->d_pos, l->d_rtag,
+                           l->d_row_off, l->d_rowlen, l->d_hash_items, (uint32_t)l->n_rows, l->hash_g_log2, op, d_out, ld, (uint32_t)ctx->matrix_lists_debug);
+    else
+        hipLaunchKernelGGL(lists_matrix_kernel, dim3(l->n_items), dim3(kLmThreads), 0, ctx->stream, l->d_elems, l->d_off,
+                           l->n_windows, l->d_rowlen, l->d_items, (uint32_t)l->n_rows, op, d_out, ld, (uint32_t)ctx->matrix_lists_debug);
     kernel_time_mark(ctx);
     STORM_HIP_TRY(hipGetLastError());
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pass_report[0] = STORM_HIP_RAN_LISTS_MATRIX;
     ctx->pass_report[1] = 0;
-    ctx->pass_report[2] = (uint64_t)(l->n_groups) * l->n_elems / 2u;
-    ctx->pass_report[3] = kLmGroup;
+    const uint64_t group_rows = hash ? 1ull << l->hash_g_log2 : kLmGroup;
+    ctx->pass_report[2] = (l->n_rows + group_rows - 1u) / group_rows * l->n_elems / 2u;
+    ctx->pass_report[3] = group_rows;
     return STORM_HIP_OK;
 }
 

@@ -2224,6 +2224,7 @@ int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_
         /* [r5] a list-only container that is sparse enough: straight from the lists (K5, storm_hip_lists.hip) — no dense
          * replica is built at all then */
         int from_lists = 0;
+        if (!rc && !device_ctx(V0)) rc = -3; /* (contexts are opened on first use) */
         if (!rc && (op == 0 || op == 1 || op == 2) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL)) { /* (NULL: are the lists switched on at all) */
             if (st->have_lists == 0 && storm_build_device(h, st, 2)) rc = -3;
             from_lists = !rc && st->have_lists == 1 && storm_hip_rowlists_worthwhile(g_ctx[V0], st->l[V0]);

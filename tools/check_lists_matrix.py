@@ -30,7 +30,7 @@ def device_matrix(s, n, op="and"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--draws", default="104,524,2621,5242,10485")
+    ap.add_argument("--draws", default="5,104,524,1048,2621,5242")
     ap.add_argument("--rows", type=int, default=10000)
     ap.add_argument("--bits", type=int, default=524288)
     a = ap.parse_args()
@@ -49,9 +49,12 @@ def main():
         for op in ("and", "or", "xor"):
             ref = {"and": want, "or": lens[:, None] + lens[None, :] - want, "xor": lens[:, None] + lens[None, :] - 2 * want}[op]
             opt("matrix_lists", 1)
-            got = device_matrix(s, N, op)
-            ok = np.array_equal(got[upper], ref[upper]) and bool((got[~upper] == -7).all())
-            ran = sb.load().STORM_hip_set_option  # noqa: F841
+            ok = True
+            for kern in (1, 2):   # window kernel, hash kernel
+                opt("matrix_lists_kernel", kern)
+                got = device_matrix(s, N, op)
+                ok = ok and np.array_equal(got[upper], ref[upper]) and bool((got[~upper] == -7).all()) and _ran_lists()
+            opt("matrix_lists_kernel", 0)
             opt("matrix_lists", 0)
             dense = device_matrix(s, N, op)
             ok = ok and np.array_equal(dense[upper], ref[upper])
@@ -69,8 +72,9 @@ def main():
         assert s.add_synthetic(M, N, d, seed=42) == N
         total = s.pairw_intersect_cardinality()
         rec = {"rows": N, "bits": M, "draws": d}
-        for mode, name in ((1, "lists_ms"), (0, "dense_ms")):
+        for mode, kern, name in ((1, 1, "windows_ms"), (1, 2, "hash_ms"), (0, 0, "dense_ms")):
             opt("matrix_lists", mode)
+            opt("matrix_lists_kernel", kern)
             dev.zero_()
             t0 = time.perf_counter()
             s.pairw_matrix_device(dev.data_ptr(), N, N)
@@ -83,18 +87,29 @@ def main():
             rec[name] = round(min(ts) * 1e3, 3)
             rec[name.replace("_ms", "_sum_ok")] = int(dev.to(torch.int64).sum().item()) == total
         opt("matrix_lists", -1)
-        s.pairw_matrix_device(dev.data_ptr(), N, N)
-        rec["auto_took_lists"] = bool(sb.load().STORM_hip_last_pass and _ran_lists())
+        opt("matrix_lists_kernel", 0)
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            s.pairw_matrix_device(dev.data_ptr(), N, N)
+            ts.append(time.perf_counter() - t0)
+        rec["auto_ms"] = round(min(ts) * 1e3, 3)
+        rec["auto_took_lists"] = _ran_lists()
+        rec["auto_group_rows"] = _report()[3]
         print(json.dumps(rec), flush=True)
         s.free()
     sys.exit(1 if bad else 0)
 
 
-def _ran_lists():
+def _report():
     import ctypes as C
     out = (C.c_uint64 * 4)()
     sb.load().STORM_hip_last_pass(out)
-    return bool(out[0] & 64)
+    return [int(x) for x in out]
+
+
+def _ran_lists():
+    return bool(_report()[0] & 64)
 
 
 if __name__ == "__main__":
