@@ -95,6 +95,7 @@ def test_per_pair_matrix_left_in_device_memory(orc):
     tile kernels (STORM_hip_set_option: tilebits8_kernel and tilering_kernel), lists, bitmaps and mixed kinds."""
     import torch
     lib = sb.load()
+    assert lib.STORM_hip_set_option(b"matrix_lists", 0) == 0   # (the tile kernels on the dense replica are the subject here)
     try:
         for M, N, d in ((200000, 300, 40), (131072, 257, 9000), (65536, 600, 5000)):
             rows = [np.unique(np.random.default_rng(N + i).integers(0, M, size=d if i % 3 else d // 50 + 1)).astype(np.uint32)
@@ -122,6 +123,108 @@ def test_per_pair_matrix_left_in_device_memory(orc):
             c.free()
     finally:
         lib.STORM_hip_set_option(b"k2_tile_shape", 0)
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+
+
+def _last_pass():
+    out = (C.c_uint64 * 4)()
+    assert sb.load().STORM_hip_last_pass(out) == 0
+    return [int(x) for x in out]
+
+
+def test_per_pair_matrix_of_a_list_only_container_straight_from_its_lists(orc):
+    """K5 (storm_hip_lists.hip): STORM_pairw_matrix_device on a container whose blocks are all lists never builds the dense
+    replica — lists_hash_kernel (rows of up to ~190 positions) or lists_matrix_kernel (windows) join the rows' positions
+    per output tile in the LDS. Entry (i, j), i < j, must be what STORM_bitmap_cont_intersect_cardinality returns for rows
+    i and j (storm.c:790-814: block-id merge :75-106, two lists meet in STORM_intersect_vector16_cardinality :4-73), OR / XOR
+    from the row lengths; entries i >= j stay untouched. Both kernels forced in turn, then the automatic choice; shapes with
+    empty rows, a ragged last group, one position per row, rows in far-apart blocks, 2^22 positions; a container that grows
+    between calls; a container with a bitmap block (not eligible: the tile kernels run)."""
+    import torch
+    lib = sb.load()
+    RAN_LISTS, RAN_TILES = 64, 128
+    try:
+        for M, N, d in ((65536, 2, 5), (65536, 65, 40), (200000, 300, 60), (524288, 257, 524), (1 << 22, 130, 300),
+                        (8193, 321, 7), (70000, 1000, 1), (3000000, 513, 150)):
+            rows = synth.positions(M, N, d, seed=N + d)
+            rows[N // 3] = rows[N // 3][:0]
+            s = sb.Storm()
+            for r in rows:
+                s.add(r)
+            want = orc.storm(rows).pair_counts().astype(np.int64)
+            lens = np.array([len(r) for r in rows], dtype=np.int64)
+            upper = np.triu(np.ones((N, N), dtype=bool), k=1)
+            for op in ("and", "or", "xor"):
+                ref = {"and": want, "or": lens[:, None] + lens[None, :] - want,
+                       "xor": lens[:, None] + lens[None, :] - 2 * want}[op]
+                for lists, kernel in ((1, 1), (1, 2), (-1, 0), (0, 0)):
+                    assert lib.STORM_hip_set_option(b"matrix_lists", lists) == 0
+                    assert lib.STORM_hip_set_option(b"matrix_lists_kernel", kernel) == 0
+                    dev = torch.full((N + 1, N + 5), -7, dtype=torch.int32, device="cuda:0")
+                    s.pairw_matrix_device(dev.data_ptr(), N + 1, N + 5, op)
+                    got = dev.cpu().numpy()[:N, :N]
+                    assert np.array_equal(got[upper], ref[upper]), (M, N, d, op, lists, kernel)
+                    assert (got[~upper] == -7).all() and (dev.cpu().numpy()[N:] == -7).all(), (M, N, d, op, lists, kernel)
+                    ran = _last_pass()
+                    assert ran[0] == (RAN_TILES if lists == 0 else RAN_LISTS), (ran, lists, kernel)
+                    if lists == 1:   # (the hash kernel's groups shrink with the row length; the window kernel's are 64 rows)
+                        assert ran[3] == 64 if kernel == 1 else ran[3] in (8, 16, 32, 64), ran
+            # the container grows: the lists are rebuilt from the container as it is now
+            assert lib.STORM_hip_set_option(b"matrix_lists", 1) == 0
+            extra = synth.positions(M, 3, d, seed=7)
+            for r in extra:
+                s.add(r)
+            rows2 = list(rows) + list(extra)
+            N2 = N + 3
+            dev = torch.zeros((N2, N2), dtype=torch.int32, device="cuda:0")
+            s.pairw_matrix_device(dev.data_ptr(), N2, N2)
+            assert np.array_equal(np.triu(dev.cpu().numpy(), k=1), np.triu(orc.storm(rows2).pair_counts().astype(np.int32), k=1)), (M, N)
+            assert _last_pass()[0] == RAN_LISTS
+            s.free()
+        # one dense row among the lists (a bitmap block): not eligible, whatever the option says
+        rows = synth.positions(65536, 100, 50, seed=3)
+        rows[17] = np.arange(0, 65536, 3, dtype=np.uint32)
+        s = sb.Storm()
+        for r in rows:
+            s.add(r)
+        dev = torch.zeros((100, 100), dtype=torch.int32, device="cuda:0")
+        s.pairw_matrix_device(dev.data_ptr(), 100, 100)
+        assert _last_pass()[0] == RAN_TILES
+        assert np.array_equal(np.triu(dev.cpu().numpy(), k=1), np.triu(orc.storm(rows).pair_counts().astype(np.int32), k=1))
+        s.free()
+    finally:
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+        lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
+
+
+def test_lists_path_at_the_readme_storm_shape_sums_to_the_all_pairs_total():
+    """BASELINE c4's shape (N = 10000, M = 524288) at its two sparsest loads: the matrix written from the lists must add up to
+    STORM_pairw_intersect_cardinality of the same handle (a different kernel family: the list-probe kernel), for the kernel the
+    automatic rule picks and for the other one; a sampled window of it equals the dense replica's tile kernels."""
+    import torch
+    lib = sb.load()
+    N, M = 10000, 524288
+    try:
+        dev = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        ref = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        for d in (104, 524):
+            s = sb.Storm()
+            assert s.add_synthetic(M, N, d, seed=42) == N
+            total = s.pairw_intersect_cardinality()
+            for lists, kernel in ((-1, 0), (1, 1), (1, 2)):
+                assert lib.STORM_hip_set_option(b"matrix_lists", lists) == 0
+                assert lib.STORM_hip_set_option(b"matrix_lists_kernel", kernel) == 0
+                dev.zero_()
+                s.pairw_matrix_device(dev.data_ptr(), N, N)
+                assert _last_pass()[0] == 64
+                assert int(dev.to(torch.int64).sum().item()) == total, (d, lists, kernel)
+            assert lib.STORM_hip_set_option(b"matrix_lists", 0) == 0
+            s.pairw_matrix_device(ref.data_ptr(), N, N)
+            assert bool((dev == ref).all().item()), d
+            s.free()
+    finally:
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+        lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
 
 
 def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc):

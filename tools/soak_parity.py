@@ -31,7 +31,7 @@ def main():
     n_cases = 0
     kinds = {}
     while time.time() < t_end and n_cases < args.max_cases:
-        kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "matrix_big", "wrapper", "sparse"])
+        kind = rng.choice(["dense_small", "dense_small", "dense_big", "square", "matrix", "matrix_big", "wrapper", "sparse", "storm_lists"])
         seed = int(rng.integers(1, 1 << 30))
         probes = ctx.get_option("probes_build") == 1   # the alternative kernel forms exist in the tools build only
         opts = {"variant": int(rng.choice([-1, -1, 4, 5 if probes else 4, 3, 2])),
@@ -127,6 +127,34 @@ def main():
                 ctx.set_option("variant", 2)
                 ok = got == want and (N > 4000 or m.pairw() == want)
                 m.close()
+            elif kind == "storm_lists":   # K5: the per-pair matrix of a list-only STORM_t from its lists, both kernels
+                import torch
+                N = int(rng.integers(2, 900))
+                M = int(rng.choice([8192, 65536, 200000, 524288, 1 << 22]))
+                d = int(rng.choice([1, 5, 40, 150, 400, 1500]))
+                d = min(d, M // 64)
+                rows = synth.positions(M, N, d, seed=seed)
+                if seed % 4 == 0:
+                    rows[int(rng.integers(0, N))] = rows[0][:0]
+                s = sb.Storm()
+                for r in rows:
+                    s.add(r)
+                lib = sb.load()
+                op = ["and", "or", "xor"][int(rng.integers(0, 3))]
+                want = orc.storm(rows).pair_counts().astype(np.int64)
+                lens = np.array([len(r) for r in rows], dtype=np.int64)
+                want = {"and": want, "or": lens[:, None] + lens[None, :] - want, "xor": lens[:, None] + lens[None, :] - 2 * want}[op]
+                ok = True
+                for kernel in (1, 2):
+                    lib.STORM_hip_set_option(b"matrix_lists", 1)
+                    lib.STORM_hip_set_option(b"matrix_lists_kernel", kernel)
+                    out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+                    s.pairw_matrix_device(out.data_ptr(), N, N, op)
+                    ok = ok and np.array_equal(np.triu(out.cpu().numpy().astype(np.int64), k=1), np.triu(want, k=1))
+                lib.STORM_hip_set_option(b"matrix_lists", -1)
+                lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
+                ok = ok and int(np.triu(want, k=1).sum()) == s.pairw_intersect_cardinality() if op == "and" else ok
+                s.free()
             else:  # sparse container through storm.h (host library has its own context: defaults)
                 N = int(rng.integers(2, 700))
                 M = int(rng.choice([65536, 200000, 524288]))
