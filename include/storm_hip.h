@@ -383,6 +383,9 @@ void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l);
 int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l);
 int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
                                            uint32_t* d_out, uint64_t ld);
+/* ... and into host memory: whole rows, zeros at i >= j (what storm_hip_pairw_matrix writes) */
+int storm_hip_rowlists_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* h_out,
+                                    uint64_t ld);
 uint64_t storm_hip_rowlists_n_elems(const storm_hip_rowlists_t* l);
 
 int storm_hip_pairw_sparse(storm_hip_ctx_t* ctx, const storm_hip_sparse_t* s,

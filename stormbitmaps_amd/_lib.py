@@ -90,6 +90,7 @@ SIGNATURES = {
     "storm_hip_rowlists_destroy": (None, [vp, vp]),
     "storm_hip_rowlists_worthwhile": (C.c_int, [vp, vp]),
     "storm_hip_rowlists_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
+    "storm_hip_rowlists_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp, u64]),
     "storm_hip_rowlists_n_elems": (u64, [vp]),
     "storm_hip_pairw_sparse_begin": (C.c_int, [vp, vp, u32, u32]),
     "storm_hip_pairw_sparse_end": (C.c_int, [vp, P(u64)]),

@@ -595,8 +595,7 @@ int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists
     return (double)l->n_elems <= bits * (double)ctx->matrix_lists_permille_x10 / 10000.0;
 }
 
-int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
-                                           uint32_t* d_out, uint64_t ld) {
+static int launch_lists(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* d_out, uint64_t ld) {
     if (!ctx || !l || !d_out) {
         set_error("rowlists_pairw_matrix: NULL argument");
         return STORM_HIP_EINVAL;
@@ -623,12 +622,51 @@ int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip
                            l->n_windows, l->d_rowlen, l->d_items, (uint32_t)l->n_rows, op, d_out, ld, (uint32_t)ctx->matrix_lists_debug);
     kernel_time_mark(ctx);
     STORM_HIP_TRY(hipGetLastError());
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pass_report[0] = STORM_HIP_RAN_LISTS_MATRIX;
     ctx->pass_report[1] = 0;
     const uint64_t group_rows = hash ? 1ull << l->hash_g_log2 : kLmGroup;
     ctx->pass_report[2] = (l->n_rows + group_rows - 1u) / group_rows * l->n_elems / 2u;
     ctx->pass_report[3] = group_rows;
+    return STORM_HIP_OK;
+}
+
+int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
+                                           uint32_t* d_out, uint64_t ld) {
+    if (int rc = launch_lists(ctx, l, op, d_out, ld)) return rc;
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+
+// The same into HOST memory, whole rows (zeros at i >= j, as storm_hip_pairw_matrix writes them): the matrix is built in
+// the context's band buffer and copied out.
+int storm_hip_rowlists_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* h_out,
+                                    uint64_t ld) {
+    if (!ctx || !l || !h_out) {
+        set_error("rowlists_pairw_matrix: NULL argument");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t n = l->n_rows;
+    if (ld < n) {
+        set_error("rowlists_pairw_matrix: ld %llu < %llu rows", (unsigned long long)ld, (unsigned long long)n);
+        return STORM_HIP_EINVAL;
+    }
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    const size_t need = (size_t)n * n * sizeof(uint32_t);
+    if (need > ctx->band_capacity) {
+        if (ctx->d_band) STORM_HIP_TRY(hipFree(ctx->d_band));
+        ctx->d_band = nullptr;
+        ctx->band_capacity = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->d_band), need) != hipSuccess) {
+            set_error("rowlists_pairw_matrix: hipMalloc of %zu bytes for the output failed", need);
+            return STORM_HIP_ENOMEM;
+        }
+        ctx->band_capacity = need;
+    }
+    STORM_HIP_TRY(hipMemsetAsync(ctx->d_band, 0, need, ctx->stream));
+    if (int rc = launch_lists(ctx, l, op, ctx->d_band, n)) return rc;
+    STORM_HIP_TRY(hipMemcpy2DAsync(h_out, ld * sizeof(uint32_t), ctx->d_band, n * sizeof(uint32_t), n * sizeof(uint32_t), n,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STORM_HIP_OK;
 }
 

@@ -2179,6 +2179,17 @@ static int storm_pairw_matrix_locked(STORM_t* h, int op, uint32_t* out, uint64_t
         if (!(st = storm_state(h, &fresh))) return -3;
     }
     h->hip_epoch = epoch;
+    /* [r5] one device, a list-only container that is sparse enough: straight from the lists (K5), no dense replica */
+    if (VN == 1 && device_ctx(V0) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL)) {
+        if (st->have_lists == 0 && storm_build_device(h, st, 2)) return -3;
+        if (st->have_lists == 1 && storm_hip_rowlists_worthwhile(g_ctx[V0], st->l[V0])) {
+            if (storm_hip_rowlists_pairw_matrix(g_ctx[V0], st->l[V0], op, out, out_ld) != STORM_HIP_OK) {
+                device_error("storm_hip_rowlists_pairw_matrix");
+                return -3;
+            }
+            return 0;
+        }
+    }
     if (!st->have_dense && storm_build_device(h, st, 1)) return -3;
     return pairw_matrix_bands(st->m, n, op, out, out_ld);
 }

@@ -272,3 +272,8 @@ int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip
     (void)ctx; (void)l; (void)op; (void)d_out; (void)ld;
     return STORM_HIP_EINVAL;
 }
+int storm_hip_rowlists_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* h_out, uint64_t ld) {
+    (void)ctx; (void)l; (void)op; (void)h_out; (void)ld;
+    return STORM_HIP_EINVAL;
+}
+uint64_t storm_hip_rowlists_n_elems(const storm_hip_rowlists_t* l) { (void)l; return 0; }

@@ -169,6 +169,10 @@ def test_per_pair_matrix_of_a_list_only_container_straight_from_its_lists(orc):
                     assert ran[0] == (RAN_TILES if lists == 0 else RAN_LISTS), (ran, lists, kernel)
                     if lists == 1:   # (the hash kernel's groups shrink with the row length; the window kernel's are 64 rows)
                         assert ran[3] == 64 if kernel == 1 else ran[3] in (8, 16, 32, 64), ran
+                    # the host-output entry point takes the same path (whole rows: zeros at i >= j)
+                    host = s.pairw_matrix(op)
+                    assert np.array_equal(host.astype(np.int64), np.triu(ref, k=1)), (M, N, d, op, lists, kernel)
+                    assert _last_pass()[0] == (RAN_TILES if lists == 0 else RAN_LISTS)
             # the container grows: the lists are rebuilt from the container as it is now
             assert lib.STORM_hip_set_option(b"matrix_lists", 1) == 0
             extra = synth.positions(M, 3, d, seed=7)
