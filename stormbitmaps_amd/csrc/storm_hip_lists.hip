@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     // are used, 1024 threads: 1.34 ms at 524 positions per row (a round trip to the L2 per step, every wave waiting);
     // loads a step early: 1.10 — the step loop WITHOUT any element, barrier or store still takes 0.71 ms (195 000 steps of
     // ~130 vector instructions on sixteen waves: the CU's instruction issue), and four waves that carry four times as much
-    // each are slower still (3.1 ms: one wave per SIMD covers no latency). The steps are the cost of this formulation:
+    // each are slower still (3.1 ms: one wave per SIMD covers no latency; eight waves: 1.64). The steps are the cost of this formulation:
     // lists_hash_kernel below has none and takes over where the rows are short.
     constexpr uint32_t kInvalid = 0xffffffffu;
     constexpr uint32_t kFarRegs = 4u;
