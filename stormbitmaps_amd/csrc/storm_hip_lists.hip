@@ -7,18 +7,20 @@
 // where the rows hold 21 MB of positions between them.
 //
 // Formulation (a hash join per output tile, the table in the LDS):
-//   data   : every listed position as ONE 32-bit element, (row & 255) << 13 | position & 8191, ordered by WINDOW of 8192
+//   data   : every listed position as ONE 32-bit element, (row % 768) << 13 | position & 8191, ordered by WINDOW of 8192
 //            positions first and by GROUP of 64 rows inside a window; off[g][w] = first element of (window w, group g).
-//            The elements of a group — or of four consecutive groups, a CHUNK of 256 rows — in a window are contiguous.
-//   item   : one output tile = group gi (64 "A" rows) x chunk cj (256 "far" rows), all windows. One workgroup of 1024
+//            The elements of a group — or of twelve consecutive groups, a CHUNK of 768 rows — in a window are contiguous.
+//   item   : one output tile = group gi (64 "A" rows) x chunk cj (768 "far" rows), all windows. One workgroup of 1024
 //            threads, one item.
-//   LDS    : table[8192 positions][2 planes] of 64-bit row masks (128 KiB): bit a of table[p][q] = "A row a lists position
-//            p of the window that owns plane q"; counters[64][256] of 16 bits (32 KiB) = the tile.
+//   LDS    : table[8192 positions] of 64-bit row masks (64 KiB): bit a of table[p] = "A row a lists position p of the
+//            current window"; counters[64][768] of 16 bits (96 KiB) = the tile.
 //   step   : for every window in which both sides list something — look every far element up (one ds_read_b64; for
-//            every set bit one 16-bit LDS increment: that is one intersecting position of one row pair), while the A
-//            elements of the NEXT such window are toggled into the other plane and those of the PREVIOUS one out of it.
-//            Set and clear are both XOR: they commute, so the two may run in any order within the step even when they
-//            hit the same bit, and a step needs ONE barrier.
+//            every set bit one 16-bit LDS increment: that is one intersecting position of one row pair); then, behind a
+//            barrier, the A elements of this window are toggled out of the table and those of the next such window in.
+//            Set and clear are both XOR: they commute, so the two may run in any order even when they hit the same bit.
+//            (First form: two planes of masks, 256-row chunks, the re-toggling beside the lookups and ONE barrier per step
+//            — three times the steps, and the steps are what costs: 1.25 ms at 524 positions per row against this form's
+//            figure in DESIGN.md.)
 //   output : the tile's strict upper part is written once, row segments of 1 KiB; OR / XOR counts from the row lengths.
 //            Nothing is zero-filled and nothing is added to in global memory; entries i >= j are not touched (as the tile
 //            kernels leave them).
@@ -37,11 +39,11 @@ namespace {
 
 constexpr int kLmThreads = 1024;
 constexpr uint32_t kLmGroup = 64;        // A rows per tile
-constexpr uint32_t kLmChunkGroups = 4;   // far rows per tile: 4 groups = 256
+constexpr uint32_t kLmChunkGroups = 12;  // far rows per tile: 12 groups = 768
 constexpr uint32_t kLmChunk = kLmGroup * kLmChunkGroups;
 constexpr uint32_t kLmWinBits = 13;
 constexpr uint32_t kLmWin = 1u << kLmWinBits;
-constexpr uint32_t kLmTableBytes = kLmWin * 16u;                 // 2 planes x 8 bytes per position
+constexpr uint32_t kLmTableBytes = kLmWin * 8u;                  // a 64-bit row mask per position
 constexpr uint32_t kLmCountBytes = kLmGroup * kLmChunk * 2u;     // 16-bit counters
 static_assert(kLmTableBytes + kLmCountBytes <= 160u * 1024u, "LDS of a gfx950 CU");
 
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void lists_place_kernel(const uint32_t* __rest
     for (uint32_t e = row_off[row] + threadIdx.x; e < row_off[row + 1]; e += 256u) {
         const uint32_t p = pos[e];
         const uint32_t at = atomicAdd(&cursor[(uint64_t)g * n_windows + (p >> kLmWinBits)], 1u);
-        elems[at] = ((row & (kLmChunk - 1u)) << kLmWinBits) | (p & (kLmWin - 1u));
+        elems[at] = ((row % kLmChunk) << kLmWinBits) | (p & (kLmWin - 1u));
     }
 }
 
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     const uint32_t* __restrict__ elems, const uint32_t* __restrict__ off, uint32_t n_windows,
     const uint32_t* __restrict__ rowlen, const LmItem* __restrict__ items, uint32_t n_rows, int op,
     uint32_t* __restrict__ out, uint64_t ld, uint32_t dbg) {
-    __shared__ __attribute__((aligned(16))) uint32_t table[kLmTableBytes / 4u];   // [position][plane][2 words]
+    __shared__ __attribute__((aligned(16))) uint32_t table[kLmTableBytes / 4u];   // [position][2 words]
     __shared__ __attribute__((aligned(16))) uint32_t cnt[kLmCountBytes / 4u];     // [a][j / 2]: two 16-bit counters per word
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const LmItem it = items[blockIdx.x];
@@ -125,18 +127,18 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     // each are slower still (3.1 ms: one wave per SIMD covers no latency; eight waves: 1.64). The steps are the cost of this formulation:
     // lists_hash_kernel below has none and takes over where the rows are short.
     constexpr uint32_t kInvalid = 0xffffffffu;
-    constexpr uint32_t kFarRegs = 4u;
+    constexpr uint32_t kFarRegs = 8u;
     constexpr uint32_t kARegs = 1u;
     constexpr uint32_t kBatch = 8u;      // loads in flight per thread in the remainder loops
     constexpr uint32_t kT = (uint32_t)kLmThreads;
-    auto toggle1 = [&](uint32_t v, uint32_t plane) {
+    auto toggle1 = [&](uint32_t v) {
         if (v != kInvalid) {
             const uint32_t a = (v >> kLmWinBits) & (kLmGroup - 1u), p = v & (kLmWin - 1u);
-            atomicXor(&table[p * 4u + plane * 2u + (a >> 5)], 1u << (a & 31u));
+            atomicXor(&table[p * 2u + (a >> 5)], 1u << (a & 31u));
         }
     };
     auto count_bits = [&](uint32_t v, uint2 m) {
-        const uint32_t j = (v >> kLmWinBits) & (kLmChunk - 1u);
+        const uint32_t j = v >> kLmWinBits;   // row in chunk: < 768
         const uint32_t inc = 1u << (16u * (j & 1u));
         for (uint32_t x = m.x; x; x &= x - 1u)
             atomicAdd(&cnt[((uint32_t)__builtin_ctz(x) * kLmChunk + j) >> 1], inc);
@@ -145,32 +147,32 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     };
     // the masks of a batch are read together (one LDS round trip per batch, not per element); an invalid element reads
     // entry 0 and drops what it gets
-    auto lookup_batch = [&](const uint32_t* v, uint32_t n, uint32_t plane) {
+    auto lookup_batch = [&](const uint32_t* v, uint32_t n) {
         uint2 m[kFarRegs];
 #pragma unroll
         for (uint32_t q = 0; q < kFarRegs; ++q)
-            if (q < n) m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 4u + plane * 2u]);
+            if (q < n) m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 2u]);
 #pragma unroll
         for (uint32_t q = 0; q < kFarRegs; ++q)
             if (q < n && v[q] != kInvalid && (m[q].x | m[q].y)) count_bits(v[q], m[q]);
     };
     auto load_at = [&](uint32_t i, uint32_t e) -> uint32_t { return (i < e && !(dbg & 1u)) ? elems[i] : kInvalid; };
     // the elements of [b, e) from the `skip`-th per thread on, kBatch loads in flight
-    auto toggle_rest = [&](uint32_t b, uint32_t e, uint32_t skip, uint32_t plane) {
+    auto toggle_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
         for (uint32_t i = b + tid + skip * kT; i < e; i += kBatch * kT) {
             uint32_t v[kBatch];
 #pragma unroll
             for (uint32_t q = 0; q < kBatch; ++q) v[q] = load_at(i + q * kT, e);
 #pragma unroll
-            for (uint32_t q = 0; q < kBatch; ++q) toggle1(v[q], plane);
+            for (uint32_t q = 0; q < kBatch; ++q) toggle1(v[q]);
         }
     };
-    auto lookup_rest = [&](uint32_t b, uint32_t e, uint32_t skip, uint32_t plane) {
+    auto lookup_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
         for (uint32_t i = b + tid + skip * kT; i < e; i += kFarRegs * kT) {
             uint32_t v[kFarRegs];
 #pragma unroll
             for (uint32_t q = 0; q < kFarRegs; ++q) v[q] = load_at(i + q * kT, e);
-            lookup_batch(v, kFarRegs, plane);
+            lookup_batch(v, kFarRegs);
         }
     };
     // (a barrier for the LDS alone: __syncthreads() also waits for every global load in flight — the loads that were
@@ -181,16 +183,16 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
         asm volatile("" ::: "memory");
     };
 
-    // Step k multiplies window w[k]: its far elements and the A elements of w[k + 1] were loaded during step k - 1, the A
-    // elements of w[k - 1] are still in their registers from when they were toggled in; the step itself loads the far
-    // elements of w[k + 1] and the A elements of w[k + 2].
+    // Step k multiplies window w[k], which the table holds: its far elements (the first kFarRegs per thread) and the A
+    // elements of w[k + 1] were loaded during step k - 1, the A elements of w[k] are still in their registers from when
+    // they were toggled in. Two phases: the lookups; then, behind a barrier, w[k] is toggled out and w[k + 1] in (both XOR:
+    // any order, same table) while the far elements of w[k + 1] and the A elements of w[k + 2] are already on their way.
     load_windows();
     LmWin w0 = next_window(), w1 = next_window(), w2 = next_window();
-    uint32_t a_prev[kARegs], a_cur[kARegs], a_next[kARegs], a_next2[kARegs];
+    uint32_t a_cur[kARegs], a_next[kARegs], a_next2[kARegs];
     uint32_t f_cur[kFarRegs], f_next[kFarRegs];
 #pragma unroll
     for (uint32_t q = 0; q < kARegs; ++q) {
-        a_prev[q] = kInvalid;
         a_next2[q] = kInvalid;
         a_cur[q] = w0.ok ? load_at(w0.ab + tid + q * kT, w0.ae) : kInvalid;
         a_next[q] = w1.ok ? load_at(w1.ab + tid + q * kT, w1.ae) : kInvalid;
@@ -202,45 +204,38 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     }
     lds_barrier();   // the zeroed table
 #pragma unroll
-    for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_cur[q], 0u);
-    if (w0.ok && w0.ae - w0.ab > kARegs * kT) toggle_rest(w0.ab, w0.ae, kARegs, 0u);
+    for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_cur[q]);
+    if (w0.ok && w0.ae - w0.ab > kARegs * kT) toggle_rest(w0.ab, w0.ae, kARegs);
     lds_barrier();
-    LmWin wp{0u, 0u, 0u, 0u, false};
-    uint32_t k = 0;
     // One step. The registers a step LOADS and the ones it CONSUMES swap roles from step to step: the loop below is unrolled
     // twice over the two namings, so that no register is ever copied while its load is in flight (a copy is a use: a version
     // that rotated the names with v_mov at the end of a step waited there for every load it had just issued).
     auto step = [&](uint32_t (&fc)[kFarRegs], uint32_t (&fn)[kFarRegs], uint32_t (&an)[kARegs], uint32_t (&an2)[kARegs]) {
-        const uint32_t plane = k & 1u, other = plane ^ 1u;
 #pragma unroll
         for (uint32_t q = 0; q < kARegs; ++q) an2[q] = w2.ok ? load_at(w2.ab + tid + q * kT, w2.ae) : kInvalid;
 #pragma unroll
         for (uint32_t q = 0; q < kFarRegs; ++q) fn[q] = w1.ok ? load_at(w1.fb + tid + q * kT, w1.fe) : kInvalid;
-        lookup_batch(fc, kFarRegs, plane);
-        if (w0.fe - w0.fb > kFarRegs * kT) lookup_rest(w0.fb, w0.fe, kFarRegs, plane);
-        // window k - 1 out of the plane window k + 1 takes, window k + 1 in: both XOR, any order
-#pragma unroll
-        for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_prev[q], other);
-        if (wp.ok && wp.ae - wp.ab > kARegs * kT) toggle_rest(wp.ab, wp.ae, kARegs, other);
-#pragma unroll
-        for (uint32_t q = 0; q < kARegs; ++q) toggle1(an[q], other);
-        if (w1.ok && w1.ae - w1.ab > kARegs * kT) toggle_rest(w1.ab, w1.ae, kARegs, other);
+        lookup_batch(fc, kFarRegs);
+        if (w0.fe - w0.fb > kFarRegs * kT) lookup_rest(w0.fb, w0.fe, kFarRegs);
         lds_barrier();
 #pragma unroll
-        for (uint32_t q = 0; q < kARegs; ++q) {   // (all long since loaded)
-            a_prev[q] = a_cur[q];
-            a_cur[q] = an[q];
-        }
-        wp = w0; w0 = w1; w1 = w2;
+        for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_cur[q]);
+        if (w0.ae - w0.ab > kARegs * kT) toggle_rest(w0.ab, w0.ae, kARegs);
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) toggle1(an[q]);
+        if (w1.ok && w1.ae - w1.ab > kARegs * kT) toggle_rest(w1.ab, w1.ae, kARegs);
+        lds_barrier();
+#pragma unroll
+        for (uint32_t q = 0; q < kARegs; ++q) a_cur[q] = an[q];   // (long since loaded)
+        w0 = w1; w1 = w2;
         w2 = next_window();
-        ++k;
     };
     while (w0.ok && !(dbg & 16u)) {
         step(f_cur, f_next, a_next, a_next2);
         if (!w0.ok) break;
         step(f_next, f_cur, a_next2, a_next);
     }
-    // the tile: rows gi * 64 + a, columns cj * 256 + j, strict upper part
+    // the tile: rows gi * 64 + a, columns cj * 768 + j, strict upper part
     const uint32_t row0 = it.gi * kLmGroup, col0 = it.cj * kLmChunk;
     for (uint32_t idx = tid; idx < kLmGroup * kLmChunk; idx += (uint32_t)kLmThreads) {
         const uint32_t a = idx / kLmChunk, j = idx % kLmChunk;
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
 //   item   : group gi of G rows (G = 64 / 32 / 16 / 8: the largest whose every group lists at most kLhFill positions) x
 //            chunk cj of F = 16384 / G rows. One workgroup of 1024 threads.
 //   LDS    : open-addressing table of 8192 buckets of four 32-bit entries, position << 6 | row in group (128 KiB;
-//            multiplicative hash, overflow into the next bucket; at most 0.375 full); counters[G][F] of 16 bits (32 KiB).
+//            multiplicative hash, overflow into the next bucket; at most a quarter full); counters[G][F] of 16 bits (32 KiB).
 //   work   : build the table from the group's elements (LDS compare-and-swap), then stream the chunk's elements —
 //            contiguous in memory, eight loads in flight per thread — and read every element's home bucket (one
 //            ds_read_b128): an entry with the same position is one intersecting position of one row pair.
@@ -273,7 +268,7 @@ constexpr int kLhThreads = 1024;
 constexpr uint32_t kLhSlots = 32768u;
 constexpr uint32_t kLhEmpty = 0xffffffffu;
 constexpr uint32_t kLhCounters = 16384u;     // G x F
-constexpr uint32_t kLhFill = 12288u;         // elements of a group at most
+constexpr uint32_t kLhFill = 8192u;          // elements of a group at most (a quarter of the slots; beyond ~130 positions per row the window kernel is level)
 constexpr uint32_t kLhRowBits = 6u;          // row in group: G <= 64
 constexpr uint32_t kLhMaxPos = (1u << (32u - kLhRowBits)) - 2u;
 
@@ -300,7 +295,7 @@ __global__ __launch_bounds__(kLhThreads, 1) void lists_hash_kernel(
     __syncthreads();
     // Buckets of four entries (16 bytes): an element goes into the first free slot of its home bucket, or of the next
     // one that has any; entries are never removed, so the used slots of a bucket are a prefix and the first empty slot
-    // ends a search. At most 0.375 full, a lookup reads ONE bucket in 97 % of the cases. (The first version probed slot
+    // ends a search. At most a quarter full, a lookup reads ONE bucket in 99 % of the cases. (The first version probed slot
     // by slot: a wave walks until the longest of its 64 chains ends — 0.83 ms at 190 positions per row where this
     // takes 0.3, profiles/r05_j_*.)
     for (uint32_t e = a_b + tid; e < a_e; e += (uint32_t)kLhThreads) {
