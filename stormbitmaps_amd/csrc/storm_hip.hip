@@ -766,6 +766,14 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
     } else if (!strcmp(key, "keep_shadow")) {
         ctx->keep_shadow = value != 0;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
+    } else if (!strcmp(key, "k2_matrix_parts")) {
+        ctx->k2_matrix_parts = value != 0;
+    } else if (!strcmp(key, "k2_matrix_min_part")) {
+        if (value < 4 || value > 4096 || value % 4) {
+            set_error("k2_matrix_min_part: a multiple of 4 in 4 .. 4096 (stages of 128 bits)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_matrix_min_part = (int)value;
     } else if (!strcmp(key, "k2_matrix_split")) {
         ctx->k2_matrix_split = value != 0;
     } else if (!strcmp(key, "k2_pitch_pad")) {

@@ -146,6 +146,10 @@ struct storm_hip_ctx_s {
     int keep_shadow = 0;
     uint64_t x4_key[4] = {0, 0, 0, 0};
     int k2_matrix_split = 1; // matrix output: cut the last round's tiles along k to fill the CUs
+    int k2_matrix_parts = 0;  // ... 0: the parts add into the cleared output with atomics; 1: every part writes its own window and reduce_parts_kernel adds them up (round 5: the tile kernel gets 10 us faster at 1024 rows, the second kernel costs more than the clearing and the atomics did: profiles/r05_k_matrix_sizes.jsonl)
+    uint32_t* d_parts = nullptr;   // the parts' windows (256 x 256 uint32 each)
+    size_t parts_capacity = 0;
+    int k2_matrix_min_part = 32;  // ... into parts of at least this many 128-bit stages (a multiple of 4)
     int k2_pitch_pad = -1;  // K2/K2s: extra bytes per row of the FP4 shadow (multiple of 128; -1 = auto)
     int k2_lds_pad = 0;     // K2s: bytes of unused dynamic LDS per workgroup (caps workgroups per CU)
     int k2_lpt_rounds = 6;  // K2s: XCD lists of at most this many rounds of 128 items are sorted longest-first

@@ -1184,7 +1184,7 @@ __device__ __forceinline__ void tb_fetch(v4i& dst, uint32_t addr) {
 __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
     TileOperands ops, const MfmaItem* __restrict__ items, uint32_t* __restrict__ out, uint64_t ld,
     uint32_t n_rows, const uint32_t* __restrict__ row_counts, uint32_t and_weight, uint32_t j_base,
-    uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols) {
+    uint32_t j_count, uint32_t split_from, uint32_t i_lo, uint32_t n_cols, uint32_t* __restrict__ parts) {
     __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbRing][kTbStageBytes];
 
     STORM_CLOCK_BEGIN();
@@ -1244,10 +1244,15 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
 #pragma unroll
         for (uint32_t p = 0; p < 4; ++p) issue_piece(s, p);
 
-    const bool interior =
-        item_idx < split_from && a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
-        (rect ? (b_row0 >= j_base && b_row0 - j_base + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0)) &&
-        (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0;
+    // [r5] option k2_matrix_parts: an item that covers only a part of k (the cut last round; every tile of a matrix with fewer
+    // tiles than CUs) writes its counts into ITS OWN 256 x 256 window of `parts` with plain stores and reduce_parts_kernel adds
+    // the windows of a tile up. parts == nullptr (the default): the parts add into the cleared output with atomics. Measured
+    // (profiles/r05_k_matrix_sizes.jsonl): the atomics are 10 of this kernel's 51 us at 1024 rows, not the 36 a count of
+    // L2 atomic operations suggested, and the second kernel costs more than that.
+    uint32_t* part_tile = (item_idx >= split_from && parts) ? parts + (uint64_t)(item_idx - split_from) * (kTile * kTile) : nullptr;
+    const bool full_tile = a_row0 >= i_lo && a_row0 + kTile <= n_rows &&
+        (rect ? (b_row0 >= j_base && b_row0 - j_base + kTile <= j_count) : (b_row0 + kTile <= n_cols && a_row0 != b_row0));
+    const bool interior = full_tile && (part_tile ? true : (item_idx < split_from && (ld & 3u) == 0 && ((uintptr_t)out & 15u) == 0));
 
 
     auto run = [&](auto nbc) __attribute__((always_inline)) {
@@ -1343,22 +1348,25 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
                 uint32_t* w32 = reinterpret_cast<uint32_t*>(mine);
                 const uint4* r128 = reinterpret_cast<const uint4*>(mine);
                 const uint32_t i0 = a_row0 + wa * 64u, j0 = b_row0 + 32u * wb;
-                uint32_t* out_tile = &out[(uint64_t)(i0 - i_lo) * ld + (j0 - j_base)];
+                const uint32_t* rcs = part_tile ? nullptr : row_counts;   // (a part holds raw AND counts)
+                const uint64_t ldx = part_tile ? (uint64_t)kTile : ld;
+                uint32_t* out_tile = part_tile ? &part_tile[(i0 - a_row0) * (uint32_t)kTile + (j0 - b_row0)]
+                                               : &out[(uint64_t)(i0 - i_lo) * ld + (j0 - j_base)];
                 uint32_t nj[4] = {0u, 0u, 0u, 0u};
-                if (row_counts) {
+                if (rcs) {
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) nj[n] = row_counts[j0 + (uint32_t)n * 64u + (lane & 31u)];
+                    for (int n = 0; n < 4; ++n) nj[n] = rcs[j0 + (uint32_t)n * 64u + (lane & 31u)];
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t il = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4u * (lane >> 5);
-                        const uint32_t ni = row_counts ? row_counts[i0 + (uint32_t)m * 32u + il] : 0u;
+                        const uint32_t ni = rcs ? rcs[i0 + (uint32_t)m * 32u + il] : 0u;
 #pragma unroll
                         for (int n = 0; n < 4; ++n) {
                             const uint32_t c = (uint32_t)acc[m][n][r];
-                            w32[il * 128u + (uint32_t)n * 32u + (lane & 31u)] = row_counts ? ni + nj[n] - and_weight * c : c;
+                            w32[il * 128u + (uint32_t)n * 32u + (lane & 31u)] = rcs ? ni + nj[n] - and_weight * c : c;
                         }
                     }
                     // lane piece p = lane & 31: columns 4 p .. 4 p + 3 of the wave's 128 = block p / 8
@@ -1368,7 +1376,7 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
                         const uint32_t pc = lane & 31u;
                         const uint4 v = r128[row * 32u + pc];
                         *reinterpret_cast<uint4*>(
-                            &out_tile[(uint64_t)((uint32_t)m * 32u + row) * ld + 64u * (pc >> 3) + 4u * (pc & 7u)]) = v;
+                            &out_tile[(uint64_t)((uint32_t)m * 32u + row) * ldx + 64u * (pc >> 3) + 4u * (pc & 7u)]) = v;
                     }
                 }
                 return;
@@ -1390,6 +1398,8 @@ __global__ __launch_bounds__(kMfmaThreads, 2) void tilebits8_kernel(
                         uint32_t* dst = &out[(uint64_t)(i - i_lo) * ld + (j - j_base)];
                         if (item_idx < split_from) {
                             *dst = row_counts ? row_counts[i] + nj - and_weight * c : c;
+                        } else if (part_tile) {
+                            part_tile[(i - a_row0) * (uint32_t)kTile + (j - b_row0)] = c;
                         } else {
                             const uint32_t once = (row_counts && it.stage0 == 0) ? row_counts[i] + nj : 0u;
                             atomicAdd(dst, row_counts ? once - and_weight * c : c);
@@ -1897,6 +1907,9 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_trace) (void)hipFree(ctx->d_trace);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_band) (void)hipFree(ctx->d_band);
+    if (ctx->d_parts) (void)hipFree(ctx->d_parts);
+    ctx->d_parts = nullptr;
+    ctx->parts_capacity = 0;
     if (ctx->d_bitsegs) (void)hipFree(ctx->d_bitsegs);
     if (ctx->d_bitfirst) (void)hipFree(ctx->d_bitfirst);
     ctx->d_bitsegs = ctx->d_bitfirst = nullptr;
@@ -2633,6 +2646,45 @@ __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restr
     }
 }
 
+// [r5] Adds up the windows the k-parts of a tile wrote into `parts` (tilebits8_kernel / tilering_kernel with parts != nullptr)
+// and writes the tile's counts — same write predicate as the tile kernels, OR / XOR from the row counts. Grid (k-part item,
+// band of kReduceBand rows), thread = column; the tile's first part does the work, its parts follow it in the item list.
+constexpr uint32_t kReduceBand = 2;   // rows per workgroup of reduce_parts_kernel
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const MfmaItem* __restrict__ items, uint32_t first, uint32_t n_items,
+                                                           const uint32_t* __restrict__ parts, uint32_t* __restrict__ out,
+                                                           uint64_t ld, uint32_t n_rows,
+                                                           const uint32_t* __restrict__ row_counts, uint32_t and_weight,
+                                                           uint32_t j_base, uint32_t j_count, uint32_t i_lo, uint32_t n_cols) {
+    const uint32_t k = first + blockIdx.x;
+    const MfmaItem it = items[k];
+    if (it.stage0 != 0) return;
+    uint32_t n_parts = 1;
+    while (k + n_parts < n_items && items[k + n_parts].stage0 != 0) ++n_parts;   // (a tile's parts: stage0 ascending from 0)
+    const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
+    const bool rect = j_count != 0;
+    if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_cols)) return;
+    const uint32_t nj = row_counts ? row_counts[j] : 0u;
+    const uint32_t* src = parts + (uint64_t)blockIdx.x * (kTile * kTile) + threadIdx.x;
+    // blockIdx.y: band of kReduceBand rows; the parts' loads of a row are independent: eight in flight
+    for (uint32_t r = blockIdx.y * kReduceBand; r < blockIdx.y * kReduceBand + kReduceBand; ++r) {
+        const uint32_t i = (uint32_t)it.I * kTile + r;
+        if (i >= i_lo && i < n_rows && (rect || i < j)) {
+            uint32_t c = 0;
+            const uint32_t* row = src + r * (uint32_t)kTile;
+            uint32_t p = 0;
+            for (; p + 8u <= n_parts; p += 8u) {
+                uint32_t v[8];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) v[q] = row[(uint64_t)(p + q) * (kTile * kTile)];
+#pragma unroll
+                for (uint32_t q = 0; q < 8u; ++q) c += v[q];
+            }
+            for (; p < n_parts; ++p) c += row[(uint64_t)p * (kTile * kTile)];
+            out[(uint64_t)(i - i_lo) * ld + (j - j_base)] = row_counts ? row_counts[i] + nj - and_weight * c : c;
+        }
+    }
+}
+
 struct MatrixPlan {  // item table of one matrix-output launch, already in ctx->d_items
     uint32_t n_items = 0;  // workgroups to launch
     uint32_t n_full = 0;   // items [0, n_full) are whole tiles; the rest are k-parts that add into a cleared window
@@ -2657,7 +2709,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
         min_parts = (total_stages + kMaxExactStages - 1) / kMaxExactStages;
     }
     const size_t n_full = tiles.size() - leftover;
-    const uint32_t max_parts = std::max(min_parts, total_stages / 32);
+    const uint32_t max_parts = std::max(min_parts, total_stages / (uint32_t)ctx->k2_matrix_min_part);
     auto cost_of = [&](size_t t) { return cost ? std::max(0.05f, (*cost)[t]) : 1.0f; };
     double left_cost = 0;
     for (size_t t = n_full; t < tiles.size(); ++t) left_cost += cost_of(t);
@@ -2694,6 +2746,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
         mix(p);
         n_items += p;
     }
+    mix((uint64_t)ctx->k2_matrix_min_part);
     const uint64_t key[4] = {h, 0x4d504c414e000000ull ^ total_stages, ((uint64_t)n_items << 32) | (uint64_t)n_full,
                              (uint64_t)leftover};
     plan->n_items = (uint32_t)n_items;
@@ -2743,7 +2796,23 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     if (n_cols == 0) n_cols = n_rows;
     if (!bits) memset(ctx->x4_key, 0, sizeof(ctx->x4_key));  // callers rebuilt the shadow in the tile layout
     const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
-    if (plan.n_full < plan.n_items)
+    // [r5] option k2_matrix_parts: the k-parts of the tile kernels that ship write their own windows and a second kernel
+    // adds them up (no clearing, no atomics); otherwise — and for the other forms, and for part lists beyond 1 GiB of
+    // windows — the parts add into the cleared output
+    const uint32_t n_split = plan.n_items - plan.n_full;
+    uint32_t* d_parts = nullptr;
+    if (n_split && bits && (ctx->k2_tile_shape_eff == 2 || ctx->k2_tile_shape_eff == 5) && ctx->k2_matrix_parts &&
+        (size_t)n_split * kTile * kTile * sizeof(uint32_t) <= ((size_t)1 << 30)) {
+        const size_t need = (size_t)n_split * kTile * kTile * sizeof(uint32_t);
+        if (need > ctx->parts_capacity) {
+            if (ctx->d_parts) (void)hipFree(ctx->d_parts);
+            ctx->d_parts = nullptr;
+            ctx->parts_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&ctx->d_parts), need) == hipSuccess) ctx->parts_capacity = need;
+        }
+        if (ctx->parts_capacity >= need) d_parts = ctx->d_parts;   // (no memory for the windows: the atomics still work)
+    }
+    if (n_split && !d_parts)
         hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
                            ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
     if (bits && ctx->k2_tile_shape_eff == 3 && timing_env()) {
@@ -2762,15 +2831,15 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
     else if (bits && ctx->k2_tile_shape_eff == 5 && ctx->k2_ring_sync == 0)
         hipLaunchKernelGGL(tilering_kernel<false>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           plan.n_full, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols, d_parts);
     else if (bits && ctx->k2_tile_shape_eff == 5)
         hipLaunchKernelGGL(tilering_kernel<true>, dim3(plan.n_items), dim3(kTrThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           plan.n_full, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols, d_parts);
     else if (bits && ctx->k2_tile_shape_eff == 2)
         hipLaunchKernelGGL(tilebits8_kernel, dim3(plan.n_items), dim3(kMfmaThreads), 0, ctx->stream,
                            *bits, d_items, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count,
-                           plan.n_full, i_lo, n_cols);
+                           plan.n_full, i_lo, n_cols, d_parts);
 #ifdef STORM_HIP_PROBES
     else if (bits)
         hipLaunchKernelGGL(tilebits_kernel, dim3(plan.n_items), dim3(kTbThreads), 0, ctx->stream,
@@ -2786,6 +2855,9 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
                            ctx->stream, ctx->d_x4, pitch, d_items, ctx->d_slots, d_out, ld, n_rows,
                            d_counts, and_weight, j_base, j_count,
                            plan.n_full, i_lo, n_cols);
+    if (d_parts)
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(n_split, kTile / kReduceBand), dim3(256), 0, ctx->stream, d_items, plan.n_full,
+                           plan.n_items, d_parts, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
     if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
     if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
     return STORM_HIP_OK;

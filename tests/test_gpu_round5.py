@@ -253,6 +253,14 @@ def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc
                     got = m.pairw_matrix(op)
                     assert np.array_equal(ref, got), (M, N, op, sync, np.argwhere(ref != got)[:3].tolist())
                 hip_ctx.set_option("k2_ring_sync", 0)
+                # the k-parts into windows of their own + reduce_parts_kernel instead of atomics (option k2_matrix_parts), both kernels
+                hip_ctx.set_option("k2_matrix_parts", 1)
+                for shape in (5, 2):
+                    hip_ctx.set_option("k2_tile_shape", shape)
+                    got = m.pairw_matrix(op)
+                    assert np.array_equal(ref, got), (M, N, op, "windows", shape, np.argwhere(ref != got)[:3].tolist())
+                hip_ctx.set_option("k2_matrix_parts", 0)
+                hip_ctx.set_option("k2_tile_shape", 5)
                 if N <= 300 and op == "and":
                     assert np.array_equal(got, np.triu(orc.tile_counts(mat, 0, N, 0, N), k=1).astype(np.uint32))
             if N >= 600:   # a band of the triangle into device memory, and the rectangle of the two halves
@@ -274,6 +282,7 @@ def test_ring_tile_kernel_against_the_oracle_and_the_default_kernel(hip_ctx, orc
     finally:
         hip_ctx.set_option("k2_tile_shape", 0)
         hip_ctx.set_option("k2_ring_sync", 0)
+        hip_ctx.set_option("k2_matrix_parts", 0)
 
 
 def ref_and(m, ctx):

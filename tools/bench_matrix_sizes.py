@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Materialised output over row counts (LD windows to the headline shape), both tile kernels, M = 65536 dense:
+ms per call into device memory and fraction of the FP4 peak.   bench_matrix_sizes.py [rows,rows,...]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import stormbitmaps_amd as sb
+
+ctx = sb.HipContext(0)
+M = 65536
+for N in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "256,512,1024,2048,4096,6144,10000").split(",")]:
+    m = ctx.matrix(N, M // 64)
+    m.fill_synthetic(M, M // 2, seed=42)
+    out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+    want = m.pairw()
+    rec = {"rows": N, "bits": M}
+    for shape, parts in ((5, 1), (2, 1), (5, 0), (2, 0)):   # parts 1: own windows + reduce_parts_kernel; 0: atomics into the cleared output
+        ctx.set_option("k2_tile_shape", shape)
+        ctx.set_option("k2_matrix_parts", parts)
+        for _ in range(3):
+            m.pairw_matrix_device(out.data_ptr(), N, "and")
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            m.pairw_matrix_device(out.data_ptr(), N, "and")
+            ts.append(time.perf_counter() - t0)
+        t = min(ts)
+        rec[f"shape{shape}_{'windows' if parts else 'atomics'}_us"] = round(t * 1e6, 1)
+        assert int(out.to(torch.int64).sum().item()) == want
+    ctx.set_option("k2_tile_shape", 0)
+    ctx.set_option("k2_matrix_parts", 1)
+    rec["all_pairs_total_us"] = round(min(_t(m) for _ in range(20)) * 1e6, 1) if (_t := (lambda mm: (lambda t0: (mm.pairw(), time.perf_counter() - t0)[1])(time.perf_counter()))) else None
+    print(json.dumps(rec), flush=True)
+    del out
+    m.close()

@@ -43,6 +43,7 @@ def main():
                 "k2_shape": int(rng.choice([16, 16, 32 if probes else 16])),
                 "k2_tile_shape": int(rng.choice([0, 5, 5, 2, 2, 1, 16, 32] if probes else [0, 5, 5, 2, 2, 3, 4, 32])),
                 "k2_ring_sync": int(rng.choice([0, 0, 1])),
+                "k2_matrix_parts": int(rng.choice([0, 0, 1])),
                 "k2_strip_operands": int(rng.choice([0, 0, 5, 4, 1 if probes else 2, 2])),
                 "k2_matrix_pad": int(rng.choice([2, 2, 1, 0, 3])),
                 "k2_fold_inline": int(rng.choice([-1, -1, 0, 1])),
@@ -194,7 +195,7 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 0, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 0, "k2_ring_sync": 0, "k2_fold_inline": -1, "k2_strip_operands": 0,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 0, "k2_ring_sync": 0, "k2_matrix_parts": 0, "k2_fold_inline": -1, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
