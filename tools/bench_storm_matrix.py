@@ -38,20 +38,27 @@ def main():
         dev = torch.zeros((a.rows, a.rows), dtype=torch.int32, device="cuda:0")
         dev_ms = {}
         same = True
-        for shape in (2, 5):
-            sb.load().STORM_hip_set_option(b"k2_tile_shape", shape)
+        lib = sb.load()
+        # (matrix_lists 0: the dense replica under either tile kernel; -1: the automatic rule — the lists where they pay)
+        for name, lists, shape in (("dense_tilebits8", 0, 2), ("dense_tilering", 0, 5), ("auto", -1, 0)):
+            lib.STORM_hip_set_option(b"matrix_lists", lists)
+            lib.STORM_hip_set_option(b"k2_tile_shape", shape)
             s.pairw_matrix_device(dev.data_ptr(), a.rows, a.rows)
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
                 s.pairw_matrix_device(dev.data_ptr(), a.rows, a.rows)
                 ts.append(time.perf_counter() - t0)
-            dev_ms[shape] = round(min(ts) * 1e3, 2)
+            dev_ms[name] = round(min(ts) * 1e3, 3)
             same = same and int(dev.to(torch.int64).sum().item()) == total
-        sb.load().STORM_hip_set_option(b"k2_tile_shape", 0)
+        lib.STORM_hip_set_option(b"k2_tile_shape", 0)
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+        import ctypes as C
+        rep = (C.c_uint64 * 4)()
+        lib.STORM_hip_last_pass(rep)
         print(json.dumps({"rows": a.rows, "bits": a.bits, "draws": d, "first_call_ms": round(first * 1e3, 2),
                           "steady_ms": round(min(steady) * 1e3, 2), "output_mb": out.nbytes / 1e6,
-                          "device_output_ms_tilebits8": dev_ms[2], "device_output_ms_tilering": dev_ms[5],
+                          "device_output_ms": dev_ms, "auto_ran_lists": bool(rep[0] & 64), "auto_group_rows": int(rep[3]),
                           "device_output_sum_equals_total": same,
                           "sum_equals_all_pairs_total": int(out.sum(dtype=np.uint64)) == total}), flush=True)
         del dev

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-5 refresh on the GPU box (gpurun, from the repo root): bench (unprofiled + rocprofv3 passes), harness TSVs at c2 and c4,
-# the output kernels, the wrappers, the whole GPU suite. Everything under gpurun_out/refresh_r05/ and gpurun_out/prof_r05/.
+# the output kernels, the wrappers, K5, the soak, the whole GPU suite. Everything under gpurun_out/refresh_r05/ and
+# gpurun_out/prof_r05/.
 set -e
 R=$PWD
 O=$R/gpurun_out/refresh_r05
@@ -17,6 +18,11 @@ python3 tools/check_tile5.py --quick > $O/check_tile5.txt 2>&1 || true
 python3 tools/bench_tile_round.py > $O/tile_round.jsonl 2>&1 || true
 python3 tools/bench_wrapper.py > $O/wrapper.jsonl 2>&1 || true
 python3 tools/bench_matrix.py --reps 30 > $O/bench_matrix.jsonl 2>&1 || true
+python3 tools/check_lists_matrix.py --draws 5,52,104,190,262,524,1048,2096,3145,3670 > $O/lists_matrix.txt 2>&1 || true
+python3 tools/bench_storm_matrix.py --draws 104,524,20971 > $O/storm_matrix.jsonl 2>&1 || true
+python3 tools/bench_sparse_small.py > $O/sparse_small.jsonl 2>&1 || true
 echo "tools done"
+python3 tools/soak_parity.py --seconds 300 --seed 55 > $O/soak.txt 2>&1 || true
+tail -1 $O/soak.txt
 python3 -m pytest tests -x -q -m gpu > $O/pytest_gpu.txt 2>&1 || true
 tail -3 $O/pytest_gpu.txt
