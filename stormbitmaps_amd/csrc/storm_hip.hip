@@ -22,6 +22,8 @@
 //                4096 slots -> tiny second kernel folds the slots into the result word.
 #include "storm_hip_internal.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -585,6 +587,7 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
     if (ctx->d_positions) (void)hipFree(ctx->d_positions);
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
+    if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     if (ctx->h_stage_ring) (void)hipHostFree(ctx->h_stage_ring);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
@@ -612,6 +615,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->sparse_probe = (int)value;
+    } else if (!strcmp(key, "result_mailbox")) {
+        ctx->result_mailbox = value != 0;
     } else if (!strcmp(key, "matrix_lists")) {
         if (value < -1 || value > 1) {
             set_error("matrix_lists must be -1 (by density), 0 (never) or 1 (whenever eligible)");
@@ -847,6 +852,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "variant")) return ctx->variant;
     if (!strcmp(key, "variant_used")) return ctx->variant_used;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
+    if (!strcmp(key, "result_mailbox")) return ctx->result_mailbox;
     if (!strcmp(key, "matrix_lists")) return ctx->matrix_lists;
     if (!strcmp(key, "matrix_lists_density")) return ctx->matrix_lists_permille_x10;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
@@ -1291,7 +1297,55 @@ int launch_pairw_segments(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t stri
 
 // The context's result word to the host, through a pinned word (a pageable destination makes the runtime stage
 // the 8 bytes and costs a call ~10 us more; with G devices driven from one process that is G times).
+uint64_t* result_target(storm_hip_ctx_t* ctx) {
+    ctx->mail_armed = false;
+    if (!ctx->result_mailbox) return reinterpret_cast<uint64_t*>(ctx->d_scalar);
+    if (!ctx->h_mail) {
+        void* dev = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mail), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+            hipHostGetDevicePointer(&dev, ctx->h_mail, 0) != hipSuccess) {
+            if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+            ctx->h_mail = nullptr;
+            ctx->result_mailbox = 0;   // (no mapped host memory here: the copy + synchronize path)
+            return reinterpret_cast<uint64_t*>(ctx->d_scalar);
+        }
+        ctx->d_mail = static_cast<unsigned long long*>(dev);
+    }
+    __atomic_store_n(ctx->h_mail, ~0ull, __ATOMIC_RELEASE);   // no total is ~0: that is the API's own failure value
+    ctx->mail_armed = true;
+    return reinterpret_cast<uint64_t*>(ctx->d_mail);
+}
+
+int wait_mailbox(storm_hip_ctx_t* ctx, uint64_t* value) {
+    ctx->mail_armed = false;
+    // the device's store arrives over the bus while the kernel ends: a few hundred polls; a pass of seconds (c5) falls
+    // through to the synchronize after 2 ms of polling
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+        const unsigned long long v = __atomic_load_n(ctx->h_mail, __ATOMIC_ACQUIRE);
+        if (v != ~0ull) {
+            *value = v;
+            return STORM_HIP_OK;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((spin & 1023u) == 1023u &&
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+            break;
+    }
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const unsigned long long v = __atomic_load_n(ctx->h_mail, __ATOMIC_ACQUIRE);
+    if (v == ~0ull) {
+        set_error("the pass ended without writing its total (result mailbox)");
+        return STORM_HIP_EHIP;
+    }
+    *value = v;
+    return STORM_HIP_OK;
+}
+
 int fetch_result_word(storm_hip_ctx_t* ctx, uint64_t* h_total) {
+    if (ctx->mail_armed) return wait_mailbox(ctx, h_total);
     if (!ctx->h_scalar &&
         hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalar), 64, hipHostMallocDefault) != hipSuccess)
         ctx->h_scalar = nullptr;
@@ -1344,8 +1398,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
 int storm_hip_pairw_dense_begin(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                                 uint32_t shard_rank, uint32_t shard_count) {
     if (check_ctx(ctx)) return STORM_HIP_EINVAL;
-    return storm_hip_pairw_dense_launch(ctx, m, shard_rank, shard_count,
-                                        reinterpret_cast<uint64_t*>(ctx->d_scalar));
+    return storm_hip_pairw_dense_launch(ctx, m, shard_rank, shard_count, result_target(ctx));
 }
 
 int storm_hip_pairw_dense_end(storm_hip_ctx_t* ctx, uint64_t* h_total) {
@@ -1383,7 +1436,7 @@ int storm_hip_pairw_dense_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_t* m, co
     }
     memset(ctx->pass_report, 0, sizeof(ctx->pass_report));
     ctx->variant_used = 4;
-    if (int rc = launch_pairw_bits_upload(ctx, m, host_rows, src_stride_words, reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+    if (int rc = launch_pairw_bits_upload(ctx, m, host_rows, src_stride_words, result_target(ctx)))
         return rc;
     return fetch_result_word(ctx, h_total);
     });
@@ -1408,13 +1461,10 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
     // the popcount kernel otherwise (or when forced by `variant`)
     const bool big = a->stride_words * 32ull * 64ull < (1ull << 32);
     if (a->stride_words == b->stride_words && (ctx->variant >= 3 || (ctx->variant < 0 && big))) {
-        if (int rc = launch_square_mfma(ctx, a, b, reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+        if (int rc = launch_square_mfma(ctx, a, b, result_target(ctx)))
             return rc;
         ctx->variant_used = 4;
-        STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t),
-                                     hipMemcpyDeviceToHost, ctx->stream));
-        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        return STORM_HIP_OK;
+        return fetch_result_word(ctx, h_total);
     }
     ctx->variant_used = 2;
     const uint32_t seg_rows = (uint32_t)ctx->seg_rows;
@@ -1432,12 +1482,9 @@ int storm_hip_square_dense(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* a,
                        (uint32_t)b->n_rows, seg_rows, spb, n_segs, n_chunks, ctx->d_slots);
     STORM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
-                       ctx->d_scalar);
+                       reinterpret_cast<unsigned long long*>(result_target(ctx)));
     STORM_HIP_TRY(hipGetLastError());
-    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return STORM_HIP_OK;
+    return fetch_result_word(ctx, h_total);
     });
 }
 
@@ -1674,12 +1721,9 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
                        m->n_words, ctx->d_slots);
     STORM_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(fold_slots_kernel, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_slots,
-                       ctx->d_scalar);
+                       reinterpret_cast<unsigned long long*>(result_target(ctx)));
     STORM_HIP_TRY(hipGetLastError());
-    STORM_HIP_TRY(hipMemcpyAsync(h_total, ctx->d_scalar, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return STORM_HIP_OK;
+    return fetch_result_word(ctx, h_total);
     });
 }
 

@@ -146,6 +146,11 @@ int storm_hip_comm_allreduce_result(storm_hip_ctx_t* ctx, storm_hip_comm_t* comm
         return STORM_HIP_EINVAL;
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (ctx->mail_armed) {   // the pass was launched into the host mailbox (option result_mailbox): its value goes up again
+        uint64_t mine = 0;
+        if (int rc = storm::wait_mailbox(ctx, &mine)) return rc;
+        return storm_hip_comm_allreduce_u64(ctx, comm, &mine) ? STORM_HIP_EHIP : ((*total = mine), STORM_HIP_OK);
+    }
     if (int rc = g_rccl.AllReduce(ctx->d_scalar, comm->d_word, 1, kNcclUint64, kNcclSum, comm->comm, ctx->stream))
         return rccl_fail("ncclAllReduce", rc);
     STORM_HIP_TRY(hipMemcpyAsync(comm->h_word, comm->d_word, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

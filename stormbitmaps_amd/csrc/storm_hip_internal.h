@@ -82,6 +82,14 @@ struct storm_hip_ctx_s {
     unsigned long long* d_slots = nullptr;   // kSlots partial sums
     unsigned long long* d_scalar = nullptr;  // one uint64 result
     unsigned long long* h_scalar = nullptr;  // pinned host word the result is read back through
+    // [r5] result mailbox: a pinned, device-visible host word the LAST kernel of a synchronous all-pairs call writes the
+    // total into directly; the host polls it (sentinel ~0 = not there yet) instead of queueing an 8-byte copy behind the
+    // kernel and sleeping in hipStreamSynchronize — 5 - 7 us of a call that is 18 - 30 us at the sparse end and at LD-window
+    // row counts. Option result_mailbox (1 on / 0 off: the copy + synchronize of rounds 1 - 4).
+    unsigned long long* h_mail = nullptr;
+    unsigned long long* d_mail = nullptr;    // the same word as the device sees it
+    int result_mailbox = 1;
+    bool mail_armed = false;                 // the call in flight was launched into the mailbox
     void* h_stage_ring = nullptr;            // pinned staging ring of the sparse arena builder (storm_hip_sparse.hip: Stager), allocated on first use
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
     size_t segs_capacity = 0;
@@ -234,6 +242,10 @@ int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 void release_mfma_state(storm_hip_ctx_t* ctx);
 // ctx->d_scalar -> *h_total through the context's pinned word; synchronises the stream (storm_hip.hip)
 int fetch_result_word(storm_hip_ctx_t* ctx, uint64_t* h_total);
+// where a synchronous call launches its total: the mailbox (armed with the sentinel) or, without one, ctx->d_scalar
+uint64_t* result_target(storm_hip_ctx_t* ctx);
+// the armed mailbox's value once it has arrived (polls; falls back to a stream synchronize); STORM_HIP_EHIP if it never does
+int wait_mailbox(storm_hip_ctx_t* ctx, uint64_t* value);
 // folds ctx->d_slots into *d_total (device pointer) and re-zeroes the slots (storm_hip.hip)
 int launch_fold_slots(storm_hip_ctx_t* ctx, uint64_t* d_total);
 // record the next event of the "time_kernels" series on the launch stream (no-op when off)

@@ -3328,10 +3328,8 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
     ctx->last_info[1] = ctx->bit_max_stages;
     ctx->last_info[2] = 1;
     ctx->last_info[3] = ctx->n_bit_segs;
-    if (ctx->n_bit_groups == 0) {
-        STORM_HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(uint64_t), ctx->stream));
-        return STORM_HIP_OK;
-    }
+    if (ctx->n_bit_groups == 0)   // (nothing to multiply: the fold of the empty slots writes the 0 — d_total may be the host mailbox)
+        return launch_fold_slots(ctx, d_total);
     kernel_time_mark(ctx);
     const dim3 grid(ctx->n_bit_groups), block(kStripThreads);
 #ifdef STORM_HIP_PROBES

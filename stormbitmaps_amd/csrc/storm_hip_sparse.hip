@@ -1370,6 +1370,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     }
     storm_hip_sparse_t* s = const_cast<storm_hip_sparse_t*>(cs);
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t* const d_result = result_target(ctx);   // the mailbox, or ctx->d_scalar
     memcpy(ctx->sparse_census, s->census, sizeof(s->census));
     memset(ctx->pass_report, 0, sizeof(ctx->pass_report));
     // Matrix-core path when the columns are big enough to fill the chip (same rule as the dense
@@ -1457,7 +1458,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             // (option k2_fold_inline as for the strips; the slot words' 48-bit sums hold any total below 2^47 / 4096 x 256)
             probe_folds = ranges.empty() && ctx->k2_fold_inline != 0 && s->n_probe_launch <= 16384u &&
                           s->probe_lookups_launch < (1ull << 38);
-            unsigned long long* fold_out = probe_folds ? reinterpret_cast<unsigned long long*>(ctx->d_scalar) : nullptr;
+            unsigned long long* fold_out = probe_folds ? reinterpret_cast<unsigned long long*>(d_result) : nullptr;
 #define STORM_PROBE_LAUNCH(T)                                                                                          \
     hipLaunchKernelGGL(probe_lists_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_elems,       \
                        s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots, \
@@ -1485,7 +1486,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             rows_dst <= s->pool_rows_ready + 512) {
             if (int rc = launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(s->d_pool), s->pitch * 8ull,
                                                   ranges, kBlockWords / 4u, shard_rank, shard_count,
-                                                  reinterpret_cast<uint64_t*>(ctx->d_scalar), s->n_probe_launch > 0))
+                                                  d_result, s->n_probe_launch > 0))
                 return rc;
             ctx->last_info[3] = s->n_probe_cols_launch;
             return STORM_HIP_OK;
@@ -1493,7 +1494,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
         if (int rc = launch_pairw_mfma_ranges(ctx, s->d_pool, s->pitch, s->pool_rows_ready + 512,
                                               std::max<uint64_t>(rows_dst, 512), ranges,
                                               shard_rank, shard_count, variant == 5 ? 2 : variant == 4 ? 1 : 0,
-                                              reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+                                              d_result))
             return rc;
         ctx->last_info[3] = s->n_probe_cols_launch;  // block columns counted by the list-probe kernel
         return STORM_HIP_OK;
@@ -1534,7 +1535,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     }
     if (int rc = launch_pairw_segments(ctx, s->d_pool, s->pitch, s->d_segs, s->n_segs,
                                        s->seg_row_sum,
-                                       reinterpret_cast<uint64_t*>(ctx->d_scalar)))
+                                       d_result))
         return rc;
     return STORM_HIP_OK;
     });
