@@ -2626,15 +2626,15 @@ static int ensure_counts_scratch(storm_hip_ctx_t* ctx, size_t n, uint32_t** out)
 }
 
 // Clears the output window of the tiles whose k range is split over several items (same write
-// predicate as pairw_fp4_kernel<., true>). Grid (k-part item, band of 16 rows), thread = column.
+// predicate as pairw_fp4_kernel<., true>). Grid (cut tile, band of 16 rows), thread = column. (Until round 5 the grid ran over
+// the PARTS and all but the first part of a tile returned at once: 2560 workgroups for 10 windows at 1024 rows, 8 us.)
 __global__ __launch_bounds__(256) void zero_tiles_kernel(const MfmaItem* __restrict__ items,
                                                          uint32_t first,
                                                          uint32_t* __restrict__ out, uint64_t ld,
                                                          uint32_t n_rows, uint32_t j_base,
                                                          uint32_t j_count, uint32_t i_lo,
                                                          uint32_t n_cols) {
-    const MfmaItem it = items[first + blockIdx.x];
-    if (it.stage0 != 0) return;  // one window per tile: its first k-part clears it
+    const MfmaItem it = items[first + blockIdx.x];   // `first`: where the records of the cut tiles begin (behind all items)
     const uint32_t j = (uint32_t)it.J * kTile + threadIdx.x;
     const bool rect = j_count != 0;
     if (!(rect ? (j >= j_base && j - j_base < j_count) : j < n_cols)) return;
@@ -2688,6 +2688,8 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const MfmaItem* __res
 struct MatrixPlan {  // item table of one matrix-output launch, already in ctx->d_items
     uint32_t n_items = 0;  // workgroups to launch
     uint32_t n_full = 0;   // items [0, n_full) are whole tiles; the rest are k-parts that add into a cleared window
+    uint32_t n_cut = 0;    // tiles that are cut into parts: behind the items the table holds one record per such tile
+                           // (what zero_tiles_kernel walks: one workgroup column per window, not one per part)
 };
 
 // Builds and uploads the item table (before the caller launches anything else, so that the one
@@ -2751,6 +2753,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
                              (uint64_t)leftover};
     plan->n_items = (uint32_t)n_items;
     plan->n_full = (uint32_t)n_full;
+    plan->n_cut = (uint32_t)leftover;
     if (ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key))) return STORM_HIP_OK;
     std::vector<MfmaItem> items;
     items.reserve(n_items);
@@ -2765,6 +2768,7 @@ static int plan_matrix_tiles(storm_hip_ctx_t* ctx, const std::vector<std::pair<u
             items.push_back({tiles[t].first, tiles[t].second, s0, s1 - s0});
         }
     }
+    for (size_t t = n_full; t < tiles.size(); ++t) items.push_back({tiles[t].first, tiles[t].second, 0u, 0u});   // the cut tiles once more: the windows to clear
     // the context's item buffer (shared with the tile kernel's sum mode, whose cached table is
     // dropped here); hipMalloc / hipFree per call would cost more than the kernel's tail
     if (items.size() > ctx->items_capacity) {
@@ -2813,8 +2817,8 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         if (ctx->parts_capacity >= need) d_parts = ctx->d_parts;   // (no memory for the windows: the atomics still work)
     }
     if (n_split && !d_parts)
-        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_items - plan.n_full, kTile / 16), dim3(256), 0,
-                           ctx->stream, d_items, plan.n_full, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
+        hipLaunchKernelGGL(zero_tiles_kernel, dim3(plan.n_cut, kTile / 16), dim3(256), 0,
+                           ctx->stream, d_items, plan.n_items, d_out, ld, n_rows, j_base, j_count, i_lo, n_cols);
     if (bits && ctx->k2_tile_shape_eff == 3 && timing_env()) {
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, tile16_bits_kernel, kTiThreads, kTiLdsBytes);
