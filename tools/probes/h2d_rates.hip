@@ -125,6 +125,26 @@ int main(int argc, char** argv) {
             });
             printf(", \"panels_mode%d_GBs\": %.1f", mode, (double)rows * panels * row / t / 1e9);
         }
+        // the same dependency through stream memory operations: a flag written behind every copy, waited for on the other stream
+        int can = 0;
+        (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0);
+        uint32_t* flag = nullptr;
+        if (can && hipExtMallocWithFlags((void**)&flag, 8, hipMallocSignalMemory) == hipSuccess) {
+            uint32_t seq = 0;
+            t = best([&] {
+                for (int p = 0; p < panels; ++p) {
+                    (void)hipMemcpy2DAsync(dev + p * rows * pitch, pitch, pageable + p * rows * row, row, row, rows, hipMemcpyHostToDevice, sc);
+                    (void)hipStreamWriteValue32(sc, flag, ++seq, 0);
+                    (void)hipStreamWaitValue32(sk, flag, seq, hipStreamWaitValueGte, 0xffffffffu);
+                    (void)hipMemsetAsync(dev + bytes - 64, 0, 64, sk);
+                }
+                (void)hipStreamSynchronize(sc);
+                (void)hipStreamSynchronize(sk);
+            });
+            printf(", \"panels_stream_values_GBs\": %.1f", (double)rows * panels * row / t / 1e9);
+        } else {
+            printf(", \"stream_wait_value\": %d", can);
+        }
     }
     printf("}\n");
     return 0;
