@@ -683,8 +683,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_shadow_budget_mb = (int)value;
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 0 (chosen by the matrix), 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 16 or 32 (FP4 shadow)");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 6 && value != 16 && value != 32) {
+            set_error("k2_tile_shape must be 0 (chosen by the matrix), 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 6 (small tiles over their whole k range, one k quarter per wave), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
@@ -696,6 +696,24 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->k2_tile_shape = (int)value;
     } else if (!strcmp(key, "k2_ring_sync")) {
         ctx->k2_ring_sync = value != 0;
+    } else if (!strcmp(key, "k2_wave_below")) {
+        if (value < 0 || value > (1 << 30)) {
+            set_error("k2_wave_below: 0 (never) .. 2^30 tiles of 256 x 256");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_wave_below = (int)value;
+    } else if (!strcmp(key, "k2_wave_tile")) {
+        if (value != 0 && value != 22 && value != 42) {
+            set_error("k2_wave_tile must be 0 (by the rows), 22 (64 x 64) or 42 (128 x 64)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_wave_tile = (int)value;
+    } else if (!strcmp(key, "k2_wave_small_rows")) {
+        if (value < 0 || value > (1 << 30)) {
+            set_error("k2_wave_small_rows: 0 .. 2^30 rows");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_wave_small_rows = (int)value;
     } else if (!strcmp(key, "k2_ring_cost_diag") || !strcmp(key, "k2_ring_cost_ragged")) {
         if (value < 5 || value > 100) {
             set_error("%s is a percentage of a full tile's time, 5..100", key);
@@ -867,6 +885,9 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_shard_pairs")) return ctx->k2_shard_pairs;
     if (!strcmp(key, "k2_ring_sync")) return ctx->k2_ring_sync;
     if (!strcmp(key, "k2_tile_shape")) return ctx->k2_tile_shape;
+    if (!strcmp(key, "k2_wave_below")) return ctx->k2_wave_below;
+    if (!strcmp(key, "k2_wave_tile")) return ctx->k2_wave_tile;
+    if (!strcmp(key, "k2_wave_small_rows")) return ctx->k2_wave_small_rows;
     if (!strcmp(key, "k2_tile_shape_used")) return ctx->k2_tile_shape_eff;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;

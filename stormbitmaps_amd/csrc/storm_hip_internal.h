@@ -141,6 +141,10 @@ struct storm_hip_ctx_s {
     int k2_fold_inline = -1;        // K2b: the workgroup dispatched last folds the partial sums inside the launch: -1 = for short launches (<= 4096 workgroups, where the fold launch and its gaps are a fifth of a pass), 1 = always (level at N = 10000), 0 = never (a fold launch behind the strips); profiles/r05_c_fold_ab.jsonl
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 0;  // write-mode tile kernel: 0 = by the matrix (5 for a dense matrix, 2 for the dense replica of a sparse container: sparse operands let tilebits8_kernel, which sits at the socket's power cap, clock higher; crossover near 20 % density, profiles/r05_g_*); 5 = tilering_kernel (both operands as FP4 images in the LDS, 16x16x128); 2 = tilebits8_kernel (bit operands inflated in registers, 32x32x64); 3 / 4 = K2tb; 1 / 16 / 32: tools build
+    int k2_wave_below = 400;      // [r6] k2_tile_shape 0: matrices (bands, rectangles) of fewer 256 x 256 tiles than this take tilewave_kernel (K2w: small tiles that own their whole k range; no k-parts, no window clearing, no atomics)
+    int k2_wave_tile = 0;         // K2w's tile: 0 = by the rows (64 x 64 up to k2_wave_small_rows output rows, 128 x 64 above), 22 = 64 x 64, 42 = 128 x 64
+    int k2_wave_small_rows = 3072;
+    uint32_t n_wave_items = 0;    // items of the K2w list cached in d_items (items_key)
     int k2_tile_shape_eff = 2;  // what the call in flight runs (set by launch_pairw_matrix / launch_square_matrix)
     int k2_ring_sync = 0;   // tilering_kernel: 0 = one s_barrier per stage; 1 = arrival counters in the LDS (waves may drift a stage apart; measured 2 % slower)
     int k2_ring_cost_diag = 78, k2_ring_cost_ragged = 40;  // the same for tilering_kernel (k2_tile_shape = 5)

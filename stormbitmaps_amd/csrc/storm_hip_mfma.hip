@@ -1495,6 +1495,7 @@ __device__ __forceinline__ int ti_inflb(int w) {
 #undef STORM_TI_NAME
 
 #include "tile_ring_kernel.inc"
+#include "tile_wave_kernel.inc"
 
 // ------------------------------------------------------------------------------------------
 // K2sb: the strips on BIT operands (option k2_strip_operands = 1; the default stays the FP4 shadow).
@@ -2895,6 +2896,97 @@ static void xcd_grouped_tiles(uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1
             if (pos < per_xcd[x].size()) out.push_back(per_xcd[x][pos]);
 }
 
+// ---- K2w (tilewave_kernel): small tiles that own their whole k range, for matrices of few 256 x 256 tiles ----
+// Which wave tile: 0 = none (the 256 x 256 kernels), 22 = 64 x 64, 42 = 128 x 64. `tiles256` = what the 256 x 256
+// decomposition would launch. Rows whose k range, cut four ways among the waves, reaches 2^24 bits are not eligible
+// (f32 accumulators), nor are row pitches beyond the 32-bit buffer offsets of a 128-row window.
+static int choose_wave_tile(const storm_hip_ctx_t* ctx, uint64_t tiles256, uint64_t out_rows, uint32_t total_stages,
+                            uint64_t pitch, bool bits) {
+    if (!bits || (uint64_t)total_stages * 32u >= (1ull << 24) || pitch * 128u >= (1ull << 32)) return 0;
+    const bool forced = ctx->k2_tile_shape == 6;
+    if (!forced && (ctx->k2_tile_shape != 0 || tiles256 >= (uint64_t)ctx->k2_wave_below)) return 0;
+    if (ctx->k2_wave_tile) return ctx->k2_wave_tile;
+    // 64 x 64 while the matrix gives fewer than ~4 tiles of 128 x 64 per CU (a CU should end on a short tile)
+    return out_rows <= (uint64_t)ctx->k2_wave_small_rows ? 22 : 42;
+}
+
+// Tile list of a K2w launch: A tiles [ia0, ia1) (TM rows each) against B tiles [jb0, jb1) (TN rows each); `triangle`: only
+// tiles that hold a pair i < j (block offset d = NB J - MB I > -NB), the ones that straddle the diagonal last (they
+// multiply fewer blocks: a CU's last item should be a short one). Order: groups of 4 x 8 neighbouring tiles go to one XCD
+// (block b runs on XCD b % 8: observed, speed only), so the workgroups an XCD runs side by side share their rows in its L2.
+static void wave_tile_list(uint32_t MB, uint32_t NB, uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1, bool triangle,
+                           std::vector<MfmaItem>& items, uint32_t total_stages) {
+    std::vector<std::vector<MfmaItem>> per_xcd(8), late(8);
+    uint32_t g = 0;
+    for (uint32_t gi = ia0; gi < ia1; gi += 4)
+        for (uint32_t gj = jb0; gj < jb1; gj += 8) {
+            size_t added = 0;
+            for (uint32_t i = gi; i < std::min(gi + 4, ia1); ++i)
+                for (uint32_t j = gj; j < std::min(gj + 8, jb1); ++j) {
+                    const int64_t d = (int64_t)NB * j - (int64_t)MB * i;
+                    if (triangle && d <= -(int64_t)NB) continue;   // every block below the diagonal
+                    const bool partial = triangle && d < (int64_t)MB - 1;
+                    (partial ? late : per_xcd)[g % 8].push_back({(uint16_t)i, (uint16_t)j, 0u, total_stages});
+                    ++added;
+                }
+            if (added) ++g;
+        }
+    for (auto* lists : {&per_xcd, &late}) {
+        size_t longest = 0;
+        for (auto& v : *lists) longest = std::max(longest, v.size());
+        for (size_t pos = 0; pos < longest; ++pos)
+            for (int x = 0; x < 8; ++x)
+                if (pos < (*lists)[x].size()) items.push_back((*lists)[x][pos]);
+    }
+}
+
+// Uploads the list (cached by its key while the same call repeats) and launches tilewave_kernel.
+static int run_wave_tiles(storm_hip_ctx_t* ctx, int wave_tile, uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1,
+                          bool triangle, uint32_t total_stages, const TileOperands& ops, uint32_t* d_out, uint64_t ld,
+                          uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight, uint32_t j_base,
+                          uint32_t j_count, uint32_t i_lo, uint32_t n_cols, bool sync) {
+    const uint32_t MB = wave_tile == 42 ? 4u : 2u, NB = 2u;
+    if (ia1 > 65535u || jb1 > 65535u) {
+        set_error("pairw_matrix: too many row blocks");
+        return STORM_HIP_EINVAL;
+    }
+    const uint64_t key[4] = {((uint64_t)ia0 << 32) | ia1, ((uint64_t)jb0 << 32) | jb1,
+                             0x4b32570000000000ull ^ ((uint64_t)wave_tile << 32) ^ total_stages, triangle ? 1ull : 2ull};
+    if (!(ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key)))) {
+        std::vector<MfmaItem> items;
+        wave_tile_list(MB, NB, ia0, ia1, jb0, jb1, triangle, items, total_stages);
+        if (items.size() > ctx->items_capacity) {
+            if (ctx->d_items) STORM_HIP_TRY(hipFree(ctx->d_items));
+            ctx->d_items = nullptr;
+            ctx->items_capacity = 0;
+            const size_t cap = std::max<size_t>(items.size(), 4096);
+            STORM_HIP_TRY(hipMalloc(&ctx->d_items, cap * sizeof(MfmaItem)));
+            ctx->items_capacity = cap;
+        }
+        memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
+        ctx->n_items = 0;
+        if (!items.empty()) {
+            STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, items.data(), items.size() * sizeof(MfmaItem),
+                                         hipMemcpyHostToDevice, ctx->stream));
+            STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` is pageable and leaves scope
+        }
+        memcpy(ctx->items_key, key, sizeof(key));
+        ctx->n_wave_items = (uint32_t)items.size();
+    }
+    const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
+    if (ctx->n_wave_items) {
+        if (wave_tile == 42)
+            hipLaunchKernelGGL((tilewave_kernel<4, 2>), dim3(ctx->n_wave_items), dim3(kTwThreads), 0, ctx->stream, ops, d_items,
+                               d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
+        else
+            hipLaunchKernelGGL((tilewave_kernel<2, 2>), dim3(ctx->n_wave_items), dim3(kTwThreads), 0, ctx->stream, ops, d_items,
+                               d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
+    }
+    if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
+    if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
+    return STORM_HIP_OK;
+}
+
 // Materialised upper triangle: out[i * ld + j] = popcount(row_i & row_j) for i < j < n_rows
 // (device pointer, uint32). One tile item per (I <= J) spanning all of k; f32 accumulation is
 // exact for rows of fewer than 2^24 bits.
@@ -2903,7 +2995,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // band: only rows [band_row0, band_row0 + band_rows) of the triangle, written from output row 0
     const uint64_t band_end = std::min<uint64_t>(m->n_rows, band_row0 + band_rows);
     if (band_row0 >= band_end) return STORM_HIP_OK;
-    ctx->k2_tile_shape_eff = ctx->k2_tile_shape ? ctx->k2_tile_shape : (m->sparse_origin ? 2 : 5);
+    ctx->k2_tile_shape_eff = (ctx->k2_tile_shape && ctx->k2_tile_shape != 6) ? ctx->k2_tile_shape : (m->sparse_origin ? 2 : 5);   // (6 = K2w, chosen below; not eligible: as 0)
     ctx->pass_report[0] = STORM_HIP_RAN_TILES_OUT;   // (a report of its own: the per-pair output is no all-pairs pass)
     ctx->pass_report[1] = m->n_rows * (m->n_rows - (m->n_rows != 0)) / 2 * m->n_words;
     ctx->pass_report[2] = ctx->pass_report[3] = 0;
@@ -2938,6 +3030,31 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // the headline shape since round 4's pitch pad — are never multiplied)
     const uint32_t total_stages = bits ? (m->n_words + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
+    // [r6] few tiles: small tiles that own their whole k range (tilewave_kernel) instead of k-parts of 256 x 256 tiles
+    {
+        const uint64_t band_tiles = (uint64_t)((band_end + kTile - 1) / kTile - band_row0 / kTile);
+        const uint64_t tiles256 = band_tiles * nT - (band_row0 / kTile) * band_tiles - band_tiles * (band_tiles - 1) / 2;
+        if (const int wt = choose_wave_tile(ctx, tiles256, band_end - band_row0, total_stages, pitch, bits)) {
+            ctx->k2_tile_shape_eff = 6;
+            const uint32_t TM = wt == 42 ? 128u : 64u, TN = 64u;
+            uint32_t* d_counts = nullptr;
+            int rc = STORM_HIP_OK;
+            if (op != STORM_HIP_OP_AND) {
+                rc = ensure_counts_scratch(ctx, m->n_rows, &d_counts);
+                if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, m, d_counts);
+            }
+            if (rc == STORM_HIP_OK) {
+                const TileOperands ops = {reinterpret_cast<const uint8_t*>(m->d), nullptr, pitch, 0xffffffffu,
+                                          (uint32_t)std::min<uint64_t>(m->n_rows_pad, 0xffffffffu), 0u};
+                rc = run_wave_tiles(ctx, wt, (uint32_t)(band_row0 / TM), (uint32_t)((band_end + TM - 1) / TM), 0u,
+                                    (uint32_t)((m->n_rows + TN - 1) / TN), true, total_stages, ops, d_out, ld,
+                                    (uint32_t)band_end, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u,
+                                    (uint32_t)band_row0, (uint32_t)m->n_rows, sync);
+            }
+            if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
+            return rc;
+        }
+    }
     // off-diagonal tiles first; the diagonal ones (half of their window is written) go last,
     // where run_matrix_tiles may cut them along k
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
@@ -2997,7 +3114,7 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
 int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                          const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld) {
     if (a->n_rows == 0 || b->n_rows == 0) return STORM_HIP_OK;
-    ctx->k2_tile_shape_eff = ctx->k2_tile_shape ? ctx->k2_tile_shape : ((a->sparse_origin && b->sparse_origin) ? 2 : 5);
+    ctx->k2_tile_shape_eff = (ctx->k2_tile_shape && ctx->k2_tile_shape != 6) ? ctx->k2_tile_shape : ((a->sparse_origin && b->sparse_origin) ? 2 : 5);
     const uint64_t stride_words = a->stride_words;
     const uint64_t row_bytes = stride_words * 32;
     const bool bits = ctx->k2_tile_shape_eff <= 5 && b->stride_words == stride_words;
@@ -3028,6 +3145,28 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     // (bit kernels: whole 512-bit chunks that hold DATA; the pitch's pad chunks are never multiplied)
     const uint32_t total_stages = bits ? (std::max(a->n_words, b->n_words) + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
+    if (const int wt = choose_wave_tile(ctx, (uint64_t)ta * tb, a->n_rows, total_stages, pitch, bits)) {   // [r6] few tiles
+        ctx->k2_tile_shape_eff = 6;
+        const uint32_t TM = wt == 42 ? 128u : 64u, TN = 64u;
+        uint32_t* d_counts = nullptr;
+        int rc = STORM_HIP_OK;
+        if (op != STORM_HIP_OP_AND) {
+            rc = ensure_counts_scratch(ctx, rows_a + rows_b, &d_counts);
+            if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, a, d_counts);
+            if (rc == STORM_HIP_OK) rc = launch_row_counts(ctx, b, d_counts + rows_a);
+        }
+        if (rc == STORM_HIP_OK) {
+            const TileOperands ops = {reinterpret_cast<const uint8_t*>(a->d), reinterpret_cast<const uint8_t*>(b->d), pitch,
+                                      (uint32_t)rows_a, (uint32_t)std::min<uint64_t>(a->n_rows_pad, rows_a),
+                                      (uint32_t)std::min<uint64_t>(b->n_rows_pad, rows_b)};
+            rc = run_wave_tiles(ctx, wt, 0u, (uint32_t)((a->n_rows + TM - 1) / TM), (uint32_t)(rows_a / TN),
+                                (uint32_t)((rows_a + b->n_rows + TN - 1) / TN), false, total_stages, ops, d_out, ld,
+                                (uint32_t)a->n_rows, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a,
+                                (uint32_t)b->n_rows, 0u, 0u, true);
+        }
+        if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
+        return rc;
+    }
     std::vector<std::pair<uint16_t, uint16_t>> tiles;
     xcd_grouped_tiles(0, ta, ta, ta + tb, false, tiles);
     uint32_t* d_counts = nullptr;  // per shadow row
