@@ -617,6 +617,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         ctx->sparse_probe = (int)value;
     } else if (!strcmp(key, "result_mailbox")) {
         ctx->result_mailbox = value != 0;
+    } else if (!strcmp(key, "sync_poll_us")) {
+        if (value < 0 || value > 1000000) {
+            set_error("sync_poll_us: 0 .. 1000000 microseconds");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->sync_poll_us = (int)value;
     } else if (!strcmp(key, "matrix_lists")) {
         if (value < -1 || value > 1) {
             set_error("matrix_lists must be -1 (by density), 0 (never) or 1 (whenever eligible)");
@@ -684,7 +690,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         memset(ctx->x4_key, 0, sizeof(ctx->x4_key));
     } else if (!strcmp(key, "k2_tile_shape")) {
         if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5 && value != 6 && value != 16 && value != 32) {
-            set_error("k2_tile_shape must be 0 (chosen by the matrix), 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 6 (small tiles over their whole k range, one k quarter per wave), 16 or 32 (FP4 shadow)");
+            set_error("k2_tile_shape must be 0 (chosen by the matrix), 5 (both operands as FP4 images in the LDS, 16x16x128 MFMAs), 1, 2 (bit operands inflated in registers), 3 / 4 (B as FP4 images in the LDS, 16x16x128 / 32x32x64 MFMAs), 6 (128 x 128 tiles, k-parts whose sums meet inside the launch), 16 or 32 (FP4 shadow)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES
@@ -702,18 +708,26 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
             return STORM_HIP_EINVAL;
         }
         ctx->k2_wave_below = (int)value;
-    } else if (!strcmp(key, "k2_wave_tile")) {
-        if (value != 0 && value != 22 && value != 42) {
-            set_error("k2_wave_tile must be 0 (by the rows), 22 (64 x 64) or 42 (128 x 64)");
+    } else if (!strcmp(key, "k2_part_slots")) {
+        if (value < 0 || value > 2) {
+            set_error("k2_part_slots must be 0 (by the length of the segments), 1 or 2 per CU");
             return STORM_HIP_EINVAL;
         }
-        ctx->k2_wave_tile = (int)value;
-    } else if (!strcmp(key, "k2_wave_small_rows")) {
-        if (value < 0 || value > (1 << 30)) {
-            set_error("k2_wave_small_rows: 0 .. 2^30 rows");
+        ctx->k2_part_slots = (int)value;
+    } else if (!strcmp(key, "k2_part_min_chunks")) {
+        if (value < 1 || value > 4096) {
+            set_error("k2_part_min_chunks: 1 .. 4096 chunks of 512 bits");
             return STORM_HIP_EINVAL;
         }
-        ctx->k2_wave_small_rows = (int)value;
+        ctx->k2_part_min_chunks = (int)value;
+    } else if (!strcmp(key, "k2_part_narrow")) {
+        ctx->k2_part_narrow = value != 0;
+    } else if (!strcmp(key, "k2_part_cost_diag")) {
+        if (value < 10 || value > 100) {
+            set_error("k2_part_cost_diag: 10 .. 100 percent of a full tile's chunk");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->k2_part_cost_diag = (int)value;
     } else if (!strcmp(key, "k2_ring_cost_diag") || !strcmp(key, "k2_ring_cost_ragged")) {
         if (value < 5 || value > 100) {
             set_error("%s is a percentage of a full tile's time, 5..100", key);
@@ -871,6 +885,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "variant_used")) return ctx->variant_used;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
     if (!strcmp(key, "result_mailbox")) return ctx->result_mailbox;
+    if (!strcmp(key, "sync_poll_us")) return ctx->sync_poll_us;
     if (!strcmp(key, "matrix_lists")) return ctx->matrix_lists;
     if (!strcmp(key, "matrix_lists_density")) return ctx->matrix_lists_permille_x10;
     if (!strcmp(key, "chunks_per_item")) return ctx->chunks_per_item;
@@ -886,8 +901,10 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "k2_ring_sync")) return ctx->k2_ring_sync;
     if (!strcmp(key, "k2_tile_shape")) return ctx->k2_tile_shape;
     if (!strcmp(key, "k2_wave_below")) return ctx->k2_wave_below;
-    if (!strcmp(key, "k2_wave_tile")) return ctx->k2_wave_tile;
-    if (!strcmp(key, "k2_wave_small_rows")) return ctx->k2_wave_small_rows;
+    if (!strcmp(key, "k2_part_slots")) return ctx->k2_part_slots;
+    if (!strcmp(key, "k2_part_min_chunks")) return ctx->k2_part_min_chunks;
+    if (!strcmp(key, "k2_part_cost_diag")) return ctx->k2_part_cost_diag;
+    if (!strcmp(key, "k2_part_narrow")) return ctx->k2_part_narrow;
     if (!strcmp(key, "k2_tile_shape_used")) return ctx->k2_tile_shape_eff;
     if (!strcmp(key, "k2_stream_w3_1")) return ctx->k2_stream_w3_1;
     if (!strcmp(key, "k2_stream_w3_2")) return ctx->k2_stream_w3_2;

@@ -89,6 +89,7 @@ struct storm_hip_ctx_s {
     unsigned long long* h_mail = nullptr;
     unsigned long long* d_mail = nullptr;    // the same word as the device sees it
     int result_mailbox = 1;
+    int sync_poll_us = 0;                    // [r6] synchronous matrix-output calls poll hipStreamQuery this long before they park in hipStreamSynchronize (0: park at once)
     bool mail_armed = false;                 // the call in flight was launched into the mailbox
     void* h_stage_ring = nullptr;            // pinned staging ring of the sparse arena builder (storm_hip_sparse.hip: Stager), allocated on first use
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
@@ -141,10 +142,15 @@ struct storm_hip_ctx_s {
     int k2_fold_inline = -1;        // K2b: the workgroup dispatched last folds the partial sums inside the launch: -1 = for short launches (<= 4096 workgroups, where the fold launch and its gaps are a fifth of a pass), 1 = always (level at N = 10000), 0 = never (a fold launch behind the strips); profiles/r05_c_fold_ab.jsonl
     int k2_operands_used = 4;       // what the last strip launch ran (1, 2 or 4)
     int k2_tile_shape = 0;  // write-mode tile kernel: 0 = by the matrix (5 for a dense matrix, 2 for the dense replica of a sparse container: sparse operands let tilebits8_kernel, which sits at the socket's power cap, clock higher; crossover near 20 % density, profiles/r05_g_*); 5 = tilering_kernel (both operands as FP4 images in the LDS, 16x16x128); 2 = tilebits8_kernel (bit operands inflated in registers, 32x32x64); 3 / 4 = K2tb; 1 / 16 / 32: tools build
-    int k2_wave_below = 400;      // [r6] k2_tile_shape 0: matrices (bands, rectangles) of fewer 256 x 256 tiles than this take tilewave_kernel (K2w: small tiles that own their whole k range; no k-parts, no window clearing, no atomics)
-    int k2_wave_tile = 0;         // K2w's tile: 0 = by the rows (64 x 64 up to k2_wave_small_rows output rows, 128 x 64 above), 22 = 64 x 64, 42 = 128 x 64
-    int k2_wave_small_rows = 3072;
-    uint32_t n_wave_items = 0;    // items of the K2w list cached in d_items (items_key)
+    int k2_wave_below = 400;      // [r6] k2_tile_shape 0: matrices (bands, rectangles) of fewer 256 x 256 tiles than this take tile128_kernel (K2h: 128 x 128 tiles, cut along k where they are too few, the parts' sums meeting inside the launch; no window clearing, no atomics into the output)
+    int k2_part_slots = 0;        // K2h: segments per CU the tiles' chunk stream is cut into: 0 = two once that leaves segments of 4 x k2_part_min_chunks, else one; 1 / 2: forced
+    int k2_part_min_chunks = 8;   // K2h: a k-part is at least this many 512-bit chunks
+    int k2_part_narrow = 1;       // K2h: windows of 16-bit counts where every part of a tile covers fewer than 2^16 bits of k (half the bytes the part that ends the tile has to read)
+    int k2_part_cost_diag = 80;   // K2h: what a chunk of a tile on the diagonal costs next to one of a full tile, percent
+    uint32_t n_part_items = 0;    // items of the K2h list cached in d_items (items_key)
+    uint32_t* d_tickets = nullptr;   // K2h: one arrival counter per tile (zero between launches)
+    size_t tickets_capacity = 0;
+    bool tickets_dirty = false;   // a launch failed: clear the tickets before the next one
     int k2_tile_shape_eff = 2;  // what the call in flight runs (set by launch_pairw_matrix / launch_square_matrix)
     int k2_ring_sync = 0;   // tilering_kernel: 0 = one s_barrier per stage; 1 = arrival counters in the LDS (waves may drift a stage apart; measured 2 % slower)
     int k2_ring_cost_diag = 78, k2_ring_cost_ragged = 40;  // the same for tilering_kernel (k2_tile_shape = 5)

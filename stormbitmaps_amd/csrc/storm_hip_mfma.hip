@@ -30,6 +30,7 @@
 #include "storm_hip_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <exception>
 #include <type_traits>
@@ -63,6 +64,23 @@ __device__ unsigned long long g_clock_probe[4];
 static bool timing_env() {
     static const bool on = getenv("STORM_HIP_TIMING") != nullptr;   // (read once, not per call)
     return on;
+}
+
+// The end of a synchronous call whose kernels have just been queued: hipStreamSynchronize parks the thread and is woken
+// by an interrupt (5 - 8 us of a call that runs 20 - 40); a few hundred hipStreamQuery polls see the end of a short
+// launch sooner. Option sync_poll_us: how long to poll before parking (0: park at once).
+static hipError_t wait_stream(storm_hip_ctx_t* ctx) {
+    if (ctx->sync_poll_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spin = 0;; ++spin) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q != hipErrorNotReady) return q;
+            if ((spin & 15u) == 15u &&
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > ctx->sync_poll_us)
+                break;
+        }
+    }
+    return hipStreamSynchronize(ctx->stream);
 }
 
 constexpr int kTile = 256;           // rows per tile side
@@ -1495,7 +1513,7 @@ __device__ __forceinline__ int ti_inflb(int w) {
 #undef STORM_TI_NAME
 
 #include "tile_ring_kernel.inc"
-#include "tile_wave_kernel.inc"
+#include "tile128_kernel.inc"
 
 // ------------------------------------------------------------------------------------------
 // K2sb: the strips on BIT operands (option k2_strip_operands = 1; the default stays the FP4 shadow).
@@ -2864,7 +2882,7 @@ static int run_matrix_tiles(storm_hip_ctx_t* ctx, const MatrixPlan& plan, uint64
         hipLaunchKernelGGL(reduce_parts_kernel, dim3(n_split, kTile / kReduceBand), dim3(256), 0, ctx->stream, d_items, plan.n_full,
                            plan.n_items, d_parts, d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
     if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
-    if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
+    if (sync && wait_stream(ctx) != hipSuccess) return STORM_HIP_EHIP;
     return STORM_HIP_OK;
 }
 
@@ -2896,94 +2914,173 @@ static void xcd_grouped_tiles(uint32_t i0, uint32_t i1, uint32_t j0, uint32_t j1
             if (pos < per_xcd[x].size()) out.push_back(per_xcd[x][pos]);
 }
 
-// ---- K2w (tilewave_kernel): small tiles that own their whole k range, for matrices of few 256 x 256 tiles ----
-// Which wave tile: 0 = none (the 256 x 256 kernels), 22 = 64 x 64, 42 = 128 x 64. `tiles256` = what the 256 x 256
-// decomposition would launch. Rows whose k range, cut four ways among the waves, reaches 2^24 bits are not eligible
-// (f32 accumulators), nor are row pitches beyond the 32-bit buffer offsets of a 128-row window.
-static int choose_wave_tile(const storm_hip_ctx_t* ctx, uint64_t tiles256, uint64_t out_rows, uint32_t total_stages,
-                            uint64_t pitch, bool bits) {
-    if (!bits || (uint64_t)total_stages * 32u >= (1ull << 24) || pitch * 128u >= (1ull << 32)) return 0;
-    const bool forced = ctx->k2_tile_shape == 6;
-    if (!forced && (ctx->k2_tile_shape != 0 || tiles256 >= (uint64_t)ctx->k2_wave_below)) return 0;
-    if (ctx->k2_wave_tile) return ctx->k2_wave_tile;
-    // 64 x 64 while the matrix gives fewer than ~4 tiles of 128 x 64 per CU (a CU should end on a short tile)
-    return out_rows <= (uint64_t)ctx->k2_wave_small_rows ? 22 : 42;
+// ---- K2h (tile128_kernel): 128 x 128 tiles for matrices of few 256 x 256 tiles, k-parts whose sums meet inside the launch ----
+// Eligible: bit operands, and a 128-row window within the 32-bit buffer offsets. `tiles256` = what the 256 x 256
+// decomposition would launch; k2_tile_shape = 6 forces, 0 takes K2h below k2_wave_below tiles.
+static bool choose_tile128(const storm_hip_ctx_t* ctx, uint64_t tiles256, uint64_t pitch, bool bits) {
+    if (!bits || pitch * 128u >= (1ull << 32)) return false;
+    if (ctx->k2_tile_shape == 6) return true;
+    return ctx->k2_tile_shape == 0 && tiles256 < (uint64_t)ctx->k2_wave_below;
 }
 
-// Tile list of a K2w launch: A tiles [ia0, ia1) (TM rows each) against B tiles [jb0, jb1) (TN rows each); `triangle`: only
-// tiles that hold a pair i < j (block offset d = NB J - MB I > -NB), the ones that straddle the diagonal last (they
-// multiply fewer blocks: a CU's last item should be a short one). Order: groups of 4 x 8 neighbouring tiles go to one XCD
-// (block b runs on XCD b % 8: observed, speed only), so the workgroups an XCD runs side by side share their rows in its L2.
-static void wave_tile_list(uint32_t MB, uint32_t NB, uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1, bool triangle,
-                           std::vector<MfmaItem>& items, uint32_t total_stages) {
-    std::vector<std::vector<MfmaItem>> per_xcd(8), late(8);
-    uint32_t g = 0;
-    for (uint32_t gi = ia0; gi < ia1; gi += 4)
-        for (uint32_t gj = jb0; gj < jb1; gj += 8) {
-            size_t added = 0;
-            for (uint32_t i = gi; i < std::min(gi + 4, ia1); ++i)
-                for (uint32_t j = gj; j < std::min(gj + 8, jb1); ++j) {
-                    const int64_t d = (int64_t)NB * j - (int64_t)MB * i;
-                    if (triangle && d <= -(int64_t)NB) continue;   // every block below the diagonal
-                    const bool partial = triangle && d < (int64_t)MB - 1;
-                    (partial ? late : per_xcd)[g % 8].push_back({(uint16_t)i, (uint16_t)j, 0u, total_stages});
-                    ++added;
-                }
-            if (added) ++g;
+// The item list of a K2h launch ("stream-K"): the tiles' chunks, weighted by what a chunk of that tile costs, form one
+// stream that is cut into as many equal segments as the chip has workgroup slots; a segment that runs across a tile
+// boundary is cut there, so an item is one part of one tile, a tile of several parts (their sums meet in the launch,
+// tile128_kernel) and every slot gets the same work whatever the tile count. Items longest first: the dispatcher hands the
+// short halves of cut segments to the slots whose long halves end first. Pure host computation.
+struct Tile128Plan {
+    std::vector<PartItem> items;
+    uint32_t n_tiles = 0, n_windows = 0;
+};
+static void plan_tile128(uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1, bool triangle, uint32_t total_stages,
+                         uint32_t n_cus, int slots_per_cu, int min_chunks, int diag_cost_pct, bool narrow_windows,
+                         Tile128Plan* plan) {
+    struct T { uint16_t I, J; float cost; };
+    std::vector<T> tiles;
+    // groups of 4 x 8 neighbouring tiles first (they share rows), the tiles on the diagonal last
+    for (int pass = 0; pass < 2; ++pass)
+        for (uint32_t gi = ia0; gi < ia1; gi += 4)
+            for (uint32_t gj = jb0; gj < jb1; gj += 8)
+                for (uint32_t i = gi; i < std::min(gi + 4, ia1); ++i)
+                    for (uint32_t j = gj; j < std::min(gj + 8, jb1); ++j) {
+                        if (triangle && j < i) continue;
+                        const bool diag = triangle && j == i;
+                        if (diag != (pass == 1)) continue;
+                        tiles.push_back({(uint16_t)i, (uint16_t)j, diag ? diag_cost_pct / 100.0f : 1.0f});
+                    }
+    const uint32_t nC = total_stages / 4u;
+    plan->n_tiles = (uint32_t)tiles.size();
+    plan->n_windows = 0;
+    plan->items.clear();
+    if (tiles.empty() || nC == 0) return;
+    constexpr uint32_t kMaxExactChunks = (1u << 24) / 512u - 1u;   // f32 accumulators: an item stays below 2^24 bits of k
+    min_chunks = std::max(min_chunks, (int)(nC / 32000u) + 1);      // (a tile has fewer than 2^15 parts: PartItem::part)
+    double total = 0;
+    for (const T& t : tiles) total += (double)t.cost * nC;
+    // slots: two per CU once that leaves segments of at least 4 x min_chunks, else one per CU, never segments below min_chunks
+    double slots = (double)n_cus * std::max(1, slots_per_cu);
+    if (slots_per_cu <= 0) slots = total / ((double)n_cus * 2) >= 4.0 * min_chunks ? (double)n_cus * 2 : (double)n_cus;
+    slots = std::max(1.0, std::min(slots, total / std::max(1, min_chunks)));
+    // beyond ~4 tiles per slot the cut buys little: whole tiles
+    const bool whole = (double)tiles.size() >= 4.0 * slots && nC <= kMaxExactChunks;
+    const double seg = whole ? 0.0 : total / slots;
+    double room = seg;   // what the running segment still takes
+    for (uint32_t t = 0; t < tiles.size(); ++t) {
+        std::vector<std::pair<uint32_t, uint32_t>> cuts;   // [c0, c1) per part
+        if (whole) {
+            cuts.emplace_back(0u, nC);
+        } else {
+            uint32_t pos = 0;
+            while (pos < nC) {
+                uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tiles[t].cost + 0.5));
+                take = std::min(std::min(take, nC - pos), kMaxExactChunks);
+                cuts.emplace_back(pos, pos + take);
+                pos += take;
+                room -= (double)take * tiles[t].cost;
+                if (room < 0.5 * tiles[t].cost) room += seg;
+            }
+            // parts below min_chunks join a neighbour of the same tile
+            for (size_t k = 0; cuts.size() > 1 && k < cuts.size();) {
+                if (cuts[k].second - cuts[k].first >= (uint32_t)min_chunks) { ++k; continue; }
+                const size_t into = k == 0 ? 1 : k - 1;
+                if ((cuts[into].second - cuts[into].first) + (cuts[k].second - cuts[k].first) > kMaxExactChunks) { ++k; continue; }
+                cuts[into].first = std::min(cuts[into].first, cuts[k].first);
+                cuts[into].second = std::max(cuts[into].second, cuts[k].second);
+                cuts.erase(cuts.begin() + (ptrdiff_t)k);
+                k = 0;
+            }
         }
-    for (auto* lists : {&per_xcd, &late}) {
-        size_t longest = 0;
-        for (auto& v : *lists) longest = std::max(longest, v.size());
-        for (size_t pos = 0; pos < longest; ++pos)
-            for (int x = 0; x < 8; ++x)
-                if (pos < (*lists)[x].size()) items.push_back((*lists)[x][pos]);
+        // windows of 16-bit counts while every part of the tile stays below 2^16 bits of k (127 chunks)
+        uint32_t longest = 0;
+        for (const auto& c : cuts) longest = std::max(longest, c.second - c.first);
+        const uint16_t narrow = (cuts.size() > 1 && longest <= 127u && narrow_windows) ? kThNarrow : (uint16_t)0;
+        for (size_t k = 0; k < cuts.size(); ++k)
+            plan->items.push_back({tiles[t].I, tiles[t].J, cuts[k].first * 4u, (cuts[k].second - cuts[k].first) * 4u, t,
+                                   cuts.size() > 1 ? plan->n_windows : 0u, (uint16_t)((uint16_t)k | narrow), (uint16_t)cuts.size()});
+        if (cuts.size() > 1) plan->n_windows += (uint32_t)cuts.size();
     }
+    if (!whole)
+        std::stable_sort(plan->items.begin(), plan->items.end(), [](const PartItem& a, const PartItem& b) {
+            return a.n_stages > b.n_stages;
+        });
 }
 
-// Uploads the list (cached by its key while the same call repeats) and launches tilewave_kernel.
-static int run_wave_tiles(storm_hip_ctx_t* ctx, int wave_tile, uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1,
-                          bool triangle, uint32_t total_stages, const TileOperands& ops, uint32_t* d_out, uint64_t ld,
-                          uint32_t n_rows, const uint32_t* d_counts, uint32_t and_weight, uint32_t j_base,
-                          uint32_t j_count, uint32_t i_lo, uint32_t n_cols, bool sync) {
-    const uint32_t MB = wave_tile == 42 ? 4u : 2u, NB = 2u;
+// Uploads the list (cached by its key while the same call repeats) and launches tile128_kernel.
+static int run_tile128(storm_hip_ctx_t* ctx, uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1, bool triangle,
+                       uint32_t total_stages, const TileOperands& ops, uint32_t* d_out, uint64_t ld, uint32_t n_rows,
+                       const uint32_t* d_counts, uint32_t and_weight, uint32_t j_base, uint32_t j_count, uint32_t i_lo,
+                       uint32_t n_cols, bool sync) {
     if (ia1 > 65535u || jb1 > 65535u) {
         set_error("pairw_matrix: too many row blocks");
         return STORM_HIP_EINVAL;
     }
     const uint64_t key[4] = {((uint64_t)ia0 << 32) | ia1, ((uint64_t)jb0 << 32) | jb1,
-                             0x4b32570000000000ull ^ ((uint64_t)wave_tile << 32) ^ total_stages, triangle ? 1ull : 2ull};
+                             0x4b32680000000000ull ^ ((uint64_t)(uint32_t)ctx->k2_part_slots << 36) ^
+                                 ((uint64_t)(uint32_t)ctx->k2_part_min_chunks << 24) ^ total_stages,
+                             (triangle ? 1ull : 2ull) | ((uint64_t)(uint32_t)ctx->k2_part_cost_diag << 8) |
+                                 ((uint64_t)(ctx->k2_part_narrow != 0) << 4)};
     if (!(ctx->d_items && !memcmp(key, ctx->items_key, sizeof(key)))) {
-        std::vector<MfmaItem> items;
-        wave_tile_list(MB, NB, ia0, ia1, jb0, jb1, triangle, items, total_stages);
-        if (items.size() > ctx->items_capacity) {
+        Tile128Plan plan;
+        plan_tile128(ia0, ia1, jb0, jb1, triangle, total_stages, (uint32_t)std::max(1, ctx->n_cus), ctx->k2_part_slots,
+                     ctx->k2_part_min_chunks, ctx->k2_part_cost_diag, ctx->k2_part_narrow != 0, &plan);
+        const size_t bytes = plan.items.size() * sizeof(PartItem);
+        if (bytes > ctx->items_capacity * sizeof(MfmaItem)) {
             if (ctx->d_items) STORM_HIP_TRY(hipFree(ctx->d_items));
             ctx->d_items = nullptr;
             ctx->items_capacity = 0;
-            const size_t cap = std::max<size_t>(items.size(), 4096);
+            const size_t cap = std::max<size_t>((bytes + sizeof(MfmaItem) - 1) / sizeof(MfmaItem), 4096);
             STORM_HIP_TRY(hipMalloc(&ctx->d_items, cap * sizeof(MfmaItem)));
             ctx->items_capacity = cap;
         }
         memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
         ctx->n_items = 0;
-        if (!items.empty()) {
-            STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, items.data(), items.size() * sizeof(MfmaItem),
-                                         hipMemcpyHostToDevice, ctx->stream));
-            STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` is pageable and leaves scope
+        ctx->n_part_items = 0;
+        // the parts' windows and the tiles' tickets (zero between launches: the part that ends a tile clears its ticket)
+        const size_t need = (size_t)plan.n_windows * kThWindowWords * sizeof(uint32_t);
+        if (need > ctx->parts_capacity) {
+            if (ctx->d_parts) (void)hipFree(ctx->d_parts);
+            ctx->d_parts = nullptr;
+            ctx->parts_capacity = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&ctx->d_parts), need) != hipSuccess) {
+                set_error("pairw_matrix: hipMalloc of %zu bytes for the k-parts' windows failed", need);
+                return STORM_HIP_ENOMEM;
+            }
+            ctx->parts_capacity = need;
+        }
+        if (plan.n_tiles > ctx->tickets_capacity || ctx->tickets_dirty) {
+            if (plan.n_tiles > ctx->tickets_capacity) {
+                if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+                ctx->d_tickets = nullptr;
+                ctx->tickets_capacity = 0;
+                const size_t cap = std::max<size_t>(plan.n_tiles, 4096);
+                STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->d_tickets), cap * sizeof(uint32_t)));
+                ctx->tickets_capacity = cap;
+            }
+            STORM_HIP_TRY(hipMemsetAsync(ctx->d_tickets, 0, ctx->tickets_capacity * sizeof(uint32_t), ctx->stream));
+            ctx->tickets_dirty = false;
+        }
+        if (!plan.items.empty()) {
+            STORM_HIP_TRY(hipMemcpyAsync(ctx->d_items, plan.items.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+            STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // the list is pageable and leaves scope
         }
         memcpy(ctx->items_key, key, sizeof(key));
-        ctx->n_wave_items = (uint32_t)items.size();
+        ctx->n_part_items = (uint32_t)plan.items.size();
+    } else if (ctx->tickets_dirty) {
+        STORM_HIP_TRY(hipMemsetAsync(ctx->d_tickets, 0, ctx->tickets_capacity * sizeof(uint32_t), ctx->stream));
+        ctx->tickets_dirty = false;
     }
-    const MfmaItem* d_items = static_cast<const MfmaItem*>(ctx->d_items);
-    if (ctx->n_wave_items) {
-        if (wave_tile == 42)
-            hipLaunchKernelGGL((tilewave_kernel<4, 2>), dim3(ctx->n_wave_items), dim3(kTwThreads), 0, ctx->stream, ops, d_items,
-                               d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
-        else
-            hipLaunchKernelGGL((tilewave_kernel<2, 2>), dim3(ctx->n_wave_items), dim3(kTwThreads), 0, ctx->stream, ops, d_items,
-                               d_out, ld, n_rows, d_counts, and_weight, j_base, j_count, i_lo, n_cols);
+    if (ctx->n_part_items)
+        hipLaunchKernelGGL(tile128_kernel, dim3(ctx->n_part_items), dim3(kThThreads), 0, ctx->stream, ops,
+                           static_cast<const PartItem*>(ctx->d_items), d_out, ld, n_rows, d_counts, and_weight, j_base,
+                           j_count, i_lo, n_cols, ctx->d_parts, ctx->d_tickets);
+    if (hipGetLastError() != hipSuccess) {
+        ctx->tickets_dirty = true;
+        return STORM_HIP_EHIP;
     }
-    if (hipGetLastError() != hipSuccess) return STORM_HIP_EHIP;
-    if (sync && hipStreamSynchronize(ctx->stream) != hipSuccess) return STORM_HIP_EHIP;
+    if (sync && wait_stream(ctx) != hipSuccess) {
+        ctx->tickets_dirty = true;   // (a launch that died may have left tickets behind)
+        return STORM_HIP_EHIP;
+    }
     return STORM_HIP_OK;
 }
 
@@ -3030,13 +3127,13 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
     // the headline shape since round 4's pitch pad — are never multiplied)
     const uint32_t total_stages = bits ? (m->n_words + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t nT = (uint32_t)((m->n_rows + kTile - 1) / kTile);
-    // [r6] few tiles: small tiles that own their whole k range (tilewave_kernel) instead of k-parts of 256 x 256 tiles
+    // [r6] few tiles: 128 x 128 tiles, cut along k where they are too few, the parts' sums meeting inside the launch
+    // (tile128_kernel) instead of k-parts of 256 x 256 tiles that clear and atomically add into the output
     {
         const uint64_t band_tiles = (uint64_t)((band_end + kTile - 1) / kTile - band_row0 / kTile);
         const uint64_t tiles256 = band_tiles * nT - (band_row0 / kTile) * band_tiles - band_tiles * (band_tiles - 1) / 2;
-        if (const int wt = choose_wave_tile(ctx, tiles256, band_end - band_row0, total_stages, pitch, bits)) {
+        if (choose_tile128(ctx, tiles256, pitch, bits)) {
             ctx->k2_tile_shape_eff = 6;
-            const uint32_t TM = wt == 42 ? 128u : 64u, TN = 64u;
             uint32_t* d_counts = nullptr;
             int rc = STORM_HIP_OK;
             if (op != STORM_HIP_OP_AND) {
@@ -3046,10 +3143,10 @@ int launch_pairw_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, int o
             if (rc == STORM_HIP_OK) {
                 const TileOperands ops = {reinterpret_cast<const uint8_t*>(m->d), nullptr, pitch, 0xffffffffu,
                                           (uint32_t)std::min<uint64_t>(m->n_rows_pad, 0xffffffffu), 0u};
-                rc = run_wave_tiles(ctx, wt, (uint32_t)(band_row0 / TM), (uint32_t)((band_end + TM - 1) / TM), 0u,
-                                    (uint32_t)((m->n_rows + TN - 1) / TN), true, total_stages, ops, d_out, ld,
-                                    (uint32_t)band_end, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u,
-                                    (uint32_t)band_row0, (uint32_t)m->n_rows, sync);
+                rc = run_tile128(ctx, (uint32_t)(band_row0 / kThTile), (uint32_t)((band_end + kThTile - 1) / kThTile), 0u,
+                                 (uint32_t)((m->n_rows + kThTile - 1) / kThTile), true, total_stages, ops, d_out, ld,
+                                 (uint32_t)band_end, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, 0u, 0u,
+                                 (uint32_t)band_row0, (uint32_t)m->n_rows, sync);
             }
             if (rc == STORM_HIP_EHIP) set_error("pairw_matrix: HIP failure");
             return rc;
@@ -3145,9 +3242,8 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     // (bit kernels: whole 512-bit chunks that hold DATA; the pitch's pad chunks are never multiplied)
     const uint32_t total_stages = bits ? (std::max(a->n_words, b->n_words) + 7u) / 8u * 4u : (uint32_t)(row_bytes / kStageBytes);
     const uint32_t ta = (uint32_t)(rows_a / kTile), tb = (uint32_t)(rows_b / kTile);
-    if (const int wt = choose_wave_tile(ctx, (uint64_t)ta * tb, a->n_rows, total_stages, pitch, bits)) {   // [r6] few tiles
+    if (choose_tile128(ctx, (uint64_t)ta * tb, pitch, bits)) {   // [r6] few tiles: tile128_kernel
         ctx->k2_tile_shape_eff = 6;
-        const uint32_t TM = wt == 42 ? 128u : 64u, TN = 64u;
         uint32_t* d_counts = nullptr;
         int rc = STORM_HIP_OK;
         if (op != STORM_HIP_OP_AND) {
@@ -3159,10 +3255,10 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
             const TileOperands ops = {reinterpret_cast<const uint8_t*>(a->d), reinterpret_cast<const uint8_t*>(b->d), pitch,
                                       (uint32_t)rows_a, (uint32_t)std::min<uint64_t>(a->n_rows_pad, rows_a),
                                       (uint32_t)std::min<uint64_t>(b->n_rows_pad, rows_b)};
-            rc = run_wave_tiles(ctx, wt, 0u, (uint32_t)((a->n_rows + TM - 1) / TM), (uint32_t)(rows_a / TN),
-                                (uint32_t)((rows_a + b->n_rows + TN - 1) / TN), false, total_stages, ops, d_out, ld,
-                                (uint32_t)a->n_rows, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a,
-                                (uint32_t)b->n_rows, 0u, 0u, true);
+            rc = run_tile128(ctx, 0u, (uint32_t)((a->n_rows + kThTile - 1) / kThTile), (uint32_t)(rows_a / kThTile),
+                             (uint32_t)((rows_a + b->n_rows + kThTile - 1) / kThTile), false, total_stages, ops, d_out, ld,
+                             (uint32_t)a->n_rows, d_counts, op == STORM_HIP_OP_XOR ? 2u : 1u, (uint32_t)rows_a,
+                             (uint32_t)b->n_rows, 0u, 0u, true);
         }
         if (rc == STORM_HIP_EHIP) set_error("square_matrix: HIP failure");
         return rc;

@@ -22,7 +22,8 @@ def orc():
 
 
 def _reset_tiles(ctx):
-    for k, v in (("k2_tile_shape", 0), ("k2_wave_tile", 0), ("k2_wave_below", 400), ("k2_wave_small_rows", 3072)):
+    for k, v in (("k2_tile_shape", 0), ("k2_wave_below", 400), ("k2_part_slots", 0), ("k2_part_min_chunks", 8),
+                 ("k2_part_cost_diag", 80)):
         ctx.set_option(k, v)
 
 
@@ -30,11 +31,12 @@ WAVE_SHAPES = ((4096, 256, 2048), (640, 65, 200), (1000, 257, 300), (9000, 700, 
                (520, 31, 100), (70000, 1029, 20000), (1536, 1301, 500), (64, 97, 20), (131072 + 64, 190, 40000))
 
 
-def test_wave_tile_kernel_against_the_oracle(hip_ctx, orc):
-    """tilewave_kernel (K2w, k2_tile_shape = 6: 64 x 64 and 128 x 64 tiles that own their whole k range, one k quarter per
-    wave, reduce-scatter through the LDS) against the oracle's per-pair counts (storm.c:1199-1238 with the leaf's result kept
-    per pair): triangle, AND / OR / XOR, rows of zero, ragged last tiles (1 .. 127 rows beyond a multiple of the tile), row
-    lengths that are not whole 512-bit chunks, fewer chunks than waves, one tile, more chunks than fit one trip."""
+def test_tile128_kernel_against_the_oracle(hip_ctx, orc):
+    """tile128_kernel (K2h, k2_tile_shape = 6: 128 x 128 tiles, rows staged through the LDS, k-parts whose sums meet inside
+    the launch — windows in register layout, a ticket per tile, the last part adds and writes) against the oracle's per-pair
+    counts (storm.c:1199-1238 with the leaf's result kept per pair): triangle, AND / OR / XOR, rows of zero, ragged last
+    tiles (1 .. 127 rows beyond a multiple of 128), row lengths that are not whole 512-bit chunks or whole trips of four
+    chunks, one chunk, one tile; with whole tiles, with one and two segments per CU and with parts down to one chunk."""
     try:
         hip_ctx.set_option("k2_tile_shape", 6)
         for M, N, d in WAVE_SHAPES:
@@ -46,19 +48,22 @@ def test_wave_tile_kernel_against_the_oracle(hip_ctx, orc):
             s = rc[:, None] + rc[None, :]
             want["or"] = np.triu(s - want["and"], k=1)
             want["xor"] = np.triu(s - 2 * want["and"], k=1)
-            for wt in (22, 42, 0):
-                hip_ctx.set_option("k2_wave_tile", wt)
+            for slots, min_chunks in ((0, 8), (1, 1), (2, 1), (2, 3)):
+                hip_ctx.set_option("k2_part_slots", slots)
+                hip_ctx.set_option("k2_part_min_chunks", min_chunks)
                 for op in ("and", "or", "xor"):
-                    got = m.pairw_matrix(op)
-                    assert hip_ctx.get_option("k2_tile_shape_used") == 6
-                    assert np.array_equal(want[op], got), (M, N, wt, op, np.argwhere(want[op] != got)[:3].tolist())
+                    for rep in range(2):   # (again: the tickets of the call before must have been left at zero)
+                        got = m.pairw_matrix(op)
+                        assert hip_ctx.get_option("k2_tile_shape_used") == 6
+                        assert np.array_equal(want[op], got), (M, N, slots, min_chunks, op, rep,
+                                                               np.argwhere(want[op] != got)[:3].tolist())
             m.close()
     finally:
         _reset_tiles(hip_ctx)
 
 
-def test_wave_tile_kernel_bands_rectangles_and_the_automatic_rule(hip_ctx, orc):
-    """K2w on a band of the triangle left in device memory (rows that start inside a tile), on the rectangle of two matrices
+def test_tile128_kernel_bands_rectangles_and_the_automatic_rule(hip_ctx, orc):
+    """K2h on a band of the triangle left in device memory (rows that start inside a tile), on the rectangle of two matrices
     (STORM_wrapper_square's shape, storm.c:153-171), and as what k2_tile_shape = 0 chooses for matrices of few 256 x 256 tiles —
     against the oracle on sampled tiles and against tilebits8_kernel entry by entry."""
     import torch
@@ -69,9 +74,9 @@ def test_wave_tile_kernel_bands_rectangles_and_the_automatic_rule(hip_ctx, orc):
             hip_ctx.set_option("k2_tile_shape", 2)
             ref = m.pairw_matrix("and")
             assert np.array_equal(ref[:200, :N], np.triu(orc.tile_counts(mat, 0, 200, 0, N), k=1)[:200].astype(np.uint32))
-            for wt in (22, 42):
+            for wt in (1, 2):
                 hip_ctx.set_option("k2_tile_shape", 6)
-                hip_ctx.set_option("k2_wave_tile", wt)
+                hip_ctx.set_option("k2_part_slots", wt)
                 got = m.pairw_matrix("and")
                 assert np.array_equal(ref, got), (M, N, wt, np.argwhere(ref != got)[:3].tolist())
                 band = torch.zeros((300, N + 5), dtype=torch.int32, device="cuda:0")

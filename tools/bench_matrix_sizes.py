@@ -14,9 +14,9 @@ for N in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "256,512,1024,2
     out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
     want = m.pairw()
     rec = {"rows": N, "bits": M}
-    for shape, parts in ((6, 22), (6, 42), (5, 0), (2, 0), (0, 0)):   # 6: tilewave_kernel with 64 x 64 / 128 x 64 tiles; 5 / 2: the 256 x 256 kernels, k-parts add into the cleared output; 0: the automatic rule
+    for shape, parts in ((6, 1), (6, 2), (6, 0), (5, 0), (2, 0), (0, 0)):   # 6: tile128_kernel with one / two / automatic segments per CU; 5 / 2: the 256 x 256 kernels, k-parts add into the cleared output; 0: the automatic rule
         ctx.set_option("k2_tile_shape", shape)
-        ctx.set_option("k2_wave_tile", parts if shape == 6 else 0)
+        ctx.set_option("k2_part_slots", parts if shape == 6 else 0)
         for _ in range(3):
             m.pairw_matrix_device(out.data_ptr(), N, "and")
         ts = []
@@ -25,12 +25,12 @@ for N in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "256,512,1024,2
             m.pairw_matrix_device(out.data_ptr(), N, "and")
             ts.append(time.perf_counter() - t0)
         t = min(ts)
-        rec[{6: f"wave{parts}_us", 5: "ring_kparts_us", 2: "bits8_kparts_us", 0: "auto_us"}[shape]] = round(t * 1e6, 1)
+        rec[{6: f"tile128_slots{parts}_us", 5: "ring_kparts_us", 2: "bits8_kparts_us", 0: "auto_us"}[shape]] = round(t * 1e6, 1)
         if shape == 0:
             rec["auto_kernel"] = ctx.get_option("k2_tile_shape_used")
         assert int(out.to(torch.int64).sum().item()) == want
     ctx.set_option("k2_tile_shape", 0)
-    ctx.set_option("k2_wave_tile", 0)
+    ctx.set_option("k2_part_slots", 0)
     rec["all_pairs_total_us"] = round(min(_t(m) for _ in range(20)) * 1e6, 1) if (_t := (lambda mm: (lambda t0: (mm.pairw(), time.perf_counter() - t0)[1])(time.perf_counter()))) else None
     print(json.dumps(rec), flush=True)
     del out
