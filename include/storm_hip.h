@@ -271,6 +271,21 @@ int storm_hip_strip_plan3(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank
                           uint32_t n_cus, uint32_t* out, uint64_t capacity_items, uint64_t* n_items,
                           int* run_chosen);
 
+/* The item list of the materialised-output kernel for matrices of few 256 x 256 tiles (K2h, tile128_kernel; DESIGN.md
+ * §4) on a device of `n_cus` compute units, as 8 uint32 per item, in launch order:
+ *   {I, J, first chunk, chunks, tile, part, n_parts, narrow}
+ *   = the pairs (row of the 128-row tile I, row of the 128-row tile J) over the 512-bit chunks [first, first + chunks) of
+ *     every row; `tile` numbers the tiles, an item is part `part` of the `n_parts` its tile is cut into along k (their
+ *     sums meet inside the launch; `narrow`: through windows of 16-bit counts).
+ * n_rows_b == 0: the triangle of one matrix of n_rows_a rows (tiles I <= J), band_rows != 0: only the output rows
+ * [band_row0, band_row0 + band_rows); n_rows_b != 0: the rectangle A x B (B's tiles count on behind A's rows padded to a
+ * multiple of 256). slots_per_cu / min_chunks / diag_cost_pct: the context options k2_part_slots / k2_part_min_chunks /
+ * k2_part_cost_diag. The items of a tile cover its chunks exactly once, the tiles every pair of the output exactly once.
+ * Cuts the reference loop storm.c:1199-1238 (its per-pair results kept). Host only; `out` may be NULL to query the count. */
+int storm_hip_matrix_plan(uint64_t n_rows_a, uint64_t n_rows_b, uint32_t n_words, uint64_t band_row0, uint64_t band_rows,
+                          uint32_t n_cus, int slots_per_cu, int min_chunks, int diag_cost_pct, uint32_t* out,
+                          uint64_t capacity_items, uint64_t* n_items);
+
 /* The same for the one-launch stage stream on bit operands (K2q, the default for matrices of up to 8192
  * rows on one device): the segments shard `shard_rank` of `shard_count` walks on a device of
  * `n_cus` compute units, workgroup by workgroup, as 8 uint32 per segment:

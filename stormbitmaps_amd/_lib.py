@@ -62,6 +62,7 @@ SIGNATURES = {
     "storm_hip_strip_plan3": (C.c_int, [u64, u32, u32, u32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u32,
                                         vp, u64, vp, vp]),
     "storm_hip_stream_plan": (C.c_int, [u64, u32, u32, u32, u32, vp, u64, vp, vp]),
+    "storm_hip_matrix_plan": (C.c_int, [u64, u64, u32, u64, u64, u32, C.c_int, C.c_int, C.c_int, vp, u64, vp]),
     "storm_hip_square_matrix_device": (C.c_int, [vp, vp, vp, C.c_int, vp, u64]),
     "storm_hip_square_matrix": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "storm_hip_kernel_time": (C.c_int, [vp, P(C.c_double), P(u64)]),

@@ -2923,11 +2923,18 @@ static bool choose_tile128(const storm_hip_ctx_t* ctx, uint64_t tiles256, uint64
     return ctx->k2_tile_shape == 0 && tiles256 < (uint64_t)ctx->k2_wave_below;
 }
 
-// The item list of a K2h launch ("stream-K"): the tiles' chunks, weighted by what a chunk of that tile costs, form one
-// stream that is cut into as many equal segments as the chip has workgroup slots; a segment that runs across a tile
-// boundary is cut there, so an item is one part of one tile, a tile of several parts (their sums meet in the launch,
-// tile128_kernel) and every slot gets the same work whatever the tile count. Items longest first: the dispatcher hands the
-// short halves of cut segments to the slots whose long halves end first. Pure host computation.
+// The item list of a K2h launch. An item is one part of one tile; a tile of several parts has its sums meet in the launch
+// (tile128_kernel). The chip offers `slots` places for workgroups, one or two per CU:
+//   * whole rounds of tiles (slots tiles each) stay whole;
+//   * the tiles beyond the last whole round — all of them where there are fewer tiles than slots — are cut along k into
+//     EQUAL parts, together as many as there are slots: a tile gets its share of the slots rounded down, the slots left
+//     over go to the tiles whose parts are longest (the longest part ends the launch; cutting the chunk stream at equal
+//     distances across the tile boundaries leaves crumbs that must join a neighbour, and the parts so lengthened — 28
+//     chunks where 18 were due at 1024 rows — ended the launch);
+//   * one or two slots per CU: whichever loads a CU less, counting what an item costs besides its chunks.
+// The tiles on the diagonal come last (they are the ones cut: beside a second workgroup their chunks are cheaper — one wave
+// idle, one at three blocks of four — alone on a CU they take as long as any). Items longest first: the dispatcher hands
+// the short ones to the slots that end first. Pure host computation.
 struct Tile128Plan {
     std::vector<PartItem> items;
     uint32_t n_tiles = 0, n_windows = 0;
@@ -2935,7 +2942,7 @@ struct Tile128Plan {
 static void plan_tile128(uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1, bool triangle, uint32_t total_stages,
                          uint32_t n_cus, int slots_per_cu, int min_chunks, int diag_cost_pct, bool narrow_windows,
                          Tile128Plan* plan) {
-    struct T { uint16_t I, J; float cost; };
+    struct T { uint16_t I, J; bool diag; };
     std::vector<T> tiles;
     // groups of 4 x 8 neighbouring tiles first (they share rows), the tiles on the diagonal last
     for (int pass = 0; pass < 2; ++pass)
@@ -2946,7 +2953,7 @@ static void plan_tile128(uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1,
                         if (triangle && j < i) continue;
                         const bool diag = triangle && j == i;
                         if (diag != (pass == 1)) continue;
-                        tiles.push_back({(uint16_t)i, (uint16_t)j, diag ? diag_cost_pct / 100.0f : 1.0f});
+                        tiles.push_back({(uint16_t)i, (uint16_t)j, diag});
                     }
     const uint32_t nC = total_stages / 4u;
     plan->n_tiles = (uint32_t)tiles.size();
@@ -2954,55 +2961,56 @@ static void plan_tile128(uint32_t ia0, uint32_t ia1, uint32_t jb0, uint32_t jb1,
     plan->items.clear();
     if (tiles.empty() || nC == 0) return;
     constexpr uint32_t kMaxExactChunks = (1u << 24) / 512u - 1u;   // f32 accumulators: an item stays below 2^24 bits of k
+    constexpr double kItemChunks = 5.0;                             // what an item costs besides its chunks, in chunks
     min_chunks = std::max(min_chunks, (int)(nC / 32000u) + 1);      // (a tile has fewer than 2^15 parts: PartItem::part)
-    double total = 0;
-    for (const T& t : tiles) total += (double)t.cost * nC;
-    // slots: two per CU once that leaves segments of at least 4 x min_chunks, else one per CU, never segments below min_chunks
-    double slots = (double)n_cus * std::max(1, slots_per_cu);
-    if (slots_per_cu <= 0) slots = total / ((double)n_cus * 2) >= 4.0 * min_chunks ? (double)n_cus * 2 : (double)n_cus;
-    slots = std::max(1.0, std::min(slots, total / std::max(1, min_chunks)));
-    // beyond ~4 tiles per slot the cut buys little: whole tiles
-    const bool whole = (double)tiles.size() >= 4.0 * slots && nC <= kMaxExactChunks;
-    const double seg = whole ? 0.0 : total / slots;
-    double room = seg;   // what the running segment still takes
-    for (uint32_t t = 0; t < tiles.size(); ++t) {
-        std::vector<std::pair<uint32_t, uint32_t>> cuts;   // [c0, c1) per part
-        if (whole) {
-            cuts.emplace_back(0u, nC);
-        } else {
-            uint32_t pos = 0;
-            while (pos < nC) {
-                uint32_t take = (uint32_t)std::max(1.0, std::floor(room / tiles[t].cost + 0.5));
-                take = std::min(std::min(take, nC - pos), kMaxExactChunks);
-                cuts.emplace_back(pos, pos + take);
-                pos += take;
-                room -= (double)take * tiles[t].cost;
-                if (room < 0.5 * tiles[t].cost) room += seg;
+    const uint32_t min_parts = (nC + kMaxExactChunks - 1) / kMaxExactChunks;
+    const uint32_t max_parts = std::max(min_parts, nC / (uint32_t)min_chunks);
+    const size_t nT = tiles.size();
+    std::vector<uint32_t> parts_of(nT), best_parts;
+    double best_load = 0;
+    for (int spc = 1; spc <= 2; ++spc) {
+        if (slots_per_cu > 0 && spc != slots_per_cu) continue;
+        const size_t slots = (size_t)n_cus * spc;
+        const double dcost = spc >= 2 ? diag_cost_pct / 100.0 : 1.0;
+        auto cost_of = [&](size_t t) { return tiles[t].diag ? dcost : 1.0; };
+        const size_t n_whole = min_parts > 1 ? 0 : nT / slots * slots;
+        std::fill(parts_of.begin(), parts_of.end(), 1u);
+        double rest = 0;
+        for (size_t t = n_whole; t < nT; ++t) rest += cost_of(t) * nC;
+        const double seg = rest / (double)slots;
+        size_t n_items = n_whole;
+        for (size_t t = n_whole; t < nT; ++t)
+            n_items += parts_of[t] = std::min(max_parts, std::max(min_parts, (uint32_t)(cost_of(t) * nC / std::max(seg, 1e-9))));
+        while (n_items < n_whole + slots) {   // the slots left over: to the tiles whose parts are longest
+            size_t best = nT;
+            double longest = 0;
+            for (size_t t = n_whole; t < nT; ++t) {
+                const double len = cost_of(t) * nC / parts_of[t];
+                if (parts_of[t] < max_parts && len > longest) longest = len, best = t;
             }
-            // parts below min_chunks join a neighbour of the same tile
-            for (size_t k = 0; cuts.size() > 1 && k < cuts.size();) {
-                if (cuts[k].second - cuts[k].first >= (uint32_t)min_chunks) { ++k; continue; }
-                const size_t into = k == 0 ? 1 : k - 1;
-                if ((cuts[into].second - cuts[into].first) + (cuts[k].second - cuts[k].first) > kMaxExactChunks) { ++k; continue; }
-                cuts[into].first = std::min(cuts[into].first, cuts[k].first);
-                cuts[into].second = std::max(cuts[into].second, cuts[k].second);
-                cuts.erase(cuts.begin() + (ptrdiff_t)k);
-                k = 0;
-            }
+            if (best == nT) break;
+            ++parts_of[best];
+            ++n_items;
         }
-        // windows of 16-bit counts while every part of the tile stays below 2^16 bits of k (127 chunks)
-        uint32_t longest = 0;
-        for (const auto& c : cuts) longest = std::max(longest, c.second - c.first);
-        const uint16_t narrow = (cuts.size() > 1 && longest <= 127u && narrow_windows) ? kThNarrow : (uint16_t)0;
-        for (size_t k = 0; k < cuts.size(); ++k)
-            plan->items.push_back({tiles[t].I, tiles[t].J, cuts[k].first * 4u, (cuts[k].second - cuts[k].first) * 4u, t,
-                                   cuts.size() > 1 ? plan->n_windows : 0u, (uint16_t)((uint16_t)k | narrow), (uint16_t)cuts.size()});
-        if (cuts.size() > 1) plan->n_windows += (uint32_t)cuts.size();
+        double longest = 0;
+        for (size_t t = n_whole; t < nT; ++t) longest = std::max(longest, cost_of(t) * std::ceil((double)nC / parts_of[t]));
+        // a CU's load: its slots' whole tiles and one part each, and what its items cost besides
+        const double load = spc * ((double)(n_whole / slots) * nC + longest) + kItemChunks * (double)n_items / n_cus;
+        if (best_parts.empty() || load < best_load) best_load = load, best_parts = parts_of;
     }
-    if (!whole)
-        std::stable_sort(plan->items.begin(), plan->items.end(), [](const PartItem& a, const PartItem& b) {
-            return a.n_stages > b.n_stages;
-        });
+    for (uint32_t t = 0; t < nT; ++t) {
+        const uint32_t np = best_parts[t];
+        // windows of 16-bit counts while every part of the tile stays below 2^16 bits of k (127 chunks)
+        const uint16_t narrow = (np > 1 && (nC + np - 1) / np <= 127u && narrow_windows) ? kThNarrow : (uint16_t)0;
+        for (uint32_t p = 0; p < np; ++p) {
+            const uint32_t c0 = (uint32_t)((uint64_t)nC * p / np), c1 = (uint32_t)((uint64_t)nC * (p + 1) / np);
+            plan->items.push_back({tiles[t].I, tiles[t].J, c0 * 4u, (c1 - c0) * 4u, t, np > 1 ? plan->n_windows : 0u,
+                                   (uint16_t)((uint16_t)p | narrow), (uint16_t)np});
+        }
+        if (np > 1) plan->n_windows += np;
+    }
+    std::stable_sort(plan->items.begin(), plan->items.end(),
+                     [](const PartItem& a, const PartItem& b) { return a.n_stages > b.n_stages; });
 }
 
 // Uploads the list (cached by its key while the same call repeats) and launches tile128_kernel.
@@ -3841,6 +3849,50 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
 // Host-only view of the default path's work decomposition (no device is touched): what a shard
 // of a multi-GPU run multiplies, so that the partition of the pair space can be checked — and
 // rehearsed with CPU partials — without a GPU (tests/test_dist_cpu.py).
+extern "C" int storm_hip_matrix_plan(uint64_t n_rows_a, uint64_t n_rows_b, uint32_t n_words, uint64_t band_row0,
+                                     uint64_t band_rows, uint32_t n_cus, int slots_per_cu, int min_chunks, int diag_cost_pct,
+                                     uint32_t* out, uint64_t capacity_items, uint64_t* n_items) {
+    using namespace storm;
+    if (!n_items || n_rows_a == 0 || n_words == 0 || n_cus == 0 || slots_per_cu < 0 || slots_per_cu > 2 || min_chunks < 1 ||
+        diag_cost_pct < 10 || diag_cost_pct > 100) {
+        set_error("matrix_plan: bad arguments");
+        return STORM_HIP_EINVAL;
+    }
+    try {
+        const uint32_t total_stages = (n_words + 7u) / 8u * 4u;
+        Tile128Plan plan;
+        if (n_rows_b == 0) {   // triangle (a band of it)
+            const uint64_t end = std::min(n_rows_a, band_row0 + (band_rows ? band_rows : n_rows_a));
+            if (band_row0 < end)
+                plan_tile128((uint32_t)(band_row0 / kThTile), (uint32_t)((end + kThTile - 1) / kThTile), 0u,
+                             (uint32_t)((n_rows_a + kThTile - 1) / kThTile), true, total_stages, n_cus, slots_per_cu, min_chunks,
+                             diag_cost_pct, true, &plan);
+        } else {   // rectangle: B's tiles count on behind A's rows padded to 256
+            const uint64_t rows_a = (n_rows_a + kTile - 1) / kTile * kTile;
+            plan_tile128(0u, (uint32_t)((n_rows_a + kThTile - 1) / kThTile), (uint32_t)(rows_a / kThTile),
+                         (uint32_t)((rows_a + n_rows_b + kThTile - 1) / kThTile), false, total_stages, n_cus, slots_per_cu,
+                         min_chunks, diag_cost_pct, true, &plan);
+        }
+        *n_items = plan.items.size();
+        if (out) {
+            if (capacity_items < plan.items.size()) {
+                set_error("matrix_plan: capacity %llu < %zu items", (unsigned long long)capacity_items, plan.items.size());
+                return STORM_HIP_EINVAL;
+            }
+            for (size_t k = 0; k < plan.items.size(); ++k) {
+                const PartItem& it = plan.items[k];
+                uint32_t* o = out + 8 * k;
+                o[0] = it.I, o[1] = it.J, o[2] = it.stage0 / 4u, o[3] = it.n_stages / 4u, o[4] = it.tile;
+                o[5] = (uint32_t)(it.part & (uint16_t)~kThNarrow), o[6] = it.n_parts, o[7] = (it.part & kThNarrow) ? 1u : 0u;
+            }
+        }
+        return STORM_HIP_OK;
+    } catch (const std::exception& e) {
+        set_error("matrix_plan: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+}
+
 extern "C" int storm_hip_strip_plan3(uint64_t n_rows, uint32_t n_words, uint32_t shard_rank,
                                      uint32_t shard_count, int form, int pair_space, int max_run, int tail_run,
                                      int tail_slices, int lpt_rounds, uint32_t n_cus, uint32_t* out,

@@ -112,6 +112,26 @@ def stream_plan(n_rows: int, n_words: int, rank: int = 0, world: int = 1, n_cus:
     return out, int(g.value)
 
 
+def matrix_plan(n_rows_a: int, n_words: int, n_rows_b: int = 0, band_row0: int = 0, band_rows: int = 0, n_cus: int = 256,
+                slots_per_cu: int = 0, min_chunks: int = 8, diag_cost_pct: int = 80):
+    """The items the materialised-output kernel for matrices of few tiles (K2h) launches, as an [n, 8] uint32 array of
+    {I, J, first chunk, chunks, tile, part, n_parts, narrow} (see storm_hip_matrix_plan in include/storm_hip.h). Host-only."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    lib = _lib.load()
+    n = C.c_uint64(0)
+    args = (n_rows_a, n_rows_b, n_words, band_row0, band_rows, n_cus, slots_per_cu, min_chunks, diag_cost_pct)
+    _lib.check(lib.storm_hip_matrix_plan(*args, None, 0, C.byref(n)), "storm_hip_matrix_plan")
+    out = np.zeros((int(n.value), 8), dtype=np.uint32)
+    if n.value:
+        _lib.check(lib.storm_hip_matrix_plan(*args, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)),
+                   "storm_hip_matrix_plan")
+    return out
+
+
 def allreduce_total(partial: int, device=None) -> int:
     """Sum the per-rank partial totals. Totals are < 2^63 for every supported shape
     (N^2/2 * M < 2^63), so the int64 transport is exact."""
