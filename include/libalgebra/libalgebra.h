@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #if defined(__cplusplus)
 #define STORM_RESTRICT __restrict__
@@ -70,6 +74,9 @@ void* STORM_aligned_malloc(size_t alignment, size_t size); /* alignment first: s
 void STORM_aligned_free(void* memblock);
 int STORM_get_cpuid(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

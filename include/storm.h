@@ -43,6 +43,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ------------------------------------------------------------------ list kernels (host) --
  * Single-pair helpers on host memory (reference storm.h:56-61, storm.c:4-129). They are not
@@ -317,6 +321,9 @@ int STORM_hip_comm_finalize(void);
  * still hold device copies re-create them on their next all-pairs call). Returns 0. */
 int STORM_hip_shutdown(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define STORM_HIP_OK 0
 #define STORM_HIP_EINVAL (-1) /* bad argument                                  */
@@ -213,6 +217,9 @@ int storm_hip_column_identity(storm_hip_ctx_t* ctx, const storm_hip_matrix_t* m,
  *        storm_hip_mfma.hip
  *   read-only "variant_used": what the last dense launch ran; "n_cus" */
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value);
+/* Whether storm_hip_ctx_set_option would accept (key, value), without a context (STORM_HIP_OK, or STORM_HIP_EINVAL with
+ * storm_hip_last_error() saying why): callers that remember options for contexts still to be made validate with it. */
+int storm_hip_option_check(const char* key, int64_t value);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
 /* Tuning aid: with option "k2_ring" = 18 the strip kernel records, per work item, its start and
  * end on the 100 MHz device counter, three phase marks (operands in / diagonal phase done / main
@@ -414,6 +421,9 @@ int storm_hip_pairw_sparse_end(storm_hip_ctx_t* ctx, uint64_t* h_total);
  * [2]=bitmap×bitmap, [3]=block columns */
 int storm_hip_sparse_last_census(storm_hip_ctx_t* ctx, uint64_t out[4]);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

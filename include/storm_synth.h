@@ -22,6 +22,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole export list */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define STORM_SYNTH_GOLDEN 0x9E3779B97F4A7C15ULL
 
@@ -59,6 +63,9 @@ int64_t storm_synth_fill_storm(struct STORM_s* h, uint64_t n_bits, uint64_t row0
 int64_t storm_synth_fill_contig(struct STORM_contiguous_s* h, uint64_t n_bits, uint64_t row0,
                                 uint64_t n_rows, uint32_t draws, uint64_t seed);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

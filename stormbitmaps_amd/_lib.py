@@ -69,6 +69,7 @@ SIGNATURES = {
     "storm_hip_debug_strip_trace": (C.c_int, [vp, vp, u64, P(u64)]),
     "storm_hip_pairw_dense_op": (C.c_int, [vp, vp, C.c_int, P(u64)]),
     "storm_hip_ctx_set_option": (C.c_int, [vp, cp, i64]),
+    "storm_hip_option_check": (C.c_int, [cp, i64]),
     "storm_hip_ctx_get_option": (i64, [vp, cp]),
     "storm_hip_last_launch_info": (C.c_int, [vp, P(u64 * 4)]),
     "storm_hip_comm_unique_id": (C.c_int, [vp]),

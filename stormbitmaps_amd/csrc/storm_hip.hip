@@ -595,6 +595,13 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     delete ctx;
 }
 
+int storm_hip_option_check(const char* key, int64_t value) {
+    // the same validation on a scratch context (storm_hip_ctx_set_option touches no device)
+    storm_hip_ctx_s scratch;
+    scratch.n_cus = 256;
+    return storm_hip_ctx_set_option(&scratch, key, value);
+}
+
 int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t value) {
     if (check_ctx(ctx) || !key) return STORM_HIP_EINVAL;
     if (!strcmp(key, "variant")) {
@@ -1339,8 +1346,12 @@ uint64_t* result_target(storm_hip_ctx_t* ctx) {
     ctx->mail_armed = false;
     if (!ctx->result_mailbox) return reinterpret_cast<uint64_t*>(ctx->d_scalar);
     if (!ctx->h_mail) {
+        // (on the context's own device: callers evaluate this as an ARGUMENT, before the entry point they call has set the
+        //  device — a worker thread of slot d starts out on device 0; portable: one mapping for every device)
         void* dev = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mail), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        if (hipSetDevice(ctx->device) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&ctx->h_mail), 64,
+                          hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable) != hipSuccess ||
             hipHostGetDevicePointer(&dev, ctx->h_mail, 0) != hipSuccess) {
             if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
             ctx->h_mail = nullptr;

@@ -495,10 +495,10 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
                     const uint16_t* v = static_cast<const uint16_t*>(block_ptr[b]);
                     const uint32_t base = block_id[b] * 65536u;
                     for (uint32_t k = 0; k < block_n[b]; ++k) {
-                        if (k && v[k] <= v[k - 1]) {
-                            set_error("rowlists_create: list of block %llu is not strictly ascending", (unsigned long long)b);
-                            return STORM_HIP_EINVAL;
-                        }
+                        // (a list that is not strictly ascending — a row filled by out-of-order STORM_add calls — is no error:
+                        //  the container is not eligible, *out stays NULL and the dense replica, which sets bits in any order,
+                        //  takes the call as it did before this path existed; a repeated position would toggle itself away here)
+                        if (k && v[k] <= v[k - 1]) return STORM_HIP_OK;
                         rtag[e] = (uint16_t)(r & 2047u);
                         pos[e++] = base + v[k];
                     }

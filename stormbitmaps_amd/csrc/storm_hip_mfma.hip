@@ -3718,8 +3718,23 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
 // multiplies the pairs whose later row lies in it (RowRange::back_from: the panel's tiles stationary, all rows in front
 // of them streaming past) while the next panel is on the bus. What stays exposed is the first panel's copy and the last
 // panel's pairs. One fold at the end; the work lists of the panels stay on the device between calls.
+static int pairw_bits_upload_queue(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
+                                   uint64_t src_stride_words, uint64_t* d_total);
 int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
                              uint64_t src_stride_words, uint64_t* d_total) {
+    const int rc = pairw_bits_upload_queue(ctx, m, host_rows, src_stride_words, d_total);
+    if (rc != STORM_HIP_OK) {
+        // a failure behind the first panel copy: the copies may still be reading the caller's rows (which the caller is about
+        // to get back, and may free) and writing the matrix (which the caller of this function releases): drain both streams,
+        // and disarm the mailbox this call was launched into
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->mail_armed = false;
+    }
+    return rc;
+}
+static int pairw_bits_upload_queue(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
+                                   uint64_t src_stride_words, uint64_t* d_total) {
     const uint64_t pitch = m->stride_words * 8;
     const uint64_t tiles = (m->n_rows + kStripATile - 1) / kStripATile;
     if (tiles * kStripATile > m->n_rows_pad || pitch * (uint64_t)kStripBRows >= (1ull << 32) || m->n_rows < 2) {

@@ -183,9 +183,14 @@ static __thread int g_quiet_ctx = 0; /* 1 while a best-effort caller (row stream
  * the environment does the same at the first use. Tuning and A/B only: every option keeps the results exact. */
 #define MAX_HOST_OPTIONS 16
 static struct { char key[40]; int64_t value; } g_host_opt[MAX_HOST_OPTIONS];
-static int g_n_host_opt = 0, g_env_opts_read = 0;
+static int g_n_host_opt = 0;
+static pthread_once_t g_env_opts_once = PTHREAD_ONCE_INIT;
 static void apply_host_options(storm_hip_ctx_t* ctx) {
-    for (int i = 0; i < g_n_host_opt; ++i) (void)storm_hip_ctx_set_option(ctx, g_host_opt[i].key, g_host_opt[i].value);
+    /* (every remembered option has passed storm_hip_option_check: a failure here would be a defect, not a typo) */
+    for (int i = 0; i < g_n_host_opt; ++i)
+        if (storm_hip_ctx_set_option(ctx, g_host_opt[i].key, g_host_opt[i].value) != STORM_HIP_OK)
+            fprintf(stderr, "libstorm_hip: option %s=%lld was not applied: %s\n", g_host_opt[i].key,
+                    (long long)g_host_opt[i].value, storm_hip_last_error());
 }
 static int remember_host_option(const char* key, int64_t value) {
     for (int i = 0; i < g_n_host_opt; ++i)
@@ -198,20 +203,26 @@ static int remember_host_option(const char* key, int64_t value) {
     g_host_opt[g_n_host_opt++].value = value;
     return 0;
 }
-static void read_env_options(void) {
-    if (g_env_opts_read) return;
-    g_env_opts_read = 1;
+/* STORM_HIP_OPTIONS, once per process (pthread_once: two threads with disjoint device views may create their first
+ * contexts at the same time), every entry validated before it is remembered; a typo is reported, not dropped silently */
+static void read_env_options_once(void) {
     const char* e = getenv("STORM_HIP_OPTIONS");
     if (!e) return;
     char buf[512];
     snprintf(buf, sizeof(buf), "%s", e);
-    for (char* tok = strtok(buf, ","); tok; tok = strtok(NULL, ",")) {
+    char* save = NULL;
+    for (char* tok = strtok_r(buf, ",", &save); tok; tok = strtok_r(NULL, ",", &save)) {
         char* eq = strchr(tok, '=');
-        if (!eq) continue;
-        *eq = '\0';
-        (void)remember_host_option(tok, strtoll(eq + 1, NULL, 10));
+        if (eq) *eq = '\0';
+        char* end = NULL;
+        const long long v = eq ? strtoll(eq + 1, &end, 10) : 0;
+        if (!eq || end == eq + 1 || *end != '\0' || storm_hip_option_check(tok, v) != STORM_HIP_OK ||
+            remember_host_option(tok, v) != 0)
+            fprintf(stderr, "libstorm_hip: STORM_HIP_OPTIONS: entry \"%s%s%s\" ignored%s%s\n", tok, eq ? "=" : "", eq ? eq + 1 : "",
+                    eq ? ": " : " (key=value expected)", eq ? storm_hip_last_error() : "");
     }
 }
+static void read_env_options(void) { pthread_once(&g_env_opts_once, read_env_options_once); }
 
 static storm_hip_ctx_t* device_ctx(int slot) {
     configure_from_env();
@@ -581,7 +592,16 @@ int STORM_hip_set_option(const char* key, int64_t value) {
     saved_view_t sv;
     device_lock_all(&sv);
     read_env_options();
-    int rc = remember_host_option(key, value);
+    /* validated before it is remembered or applied anywhere: an unknown key or a value out of range leaves no trace
+     * (it used to be remembered when no context existed yet, and applied to some of the contexts when some did) */
+    int rc = 0;
+    if (storm_hip_option_check(key, value) != STORM_HIP_OK) {
+        device_error("STORM_hip_set_option");
+        rc = -1;
+    } else if (remember_host_option(key, value)) {
+        host_error("STORM_hip_set_option: more options than the library remembers for contexts still to be made");
+        rc = -1;
+    }
     for (int d = 0; d < MAX_DEVICES && !rc; ++d)
         if (g_ctx[d] && storm_hip_ctx_set_option(g_ctx[d], key, value) != STORM_HIP_OK) {
             device_error("STORM_hip_set_option");

@@ -29,6 +29,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
     (void)ctx; (void)key; (void)value;
     return STORM_HIP_OK;
 }
+int storm_hip_option_check(const char* key, int64_t value) {
+    (void)value;
+    return key && key[0] && key[0] != '?' ? STORM_HIP_OK : STORM_HIP_EINVAL;   /* ("?..." stands for a typo) */
+}
 
 int storm_hip_matrix_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t n_words,
                             storm_hip_matrix_t** out) {

@@ -40,6 +40,22 @@ def test_library_exports_every_declared_symbol(lib):
     assert not unbound, unbound
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """a drop-in library exports STORM_* / storm_hip_* / storm_synth_* and nothing else — no C++
+    internals, no kernel handles (-fvisibility=hidden + csrc/exports.map) — and everything it exports is declared in a
+    header of include/ (or is a variable a header declares)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    assert len(names) > 80
+    foreign = [n for n in names if not re.match(r"(STORM|storm_hip|storm_synth)_\w+$", n)]
+    assert not foreign, foreign[:10]
+    headers = "".join(open(os.path.join(INC, rel)).read()
+                      for rel in ("storm.h", "storm_hip.h", "storm_synth.h", os.path.join("libalgebra", "libalgebra.h")))
+    undeclared = [n for n in names if not re.search(r"\b%s\b" % re.escape(n), headers)]
+    assert not undeclared, undeclared
+
+
 def test_reference_symbols_of_survey_8b_are_present(lib):
     # the 41 functions storm.c defines (SURVEY.md §8b), by family
     fams = {
@@ -208,3 +224,19 @@ def test_simd_leaves_of_the_libalgebra_surface_match_the_scalar_leaf(lib, orc):
                 assert got == want, (name, off, n, got, want)
         ran += 1
     assert ran >= 1
+
+
+def test_options_are_validated_before_they_are_remembered(lib):
+    """STORM_hip_set_option used to remember an unknown key or a value out of range when no context existed yet
+    (and 0 was returned); the contexts made later dropped it silently. storm_hip_option_check validates without a context."""
+    lib.storm_hip_option_check.restype = C.c_int
+    lib.storm_hip_option_check.argtypes = [C.c_char_p, C.c_int64]
+    assert lib.storm_hip_option_check(b"k2_tile_shape", 6) == 0
+    assert lib.storm_hip_option_check(b"k2_tile_shape", 99) != 0
+    assert lib.storm_hip_option_check(b"k2_tile_shap", 2) != 0
+    assert b"unknown" in lib.storm_hip_last_error().lower() or lib.storm_hip_last_error()
+    lib.STORM_hip_set_option.restype = C.c_int
+    lib.STORM_hip_set_option.argtypes = [C.c_char_p, C.c_int64]
+    assert lib.STORM_hip_set_option(b"k2_tile_shap", 2) == -1
+    assert lib.STORM_hip_set_option(b"k2_part_slots", 7) == -1
+    assert lib.STORM_hip_set_option(b"k2_part_slots", 0) == 0

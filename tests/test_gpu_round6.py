@@ -110,3 +110,107 @@ def test_tile128_kernel_bands_rectangles_and_the_automatic_rule(hip_ctx, orc):
         m.close()
     finally:
         _reset_tiles(hip_ctx)
+
+
+def test_lists_matrix_at_the_readme_storm_shape_against_the_oracle_on_sampled_blocks(orc):
+    """VERDICT r5 (thin spot a): K5 — the per-pair matrix of a list-only STORM_t straight from its lists — at BASELINE c4's
+    shape (N = 10000, M = 524288) used to be checked against the handle's own total and the product's own dense-replica
+    kernels only. Here two 64-row blocks of the matrix (one inside, one at the ragged end) against the oracle's row-pair
+    function (storm.c:790-814: block-id merge + STORM_intersect_vector16_cardinality, storm.c:4-73, per pair) at the two
+    sparsest README loads, for the kernel the automatic rule picks and for both list kernels forced."""
+    import torch
+    lib = sb.load()
+    N, M = 10000, 524288
+    try:
+        dev = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        for d in (104, 524):
+            s = sb.Storm()
+            assert s.add_synthetic(M, N, d, seed=42) == N
+            o = orc.storm(synth.positions(M, N, d, seed=42))
+            want = {i0: o.pair_counts(i0, i0 + 64) for i0 in (4032, N - 64)}
+            for lists, kernel in ((-1, 0), (1, 1), (1, 2)):
+                assert lib.STORM_hip_set_option(b"matrix_lists", lists) == 0
+                assert lib.STORM_hip_set_option(b"matrix_lists_kernel", kernel) == 0
+                dev.zero_()
+                s.pairw_matrix_device(dev.data_ptr(), N, N)
+                for i0, w in want.items():
+                    got = dev[i0:i0 + 64].cpu().numpy().astype(np.uint32)
+                    cols = np.arange(N)[None, :] > (i0 + np.arange(64))[:, None]
+                    assert np.array_equal(got * cols, w * cols), (d, lists, kernel, i0)
+            s.free()
+    finally:
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+        lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
+
+
+def test_tile_kernels_with_more_tiles_than_cus_against_the_oracle_on_sampled_tiles(hip_ctx, orc):
+    """VERDICT r5 (thin spot b): tilering_kernel with more tiles than CUs (whole rounds + a cut last round of k-parts) had only
+    tilebits8_kernel as its reference. N = 4700 short rows = 190 tiles of 256 x 256 on 256 CUs is below that; N = 6000 = 300
+    tiles: one whole round and a last round of 44 tiles in k-parts. Sampled 256 x 256 tiles — first, interior, on the
+    diagonal, in the ragged last column, the very last (all of the cut round) — against the oracle's per-pair counts
+    (storm.c:1199-1238 with the leaf's result kept), for both 256 x 256 kernels and K2h."""
+    import torch
+    try:
+        for M, N, d in ((1536, 6000, 500), (1000, 4700, 300)):
+            mat = synth.dense_matrix_c(M, N, d, seed=N + M)
+            m = hip_ctx.matrix_from_host(mat)
+            out = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+            nT = (N + 255) // 256
+            picks = [(0, 1), (3, 11), (5, 5), (nT - 1, nT - 1), (nT - 2, nT - 1), (2, nT - 1), (nT - 2, nT - 2), (nT // 2, nT // 2)]
+            want = {}
+            for I, J in picks:
+                i1, j1 = min(N, 256 * I + 256), min(N, 256 * J + 256)
+                want[(I, J)] = orc.tile_counts(mat, 256 * I, i1, 256 * J, j1).astype(np.uint32)
+            for shape in (5, 2, 6):
+                hip_ctx.set_option("k2_tile_shape", shape)
+                out.zero_()
+                m.pairw_matrix_device(out.data_ptr(), N, "and")
+                assert hip_ctx.get_option("k2_tile_shape_used") == shape
+                for (I, J), w in want.items():
+                    i0, j0 = 256 * I, 256 * J
+                    got = out[i0:i0 + w.shape[0], j0:j0 + w.shape[1]].cpu().numpy().astype(np.uint32)
+                    upper = (j0 + np.arange(w.shape[1]))[None, :] > (i0 + np.arange(w.shape[0]))[:, None]
+                    assert np.array_equal(got * upper, w * upper), (M, N, shape, I, J)
+            m.close()
+    finally:
+        _reset_tiles(hip_ctx)
+
+
+def test_pair_space_shards_against_the_oracle(hip_ctx, orc):
+    """VERDICT r5 (thin spot c): the pair-space shard sums at N = 6144 / 8192 (worlds 3 and 5, where the automatic run length
+    once differed by rank) were checked against the device's own column identity only: here also against the oracle's
+    blocked loop (storm.c:1199-1238) over the downloaded matrix."""
+    try:
+        for N in (6144, 8192):
+            M = 65536
+            m = hip_ctx.matrix(N, M // 64)
+            m.fill_synthetic(M, M // 3, seed=N)
+            want = orc.wrapper_diag_blocked(m.download(), 31)
+            assert m.column_identity() == want and m.pairw() == want
+            for pairs, world in ((1, 3), (1, 5), (0, 3)):
+                hip_ctx.set_option("k2_shard_pairs", pairs)
+                assert sum(m.pairw(r, world) for r in range(world)) == want, (N, pairs, world)
+            hip_ctx.set_option("k2_shard_pairs", 0)
+            m.close()
+    finally:
+        hip_ctx.set_option("k2_shard_pairs", 0)
+
+
+def test_rows_added_out_of_order_fall_back_to_the_dense_replica(orc):
+    """a list block that is not strictly ascending (a row filled by STORM_add with unsorted values) made
+    storm_hip_rowlists_create_blocks fail with EINVAL, and with it every later STORM_pairw_matrix call on the handle, where
+    the dense replica — which sets bits in any order — had worked before the lists path existed. Such a container is
+    simply not eligible for K5 now."""
+    rng = np.random.default_rng(7)
+    M, N = 200000, 300
+    rows = [np.unique(rng.integers(0, M, size=60)).astype(np.uint32) for _ in range(N)]
+    s_sorted, s_mixed = sb.Storm(), sb.Storm()
+    for i, r in enumerate(rows):
+        s_sorted.add(r)
+        s_mixed.add(r[::-1].copy() if i % 7 == 3 else r)   # some rows arrive descending
+    want = s_sorted.pairw_matrix("and")
+    assert np.array_equal(np.triu(want, k=1), np.triu(orc.storm(rows).pair_counts(), k=1))
+    for _ in range(2):
+        assert np.array_equal(s_mixed.pairw_matrix("and"), want)
+    s_sorted.free()
+    s_mixed.free()
