@@ -136,6 +136,7 @@ struct STORM_s {
     uint32_t hip_private;     /* a container the library keeps for itself (the list mirror of a
                                  STORM_contiguous_t): nobody edits its members, no fingerprint per call */
     uint64_t hip_epoch;       /* the mutation epoch (storm_host.c) the device arena was last verified at */
+    void* hip_stage;          /* [r6] the bitmap blocks STORM_add has already sent to the device (storm_host.c) */
 };
 
 /* one row of the dense container (reference storm.h:181-186) */

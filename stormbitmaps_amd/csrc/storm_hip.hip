@@ -480,6 +480,15 @@ static int ensure_segments(storm_hip_ctx_t* ctx, uint64_t n_rows, uint32_t shard
     return STORM_HIP_OK;
 }
 
+void drain_deferred(storm_hip_ctx_t* ctx, bool aged) {
+    if (aged && ctx->deferred_age++ == 0) return;   // (the call that deferred them: leave them to the next one)
+    for (void* p : ctx->deferred_free) (void)hipFree(p);
+    for (void* p : ctx->deferred_host_free) (void)hipHostFree(p);
+    ctx->deferred_free.clear();
+    ctx->deferred_host_free.clear();
+    ctx->deferred_age = 0;
+}
+
 static int check_ctx(const storm_hip_ctx_t* ctx) {
     if (!ctx) {
         set_error("NULL context");
@@ -517,6 +526,10 @@ int storm_hip_device_pci_bus_id(int device, char* buf, size_t buflen) {
     if (!buf || buflen < 13) return STORM_HIP_EINVAL;
     STORM_HIP_TRY(hipDeviceGetPCIBusId(buf, (int)buflen, device));
     return STORM_HIP_OK;
+}
+
+namespace storm {
+__global__ void warm_core_kernel() {}
 }
 
 int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
@@ -560,6 +573,27 @@ int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
         storm_hip_ctx_destroy(ctx);
         return STORM_HIP_EHIP;
     }
+    // the code objects of all translation units and the result mailbox now, not inside the first call (it costs the
+    // creation a few ms once; STORM_HIP_NO_WARM: the lazy loading of rounds 1 - 5, for tools/bench_cold.py's A/B)
+    if (!getenv("STORM_HIP_NO_WARM")) {
+        hipLaunchKernelGGL(warm_core_kernel, dim3(1), dim3(64), 0, ctx->stream);
+        warm_mfma_code(ctx->stream);
+        warm_sparse_code(ctx->stream);
+        warm_lists_code(ctx->stream);
+        (void)result_target(ctx);
+        ctx->mail_armed = false;
+        // ... and the runtime's path for copies out of pageable host memory: the first such copy of a process (a work list on
+        // its way to the device) took 7.5 ms — the whole first-call penalty of a 1024-row matrix (rocprofv3 --hip-trace)
+        {
+            std::vector<uint64_t> pageable(kSlots, 0);
+            (void)hipMemcpyAsync(ctx->d_slots, pageable.data(), pageable.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+            set_error("warm-up launches failed");
+            storm_hip_ctx_destroy(ctx);
+            return STORM_HIP_EHIP;
+        }
+    }
     if (const char* v = getenv("STORM_HIP_VARIANT")) ctx->variant = atoi(v);
     if (const char* v = getenv("STORM_HIP_SEG_ROWS")) ctx->seg_rows = atoi(v);
     if (const char* v = getenv("STORM_HIP_CHUNKS_PER_ITEM")) ctx->chunks_per_item = atoi(v);
@@ -580,9 +614,22 @@ int storm_hip_ctx_synchronize(storm_hip_ctx_t* ctx) {
     return STORM_HIP_OK;
 }
 
+int storm_hip_ctx_reserve_staging(storm_hip_ctx_t* ctx) {
+    if (check_ctx(ctx)) return STORM_HIP_EINVAL;
+    if (ctx->h_stage_ring) return STORM_HIP_OK;
+    STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (hipHostMalloc(&ctx->h_stage_ring, (size_t)24 << 20, hipHostMallocDefault) != hipSuccess) {
+        ctx->h_stage_ring = nullptr;
+        set_error("reserve_staging: hipHostMalloc of the 24 MiB staging ring failed");
+        return STORM_HIP_ENOMEM;
+    }
+    return STORM_HIP_OK;
+}
+
 void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    drain_deferred(ctx, false);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_scalar) (void)hipFree(ctx->d_scalar);
     if (ctx->d_positions) (void)hipFree(ctx->d_positions);

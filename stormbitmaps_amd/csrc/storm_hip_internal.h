@@ -91,6 +91,10 @@ struct storm_hip_ctx_s {
     int result_mailbox = 1;
     int sync_poll_us = 0;                    // [r6] synchronous matrix-output calls poll hipStreamQuery this long before they park in hipStreamSynchronize (0: park at once)
     bool mail_armed = false;                 // the call in flight was launched into the mailbox
+    // [r6] device / pinned allocations whose release (hipFree waits for the device: ~0.2 ms each, eleven of them behind an
+    // arena build) is put off until the call AFTER the one that made them obsolete, or the context's end
+    std::vector<void*> deferred_free, deferred_host_free;
+    uint32_t deferred_age = 0;
     void* h_stage_ring = nullptr;            // pinned staging ring of the sparse arena builder (storm_hip_sparse.hip: Stager), allocated on first use
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
     size_t segs_capacity = 0;
@@ -250,6 +254,12 @@ int launch_square_matrix(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
                          const storm_hip_matrix_s* b, int op, uint32_t* d_out, uint64_t ld);
 int launch_row_counts(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_t* d_counts);
 void release_mfma_state(storm_hip_ctx_t* ctx);
+// releases what was put off (storm_hip_ctx_s::deferred_free); `aged`: only what an earlier call left behind
+void drain_deferred(storm_hip_ctx_t* ctx, bool aged);
+// one empty launch per translation unit (storm_hip_ctx_create): loads the TU's code object ahead of the first real call
+void warm_mfma_code(hipStream_t stream);
+void warm_sparse_code(hipStream_t stream);
+void warm_lists_code(hipStream_t stream);
 // ctx->d_scalar -> *h_total through the context's pinned word; synchronises the stream (storm_hip.hip)
 int fetch_result_word(storm_hip_ctx_t* ctx, uint64_t* h_total);
 // where a synchronous call launches its total: the mailbox (armed with the sentinel) or, without one, ctx->d_scalar

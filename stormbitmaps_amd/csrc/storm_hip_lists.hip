@@ -35,6 +35,13 @@
 
 using namespace storm;
 
+// (an empty launch at context creation loads this file's code object ahead of the first real call: storm_hip_ctx_create)
+namespace storm {
+__global__ void warm_lists_kernel() {}
+void warm_lists_code(hipStream_t stream) { hipLaunchKernelGGL(warm_lists_kernel, dim3(1), dim3(64), 0, stream); }
+}  // namespace storm
+
+
 namespace {
 
 constexpr int kLmThreads = 1024;

@@ -1918,6 +1918,12 @@ static void release_panel_lists(storm_hip_ctx_t* ctx) {
     ctx->copy_stream = nullptr;
 }
 
+// One empty launch per translation unit at context creation: the runtime loads a TU's code object at the first launch of
+// one of its kernels (a few ms for this file's), and the first storm.h call — the only one the reference's harness times,
+// benchmark.cpp:605-613 — used to pay for it.
+__global__ void warm_mfma_kernel() {}
+void warm_mfma_code(hipStream_t stream) { hipLaunchKernelGGL(warm_mfma_kernel, dim3(1), dim3(64), 0, stream); }
+
 void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_x4) (void)hipFree(ctx->d_x4);
     if (ctx->d_items) (void)hipFree(ctx->d_items);
@@ -1929,6 +1935,9 @@ void release_mfma_state(storm_hip_ctx_t* ctx) {
     if (ctx->d_parts) (void)hipFree(ctx->d_parts);
     ctx->d_parts = nullptr;
     ctx->parts_capacity = 0;
+    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+    ctx->d_tickets = nullptr;
+    ctx->tickets_capacity = 0;
     if (ctx->d_bitsegs) (void)hipFree(ctx->d_bitsegs);
     if (ctx->d_bitfirst) (void)hipFree(ctx->d_bitfirst);
     ctx->d_bitsegs = ctx->d_bitfirst = nullptr;
@@ -2130,10 +2139,33 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
             }
         }
     };
+    // Every slice holds the same items but for its slice number: the list of one slice is built (and, for the long runs,
+    // sorted longest first) ONCE per run length and copied with the number filled in — built and sorted slice by slice,
+    // three candidate run lengths and the final list cost the first call at the headline shape 1.4 ms of host time, a first
+    // call at 10000 x 524288 twenty times that [r6].
+    const uint32_t kTailLen = std::min(kMaxRun, kTailRun);
+    std::vector<StripItem> proto_main, proto_tail;
+    bool have_main = false, have_tail = false;
+    auto by_length = [&](const StripItem& p, const StripItem& q) {
+        return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
+    };
+    auto emit_copy = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
+        std::vector<StripItem>& proto = max_run == kMaxRun ? proto_main : proto_tail;
+        bool& have = max_run == kMaxRun ? have_main : have_tail;
+        if (!have) {
+            emit_slice_all(0u, max_run, proto);
+            if (max_run == kMaxRun) std::stable_sort(proto.begin(), proto.end(), by_length);
+            have = true;
+        }
+        const uint32_t ks_data = sh.one_slice_probe ? ks % 8u : ks;
+        const size_t at = dst.size();
+        dst.insert(dst.end(), proto.begin(), proto.end());
+        for (size_t k = at; k < dst.size(); ++k) dst[k].ks = ks_data;
+    };
     // pair mode: this shard's share of the slice — the slice's items, longest first onto the least loaded shard
     // (every shard walks the slices in the same order and computes the same deal)
     auto emit_slice = [&](uint32_t ks, uint32_t max_run, std::vector<StripItem>& dst) {
-        if (!pair_mode) return emit_slice_all(ks, max_run, dst);
+        if (!pair_mode) return (max_run == kMaxRun || max_run == kTailLen) ? emit_copy(ks, max_run, dst) : emit_slice_all(ks, max_run, dst);
         std::vector<StripItem> all;
         emit_slice_all(ks, max_run, all);
         std::stable_sort(all.begin(), all.end(), [&](const StripItem& p, const StripItem& q) {
@@ -2171,7 +2203,10 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
     }
     const uint32_t kTail = (uint32_t)std::max(0, sh.tail_slices);
     std::vector<std::vector<StripItem>> per_xcd(8);
-    for (int x = 0; x < 8; ++x) {
+    // (an estimate — `makespan` asked for — is made from the list of XCD 0 alone: the slices are dealt to the XCDs in turn
+    //  from 0, so its list is as long as any; the other seven lists and the launch order are not built)
+    const int n_lists = makespan ? 1 : 8;
+    for (int x = 0; x < n_lists; ++x) {
         const std::vector<uint32_t>& sl = slices_of[x];
         const size_t n_main = sl.size() > kTail ? sl.size() - kTail : 0;
         // Within a slice, longest first: the XCD's dispatcher deals consecutive workgroups to its
@@ -2179,11 +2214,13 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
         // one A tile) sends all the long ones to the same engines and leaves the others idle
         // (schedule trace: 60 % of the slots occupied; max_run = 64, 72 or 100 lost 10-25 %).
         for (size_t k = 0; k < n_main; ++k) {
+            if (!pair_mode) {   // (the copy of the sorted list of one slice)
+                emit_slice(sl[k], kMaxRun, per_xcd[x]);
+                continue;
+            }
             std::vector<StripItem> one;
             emit_slice(sl[k], kMaxRun, one);
-            std::stable_sort(one.begin(), one.end(), [&](const StripItem& p, const StripItem& q) {
-                return (p.j1 - p.j0) + p.diag * kPerTile > (q.j1 - q.j0) + q.diag * kPerTile;
-            });
+            std::stable_sort(one.begin(), one.end(), by_length);
             per_xcd[x].insert(per_xcd[x].end(), one.begin(), one.end());
         }
         std::vector<StripItem> tail;
@@ -2207,18 +2244,26 @@ static void build_strip_items(const StripShaping& sh, const std::vector<RowRange
         // List-scheduling estimate of the launch, in stage times: an XCD hands its list, in order, to its workgroup
         // slots (4 per CU); an item costs its stages + ~5 for the prologue (A rows, two images) + 3 more for the
         // non-pipelined diagonal phase. Used to choose the run length (k2_max_run = 0).
-        double worst = 0;
-        for (int x = 0; x < 8; ++x) {
-            std::vector<double> slot(std::max<uint32_t>(1, slots_per_xcd), 0.0);  // a min-heap of the slots' free times
-            auto later = [](double p, double q) { return p > q; };
-            for (const StripItem& it : per_xcd[x]) {
-                std::pop_heap(slot.begin(), slot.end(), later);
-                slot.back() += (double)(it.j1 - it.j0) + (it.diag ? kPerTile + 3.0 : 0.0) + 5.0;
-                std::push_heap(slot.begin(), slot.end(), later);
-            }
-            worst = std::max(worst, *std::max_element(slot.begin(), slot.end()));
+        // [r6] Only the list of XCD 0 is walked (above), and of a long list only the last 16 rounds, behind an evenly loaded start: what decides
+        // between the run lengths is the tail. The full walk of all eight lists took 2.5 ms of a first call at the
+        // headline shape (three candidates), 25 ms at 10000 x 524288.
+        auto cost_of = [&](const StripItem& it) { return (double)(it.j1 - it.j0) + (it.diag ? kPerTile + 3.0 : 0.0) + 5.0; };
+        const std::vector<StripItem>& list = per_xcd[0];
+        const size_t n_slots = std::max<uint32_t>(1, slots_per_xcd);
+        const size_t start = list.size() > 16 * n_slots ? list.size() - 16 * n_slots : 0;
+        double before = 0;
+        for (size_t k = 0; k < start; ++k) before += cost_of(list[k]);
+        std::vector<double> slot(n_slots, before / (double)n_slots);  // a min-heap of the slots' free times
+        auto later = [](double p, double q) { return p > q; };
+        for (size_t k = start; k < list.size(); ++k) {
+            std::pop_heap(slot.begin(), slot.end(), later);
+            slot.back() += cost_of(list[k]);
+            std::push_heap(slot.begin(), slot.end(), later);
         }
+        const double worst = *std::max_element(slot.begin(), slot.end());
         *makespan = worst;
+        items.clear();
+        return;
     }
     items.clear();
     if (sh.persistent) {  // one contiguous queue per XCD

@@ -29,6 +29,13 @@
 
 using namespace storm;
 
+// (an empty launch at context creation loads this file's code object ahead of the first real call: storm_hip_ctx_create)
+namespace storm {
+__global__ void warm_sparse_kernel() {}
+void warm_sparse_code(hipStream_t stream) { hipLaunchKernelGGL(warm_sparse_kernel, dim3(1), dim3(64), 0, stream); }
+}  // namespace storm
+
+
 constexpr uint64_t kPoolPitchDefault = 1024;
 
 struct storm_hip_sparse_s {
@@ -401,6 +408,7 @@ struct Stager {
         for (hipEvent_t e : ev)
             if (e) (void)hipEventDestroy(e);
     }
+    static_assert(kBuf * kBufs == ((size_t)24 << 20), "storm_hip_ctx_reserve_staging allocates the same ring");
     int init() {
         if (!ctx->h_stage_ring) {
             if (hipHostMalloc(&ctx->h_stage_ring, kBuf * kBufs, hipHostMallocDefault) != hipSuccess) {
@@ -494,6 +502,140 @@ int upload(T** d, const T* h, size_t n, hipStream_t stream) {
 
 }  // namespace
 
+// ---- [r6] block stage: bitmap blocks travel to the device WHILE the container is being built ---------------------
+// A STORM_t of dense rows is 8 KiB per block (655 MB at BASELINE c4's 50 % load): built from pointers at the first
+// all-pairs call (storm_hip_sparse_create_blocks) those bytes cross the bus inside that call — 91 ms, the one call the
+// reference's harness times (benchmark.cpp:605-613). STORM_add hands every bitmap block it finishes to a stage instead:
+// 8 KiB into a pinned ring, 4 MiB at a time on its way into 64 MiB device chunks, a token back. The arena build then
+// gathers the pool rows from the chunks with one kernel (storm_hip_sparse_create_blocks_staged) — the regrouping by
+// block column needs every row, so the final layout cannot be streamed into.
+struct storm_hip_stage_s {
+    static constexpr size_t kBlockBytes = 8192, kChunkBlocks = 8192, kBufBlocks = 512;
+    std::vector<uint8_t*> chunks;   // 64 MiB each
+    uint64_t n_blocks = 0;          // tokens handed out
+    uint8_t* h_ring = nullptr;      // two buffers of kBufBlocks blocks, pinned
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    int cur = 0;
+    uint32_t fill = 0;              // blocks in the current buffer
+    uint64_t base = 0;              // token of the current buffer's first block
+    const uint8_t** d_chunk_table = nullptr;   // the chunks' addresses on the device (rebuilt per gather)
+};
+
+namespace {
+
+int stage_send(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
+    if (st->fill == 0) return STORM_HIP_OK;
+    const uint8_t* buf = st->h_ring + (size_t)st->cur * storm_hip_stage_s::kBufBlocks * storm_hip_stage_s::kBlockBytes;
+    uint64_t t = st->base, left = st->fill;
+    while (left) {   // (a buffer that was sent before it was full may run across a chunk boundary)
+        const uint64_t chunk = t / storm_hip_stage_s::kChunkBlocks, off = t % storm_hip_stage_s::kChunkBlocks;
+        while (st->chunks.size() <= chunk) {
+            uint8_t* c = nullptr;
+            if (hipMalloc(reinterpret_cast<void**>(&c), storm_hip_stage_s::kChunkBlocks * storm_hip_stage_s::kBlockBytes) != hipSuccess) {
+                set_error("block stage: hipMalloc of a 64 MiB chunk failed");
+                return STORM_HIP_ENOMEM;
+            }
+            st->chunks.push_back(c);
+        }
+        const uint64_t n = std::min<uint64_t>(left, storm_hip_stage_s::kChunkBlocks - off);
+        STORM_HIP_TRY(hipMemcpyAsync(st->chunks[chunk] + off * storm_hip_stage_s::kBlockBytes,
+                                     buf + (t - st->base) * storm_hip_stage_s::kBlockBytes, n * storm_hip_stage_s::kBlockBytes,
+                                     hipMemcpyHostToDevice, ctx->stream));
+        t += n;
+        left -= n;
+    }
+    STORM_HIP_TRY(hipEventRecord(st->ev[st->cur], ctx->stream));
+    st->used[st->cur] = true;
+    st->cur ^= 1;
+    st->base += st->fill;
+    st->fill = 0;
+    if (st->used[st->cur]) STORM_HIP_TRY(hipEventSynchronize(st->ev[st->cur]));   // the buffer about to be filled has left
+    return STORM_HIP_OK;
+}
+
+// pool row `dst` <- staged block `token`: one workgroup per block, 32 bytes per thread
+__global__ __launch_bounds__(256) void gather_staged_kernel(const uint8_t* const* __restrict__ chunks,
+                                                            const uint64_t* __restrict__ table, uint64_t* __restrict__ pool,
+                                                            uint64_t pitch_words) {
+    const uint64_t dst = table[2 * blockIdx.x], token = table[2 * blockIdx.x + 1];
+    const uint4* src = reinterpret_cast<const uint4*>(chunks[token / storm_hip_stage_s::kChunkBlocks] +
+                                                      (token % storm_hip_stage_s::kChunkBlocks) * storm_hip_stage_s::kBlockBytes);
+    uint4* out = reinterpret_cast<uint4*>(pool + dst * pitch_words);
+    out[threadIdx.x] = src[threadIdx.x];
+    out[threadIdx.x + 256] = src[threadIdx.x + 256];
+}
+
+}  // namespace
+
+int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out) {
+    return guarded("storm_hip_stage_create", [&]() -> int {
+        if (!ctx || !out) {
+            set_error("stage_create: NULL context or output");
+            return STORM_HIP_EINVAL;
+        }
+        *out = nullptr;
+        STORM_HIP_TRY(hipSetDevice(ctx->device));
+        std::unique_ptr<storm_hip_stage_t> st(new storm_hip_stage_t());
+        if (hipHostMalloc(reinterpret_cast<void**>(&st->h_ring), 2 * storm_hip_stage_s::kBufBlocks * storm_hip_stage_s::kBlockBytes,
+                          hipHostMallocDefault) != hipSuccess) {
+            set_error("stage_create: hipHostMalloc of the 8 MiB ring failed");
+            return STORM_HIP_ENOMEM;
+        }
+        (void)storm_hip_ctx_reserve_staging(ctx);   // the arena builder's ring, too, while nobody is waiting
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming) != hipSuccess) {
+                storm_hip_stage_destroy(ctx, st.release());
+                return STORM_HIP_EHIP;
+            }
+        *out = st.release();
+        return STORM_HIP_OK;
+    });
+}
+
+int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint64_t* words, uint64_t* token) {
+    return guarded("storm_hip_stage_add", [&]() -> int {
+        if (!ctx || !st || !words || !token) {
+            set_error("stage_add: NULL argument");
+            return STORM_HIP_EINVAL;
+        }
+        memcpy(st->h_ring + ((size_t)st->cur * storm_hip_stage_s::kBufBlocks + st->fill) * storm_hip_stage_s::kBlockBytes, words,
+               storm_hip_stage_s::kBlockBytes);
+        *token = st->n_blocks++;
+        if (++st->fill == storm_hip_stage_s::kBufBlocks) {
+            STORM_HIP_TRY(hipSetDevice(ctx->device));
+            return stage_send(ctx, st);
+        }
+        return STORM_HIP_OK;
+    });
+}
+
+uint64_t storm_hip_stage_count(const storm_hip_stage_t* st) { return st ? st->n_blocks : 0; }
+
+void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
+    if (!st) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);   // copies out of the ring, gathers out of the chunks
+    }
+    // (put off: ten 64 MiB chunks and the ring cost 3 ms to release, inside the first all-pairs call)
+    for (uint8_t* c : st->chunks) {
+        if (ctx) ctx->deferred_free.push_back(c);
+        else (void)hipFree(c);
+    }
+    if (st->d_chunk_table) {
+        if (ctx) ctx->deferred_free.push_back(st->d_chunk_table);
+        else (void)hipFree(st->d_chunk_table);
+    }
+    if (st->h_ring) {
+        if (ctx) ctx->deferred_host_free.push_back(st->h_ring);
+        else (void)hipHostFree(st->h_ring);
+    }
+    for (hipEvent_t e : st->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete st;
+}
+
 // Builds the device arena from the flat block description of storm_hip.h. `bitmaps_in_stream`:
 // the bitmap blocks' words are not in `bitmap_pool` but inside `list_pool` itself (then a byte
 // stream viewed as uint16, block_data_offset of a bitmap block in uint16 units): the whole stream
@@ -501,7 +643,8 @@ int upload(T** d, const T* h, size_t n, hipStream_t stream) {
 static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                        const uint64_t* row_block_offset, const uint32_t* block_id,
                        const uint8_t* block_kind, const uint32_t* block_n,
-                       const void* const* block_ptr, storm_hip_sparse_t** out) {
+                       const void* const* block_ptr, storm_hip_sparse_t** out,
+                       storm_hip_stage_t* stage = nullptr, const uint64_t* stage_token = nullptr) {
     if (!ctx || !out) {
         set_error("sparse_create: NULL context or output");
         return STORM_HIP_EINVAL;
@@ -671,12 +814,19 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         uint32_t *atoms = nullptr, *bad = nullptr, *pllen = nullptr;
         uint64_t *loff = nullptr, *ploff = nullptr;
         uint16_t *lists = nullptr, *pos_tmp = nullptr;
+        storm_hip_ctx_t* ctx = nullptr;
         ~DevTemps() {
-            (void)hipFree(lrow); (void)hipFree(loff); (void)hipFree(llen); (void)hipFree(lists);
-            (void)hipFree(tags); (void)hipFree(rend); (void)hipFree(rdst); (void)hipFree(atoms);
-            (void)hipFree(bad); (void)hipFree(pllen); (void)hipFree(ploff); (void)hipFree(pos_tmp);
+            // (the build has waited for its last kernel; a hipFree waits for the device once more and costs ~0.2 ms: put off)
+            for (void* p : {(void*)lrow, (void*)loff, (void*)llen, (void*)lists, (void*)tags, (void*)rend, (void*)rdst,
+                            (void*)atoms, (void*)bad, (void*)pllen, (void*)ploff, (void*)pos_tmp})
+                if (p) {
+                    if (ctx) ctx->deferred_free.push_back(p);
+                    else (void)hipFree(p);
+                }
         }
     } dt;
+    dt.ctx = ctx;
+    drain_deferred(ctx, false);   // (whatever an earlier build left behind)
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     Stager stager(ctx);
     if (int rc0 = stager.init()) return rc0;
@@ -943,7 +1093,41 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         // bitmap-kind blocks: straight into their pool rows — in pool-row order the blocks of a column are
         // consecutive rows, so a run of them is ONE contiguous destination (no staging copy on the device, no
         // placement kernel; the words may sit at any alignment on the host: a serialized stream)
-        if (!dense_row.empty()) {
+        // [r6] ... unless every one of them already lies on the device (the block stage filled while the rows were
+        // added): one kernel gathers the pool rows from the stage's chunks
+        bool gathered = false;
+        if (!dense_row.empty() && stage && stage_token) {
+            bool all = true;
+            for (uint64_t b : dense_blk) all = all && stage_token[b] < stage->n_blocks;
+            if (all) {
+                if ((rc = stage_send(ctx, stage)) != STORM_HIP_OK) break;   // the blocks still in the ring
+                std::vector<uint64_t> table(2 * dense_row.size());
+                for (size_t k = 0; k < dense_row.size(); ++k) table[2 * k] = dense_row[k], table[2 * k + 1] = stage_token[dense_blk[k]];
+                uint64_t* d_table = nullptr;
+                if (stage->d_chunk_table) (void)hipFree(stage->d_chunk_table);
+                stage->d_chunk_table = nullptr;
+                if (hipMalloc(reinterpret_cast<void**>(&stage->d_chunk_table), stage->chunks.size() * sizeof(uint8_t*)) != hipSuccess ||
+                    hipMalloc(reinterpret_cast<void**>(&d_table), table.size() * sizeof(uint64_t)) != hipSuccess) {
+                    set_error("sparse_create: hipMalloc of the gather table failed");
+                    rc = STORM_HIP_ENOMEM;
+                    break;
+                }
+                if (hipMemcpyAsync(stage->d_chunk_table, stage->chunks.data(), stage->chunks.size() * sizeof(uint8_t*),
+                                   hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                    hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                    (void)hipFree(d_table);
+                    rc = STORM_HIP_EHIP;
+                    break;
+                }
+                hipLaunchKernelGGL(gather_staged_kernel, dim3((uint32_t)dense_row.size()), dim3(256), 0, ctx->stream,
+                                   stage->d_chunk_table, d_table, s->d_pool, (uint64_t)s->pitch);
+                const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;   // `table` is pageable
+                (void)hipFree(d_table);
+                if (!ok) { rc = STORM_HIP_EHIP; break; }
+                gathered = true;
+            }
+        }
+        if (!dense_row.empty() && !gathered) {
             std::vector<uint32_t> order(dense_row.size());
             for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
             std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dense_row[x] < dense_row[y]; });
@@ -1153,6 +1337,22 @@ int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64
         return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out);
     } catch (const std::exception& e) {
         set_error("sparse_create_blocks: %s", e.what());
+        return STORM_HIP_ENOMEM;
+    }
+}
+
+// [r6] The same with the bitmap blocks already on the device: token[b] = what storm_hip_stage_add returned for block b
+// (any value >= the stage's count, e.g. ~0: not staged). When every bitmap block is staged the pool rows are gathered from
+// the stage and nothing of them crosses the bus; otherwise this is storm_hip_sparse_create_blocks (block_ptr must be
+// valid either way).
+int storm_hip_sparse_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                          const uint64_t* row_block_offset, const uint32_t* block_id,
+                                          const uint8_t* block_kind, const uint32_t* block_n, const void* const* block_ptr,
+                                          storm_hip_stage_t* stage, const uint64_t* token, storm_hip_sparse_t** out) {
+    try {
+        return build_arena(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out, stage, token);
+    } catch (const std::exception& e) {
+        set_error("sparse_create_blocks_staged: %s", e.what());
         return STORM_HIP_ENOMEM;
     }
 }
@@ -1370,6 +1570,7 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     }
     storm_hip_sparse_t* s = const_cast<storm_hip_sparse_t*>(cs);
     STORM_HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->deferred_free.empty() || !ctx->deferred_host_free.empty()) drain_deferred(ctx, true);
     uint64_t* const d_result = result_target(ctx);   // the mailbox, or ctx->d_scalar
     memcpy(ctx->sparse_census, s->census, sizeof(s->census));
     memset(ctx->pass_report, 0, sizeof(ctx->pass_report));

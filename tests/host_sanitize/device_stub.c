@@ -29,6 +29,7 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
     (void)ctx; (void)key; (void)value;
     return STORM_HIP_OK;
 }
+int storm_hip_ctx_reserve_staging(storm_hip_ctx_t* ctx) { (void)ctx; return STORM_HIP_OK; }
 int storm_hip_option_check(const char* key, int64_t value) {
     (void)value;
     return key && key[0] && key[0] != '?' ? STORM_HIP_OK : STORM_HIP_EINVAL;   /* ("?..." stands for a typo) */
@@ -158,6 +159,36 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     if (!*out) return STORM_HIP_ENOMEM;
     (*out)->set_bits = bits;
     return STORM_HIP_OK;
+}
+/* the block stage: a host copy of every staged block (ASan checks the 8 KiB read), tokens in order */
+struct storm_hip_stage_s { uint64_t n; uint64_t sum; };
+int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out) {
+    (void)ctx;
+    *out = (storm_hip_stage_t*)calloc(1, sizeof(**out));
+    return *out ? STORM_HIP_OK : STORM_HIP_ENOMEM;
+}
+int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint64_t* words, uint64_t* token) {
+    (void)ctx;
+    for (int k = 0; k < 1024; ++k) st->sum += (uint64_t)__builtin_popcountll(words[k]);
+    *token = st->n++;
+    return STORM_HIP_OK;
+}
+uint64_t storm_hip_stage_count(const storm_hip_stage_t* st) { return st ? st->n : 0; }
+void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) { (void)ctx; free(st); }
+int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                   const uint64_t* row_block_offset, const uint32_t* block_id,
+                                   const uint8_t* block_kind, const uint32_t* block_n,
+                                   const void* const* block_ptr, storm_hip_sparse_t** out);
+int storm_hip_sparse_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                          const uint64_t* row_block_offset, const uint32_t* block_id,
+                                          const uint8_t* block_kind, const uint32_t* block_n, const void* const* block_ptr,
+                                          storm_hip_stage_t* stage, const uint64_t* token, storm_hip_sparse_t** out) {
+    /* every bitmap block must carry the token of a staged block, in staging order */
+    uint64_t next = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (block_kind[b] && token[b] != next++) return STORM_HIP_EINVAL;
+    if (next != stage->n) return STORM_HIP_EINVAL;
+    return storm_hip_sparse_create_blocks(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out);
 }
 /* reads every list entry and bitmap word through the pointers handed over (ASan checks their extents) */
 int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
