@@ -424,6 +424,10 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
                                      const void* const* block_ptr, storm_hip_rowlists_t** out);
 void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l);
 int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l);
+/* the same rule from the counts alone (rows, listed positions, bits per row), BEFORE anything is built: a container the
+ * rule sends to the dense replica should not pay for row lists it will not use (9 ms of a first call at 3670 positions
+ * per row of BASELINE c4's shape) */
+int storm_hip_rowlists_worthwhile_counts(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_elems, uint64_t n_bits);
 int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
                                            uint32_t* d_out, uint64_t ld);
 /* ... and into host memory: whole rows, zeros at i >= j (what storm_hip_pairw_matrix writes) */

@@ -97,6 +97,7 @@ SIGNATURES = {
     "storm_hip_rowlists_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_rowlists_destroy": (None, [vp, vp]),
     "storm_hip_rowlists_worthwhile": (C.c_int, [vp, vp]),
+    "storm_hip_rowlists_worthwhile_counts": (C.c_int, [vp, u64, u64, u64]),
     "storm_hip_rowlists_pairw_matrix_device": (C.c_int, [vp, vp, C.c_int, vp, u64]),
     "storm_hip_rowlists_pairw_matrix": (C.c_int, [vp, vp, C.c_int, vp, u64]),
     "storm_hip_rowlists_n_elems": (u64, [vp]),

@@ -30,6 +30,7 @@
 // 2^24 (group, window) cells. Anything else keeps the dense replica.
 #include "storm_hip_internal.h"
 
+#include <chrono>
 #include <cstring>
 #include <memory>
 
@@ -56,25 +57,43 @@ static_assert(kLmTableBytes + kLmCountBytes <= 160u * 1024u, "LDS of a gfx950 CU
 
 struct LmItem { uint32_t gi, cj; };
 
-// counts per (group, window) cell, then the elements into their cells (order inside a cell: whatever the atomics give)
+// counts per (group, window) cell, then the elements into their cells (order inside a cell: whatever the atomics give).
+// [r6] A row's positions ascend, so what a row holds of one window is one RUN of its list: the thread that finds a run's
+// first element finds its end by bisection and books the whole run with ONE atomic (10000 rows x 64 windows instead of 36
+// million elements at 3670 positions per row: 4.7 + 7.7 ms of a first call for the two kernels before).
+__device__ __forceinline__ uint32_t lists_run_end(const uint32_t* __restrict__ pos, uint32_t e, uint32_t r1, uint32_t w) {
+    uint32_t lo = e + 1u, hi = r1;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((pos[mid] >> kLmWinBits) == w) lo = mid + 1u;
+        else hi = mid;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void lists_count_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ row_off,
                                                           uint32_t n_rows, uint32_t n_windows, uint32_t* __restrict__ cells) {
     const uint32_t row = blockIdx.x;
     if (row >= n_rows) return;
-    const uint32_t g = row / kLmGroup;
-    for (uint32_t e = row_off[row] + threadIdx.x; e < row_off[row + 1]; e += 256u)
-        atomicAdd(&cells[(uint64_t)g * n_windows + (pos[e] >> kLmWinBits)], 1u);
+    const uint32_t g = row / kLmGroup, r0 = row_off[row], r1 = row_off[row + 1];
+    for (uint32_t e = r0 + threadIdx.x; e < r1; e += 256u) {
+        const uint32_t w = pos[e] >> kLmWinBits;
+        if (e != r0 && (pos[e - 1u] >> kLmWinBits) == w) continue;
+        atomicAdd(&cells[(uint64_t)g * n_windows + w], lists_run_end(pos, e, r1, w) - e);
+    }
 }
 __global__ __launch_bounds__(256) void lists_place_kernel(const uint32_t* __restrict__ pos, const uint32_t* __restrict__ row_off,
                                                           uint32_t n_rows, uint32_t n_windows, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ elems) {
     const uint32_t row = blockIdx.x;
     if (row >= n_rows) return;
-    const uint32_t g = row / kLmGroup;
-    for (uint32_t e = row_off[row] + threadIdx.x; e < row_off[row + 1]; e += 256u) {
-        const uint32_t p = pos[e];
-        const uint32_t at = atomicAdd(&cursor[(uint64_t)g * n_windows + (p >> kLmWinBits)], 1u);
-        elems[at] = ((row % kLmChunk) << kLmWinBits) | (p & (kLmWin - 1u));
+    const uint32_t g = row / kLmGroup, r0 = row_off[row], r1 = row_off[row + 1];
+    const uint32_t tag = (row % kLmChunk) << kLmWinBits;
+    for (uint32_t e = r0 + threadIdx.x; e < r1; e += 256u) {
+        const uint32_t w = pos[e] >> kLmWinBits;
+        if (e != r0 && (pos[e - 1u] >> kLmWinBits) == w) continue;
+        const uint32_t end = lists_run_end(pos, e, r1, w);
+        const uint32_t at = atomicAdd(&cursor[(uint64_t)g * n_windows + w], end - e);
+        for (uint32_t k = e; k < end; ++k) elems[at + (k - e)] = tag | (pos[k] & (kLmWin - 1u));
     }
 }
 
@@ -430,6 +449,32 @@ void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l) {
     delete l;
 }
 
+namespace {
+struct LxBlock {
+    uint32_t at;     // where the block's positions go (= where its list lies in the raw upload), in elements
+    uint32_t n;      // list length
+    uint32_t base;   // block id x 65536: what its 16-bit values count from
+    uint32_t row;
+};
+// raw 16-bit lists -> global positions and row tags; one wave per block; *bad: a list that does not ascend strictly
+__global__ __launch_bounds__(256) void lists_expand_kernel(const uint16_t* __restrict__ raw, const LxBlock* __restrict__ blocks,
+                                                           uint32_t n_blocks, uint32_t* __restrict__ pos,
+                                                           uint16_t* __restrict__ rtag, uint32_t* __restrict__ bad) {
+    const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= n_blocks) return;
+    const LxBlock x = blocks[b];
+    const uint16_t tag = (uint16_t)(x.row & 2047u);
+    bool wrong = false;
+    for (uint32_t k = threadIdx.x & 63u; k < x.n; k += 64u) {
+        const uint32_t v = raw[x.at + k];
+        if (k && raw[x.at + k - 1u] >= v) wrong = true;
+        pos[x.at + k] = x.base + v;
+        rtag[x.at + k] = tag;
+    }
+    if (wrong) atomicOr(bad, 1u);
+}
+}  // namespace
+
 int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                                      const uint64_t* row_block_offset, const uint32_t* block_id,
                                      const uint8_t* block_kind, const uint32_t* block_n,
@@ -491,46 +536,78 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         l->n_groups = n_groups;
         l->n_windows = n_windows;
 
-        // ---- rows as global positions (checked: strictly ascending — a repeated position would toggle itself away)
-        std::vector<uint32_t> pos(n_elems), row_off(n_rows + 1), rowlen(n_rows);
-        std::vector<uint16_t> rtag(n_elems);
+        // ---- rows as global positions. [r6] The host walks the BLOCKS only (where a list starts, how long it is, what its
+        //      positions count from); the lists go up as they lie — 2 bytes per position through the pinned ring, packed by
+        //      four threads while the copy before flies — and one kernel turns them into positions and row tags and checks that
+        //      every list ascends strictly (a repeated position would toggle itself away). Until round 5 the host expanded
+        //      every position itself and shipped 6 bytes for each out of pageable vectors: 118 ms of a first call at 3670
+        //      positions per row where a steady call takes 6.
+        auto T0 = std::chrono::steady_clock::now();
+        const bool timing = getenv("STORM_HIP_TIMING") != nullptr;
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[rowlists_create] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+            T0 = t;
+        };
+        std::vector<uint32_t> row_off(n_rows + 1), rowlen(n_rows);
+        std::vector<LxBlock> xb;
+        std::vector<std::pair<const void*, size_t>> run;
+        xb.reserve(n_blocks);
+        run.reserve(n_blocks);
         {
             uint64_t e = 0;
             for (uint64_t r = 0; r < n_rows; ++r) {
                 row_off[r] = (uint32_t)e;
                 for (uint64_t b = row_block_offset[r]; b < row_block_offset[r + 1]; ++b) {
-                    const uint16_t* v = static_cast<const uint16_t*>(block_ptr[b]);
-                    const uint32_t base = block_id[b] * 65536u;
-                    for (uint32_t k = 0; k < block_n[b]; ++k) {
-                        // (a list that is not strictly ascending — a row filled by out-of-order STORM_add calls — is no error:
-                        //  the container is not eligible, *out stays NULL and the dense replica, which sets bits in any order,
-                        //  takes the call as it did before this path existed; a repeated position would toggle itself away here)
-                        if (k && v[k] <= v[k - 1]) return STORM_HIP_OK;
-                        rtag[e] = (uint16_t)(r & 2047u);
-                        pos[e++] = base + v[k];
-                    }
+                    if (!block_n[b]) continue;
+                    xb.push_back({(uint32_t)e, block_n[b], block_id[b] * 65536u, (uint32_t)r});
+                    run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
+                    e += block_n[b];
                 }
                 rowlen[r] = (uint32_t)e - row_off[r];
             }
             row_off[n_rows] = (uint32_t)e;
         }
+        lap("block walk");
         STORM_HIP_TRY(hipSetDevice(ctx->device));
         struct Temps {
-            uint32_t *pos = nullptr, *row_off = nullptr, *cursor = nullptr;   // (pos and row_off: the arena's own, see below)
-            ~Temps() { (void)hipFree(cursor); }
+            uint32_t *pos = nullptr, *row_off = nullptr, *cursor = nullptr, *bad = nullptr;   // (pos and row_off: the arena's own, see below)
+            uint16_t* raw = nullptr;
+            LxBlock* xb = nullptr;
+            storm_hip_ctx_t* ctx = nullptr;
+            ~Temps() {   // (put off: a hipFree waits for the device, ~0.2 ms each — storm_hip_ctx_s::deferred_free)
+                for (void* p : {(void*)cursor, (void*)bad, (void*)raw, (void*)xb})
+                    if (p) ctx->deferred_free.push_back(p);
+            }
         } t;
+        t.ctx = ctx;
+        drain_deferred(ctx, false);
         const size_t n_cells = (size_t)(n_groups + 1u) * n_windows;
         STORM_HIP_TRY(hipMalloc(&l->d_pos, n_elems * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_row_off, (n_rows + 1) * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_rtag, n_elems * sizeof(uint16_t)));
         t.pos = l->d_pos;
         t.row_off = l->d_row_off;
-        STORM_HIP_TRY(hipMemcpyAsync(l->d_rtag, rtag.data(), n_elems * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+        STORM_HIP_TRY(hipMalloc(&t.raw, (n_elems + 8) * sizeof(uint16_t)));
+        STORM_HIP_TRY(hipMalloc(&t.xb, xb.size() * sizeof(LxBlock)));
+        STORM_HIP_TRY(hipMalloc(&t.bad, sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&t.cursor, n_cells * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_elems, n_elems * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_off, n_cells * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_rowlen, n_rows * sizeof(uint32_t)));
-        STORM_HIP_TRY(hipMemcpyAsync(t.pos, pos.data(), n_elems * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        STORM_HIP_TRY(hipMemsetAsync(t.bad, 0, sizeof(uint32_t), ctx->stream));
+        STORM_HIP_TRY(hipMemcpyAsync(t.xb, xb.data(), xb.size() * sizeof(LxBlock), hipMemcpyHostToDevice, ctx->stream));
+        lap("allocations");
+        {
+            Stager stager(ctx);
+            if (int rc = stager.init()) return rc;
+            if (int rc = stager.send_run(reinterpret_cast<uint8_t*>(t.raw), run)) return rc;
+        }
+        lap("lists through the ring");
+        hipLaunchKernelGGL(lists_expand_kernel, dim3((uint32_t)((xb.size() + 3) / 4)), dim3(256), 0, ctx->stream, t.raw, t.xb,
+                           (uint32_t)xb.size(), t.pos, l->d_rtag, t.bad);
+        STORM_HIP_TRY(hipGetLastError());
         STORM_HIP_TRY(hipMemcpyAsync(t.row_off, row_off.data(), (n_rows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         STORM_HIP_TRY(hipMemcpyAsync(l->d_rowlen, rowlen.data(), n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
         STORM_HIP_TRY(hipMemsetAsync(t.cursor, 0, n_cells * sizeof(uint32_t), ctx->stream));
@@ -538,8 +615,15 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
                            (uint32_t)n_rows, n_windows, t.cursor);
         STORM_HIP_TRY(hipGetLastError());
         std::vector<uint32_t> cells(n_cells), offs(n_cells);
+        uint32_t bad = 0;
         STORM_HIP_TRY(hipMemcpyAsync(cells.data(), t.cursor, n_cells * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        STORM_HIP_TRY(hipMemcpyAsync(&bad, t.bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
         STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // (a list that is not strictly ascending — a row filled by out-of-order STORM_add calls — is no error: the container is
+        //  not eligible, *out stays NULL and the dense replica, which sets bits in any order, takes the call as it did before
+        //  this path existed)
+        if (bad) return STORM_HIP_OK;
+        lap("expand + count on the device");
         {   // window-major order of the cells: off[g][w] runs over w first ... no: over g inside w
             uint64_t run = 0;
             for (uint32_t w = 0; w < n_windows; ++w)
@@ -560,6 +644,7 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         hipLaunchKernelGGL(lists_place_kernel, dim3((uint32_t)n_rows), dim3(256), 0, ctx->stream, t.pos, t.row_off,
                            (uint32_t)n_rows, n_windows, t.cursor, l->d_elems);
         STORM_HIP_TRY(hipGetLastError());
+        lap("offsets, place launched");
         const std::vector<LmItem> items = tile_order(n_rows, kLmGroup, kLmChunk);
         l->n_items = (uint32_t)items.size();
         STORM_HIP_TRY(hipMalloc(&l->d_items, items.size() * sizeof(LmItem)));
@@ -580,21 +665,27 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
             STORM_HIP_TRY(hipMalloc(&l->d_hash_items, hitems.size() * sizeof(LmItem)));
             STORM_HIP_TRY(hipMemcpyAsync(l->d_hash_items, hitems.data(), hitems.size() * sizeof(LmItem), hipMemcpyHostToDevice, ctx->stream));
         }
+        lap("tile lists");
         STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        lap("place on the device");
         *out = owner.release();
         return STORM_HIP_OK;
     });
 }
 
 // 1: the lists are expected to beat the dense replica's multiply (or the option says so); 0: keep the dense path
-int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l) {
+int storm_hip_rowlists_worthwhile_counts(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_elems, uint64_t n_bits) {
     if (!ctx || ctx->matrix_lists == 0) return 0;
-    if (!l) return 1;   // "is the path switched on at all": worth building the lists to find out
     if (ctx->matrix_lists > 0) return 1;
     // density of the dense replica the lists stand for (its rows are padded to 512 bits); crossover measured at the
     // README's STORM_t shape: profiles/r05_j_storm_matrix_lists.jsonl
-    const double bits = (double)((l->n_bits + 511u) / 512u * 512u) * (double)l->n_rows;
-    return (double)l->n_elems <= bits * (double)ctx->matrix_lists_permille_x10 / 10000.0;
+    const double bits = (double)((n_bits + 511u) / 512u * 512u) * (double)n_rows;
+    return (double)n_elems <= bits * (double)ctx->matrix_lists_permille_x10 / 10000.0;
+}
+int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l) {
+    if (!ctx || ctx->matrix_lists == 0) return 0;
+    if (!l) return 1;   // "is the path switched on at all"
+    return storm_hip_rowlists_worthwhile_counts(ctx, l->n_rows, l->n_elems, l->n_bits);
 }
 
 static int launch_lists(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* d_out, uint64_t ld) {

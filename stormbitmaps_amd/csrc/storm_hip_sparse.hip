@@ -393,103 +393,7 @@ __global__ __launch_bounds__(kThreads) void probe_deal_kernel(const uint32_t* __
     }
 }
 
-// Host data -> device through a small ring of pinned buffers: the pieces of a chunk are packed by a few threads
-// while the previous chunk's copy is in flight (pageable uploads of 1.7 GB were 0.15 s of c4's first call).
-struct Piece { const void* src; size_t bytes; size_t dst_off; size_t zero_after = 0; };  // dst_off: byte offset from the chunk's device base; zero_after: bytes of zeros behind the piece
-struct Stager {
-    static constexpr size_t kBuf = 8u << 20;  // 8 MiB per buffer: 0.16 ms of PCIe time each
-    static constexpr int kBufs = 3;
-    storm_hip_ctx_t* ctx;
-    hipEvent_t ev[kBufs] = {nullptr, nullptr, nullptr};
-    bool used[kBufs] = {false, false, false};
-    int next = 0;
-    explicit Stager(storm_hip_ctx_t* c) : ctx(c) {}
-    ~Stager() {
-        for (hipEvent_t e : ev)
-            if (e) (void)hipEventDestroy(e);
-    }
-    static_assert(kBuf * kBufs == ((size_t)24 << 20), "storm_hip_ctx_reserve_staging allocates the same ring");
-    int init() {
-        if (!ctx->h_stage_ring) {
-            if (hipHostMalloc(&ctx->h_stage_ring, kBuf * kBufs, hipHostMallocDefault) != hipSuccess) {
-                ctx->h_stage_ring = nullptr;
-                set_error("sparse_create: hipHostMalloc of the %zu-byte staging ring failed", kBuf * kBufs);
-                return STORM_HIP_ENOMEM;
-            }
-        }
-        for (int i = 0; i < kBufs; ++i)
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return STORM_HIP_EHIP;
-        return STORM_HIP_OK;
-    }
-    // pieces[p0, p1): consecutive in the device destination (dst_off ascending from 0, no gaps beyond `span`)
-    int send(uint8_t* d_base, const Piece* pieces, size_t n, size_t span) {
-        uint8_t* buf = static_cast<uint8_t*>(ctx->h_stage_ring) + (size_t)next * kBuf;
-        if (used[next] && hipEventSynchronize(ev[next]) != hipSuccess) return STORM_HIP_EHIP;
-        const unsigned parts = span >= (1u << 20) ? 4u : 1u;   // (2 / 4 / 8 / 12 packers: 31 / 24 / 28 / 32 ms for c4's 420 MB of lists)
-        auto pack = [&](unsigned part) {
-            for (size_t i = n * part / parts; i < n * (part + 1) / parts; ++i) {
-                memcpy(buf + pieces[i].dst_off, pieces[i].src, pieces[i].bytes);
-                if (pieces[i].zero_after) memset(buf + pieces[i].dst_off + pieces[i].bytes, 0, pieces[i].zero_after);
-            }
-        };
-        if (parts > 1) {
-            std::thread helpers[3];
-            for (unsigned t = 1; t < parts; ++t) helpers[t - 1] = std::thread(pack, t);
-            pack(0);
-            for (unsigned t = 1; t < parts; ++t) helpers[t - 1].join();
-        } else {
-            pack(0);
-        }
-        if (hipMemcpyAsync(d_base, buf, span, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-            hipEventRecord(ev[next], ctx->stream) != hipSuccess)
-            return STORM_HIP_EHIP;
-        used[next] = true;
-        next = (next + 1) % kBufs;
-        return STORM_HIP_OK;
-    }
-    // Rows of `stride` bytes from d_base, the first `bytes` of each from one host piece, zeros behind (whole rows per
-    // chunk: stride <= kBuf).
-    int send_rows(uint8_t* d_base, const std::vector<const void*>& rows, size_t bytes, size_t stride) {
-        const size_t per_chunk = kBuf / stride;
-        std::vector<Piece> chunk;
-        for (size_t r0 = 0; r0 < rows.size(); r0 += per_chunk) {
-            const size_t n = std::min(per_chunk, rows.size() - r0);
-            chunk.clear();
-            for (size_t i = 0; i < n; ++i) chunk.push_back({rows[r0 + i], bytes, i * stride, stride - bytes});
-            if (int rc = send(d_base + r0 * stride, chunk.data(), n, n * stride)) return rc;
-        }
-        return STORM_HIP_OK;
-    }
-    // A run of pieces that is contiguous on the device from d_base (piece i starts where piece i - 1 ended),
-    // cut into chunks of at most one buffer. A single piece larger than a buffer is cut as well.
-    int send_run(uint8_t* d_base, const std::vector<std::pair<const void*, size_t>>& run) {
-        std::vector<Piece> chunk;
-        size_t chunk_base = 0, at = 0, fill = 0;
-        auto flush = [&]() -> int {
-            if (chunk.empty()) return STORM_HIP_OK;
-            const int rc = send(d_base + chunk_base, chunk.data(), chunk.size(), fill);
-            chunk.clear();
-            chunk_base = at;
-            fill = 0;
-            return rc;
-        };
-        for (const auto& pc : run) {
-            const uint8_t* src = static_cast<const uint8_t*>(pc.first);
-            size_t left = pc.second;
-            while (left) {
-                if (fill == kBuf)
-                    if (int rc = flush()) return rc;
-                const size_t take = std::min(left, kBuf - fill);
-                chunk.push_back({src, take, fill});
-                src += take;
-                left -= take;
-                fill += take;
-                at += take;
-            }
-        }
-        return flush();
-    }
-};
+// (Piece / Stager: the pinned staging ring, shared with the row lists of storm_hip_lists.hip: storm_hip_internal.h)
 
 template <typename T>
 int upload(T** d, const T* h, size_t n, hipStream_t stream) {

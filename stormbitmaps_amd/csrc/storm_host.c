@@ -2314,6 +2314,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
  * returns for rows i < j, for every pair at once. The rows are laid out as a dense bit matrix on the device (built
  * on the first call, kept with the handle like the arena, checked against the container's fingerprint) and the tile
  * kernels of STORM_contig_pairw_matrix write the triangle. */
+static int storm_lists_worthwhile(const STORM_t* h);
 static int storm_pairw_matrix_locked(STORM_t* h, int op, uint32_t* out, uint64_t out_rows, uint64_t out_ld) {
     if (!h) return -1;
     if (!out) return -2;
@@ -2332,7 +2333,8 @@ static int storm_pairw_matrix_locked(STORM_t* h, int op, uint32_t* out, uint64_t
     }
     h->hip_epoch = epoch;
     /* [r5] one device, a list-only container that is sparse enough: straight from the lists (K5), no dense replica */
-    if (VN == 1 && device_ctx(V0) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL)) {
+    if (VN == 1 && device_ctx(V0) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL) &&
+        (st->have_lists != 0 || storm_lists_worthwhile(h))) {
         if (st->have_lists == 0 && storm_build_device(h, st, 2)) return -3;
         if (st->have_lists == 1 && storm_hip_rowlists_worthwhile(g_ctx[V0], st->l[V0])) {
             if (storm_hip_rowlists_pairw_matrix(g_ctx[V0], st->l[V0], op, out, out_ld) != STORM_HIP_OK) {
@@ -2364,9 +2366,39 @@ static int one_slot_or_refuse(const char* who) {
     host_error(msg);
     return -5;
 }
+/* whether the per-pair matrix of `h` should come from its row lists (K5): the rule of storm_hip_rowlists_worthwhile on the
+ * counts the block headers give — asked BEFORE the lists are built, so that a container the rule sends to the dense replica
+ * does not pay for both */
+static int storm_lists_worthwhile(const STORM_t* h) {
+    uint64_t n_elems = 0, max_id = 0;
+    for (uint32_t i = 0; i < h->n_conts; ++i)
+        for (uint32_t b = 0; b < h->conts[i].n_bitmaps; ++b) {
+            const STORM_bitmap_t* blk = &h->conts[i].bitmaps[b];
+            if (blk->n_bitmap) return 0; /* a bitmap block: the dense replica's case */
+            n_elems += blk->n_scalar;
+            if (blk->n_scalar && blk->id > max_id) max_id = blk->id;
+        }
+    return storm_hip_rowlists_worthwhile_counts(g_ctx[V0], h->n_conts, n_elems, (max_id + 1) * 65536ull);
+}
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+#define HOST_LAP(what)                                                                        \
+    do {                                                                                      \
+        if (lap_on) {                                                                         \
+            const double t_ = now_ms();                                                       \
+            fprintf(stderr, "[storm_host] %-34s %8.2f ms\n", what, t_ - lap_t0);              \
+            lap_t0 = t_;                                                                      \
+        }                                                                                     \
+    } while (0)
 int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_rows, uint64_t out_ld) {
     if (!h) return -1;
     if (!d_out) return -2;
+    const int lap_on = getenv("STORM_HIP_TIMING") != NULL;
+    double lap_t0 = lap_on ? now_ms() : 0;
     device_lock();
     int rc = one_slot_or_refuse("STORM_pairw_matrix_device");
     const uint64_t n = h->n_conts;
@@ -2387,16 +2419,20 @@ int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_
         /* [r5] a list-only container that is sparse enough: straight from the lists (K5, storm_hip_lists.hip) — no dense
          * replica is built at all then */
         int from_lists = 0;
+        HOST_LAP("state, fingerprint");
         if (!rc && !device_ctx(V0)) rc = -3; /* (contexts are opened on first use) */
-        if (!rc && (op == 0 || op == 1 || op == 2) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL)) { /* (NULL: are the lists switched on at all) */
+        if (!rc && (op == 0 || op == 1 || op == 2) && storm_hip_rowlists_worthwhile(g_ctx[V0], NULL) && /* (NULL: are the lists switched on at all) */
+            (st->have_lists != 0 || storm_lists_worthwhile(h))) {
             if (st->have_lists == 0 && storm_build_device(h, st, 2)) rc = -3;
             from_lists = !rc && st->have_lists == 1 && storm_hip_rowlists_worthwhile(g_ctx[V0], st->l[V0]);
         }
+        HOST_LAP("row lists built");
         if (!rc && from_lists) {
             if (storm_hip_rowlists_pairw_matrix_device(g_ctx[V0], st->l[V0], op, d_out, out_ld) != STORM_HIP_OK) {
                 device_error("storm_hip_rowlists_pairw_matrix_device");
                 rc = -3;
             }
+            HOST_LAP("matrix from the lists");
         } else {
             if (!rc && !st->have_dense && storm_build_device(h, st, 1)) rc = -3;
             if (!rc && storm_hip_pairw_matrix_device(g_ctx[V0], st->m[V0], op, d_out, out_ld) != STORM_HIP_OK) {

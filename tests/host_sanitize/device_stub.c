@@ -303,6 +303,10 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
 }
 void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l) { (void)ctx; (void)l; }
 int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l) { (void)ctx; return l == NULL; }
+int storm_hip_rowlists_worthwhile_counts(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_elems, uint64_t n_bits) {
+    (void)ctx; (void)n_rows; (void)n_elems; (void)n_bits;
+    return 0;
+}
 int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op, uint32_t* d_out, uint64_t ld) {
     (void)ctx; (void)l; (void)op; (void)d_out; (void)ld;
     return STORM_HIP_EINVAL;
