@@ -663,6 +663,12 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
 #endif
         ctx->variant = (int)value;
+    } else if (!strcmp(key, "probe_bundle")) {
+        if (value != -1 && value != 1 && value != 4) {
+            set_error("probe_bundle must be -1 (auto: 1), 1 (one group of 128 rows per workgroup) or 4 (bundles of four)");
+            return STORM_HIP_EINVAL;
+        }
+        ctx->probe_bundle = (int)value;
     } else if (!strcmp(key, "sparse_probe")) {
         if (value < -1 || value > 1) {
             set_error("sparse_probe must be -1 (auto), 0 (never) or 1 (every eligible column)");
@@ -939,6 +945,7 @@ int64_t storm_hip_ctx_get_option(storm_hip_ctx_t* ctx, const char* key) {
     if (!strcmp(key, "variant_used")) return ctx->variant_used;
     if (!strcmp(key, "seg_rows")) return ctx->seg_rows;
     if (!strcmp(key, "result_mailbox")) return ctx->result_mailbox;
+    if (!strcmp(key, "probe_bundle")) return ctx->probe_bundle;
     if (!strcmp(key, "sync_poll_us")) return ctx->sync_poll_us;
     if (!strcmp(key, "matrix_lists")) return ctx->matrix_lists;
     if (!strcmp(key, "matrix_lists_density")) return ctx->matrix_lists_permille_x10;

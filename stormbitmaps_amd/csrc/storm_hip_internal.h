@@ -109,6 +109,7 @@ struct storm_hip_ctx_s {
     // options
     int variant = -1;       // -1 auto, 0/1/2 popcount kernel (B path), 3 MFMA tiles, 4 MFMA strips
     int variant_used = 2;   // what the last dense launch ran
+    int probe_bundle = -1;  // [r6] list-probe kernel: -1 / 1 = one group of 128 rows per workgroup (probe_lists_kernel), 4 = bundles of four groups per workgroup (probe_lists_fat_kernel: a quarter of the loads and workgroups, measured 5 - 25 % SLOWER at every c4 load, profiles/r06_*_probe_bundle.txt)
     int sparse_probe = -1;  // sparse container: list-probe kernel for columns of short lists (-1 auto, 0 never, 1 always)
     int matrix_lists = -1;  // per-pair matrix of a list-only sparse container from its lists (K5, storm_hip_lists.hip): -1 by density, 0 never, 1 whenever eligible
     int matrix_lists_kernel = 0;  // K5: 0 = by the row length, 1 = lists_matrix_kernel (windows), 2 = lists_hash_kernel where a group fits the table

@@ -57,6 +57,11 @@ struct storm_hip_sparse_s {
     uint16_t* d_probe_pos16 = nullptr;  // 2 x the positions alone (byte offsets into a count table), same index ranges, own order
     struct ProbeItemHost { uint32_t a_begin, a_end, n_begin, n_end, b_begin, b_end, a0, col; };
     std::vector<ProbeItemHost> probe_items;  // all eligible columns (family order); filtered per launch
+    // [r6] the same work in bundles of kFatGroups groups (probe_lists_fat_kernel): atoms at[k] .. at[k + 1] of the groups
+    // of the bundle, the far piece, first = the bundle's near parts are this item's
+    struct ProbeFatItemHost { uint32_t at[5]; uint32_t b_begin, b_end, first, col; };
+    std::vector<ProbeFatItemHost> probe_fat_items;
+    int probe_bundle_launch = 1;   // which list the device holds (1: probe_items, 4: probe_fat_items)
     void* d_probe_items = nullptr;
     size_t probe_items_capacity = 0;
     uint64_t probe_key = ~0ull;
@@ -182,6 +187,8 @@ __global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SI
     __syncthreads();
     uint32_t count = 0;
     if (it.n_end > it.n_begin) {  // the group's own rows among themselves
+        // (one lookup per own element — sum_p C(Cn[p], 2) = half the sum of (Cn[p] - 1) over the group's elements — instead of
+        //  this scan of all 8192 counters was built in round 6 and is 4 % SLOWER at every c4 load: it costs two barriers more)
         for (uint32_t w = tid; w < (1u << kProbeOctBits) / 2u; w += (uint32_t)kT) {
             const uint32_t c2 = Cn32[w], lo = c2 & 0xffffu, hi = c2 >> 16;
             count += (lo * (lo - 1u) + hi * (hi - 1u)) >> 1;  // both products are even
@@ -248,6 +255,185 @@ __global__ __launch_bounds__(kT, 8) void probe_lists_kernel(  // (8 waves per SI
             const unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cnt += v >> 48;
             sum += v & ((1ull << 48) - 1ull);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cnt += __shfl_down(cnt, o, 64);
+            sum += __shfl_down(sum, o, 64);
+        }
+        __syncthreads();
+        if ((tid & 63u) == 0) {
+            fold_ws[tid >> 6] = cnt;
+            fold_ws[(kT / 64) + (tid >> 6)] = sum;
+        }
+        __syncthreads();
+        cnt = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < kT / 64; ++w) {
+            cnt += fold_ws[w];
+            total += fold_ws[(kT / 64) + w];
+        }
+        if (cnt == expected) break;
+    }
+    for (uint32_t i = tid; i < fold_slots; i += (uint32_t)kT)
+        __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) out[0] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// [r6] K4 with FAT workgroups (probe_lists_fat_kernel): one workgroup = a BUNDLE of kFatGroups = 4 consecutive groups of
+// a (column, octant) stream against a chunk of the stream behind the bundle. probe_lists_kernel's items are all fixed cost
+// at the sparse end (5056 workgroups at c4's 104 draws per row: the item record, the group's positions and the far
+// positions are three dependent trips to memory, then a 16 KiB table zeroed, filled and scanned, for ~8000 lookups):
+//   * the far positions are loaded ONCE per bundle and looked up in four tables (a quarter of the loads and of the
+//     workgroups, the fixed costs shared by four groups);
+//   * the first far pieces are on their way BEFORE the tables are built (their addresses need the item record only);
+//   * the pairs inside a group, sum_p C(Cn[p], 2), come from the group's own elements — (Cn[p] - 1) per element, halved
+//     once per workgroup (the sum over a group is n (n - 1) per position: even) — instead of a scan of all 8192
+//     counters; the pairs between two groups of the bundle from the later group's elements in the earlier group's table.
+// Tables: 4 x 16 KiB of 16-bit counts. Same slots / in-launch fold as probe_lists_kernel.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kFatGroups = 4;
+struct ProbeFatItem {
+    uint32_t at[kFatGroups + 1];   // elements of group k of the bundle in this octant: [at[k], at[k + 1])
+    uint32_t b_begin, b_end;       // chunk of the elements of the rows behind the bundle
+    uint32_t first;                // 1: the bundle's own pairs (inside and between its groups) belong to this item
+};
+template <int kT>
+__global__ __launch_bounds__(kT, kT / 128) void probe_lists_fat_kernel(   // (two workgroups per CU by LDS: 2 x 64 KiB)
+    const uint16_t* __restrict__ pos16, const ProbeFatItem* __restrict__ items, uint32_t item_stride, uint32_t item_first,
+    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out, uint32_t fold_slots) {
+    constexpr uint32_t kTableWords = (1u << kProbeOctBits) / 2u;   // two 16-bit counts per word
+    __shared__ __attribute__((aligned(16))) uint32_t Cn32[kFatGroups * kTableWords];
+    __shared__ unsigned long long fold_ws[2 * (kT / 64)];
+    const ProbeFatItem it = items[(uint64_t)blockIdx.x * item_stride + item_first];
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kOff = 2u * ((1u << kProbeOctBits) - 1u);   // pos16 holds 2 x the position: a byte offset
+    // far body: the first trip's pieces leave before anything else (clamped to the item's last piece, as below)
+    uint32_t e = it.b_begin;
+    const uint32_t head_end = min(it.b_end, (it.b_begin + 7u) & ~7u);
+    const uint32_t body0 = head_end;
+    const uint32_t body_end = body0 + ((it.b_end - body0) & ~7u);
+    constexpr uint32_t kStep = (uint32_t)kT * 8u;
+    const bool has_body = body_end > body0;
+    const uint32_t last = has_body ? body_end - 8u : 0u;
+    uint4 v[2];
+    if (has_body) {
+#pragma unroll
+        for (uint32_t j = 0; j < 2; ++j) v[j] = *reinterpret_cast<const uint4*>(&pos16[min(body0 + tid * 8u + j * kStep, last)]);
+    }
+    for (uint32_t w = tid * 4u; w < kFatGroups * kTableWords; w += (uint32_t)kT * 4u)
+        *reinterpret_cast<uint4*>(&Cn32[w]) = uint4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    // the four histograms (any order of an atom's positions will do; pos16 holds them dealt by LDS bank)
+#pragma unroll
+    for (uint32_t k = 0; k < kFatGroups; ++k) {
+        auto bump = [&](uint32_t p2) { atomicAdd(&Cn32[k * kTableWords + ((p2 & kOff) >> 2)], 1u << (8u * (p2 & 2u))); };
+        const uint32_t a0 = it.at[k], a1 = it.at[k + 1];
+        const uint32_t h_end = min(a1, (a0 + 7u) & ~7u);
+        if (a0 + tid < h_end) bump(pos16[a0 + tid]);
+        const uint32_t hb_end = h_end + ((a1 - h_end) & ~7u);
+        for (uint32_t q = h_end + tid * 8u; q < hb_end; q += (uint32_t)kT * 8u) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(&pos16[q]);
+            bump(v0.x & 0xffffu); bump(v0.x >> 16); bump(v0.y & 0xffffu); bump(v0.y >> 16);
+            bump(v0.z & 0xffffu); bump(v0.z >> 16); bump(v0.w & 0xffffu); bump(v0.w >> 16);
+        }
+        if (hb_end + tid < a1) bump(pos16[hb_end + tid]);
+    }
+    __syncthreads();
+    const uint8_t* Cb = reinterpret_cast<const uint8_t*>(Cn32);
+    auto look = [&](uint32_t k, uint32_t p2) { return (uint32_t)*reinterpret_cast<const uint16_t*>(Cb + k * (kTableWords * 4u) + p2); };
+    uint32_t count = 0;
+    if (it.first) {
+        // the bundle's own pairs: an element of group k against the groups in front of it, and (twice) inside its own
+        uint32_t self2 = 0;
+        // (in pieces of 8 positions per lane, as the far stream: consecutive positions of an atom share an LDS bank —
+        //  they are dealt that way — and lanes that take consecutive positions collide eightfold: 0.34 of the LDS cycles
+        //  were bank conflicts against 0.09 in probe_lists_kernel, profiles/r06_*_probe_bundle.txt)
+#pragma unroll
+        for (uint32_t k = 0; k < kFatGroups; ++k) {
+            auto own = [&](uint32_t p2) {
+                p2 &= kOff;
+                self2 += look(k, p2) - 1u;
+#pragma unroll
+                for (uint32_t j = 0; j < kFatGroups; ++j)
+                    if (j < k) count += look(j, p2);
+            };
+            const uint32_t a0 = it.at[k], a1 = it.at[k + 1];
+            const uint32_t h_end = min(a1, (a0 + 7u) & ~7u);
+            if (a0 + tid < h_end) own(pos16[a0 + tid]);
+            const uint32_t hb_end = h_end + ((a1 - h_end) & ~7u);
+            for (uint32_t q = h_end + tid * 8u; q < hb_end; q += (uint32_t)kT * 8u) {
+                const uint4 v0 = *reinterpret_cast<const uint4*>(&pos16[q]);
+                own(v0.x & 0xffffu); own(v0.x >> 16); own(v0.y & 0xffffu); own(v0.y >> 16);
+                own(v0.z & 0xffffu); own(v0.z >> 16); own(v0.w & 0xffffu); own(v0.w >> 16);
+            }
+            if (hb_end + tid < a1) own(pos16[hb_end + tid]);
+        }
+        // sum over the workgroup, halved (exact: n (n - 1) per position)
+        uint64_t s2 = self2;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_down(s2, o, 64);
+        if ((tid & 63u) == 0) fold_ws[tid >> 6] = s2;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = 0;
+#pragma unroll
+            for (int w = 0; w < kT / 64; ++w) t += fold_ws[w];
+            count += (uint32_t)(t >> 1);
+        }
+        __syncthreads();   // (fold_ws is used again below)
+    }
+    // far: every position against the four tables (a missing group's table is empty)
+    auto visit4 = [&](uint32_t p2) {
+        p2 &= kOff;
+        count += look(0, p2) + look(1, p2) + look(2, p2) + look(3, p2);
+    };
+    if (e + tid < head_end) visit4(pos16[e + tid]);
+    if (has_body) {
+        for (uint32_t q = body0 + tid * 8u; q < body_end; q += 2u * kStep) {
+            uint4 nx[2];
+#pragma unroll
+            for (uint32_t j = 0; j < 2; ++j) nx[j] = *reinterpret_cast<const uint4*>(&pos16[min(q + (2u + j) * kStep, last)]);
+#pragma unroll
+            for (uint32_t j = 0; j < 2; ++j) {
+                const uint32_t p[8] = {v[j].x & 0xffffu, v[j].x >> 16, v[j].y & 0xffffu, v[j].y >> 16,
+                                       v[j].z & 0xffffu, v[j].z >> 16, v[j].w & 0xffffu, v[j].w >> 16};
+                uint32_t s8 = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t p2 = p[k] & kOff;
+                    s8 += look(0, p2) + look(1, p2) + look(2, p2) + look(3, p2);
+                }
+                count += (q + j * kStep < body_end) ? s8 : 0u;
+            }
+            v[0] = nx[0];
+            v[1] = nx[1];
+        }
+    }
+    if (body_end + tid < it.b_end) visit4(pos16[body_end + tid]);
+    uint64_t mine = count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+    if (out == nullptr) {   // another kernel of the pass adds into the slots too: a fold launch follows
+        if ((tid & 63u) == 0 && mine != 0)
+            atomicAdd(&slots[(blockIdx.x * 16u + (tid >> 6)) & (kSlots - 1)], (unsigned long long)mine);
+        return;
+    }
+    // the fold inside the launch, as in probe_lists_kernel
+    if ((tid & 63u) == 0)
+        atomicAdd(&slots[(blockIdx.x * (uint32_t)(kT / 64) + (tid >> 6)) & (fold_slots - 1u)],
+                  (unsigned long long)mine + (1ull << 48));
+    if (blockIdx.x != gridDim.x - 1u) return;
+    const unsigned long long expected = (unsigned long long)gridDim.x * (unsigned long long)(kT / 64);
+    unsigned long long total = 0;
+    for (;;) {
+        unsigned long long cnt = 0, sum = 0;
+        for (uint32_t i = tid; i < fold_slots; i += (uint32_t)kT) {
+            const unsigned long long x = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cnt += x >> 48;
+            sum += x & ((1ull << 48) - 1ull);
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -970,6 +1156,81 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             for (size_t pos = 0; pos < longest; ++pos)
                 for (int x = 0; x < 8; ++x)
                     if (pos < queue[x].size()) s->probe_items.push_back(queue[x][pos]);
+            // [r6] the same work in bundles of kFatGroups groups (probe_lists_fat_kernel): the same chunk grid (a bundle
+            // needs the rest of the chunk its successor atom lies in and every later chunk), the same families and queues
+            {
+                struct FatFamily {
+                    uint64_t work = 0;
+                    std::vector<storm_hip_sparse_s::ProbeFatItemHost> items;
+                };
+                std::vector<FatFamily> fat;
+                for (size_t i = 0; i < row_start.size(); ++i) {
+                    const std::vector<uint32_t>& rs = row_start[i];   // (ends with the end of the octant since the loop above)
+                    if (rs.size() < 2) continue;
+                    const uint32_t n_c = (uint32_t)rs.size() - 1u;
+                    const uint32_t e = (uint32_t)(i / kProbeOctants);
+                    const uint32_t n_atoms = (n_c + kProbeRows - 1) / kProbeRows;
+                    auto atom_start = [&](uint32_t t) { return rs[std::min(t * (uint32_t)kProbeRows, n_c)]; };
+                    std::vector<uint32_t> chunk_first;
+                    for (uint32_t t = 1; t < n_atoms;) {
+                        chunk_first.push_back(t);
+                        const uint64_t from = atom_start(t);
+                        ++t;
+                        while (t < n_atoms && atom_start(t) - from < kProbeChunk) ++t;
+                    }
+                    chunk_first.push_back(n_atoms);
+                    const size_t fam0 = fat.size();
+                    fat.resize(fam0 + chunk_first.size());
+                    for (uint32_t g0 = 0; g0 < n_atoms; g0 += kFatGroups) {
+                        const uint32_t g1 = std::min(g0 + kFatGroups, n_atoms);
+                        storm_hip_sparse_s::ProbeFatItemHost it{};
+                        for (uint32_t k = 0; k <= kFatGroups; ++k) it.at[k] = atom_start(std::min(g0 + k, g1));
+                        it.col = e;
+                        const uint32_t own = it.at[kFatGroups] - it.at[0];
+                        if (own == 0) continue;   // no listed position of the bundle's rows in this octant
+                        if (g1 >= n_atoms) {      // the last bundle has nobody behind it
+                            it.b_begin = it.b_end = it.at[kFatGroups];
+                            it.first = 1;
+                            fat[fam0 + chunk_first.size() - 1].items.push_back(it);
+                            fat[fam0 + chunk_first.size() - 1].work += 8192u * (g1 - g0);
+                            continue;
+                        }
+                        size_t c = 0;
+                        while (c + 1 < chunk_first.size() && chunk_first[c + 1] <= g1) ++c;
+                        bool first = true;
+                        for (; c + 1 < chunk_first.size(); ++c) {
+                            const uint32_t b1 = atom_start(chunk_first[c + 1]);
+                            const uint32_t b0 = std::min(first ? it.at[kFatGroups] : atom_start(chunk_first[c]), b1);
+                            if (first || b1 > b0) {
+                                it.b_begin = b0;
+                                it.b_end = b1;
+                                it.first = first ? 1u : 0u;
+                                fat[fam0 + c].items.push_back(it);
+                                fat[fam0 + c].work += (uint64_t)(b1 - b0) * (g1 - g0) + 8192u * (g1 - g0);
+                            }
+                            first = false;
+                        }
+                    }
+                }
+                std::vector<size_t> forder(fat.size());
+                for (size_t f = 0; f < forder.size(); ++f) forder[f] = f;
+                std::stable_sort(forder.begin(), forder.end(), [&](size_t x, size_t y) { return fat[x].work > fat[y].work; });
+                std::vector<std::vector<storm_hip_sparse_s::ProbeFatItemHost>> fqueue(8);
+                uint64_t fload[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (size_t f : forder) {
+                    if (fat[f].items.empty()) continue;
+                    int q = 0;
+                    for (int x = 1; x < 8; ++x)
+                        if (fload[x] < fload[q]) q = x;
+                    fqueue[q].insert(fqueue[q].end(), fat[f].items.begin(), fat[f].items.end());
+                    fload[q] += fat[f].work;
+                }
+                size_t flongest = 0;
+                for (int x = 0; x < 8; ++x) flongest = std::max(flongest, fqueue[x].size());
+                for (size_t pos = 0; pos < flongest; ++pos)
+                    for (int x = 0; x < 8; ++x)
+                        if (pos < fqueue[x].size()) s->probe_fat_items.push_back(fqueue[x][pos]);
+            }
         }
     }
 
@@ -1496,36 +1757,61 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             for (size_t e = 0; e < s->cols.size(); ++e)
                 use_probe[e] = s->col_probe[e];
         {
-            uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count);
+            // [r6] one group per workgroup (probe_lists_kernel) unless the option asks for bundles of four
+            // (probe_bundle 4: probe_lists_fat_kernel — measured 5 - 25 % slower at every c4 load); both lists hold the same work
+            const int bundle = ctx->probe_bundle == 4 ? (int)kFatGroups : 1;
+            uint64_t key = 1469598103934665603ull ^ ((uint64_t)shard_rank << 32 | shard_count) ^ ((uint64_t)bundle << 56);
             for (uint8_t u : use_probe) key = (key ^ u) * 1099511628211ull;
             if (key != s->probe_key) {
+                static_assert(sizeof(ProbeFatItem) >= sizeof(ProbeItem), "one device buffer for either list");
                 std::vector<ProbeItem> mine;
+                std::vector<ProbeFatItem> fat;
                 uint32_t cols_used = 0;
                 for (size_t e = 0; e < use_probe.size(); ++e) cols_used += use_probe[e];
-                for (const auto& pi : s->probe_items)
-                    if (use_probe[pi.col])
-                        mine.push_back({pi.a_begin, pi.a_end, pi.n_begin, pi.n_end, pi.b_begin, pi.b_end, pi.a0});
-                if (mine.size() > s->probe_items_capacity) {
+                if (bundle == 1) {
+                    for (const auto& pi : s->probe_items)
+                        if (use_probe[pi.col])
+                            mine.push_back({pi.a_begin, pi.a_end, pi.n_begin, pi.n_end, pi.b_begin, pi.b_end, pi.a0});
+                } else {
+                    for (const auto& pi : s->probe_fat_items)
+                        if (use_probe[pi.col])
+                            fat.push_back({{pi.at[0], pi.at[1], pi.at[2], pi.at[3], pi.at[4]}, pi.b_begin, pi.b_end, pi.first});
+                }
+                const size_t n_mine = bundle == 1 ? mine.size() : fat.size();
+                if (n_mine > s->probe_items_capacity) {
                     if (s->d_probe_items) STORM_HIP_TRY(hipFree(s->d_probe_items));
                     s->d_probe_items = nullptr;
                     s->probe_items_capacity = 0;
-                    STORM_HIP_TRY(hipMalloc(&s->d_probe_items, std::max<size_t>(mine.size(), 1024) * sizeof(ProbeItem)));
-                    s->probe_items_capacity = std::max<size_t>(mine.size(), 1024);
+                    STORM_HIP_TRY(hipMalloc(&s->d_probe_items, std::max<size_t>(n_mine, 1024) * sizeof(ProbeFatItem)));
+                    s->probe_items_capacity = std::max<size_t>(n_mine, 1024);
                 }
-                if (!mine.empty()) {
-                    STORM_HIP_TRY(hipMemcpyAsync(s->d_probe_items, mine.data(), mine.size() * sizeof(ProbeItem),
+                if (n_mine) {
+                    STORM_HIP_TRY(hipMemcpyAsync(s->d_probe_items, bundle == 1 ? (const void*)mine.data() : (const void*)fat.data(),
+                                                 n_mine * (bundle == 1 ? sizeof(ProbeItem) : sizeof(ProbeFatItem)),
                                                  hipMemcpyHostToDevice, ctx->stream));
                     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
                 }
                 // shard r of G takes items r, r + G, ...: the grid covers ceil((n - r) / G) of them
-                s->n_probe_launch = mine.size() > shard_rank
-                                        ? (uint32_t)((mine.size() - shard_rank + shard_count - 1) / shard_count)
-                                        : 0u;
+                s->n_probe_launch = n_mine > shard_rank ? (uint32_t)((n_mine - shard_rank + shard_count - 1) / shard_count) : 0u;
                 s->n_probe_cols_launch = cols_used;
-                // lookups of this shard's items: the streamed far positions + the own rows' elements
+                // lookups of this shard's items: a streamed far position against every group of the item + the own rows'
+                // elements (against their own group and, in a bundle, the groups in front of it)
                 s->probe_lookups_launch = 0;
-                for (size_t k = shard_rank; k < mine.size(); k += shard_count)
-                    s->probe_lookups_launch += (uint64_t)(mine[k].b_end - mine[k].b_begin) + (mine[k].n_end - mine[k].n_begin);
+                if (bundle == 1) {
+                    for (size_t k = shard_rank; k < mine.size(); k += shard_count)
+                        s->probe_lookups_launch += (uint64_t)(mine[k].b_end - mine[k].b_begin) + (mine[k].n_end - mine[k].n_begin);
+                } else {
+                    for (size_t k = shard_rank; k < fat.size(); k += shard_count) {
+                        uint32_t groups = 0;
+                        for (uint32_t g = 0; g < kFatGroups; ++g) {
+                            const uint32_t len = fat[k].at[g + 1] - fat[k].at[g];
+                            groups += len != 0;
+                            if (fat[k].first) s->probe_lookups_launch += (uint64_t)len * (g + 1u);
+                        }
+                        s->probe_lookups_launch += (uint64_t)(fat[k].b_end - fat[k].b_begin) * groups;
+                    }
+                }
+                s->probe_bundle_launch = bundle;
                 s->probe_key = key;
             }
         }
@@ -1558,7 +1844,10 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
             // dependent trips to memory, then the histogram — and what covers that is workgroups per CU; long ones want
             // the workgroups of a CU in step on the same chunk of the stream (its L2 lines are read once per XCD).
             const uint64_t per_item = s->probe_lookups_launch / s->n_probe_launch;
-            const int threads = per_item < 400000u ? 256 : per_item < 1500000u ? 512 : kProbeThreads;
+            const int threads = s->probe_bundle_launch != 1 ? (per_item < 1500000u ? 512 : kProbeThreads)
+                                : per_item < 400000u        ? 256
+                                : per_item < 1500000u       ? 512
+                                                            : kProbeThreads;
             // lists only (no pool rows to multiply) and a short launch: the probe kernel folds inside the launch
             // (option k2_fold_inline as for the strips; the slot words' 48-bit sums hold any total below 2^47 / 4096 x 256)
             probe_folds = ranges.empty() && ctx->k2_fold_inline != 0 && s->n_probe_launch <= 16384u &&
@@ -1568,9 +1857,16 @@ int storm_hip_pairw_sparse_begin(storm_hip_ctx_t* ctx, const storm_hip_sparse_t*
     hipLaunchKernelGGL(probe_lists_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_elems,       \
                        s->d_probe_pos16, static_cast<const ProbeItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots, \
                        fold_out, 256u)
-            if (threads == 256) STORM_PROBE_LAUNCH(256);
+#define STORM_PROBE_FAT_LAUNCH(T)                                                                                      \
+    hipLaunchKernelGGL(probe_lists_fat_kernel<T>, dim3(s->n_probe_launch), dim3(T), 0, ctx->stream, s->d_probe_pos16,     \
+                       static_cast<const ProbeFatItem*>(s->d_probe_items), shard_count, shard_rank, ctx->d_slots, fold_out, 256u)
+            if (s->probe_bundle_launch != 1) {
+                if (threads == 512) STORM_PROBE_FAT_LAUNCH(512);
+                else STORM_PROBE_FAT_LAUNCH(kProbeThreads);
+            } else if (threads == 256) STORM_PROBE_LAUNCH(256);
             else if (threads == 512) STORM_PROBE_LAUNCH(512);
             else STORM_PROBE_LAUNCH(kProbeThreads);
+#undef STORM_PROBE_FAT_LAUNCH
 #undef STORM_PROBE_LAUNCH
             STORM_HIP_TRY(hipGetLastError());
         }

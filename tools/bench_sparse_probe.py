@@ -23,6 +23,8 @@ def main():
         data = s.serialize()
         s.free()
         ctx = sb.HipContext(0)
+        if os.environ.get("STORM_PROBE_BUNDLE"):   # 1: probe_lists_kernel, 4: probe_lists_fat_kernel [r6]
+            ctx.set_option("probe_bundle", int(os.environ["STORM_PROBE_BUNDLE"]))
         h = C.c_void_p()
         assert lib.storm_hip_sparse_create_serialized(ctx._h, data.ctypes.data_as(C.c_void_p), data.size, C.byref(h)) == 0
         out = C.c_uint64()

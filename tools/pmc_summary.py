@@ -12,7 +12,7 @@ def main():
     for path in paths:
         for r in csv.DictReader(open(path)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-            if name.startswith("storm::"):
+            if name.startswith("storm::") or "probe_lists" in name or "tile128" in name:
                 acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
