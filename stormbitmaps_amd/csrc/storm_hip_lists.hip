@@ -597,11 +597,17 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         STORM_HIP_TRY(hipMalloc(&l->d_off, n_cells * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMalloc(&l->d_rowlen, n_rows * sizeof(uint32_t)));
         STORM_HIP_TRY(hipMemsetAsync(t.bad, 0, sizeof(uint32_t), ctx->stream));
-        STORM_HIP_TRY(hipMemcpyAsync(t.xb, xb.data(), xb.size() * sizeof(LxBlock), hipMemcpyHostToDevice, ctx->stream));
         lap("allocations");
         {
+            // (the block table — 1.3 MB at the README's STORM_t shape — through the pinned ring as well. Copied with
+            //  hipMemcpyAsync out of the pageable vector and the vector freed at the end of this function, the FIRST matrix
+            //  kernel after the build started 10 - 30 ms late on the card in 6 of 10 fresh processes, always after a pause:
+            //  0.88 ms by events, 11 - 29 ms by the host, with hipEventQuery polling as late as hipStreamSynchronize; gone with
+            //  glibc's MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ raised, gone with this line. An isolated copy +
+            //  munmap + launch does not show it (tools/probes/pin_evict.hip); LAB_NOTES "K5 first call, the late kernel")
             Stager stager(ctx);
             if (int rc = stager.init()) return rc;
+            if (int rc = stager.send_run(reinterpret_cast<uint8_t*>(t.xb), {{xb.data(), xb.size() * sizeof(LxBlock)}})) return rc;
             if (int rc = stager.send_run(reinterpret_cast<uint8_t*>(t.raw), run)) return rc;
         }
         lap("lists through the ring");
@@ -725,6 +731,24 @@ static int launch_lists(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int
 
 int storm_hip_rowlists_pairw_matrix_device(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l, int op,
                                            uint32_t* d_out, uint64_t ld) {
+    if (getenv("STORM_HIP_TIMING") != nullptr) {   // the kernel alone by the card's clock beside the host's view of launch + wait
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        STORM_HIP_TRY(hipSetDevice(ctx->device));
+        STORM_HIP_TRY(hipEventCreate(&e0));
+        STORM_HIP_TRY(hipEventCreate(&e1));
+        const auto t0 = std::chrono::steady_clock::now();
+        STORM_HIP_TRY(hipEventRecord(e0, ctx->stream));
+        if (int rc = launch_lists(ctx, l, op, d_out, ld)) return rc;
+        STORM_HIP_TRY(hipEventRecord(e1, ctx->stream));
+        STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        float ms = 0;
+        STORM_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        fprintf(stderr, "[rowlists_matrix] kernel by events %8.3f ms, launch + wait on the host %8.3f ms\n", ms,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return STORM_HIP_OK;
+    }
     if (int rc = launch_lists(ctx, l, op, d_out, ld)) return rc;
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return STORM_HIP_OK;

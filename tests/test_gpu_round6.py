@@ -216,3 +216,68 @@ def test_rows_added_out_of_order_fall_back_to_the_dense_replica(orc):
         assert np.array_equal(s_mixed.pairw_matrix("and"), want)
     s_sorted.free()
     s_mixed.free()
+
+
+def test_list_probe_with_bundles_of_four_groups_against_the_oracle(orc):
+    """K4's second form (probe_bundle = 4: probe_lists_fat_kernel, four 128-row groups' tables per workgroup, the far
+    stream read once per bundle) is an option, not the default (measured slower, profiles/r06_a_probe_bundle.txt); it must
+    still give the reference's totals (storm.c:790-814 per pair, :1088-1115 blocked): row counts that leave a ragged last
+    bundle (1 .. 3 groups), a ragged last group, lists only and mixed kinds, then back to one group per workgroup on the
+    same handle (the work list is rebuilt when the option changes)."""
+    lib = sb._lib.load()
+    rng = np.random.default_rng(23)
+    M = 2 * 65536 + 999
+    try:
+        for n_rows, draws in ((130, 60), (517, 500), (640, 3000), (1100, 900), (385, 9000)):
+            rows = []
+            for r in range(n_rows):
+                d = draws if r % 9 else (0 if r % 18 == 0 else 1)
+                if draws == 9000 and r % 4 == 0:
+                    d = 50000                                        # some blocks become bitmaps
+                rows.append(np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32))
+            want = orc.storm(rows).pairw_blocked(0)
+            s = sb.Storm()
+            for v in rows:
+                s.add(v)
+            got = []
+            for bundle in (4, 1, 4):
+                assert lib.STORM_hip_set_option(b"probe_bundle", bundle) == 0
+                got.append(s.pairw_intersect_cardinality_blocked(0))
+                got.append(s.pairw_intersect_cardinality())
+            assert got == [want] * 6, (n_rows, draws, got, want)
+            s.free()
+    finally:
+        lib.STORM_hip_set_option(b"probe_bundle", -1)
+
+
+def test_first_matrix_call_on_the_row_lists_equals_the_steady_calls_and_the_oracle(orc):
+    """The reference's harness times ONE call right after construction (benchmark.cpp:605-613). On K5 that call uploads the
+    raw lists through the pinned ring and orders them by window on the device (lists_expand / lists_count / lists_place
+    kernels); the handle is then changed (rows added: the epoch moves, the lists are rebuilt) and called again. Every call
+    == the oracle's per-pair counts (storm.c:790-814), for both K5 kernels and for the automatic rule."""
+    lib = sb._lib.load()
+    rng = np.random.default_rng(31)
+    M = 5 * 65536 + 4242
+    try:
+        for n_rows, draws, lists, kernel in ((300, 90, 1, 1), (530, 700, 1, 2), (257, 2500, 1, 0), (400, 300, -1, 0)):
+            rows = [np.unique(rng.integers(0, M, size=(draws if r % 11 else r % 2), dtype=np.uint64)).astype(np.uint32)
+                    for r in range(n_rows)]
+            assert lib.STORM_hip_set_option(b"matrix_lists", lists) == 0
+            assert lib.STORM_hip_set_option(b"matrix_lists_kernel", kernel) == 0
+            s = sb.Storm()
+            for v in rows[:n_rows - 70]:
+                s.add(v)
+            want = np.triu(orc.storm(rows[:n_rows - 70]).pair_counts(), k=1)
+            first = s.pairw_matrix("and")
+            again = s.pairw_matrix("and")
+            assert np.array_equal(np.triu(first, k=1), want) and np.array_equal(again, first), (n_rows, draws, lists, kernel)
+            for v in rows[n_rows - 70:]:
+                s.add(v)
+            want = np.triu(orc.storm(rows).pair_counts(), k=1)
+            first = s.pairw_matrix("and")
+            again = s.pairw_matrix("and")
+            assert np.array_equal(np.triu(first, k=1), want) and np.array_equal(again, first), (n_rows, draws, lists, kernel)
+            s.free()
+    finally:
+        lib.STORM_hip_set_option(b"matrix_lists", -1)
+        lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
