@@ -229,7 +229,7 @@ def main():
                 dist.all_reduce(barrier_word, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize(dev)
 
-    # The chip needs ~30 passes (~30 ms) from idle to settle (tools/bench_ramp.py: passes 3..25
+    # The chip needs ~30 passes (~30 ms) from idle to settle (tools/archive/bench_ramp.py: passes 3..25
     # run 1.17 -> 0.92 ms, steady 0.88): an untimed pre-warm in front of the W warmup steps makes
     # the figure independent of how small W is. Same work as a step, results discarded.
     # Every rank must run the SAME number of steps (each step carries a collective).

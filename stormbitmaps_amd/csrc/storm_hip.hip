@@ -1476,7 +1476,7 @@ int storm_hip_pairw_dense_launch(storm_hip_ctx_t* ctx, const storm_hip_matrix_t*
     }
     STORM_HIP_TRY(hipSetDevice(ctx->device));
     // variant -1 = auto: the matrix-core strips at every size (rows beyond their 32-bit DMA offsets
-    // are multiplied k-chunk by k-chunk over a compact shadow). Measured (tools/bench_crossover.py):
+    // are multiplied k-chunk by k-chunk over a compact shadow). Measured (tools/archive/bench_crossover.py):
     // they beat the popcount kernel from N = 64 up (10-37 us vs its 42-84 us latency floor at
     // N <= 256).
     int variant = ctx->variant;

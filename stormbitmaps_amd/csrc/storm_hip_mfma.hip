@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(kStripThreads, 3) void bitstream_kernel(
     // (64-byte units from X; build_bitstream): a wave alone on its SIMD issues one instruction every four cycles,
     // and the first version's address arithmetic between the barrier and the first MFMA of a stage (the cursor
     // over the segment records, a 64-bit multiply) cost a lone wave 265 of its 1760 cycles per stage
-    // (tools/stream_trace.py). The consume side walks the segment records (what a stage is to this wave).
+    // (tools/archive/stream_trace.py). The consume side walks the segment records (what a stage is to this wave).
     const uint32_t bs0 = first_stage[blockIdx.x];
     const uint32_t T = first_stage[blockIdx.x + 1] - bs0;
     uint32_t issued = 0;     // stages handed to the DMA so far
@@ -2304,7 +2304,7 @@ static StripShaping choose_strip_shaping(const StripOptions& o, const std::vecto
     sh.max_run = o.max_run;
     if (o.max_run != 0) return sh;
     // auto: the run length whose list schedules shortest (the tail of the launch decides between them: N = 6144 is
-    // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/sweep_maxrun.py)
+    // 6 % faster with 64, N = 7168 / 8192 with 96, N = 3072 with 128; tools/archive/sweep_maxrun.py)
     const uint32_t slots = (uint32_t)std::max(1, o.n_cus / 8 * 4);
     const bool timing = timing_env();
     double best = 0;
@@ -3460,7 +3460,7 @@ static void build_bitstream(const BitstreamShaping& sh, const std::vector<RowRan
     // Shares of ONE round are not equal. The waves of a SIMD do not take turns: its arbiter issues for the oldest
     // wave that can go, and a wave alone reaches ~60 % of the matrix pipe (one instruction every four cycles). Of
     // three equal shares per CU the first-dispatched workgroup ends after 0.55 of the kernel, the second at 0.75,
-    // the third runs the last quarter nearly alone (N = 2048: 24 / 33 / 42 us; tools/stream_trace.py, end by
+    // the third runs the last quarter nearly alone (N = 2048: 24 / 33 / 42 us; tools/archive/stream_trace.py, end by
     // dispatch round; workgroup w is dispatched in round w / n_cus, one per CU per round). Shares in the proportion
     // 100 : 120 : 60 let the three end closer together: -3 % at N = 2048, -6 % at 3072 ... 4096, -2 % at 6144
     // against the dynamic deal (profiles/r03_e_stream_weights.txt; the optimum is flat: 100 : 100 : 50 and
@@ -3880,7 +3880,7 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
                       uint32_t shard_count, uint64_t* d_total) {
     const int strip_mode = ctx->variant == 5 ? 2 : ctx->variant == 4 ? 1 : 0;
     // (a matrix created before the option was set may lack the zero rows up to a multiple of 256)
-    // Which strips (option k2_strip_operands; 0 = by measurement, same box, M = 65536, tools/sweep_k2b.py,
+    // Which strips (option k2_strip_operands; 0 = by measurement, same box, M = 65536, tools/archive/sweep_k2b.py,
     // profiles/r04_a_sweep_k2b.jsonl): the strips on bit operands with the FP4 image built in the LDS (K2b,
     // strip16_bits_kernel) are ahead of the one-launch stream (K2q) and of the FP4 strips at every size —
     // 8.2 / 9.5 / 14.9 us at N = 256, 17.1 / 20.2 / 31.8 at 1024, 41.9 / 43.4 / 60.4 at 2048, 142 / 143 / 169 at

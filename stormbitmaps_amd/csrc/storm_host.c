@@ -287,7 +287,7 @@ static void* pool_main(void* p) {
 
 /* Threads only pay when the slots are different GPUs: the HIP runtime serialises calls to ONE device, and the
  * same ordinal configured several times (a rehearsal on one card) is faster driven from one thread (measured,
- * tools/bench_inprocess.py: 246 against 324 us per call for 8 contexts on one MI355X).
+ * tools/archive/bench_inprocess.py: 246 against 324 us per call for 8 contexts on one MI355X).
  * STORM_HIP_HOST_THREADS=0 / 1 overrides. */
 static int use_host_threads(void) {
     const char* e = getenv("STORM_HIP_HOST_THREADS");

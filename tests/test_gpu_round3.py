@@ -107,7 +107,7 @@ def test_stream_kernel_through_the_storm_h_containers(orc):
 
 
 def test_stream_kernel_at_full_mid_sizes_against_the_column_identity(hip_ctx):
-    """The sizes tools/midsize_pass.py reports (M = 65536, dense): totals against the size-independent
+    """The sizes tools/archive/midsize_pass.py reports (M = 65536, dense): totals against the size-independent
     identity sum_c C(n_c, 2), repeated (the last workgroup to arrive folds the partial sums and leaves
     slots and ticket zeroed for the next pass)."""
     try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """All dense BASELINE configs on one GPU with the default path (c4, the sparse container, is
-tools/bench_sparse.py): per config one JSON line with the pass time (HIP events on the launch
+tools/archive/bench_sparse.py): per config one JSON line with the pass time (HIP events on the launch
 stream, data resident), words/s, and the total checked against the column identity."""
 import argparse
 import json

@@ -1,0 +1,34 @@
+#!/bin/bash
+# gpurun_out/refresh_r06 + prof_r06 + prof_tile128_r06 (tools/refresh_r06.sh on the GPU box) -> profiles/r06_b_* ; from the
+# repo root, on the CPU side
+set -e
+P=gpurun_out/prof_r06; O=gpurun_out/refresh_r06; T=gpurun_out/prof_tile128_r06
+python3 tools/pmc_traffic.py $P/fetch/p_counter_collection.csv $P/write/p_counter_collection.csv 4 10000 1024 profiles/pmc_hbm_bytes_per_launch.json --merge | head -4
+python3 tools/pmc_summary.py profiles/r06_b_pmc_summary_bench_c2.csv $P/pmc1/p_counter_collection.csv $P/pmc2/p_counter_collection.csv $P/fetch/p_counter_collection.csv $P/write/p_counter_collection.csv
+cp $P/trace/t_kernel_stats.csv profiles/r06_b_kernel_stats_bench_c2.csv
+cp $P/bench.json profiles/r06_b_bench_c2_profiled.json
+cp $O/bench_unprofiled.json profiles/r06_b_bench_c2.json
+cp $O/storm_benchmark_c2.tsv profiles/r06_b_storm_benchmark_c2.tsv
+cp $O/storm_benchmark_c4.tsv profiles/r06_b_storm_benchmark_c4.tsv
+grep "^{" $O/cold.jsonl > profiles/r06_b_cold_start.jsonl
+grep "^{" $O/matrix_sizes.jsonl > profiles/r06_b_matrix_sizes.jsonl
+cp $T/summary.txt profiles/r06_b_tile128_kernel.txt
+if [ -e $O/pytest_gpu.txt ]; then
+  cp $O/pytest_gpu.txt profiles/r06_b_pytest_gpu.txt
+  grep "^{" $O/wrapper.jsonl > profiles/r06_b_wrapper_streamed.jsonl
+  grep "^{" $O/pass_sizes.jsonl > profiles/r06_b_pass_sizes.jsonl
+  grep "^{" $O/lists_matrix.txt > profiles/r06_b_storm_matrix_lists.jsonl
+  grep "^{" $O/storm_matrix.jsonl > profiles/r06_b_storm_matrix_c4.jsonl
+  grep "^{" $O/sparse_small.jsonl > profiles/r06_b_sparse_small_calls.jsonl
+  tail -1 $O/soak.txt > profiles/r06_b_soak_parity.jsonl
+  grep -v "^/opt" $O/check_tile5.txt | tail -8 > profiles/r06_b_tile_kernels_c2.jsonl
+fi
+python3 - <<'PY'
+import json,csv
+d=json.load(open('profiles/r06_b_bench_c2.json'))
+print("bench ms/step", d['ms_per_step'], "frac", d['roofline']['frac'], "kernel_ms", d['roofline']['kernel_ms'], "traffic", d['roofline']['traffic'])
+for r in csv.DictReader(open('profiles/r06_b_kernel_stats_bench_c2.csv')):
+    if 'strip16_bits' in r['Name']: print("rocprof", r['Calls'], r['AverageNs'], r['MinNs'])
+PY
+grep "strip16_bits_kernel,derived" profiles/r06_b_pmc_summary_bench_c2.csv | cut -c1-160
+tail -1 profiles/r06_b_pytest_gpu.txt 2>/dev/null || true
