@@ -657,6 +657,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_fp4_kernel(
 #undef STORM_FETCH16
 #undef STORM_MUL16
 #undef STORM_LGKM
+#undef STORM_LGKM_STR
 
     uint64_t mine = 0;
 #pragma unroll
@@ -826,8 +827,9 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
         acc[m][(s) & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
             v8i{a[(s) >> 2][m].x, a[(s) >> 2][m].y, a[(s) >> 2][m].z, a[(s) >> 2][m].w, 0, 0, 0, 0}, \
             v8i{frag.x, frag.y, frag.z, frag.w, 0, 0, 0, 0}, acc[m][(s) & 3], 4, 4, 0, 0, 0, 0)
-#define STORM_LGKM(n)                                       \
-    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+#define STORM_LGKM_STR(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define STORM_LGKM(n)    \
+    STORM_LGKM_STR(n);   \
     __builtin_amdgcn_sched_barrier(0)
 #define STORM_VM2()                                         \
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        \
@@ -915,6 +917,32 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     //      fragments, inflated beside the MFMAs and written as image t + 2; the lgkmcnt values count the
     //      operations that may stay in flight behind the fragment needed. Beyond the last stage the next
     //      image, the piece and the image written are stale and never consumed: the body is branch-free.
+    // (STORM_SB16_ABLATE, tools builds only — WRONG totals by design: 1 = the stage's second image store and its inflation
+    //  left out, 2 = both; the time that saves is the most a structure that shares one B image between two A tiles could win:
+    //  profiles/r06_c_k2b_image_store_ablation.txt. The lgkmcnt values behind a missing store count one operation fewer.)
+#if defined(STORM_SB16_ABLATE) && STORM_SB16_ABLATE >= 2
+#define STORM_SB16_WR0(I)
+#else
+#define STORM_SB16_WR0(I) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr0), "v"(e0), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory");
+#endif
+#if defined(STORM_SB16_ABLATE) && STORM_SB16_ABLATE >= 1
+#define STORM_SB16_WR1(I)
+#else
+#define STORM_SB16_WR1(I) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr1), "v"(e1), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory");
+#endif
+#if !defined(STORM_SB16_ABLATE) || STORM_SB16_ABLATE == 0
+#define STORM_SB16_LGKM_A 3
+#define STORM_SB16_LGKM_B 4
+#define STORM_SB16_LGKM_C 3
+#elif STORM_SB16_ABLATE == 1
+#define STORM_SB16_LGKM_A 3
+#define STORM_SB16_LGKM_B 3
+#define STORM_SB16_LGKM_C 2
+#else
+#define STORM_SB16_LGKM_A 2
+#define STORM_SB16_LGKM_B 2
+#define STORM_SB16_LGKM_C 2
+#endif
 #define STORM_SB16_BODY(I, fa, fb, fc)                                                                      \
     {                                                                                                       \
         issue(t + 4u, ((I) + 1) % 3);   /* into the slot of stage t + 1, read an iteration ago */           \
@@ -925,12 +953,12 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
         STORM_FETCH16(fa, (I) * kStripStageBytes, 3); STORM_LGKM(3); STORM_MUL16(1, fb); __builtin_amdgcn_sched_barrier(0); \
         STORM_FETCH16(fb, (I) * kStripStageBytes, 4); STORM_LGKM(2);   /* the piece and fc have landed */   \
         e0 = sb16_inflate(wb, rot0); STORM_MUL16(2, fc); __builtin_amdgcn_sched_barrier(0);                 \
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr0), "v"(e0), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory"); \
-        STORM_FETCH16(fc, (I) * kStripStageBytes, 5); STORM_LGKM(3);                                        \
+        STORM_SB16_WR0(I)                                                                                   \
+        STORM_FETCH16(fc, (I) * kStripStageBytes, 5); STORM_LGKM(STORM_SB16_LGKM_A);                        \
         e1 = sb16_inflate(wb, rot1); STORM_MUL16(3, fa); __builtin_amdgcn_sched_barrier(0);                 \
-        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr1), "v"(e1), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory"); \
-        STORM_FETCH16(fa, (I) * kStripStageBytes, 6); STORM_LGKM(4); STORM_MUL16(4, fb); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fb, (I) * kStripStageBytes, 7); STORM_LGKM(3); STORM_MUL16(5, fc); __builtin_amdgcn_sched_barrier(0); \
+        STORM_SB16_WR1(I)                                                                                   \
+        STORM_FETCH16(fa, (I) * kStripStageBytes, 6); STORM_LGKM(STORM_SB16_LGKM_B); STORM_MUL16(4, fb); __builtin_amdgcn_sched_barrier(0); \
+        STORM_FETCH16(fb, (I) * kStripStageBytes, 7); STORM_LGKM(STORM_SB16_LGKM_C); STORM_MUL16(5, fc); __builtin_amdgcn_sched_barrier(0); \
         STORM_FETCH16(fc, (((I) + 1) % 3) * kStripStageBytes, 0); STORM_LGKM(2); STORM_MUL16(6, fa); __builtin_amdgcn_sched_barrier(0); \
         STORM_FETCH16(fa, (((I) + 1) % 3) * kStripStageBytes, 1); STORM_LGKM(2); STORM_MUL16(7, fb); __builtin_amdgcn_sched_barrier(0); \
         ++t;                                                                                                \
@@ -951,11 +979,17 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued beyond the last stage: none may land in a successor's LDS
 #undef STORM_SB16_BODY
+#undef STORM_SB16_WR0
+#undef STORM_SB16_WR1
+#undef STORM_SB16_LGKM_A
+#undef STORM_SB16_LGKM_B
+#undef STORM_SB16_LGKM_C
 #undef STORM_VM2
 #undef STORM_FETCH16V
 #undef STORM_FETCH16
 #undef STORM_MUL16
 #undef STORM_LGKM
+#undef STORM_LGKM_STR
 
     STORM_CLOCK_END();
     uint64_t mine = 0;
