@@ -801,8 +801,8 @@ int storm_hip_ctx_set_option(storm_hip_ctx_t* ctx, const char* key, int64_t valu
         }
         (key[13] == 'd' ? ctx->k2_tile_cost_diag : ctx->k2_tile_cost_ragged) = (int)value;
     } else if (!strcmp(key, "k2_strip_operands")) {
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 5) {
-            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup), 3 (the same with a ring per wave), 4 (FP4 shadow) or 5 (bit operands, FP4 image built in the LDS)");
+        if (value < 0 || value > 6) {
+            set_error("k2_strip_operands must be 0 (by size), 1 (bit operands, one item per workgroup), 2 (bit operands, one stream per workgroup), 3 (the same with a ring per wave), 4 (FP4 shadow), 5 (bit operands, FP4 image built in the LDS) or 6 (the same with 512-row A tiles, two halves behind one image)");
             return STORM_HIP_EINVAL;
         }
 #ifndef STORM_HIP_PROBES

@@ -239,7 +239,8 @@ int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const 
 int strip_operands_of(const storm_hip_ctx_t* ctx);   // 5 = K2b, 4 = FP4 strips, ... (storm_hip_mfma.hip)
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch_bytes,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
-                             uint32_t shard_count, uint64_t* d_total, bool slots_hold_sums = false);
+                             uint32_t shard_count, uint64_t* d_total, bool slots_hold_sums = false,
+                             uint32_t a_tile = 256u);   // a_tile 512: strip16_bits2_kernel (the last tile's rows up to the multiple of 512 must exist and be zero)
 // pairs x words of a set of row ranges, divided among shard_count shards (the report's algorithmic word pairs)
 static inline uint64_t ranges_word_pairs(const std::vector<RowRange>& ranges, uint64_t words, uint32_t shard_count) {
     uint64_t pairs = 0;

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kStripThreads, 4) void strip16_fp4_kernel(
 // ------------------------------------------------------------------------------------------
 constexpr int kSb16ImgRing = 3;                                   // FP4 images (8 KiB each)
 constexpr int kSb16BitRing = 3;                                   // bit stages (4 KiB each; a wave touches only its own 1 KiB piece)
-constexpr int kSb16BitStage = kStripBRows * 64;                   // 4 KiB of bits per B stage
+[[maybe_unused]] constexpr int kSb16BitStage = kStripBRows * 64;                   // 4 KiB of bits per B stage (the kernels keep one 1 KiB piece per WAVE: 4 or 8 KiB)
 constexpr uint32_t kSb16ImgBytes = kSb16ImgRing * kStripStageBytes;
 constexpr uint32_t kSb16Mask = 0x22222222u;
 
@@ -728,336 +728,19 @@ __device__ __forceinline__ v4i sb16_inflate(v4i w, uint32_t rot) {
     return e;
 }
 
-__global__ __launch_bounds__(kStripThreads, 4) void strip16_bits_kernel(
-    const uint8_t* __restrict__ X, uint64_t row_bytes, const StripItem* __restrict__ items,
-    unsigned long long* __restrict__ slots, unsigned long long* __restrict__ out, uint32_t fold_slots) {
-    __shared__ __attribute__((aligned(1024))) uint8_t lds_raw[kSb16ImgBytes + kSb16BitRing * kSb16BitStage];
-
-    STORM_CLOCK_BEGIN();
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t wm = wave;
-    const StripItem it = items[blockIdx.x];
-    const uint64_t kbyte = (uint64_t)(it.ks >> 1) * 64u;
-    // class pair of this k-slice: rotate right by c - 1 (mod 32)
-    const uint32_t rot0 = (it.ks & 1u) ? 1u : 31u;   // classes 2 / 0
-    const uint32_t rot1 = (it.ks & 1u) ? 2u : 0u;    // classes 3 / 1
-    const uint32_t D = it.diag ? (uint32_t)(kStripATile / kStripBRows) : 0u;
-    const uint32_t T = D + (it.j1 - it.j0);
-    // Stage s lives in ring slot (s + cslot) % 3 of both rings, with cslot chosen so that the first
-    // pipelined stage (s = D) sits in slot 0: the three instances of the loop body below then address
-    // their images and pieces with IMMEDIATE offsets (the first version computed five addresses and three
-    // remainders per stage: 33 vector and 57 scalar instructions per 32 MFMAs, profiles/r04_a_*).
-    const uint32_t cslot = (3u - D % 3u) % 3u;
-
-    const uint32_t lds_base =
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)&lds_raw[0];
-    // the wave's piece of a B stage: 16 rows x four 16-byte quarters. Lanes 4g .. 4g + 3 hold the quarters of
-    // one row, and the two rows of a store's 8-lane group are 8 apart: their image slots then differ in the
-    // swizzle's top bit and the group's 8 x 16 bytes land on 32 different banks (rows r, r + 1 share a swizzle:
-    // every ds_write_b128 would be a two-way conflict)
-    const uint32_t pr = wave * 16u + (lane >> 3) + 8u * ((lane >> 2) & 1u);
-    const uint32_t goff0 = pr * (uint32_t)row_bytes + (lane & 3u) * 16u;
-    const uint32_t bits_rd = lds_base + kSb16ImgBytes + wave * 1024u + lane * 16u;
-    // where that piece's two k-steps go in an FP4 image: row pr, slot (kk * 4 + quarter) ^ (pr / 2) % 8
-    const uint32_t img_wr0 = lds_base + pr * (uint32_t)kStripRowBytes + (((lane & 3u) ^ ((pr >> 1) & 7u)) * 16u);
-    const uint32_t img_wr1 = img_wr0 ^ 64u;
-
-    // LDS-DMA of the wave's piece of stage s into bit slot `slot`. Stages beyond the last one re-read the
-    // last block (never consumed): every iteration issues exactly one piece, so every wait is vmcnt(2).
-    auto issue = [&](uint32_t s, uint32_t slot) {
-        const uint32_t sc = min(s, T - 1u);
-        const uint32_t blk = sc < D ? it.a_row0 / (uint32_t)kStripBRows + sc : it.j1 - 1u - (sc - D);
-        const uint8_t* base = X + (uint64_t)(blk * (uint32_t)kStripBRows) * row_bytes + kbyte;
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), 0, -1, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rsrc, (lptr_t)(lds_raw + kSb16ImgBytes + slot * kSb16BitStage + wave * 1024u), 16,
-            (int)goff0, 0, 0, 0);
-    };
-
-    // A fragments: rows wm*64 + m*16 + (lane & 15), quarter lane >> 4 of the chunk; a[kk][m] = class kk.
-    // (loaded in front of the DMA pieces, so that the wait for them leaves the pieces in flight)
-    v4i a[2][4];
-    {
-        const uint8_t* ap = X + (uint64_t)(it.a_row0 + wm * 64u + (lane & 15u)) * row_bytes + kbyte +
-                            (lane >> 4) * 16u;
-        v4i aw[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) aw[m] = *reinterpret_cast<const v4i*>(ap + (uint64_t)m * 16u * row_bytes);
-        issue(0u, cslot);
-        issue(1u, (cslot + 1u) % 3u);
-        issue(2u, (cslot + 2u) % 3u);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            a[0][m] = sb16_inflate(aw[m], rot0);
-            a[1][m] = sb16_inflate(aw[m], rot1);
-        }
-    }
-
-    v4f acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = v4f{};
-
-    // fragment (kk, n) of an image: row n*16 + (lane & 15), 16-byte slot kk*4 + (lane >> 4), swizzled
-    const uint32_t swz = ((lane & 15u) >> 1) & 7u;
-    uint32_t boff[2];
-    boff[0] = lds_base + (lane & 15u) * kStripRowBytes + (((lane >> 4) ^ swz) * 16u);
-    boff[1] = boff[0] ^ 64u;
-
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(a[kk][m]));  // retire the A loads here
-
-    // fragment of step s (k-step s >> 2, B block s & 3) of the image at byte offset `img` (a constant)
-#define STORM_FETCH16(dst, img, s)                                                        \
-    asm volatile("ds_read_b128 %0, %1 offset:%2"                                          \
-                 : "=&v"(dst)                                                             \
-                 : "v"(boff[(s) >> 2]), "n"((img) + ((s) & 3) * 16 * kStripRowBytes))
-#define STORM_FETCH16V(dst, img, s)                                                       \
-    asm volatile("ds_read_b128 %0, %1 offset:%2"                                          \
-                 : "=&v"(dst)                                                             \
-                 : "v"(boff[(s) >> 2] + (img)), "n"(((s) & 3) * 16 * kStripRowBytes))
-#define STORM_MUL16(s, frag)                                                              \
-    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                         \
-        acc[m][(s) & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(               \
-            v8i{a[(s) >> 2][m].x, a[(s) >> 2][m].y, a[(s) >> 2][m].z, a[(s) >> 2][m].w, 0, 0, 0, 0}, \
-            v8i{frag.x, frag.y, frag.z, frag.w, 0, 0, 0, 0}, acc[m][(s) & 3], 4, 4, 0, 0, 0, 0)
-#define STORM_LGKM_STR(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
-#define STORM_LGKM(n)    \
-    STORM_LGKM_STR(n);   \
-    __builtin_amdgcn_sched_barrier(0)
-#define STORM_VM2()                                         \
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        \
-    __builtin_amdgcn_sched_barrier(0)
-
-    v4i wb = {};
-    // the wave's quarter of the image of stage s, start to finish (prologue and diagonal phase)
-    auto build_image = [&](uint32_t s) {
-        const uint32_t slot = (s + cslot) % 3u;
-        asm volatile("ds_read_b128 %0, %1" : "=&v"(wb) : "v"(bits_rd + slot * (uint32_t)kSb16BitStage));
-        STORM_LGKM(0);
-        const v4i e0 = sb16_inflate(wb, rot0);
-        asm volatile("ds_write_b128 %0, %1" ::"v"(img_wr0 + slot * (uint32_t)kStripStageBytes), "v"(e0) : "memory");
-        const v4i e1 = sb16_inflate(wb, rot1);
-        asm volatile("ds_write_b128 %0, %1" ::"v"(img_wr1 + slot * (uint32_t)kStripStageBytes), "v"(e1) : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // scalar loads of the item record
-    // Invariant at the top of iteration t, in front of its issue: the pieces of stages <= t + 3 have been
-    // issued, those of stages <= t + 1 have landed and been turned into images.
-    STORM_VM2();        // stage 0 (1 and 2 in flight)
-    build_image(0u);
-    STORM_LGKM(0);      // the piece has been read: its slot takes stage 3
-    issue(3u, cslot);
-    STORM_VM2();        // stage 1
-    build_image(1u);
-
-    v4i b0 = {}, b1 = {}, b2 = {}, b3 = {};
-    uint32_t t = 0;
-    // ---- the A tile's own 4 blocks: wave wm skips the blocks before its own rows, keeps the
-    //      strict upper triangle of its own 64 x 64 block and takes the later blocks whole
-#pragma unroll 1
-    for (; t < D; ++t) {
-        STORM_LGKM(0);                   // own image writes
-        __builtin_amdgcn_s_barrier();    // images t and t + 1 complete, the slot of image t - 1 free
-        issue(t + 4u, (t + 1u + cslot) % 3u);
-        STORM_VM2();                     // stage t + 2
-        build_image(t + 2u);
-        if (t >= wm) {
-            const uint32_t sb = ((t + cslot) % 3u) * kStripStageBytes;
-            STORM_FETCH16V(b0, sb, 0);
-            STORM_FETCH16V(b1, sb, 1);
-            STORM_FETCH16V(b2, sb, 2);
-            STORM_FETCH16V(b3, sb, 3);
-            STORM_LGKM(3); STORM_MUL16(0, b0); __builtin_amdgcn_sched_barrier(0);
-            STORM_FETCH16V(b0, sb, 4);
-            STORM_LGKM(3); STORM_MUL16(1, b1); __builtin_amdgcn_sched_barrier(0);
-            STORM_FETCH16V(b1, sb, 5);
-            STORM_LGKM(3); STORM_MUL16(2, b2); __builtin_amdgcn_sched_barrier(0);
-            STORM_FETCH16V(b2, sb, 6);
-            STORM_LGKM(3); STORM_MUL16(3, b3); __builtin_amdgcn_sched_barrier(0);
-            STORM_FETCH16V(b3, sb, 7);
-            STORM_LGKM(3); STORM_MUL16(4, b0); __builtin_amdgcn_sched_barrier(0);
-            STORM_LGKM(2); STORM_MUL16(5, b1); __builtin_amdgcn_sched_barrier(0);
-            STORM_LGKM(1); STORM_MUL16(6, b2); __builtin_amdgcn_sched_barrier(0);
-            STORM_LGKM(0); STORM_MUL16(7, b3); __builtin_amdgcn_sched_barrier(0);
-            if (t == wm) {
-                // The accumulators hold exactly this wave's own 64 x 64 block (earlier stages were
-                // skipped): clear the pairs i >= j in place. C/D map: col = lane & 15,
-                // row = 4 * (lane >> 4) + reg.
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        if (m > n) acc[m][n] = v4f{};
-                        if (m == n) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const uint32_t row = 4u * (lane >> 4) + (uint32_t)r;
-                                acc[m][n][r] = row < (lane & 15u) ? acc[m][n][r] : 0.0f;
-                            }
-                        }
-                    }
-            }
-        }
-    }
-    // ---- later blocks, software-pipelined across stage boundaries. Iteration t, behind barrier t:
-    //      LDS operations in flight on entry: the fragments of steps 0 and 1 of image t (fa, fb). Fragments
-    //      are read TWO steps ahead into a rotation of three registers (the FP4 strips: three ahead, four
-    //      registers — the four this kernel needs for the piece and its inflated classes; with four waves
-    //      per SIMD a step of 4 MFMAs is ~250 clocks of wall time, twice the LDS latency). 8 steps per
-    //      stage rotate the three names by two and the ring slot by one: the body is instantiated three
-    //      times, I = the slot of the image it multiplies. The piece of stage t + 2 is read behind the
-    //      fragments, inflated beside the MFMAs and written as image t + 2; the lgkmcnt values count the
-    //      operations that may stay in flight behind the fragment needed. Beyond the last stage the next
-    //      image, the piece and the image written are stale and never consumed: the body is branch-free.
-    // (STORM_SB16_ABLATE, tools builds only — WRONG totals by design: 1 = the stage's second image store and its inflation
-    //  left out, 2 = both; the time that saves is the most a structure that shares one B image between two A tiles could win:
-    //  profiles/r06_c_k2b_image_store_ablation.txt. The lgkmcnt values behind a missing store count one operation fewer.)
-#if defined(STORM_SB16_ABLATE) && STORM_SB16_ABLATE >= 2
-#define STORM_SB16_WR0(I)
-#else
-#define STORM_SB16_WR0(I) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr0), "v"(e0), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory");
-#endif
-#if defined(STORM_SB16_ABLATE) && STORM_SB16_ABLATE >= 1
-#define STORM_SB16_WR1(I)
-#else
-#define STORM_SB16_WR1(I) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(img_wr1), "v"(e1), "n"((((I) + 2) % 3) * kStripStageBytes) : "memory");
-#endif
-#if !defined(STORM_SB16_ABLATE) || STORM_SB16_ABLATE == 0
-#define STORM_SB16_LGKM_A 3
-#define STORM_SB16_LGKM_B 4
-#define STORM_SB16_LGKM_C 3
-#elif STORM_SB16_ABLATE == 1
-#define STORM_SB16_LGKM_A 3
-#define STORM_SB16_LGKM_B 3
-#define STORM_SB16_LGKM_C 2
-#else
-#define STORM_SB16_LGKM_A 2
-#define STORM_SB16_LGKM_B 2
-#define STORM_SB16_LGKM_C 2
-#endif
-#define STORM_SB16_BODY(I, fa, fb, fc)                                                                      \
-    {                                                                                                       \
-        issue(t + 4u, ((I) + 1) % 3);   /* into the slot of stage t + 1, read an iteration ago */           \
-        STORM_VM2();                    /* the piece of stage t + 2 has landed */                           \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(wb) : "v"(bits_rd), "n"((((I) + 2) % 3) * kSb16BitStage)); \
-        v4i e0, e1;                                                                                         \
-        STORM_FETCH16(fc, (I) * kStripStageBytes, 2); STORM_LGKM(3); STORM_MUL16(0, fa); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fa, (I) * kStripStageBytes, 3); STORM_LGKM(3); STORM_MUL16(1, fb); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fb, (I) * kStripStageBytes, 4); STORM_LGKM(2);   /* the piece and fc have landed */   \
-        e0 = sb16_inflate(wb, rot0); STORM_MUL16(2, fc); __builtin_amdgcn_sched_barrier(0);                 \
-        STORM_SB16_WR0(I)                                                                                   \
-        STORM_FETCH16(fc, (I) * kStripStageBytes, 5); STORM_LGKM(STORM_SB16_LGKM_A);                        \
-        e1 = sb16_inflate(wb, rot1); STORM_MUL16(3, fa); __builtin_amdgcn_sched_barrier(0);                 \
-        STORM_SB16_WR1(I)                                                                                   \
-        STORM_FETCH16(fa, (I) * kStripStageBytes, 6); STORM_LGKM(STORM_SB16_LGKM_B); STORM_MUL16(4, fb); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fb, (I) * kStripStageBytes, 7); STORM_LGKM(STORM_SB16_LGKM_C); STORM_MUL16(5, fc); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fc, (((I) + 1) % 3) * kStripStageBytes, 0); STORM_LGKM(2); STORM_MUL16(6, fa); __builtin_amdgcn_sched_barrier(0); \
-        STORM_FETCH16(fa, (((I) + 1) % 3) * kStripStageBytes, 1); STORM_LGKM(2); STORM_MUL16(7, fb); __builtin_amdgcn_sched_barrier(0); \
-        ++t;                                                                                                \
-        if (t >= T) break;                                                                                  \
-        __builtin_amdgcn_s_barrier();                                                                       \
-    }
-    if (t < T) {
-        STORM_LGKM(0);
-        __builtin_amdgcn_s_barrier();
-        STORM_FETCH16(b0, 0, 0);   // stage D sits in slot 0
-        STORM_FETCH16(b1, 0, 1);
-        for (;;) {
-            STORM_SB16_BODY(0, b0, b1, b2)   // leaves steps 0, 1 of the next image in b2, b0
-            STORM_SB16_BODY(1, b2, b0, b1)   // ... in b1, b2
-            STORM_SB16_BODY(2, b1, b2, b0)   // ... in b0, b1
-        }
-        STORM_LGKM(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued beyond the last stage: none may land in a successor's LDS
-#undef STORM_SB16_BODY
-#undef STORM_SB16_WR0
-#undef STORM_SB16_WR1
-#undef STORM_SB16_LGKM_A
-#undef STORM_SB16_LGKM_B
-#undef STORM_SB16_LGKM_C
-#undef STORM_VM2
-#undef STORM_FETCH16V
-#undef STORM_FETCH16
-#undef STORM_MUL16
-#undef STORM_LGKM
-#undef STORM_LGKM_STR
-
-    STORM_CLOCK_END();
-    uint64_t mine = 0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {  // 16 x 64 entries below 2^24 each: a uint32 cannot overflow
-        uint32_t part = 0;
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part += (uint32_t)acc[m][n][r];
-        mine += part;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
-    // (lane and thread index are taken afresh: kept alive across the stage loop they cost two registers
-    //  the loop does not have — the first build spilled them)
-    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t tid_e = wave * 64u + lane_e;
-    if (out == nullptr) {   // the partial sums stay in the slots: a fold launch follows (fold_slots_kernel)
-        if (lane_e == 0 && mine != 0)
-            atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (kSlots - 1)],
-                      (unsigned long long)mine);
-        return;
-    }
-    // ---- the fold inside the launch [r5]: a wave's sum and its ARRIVAL travel in ONE fire-and-forget atomic — the slot
-    //      word's low 48 bits take the sum, the high 16 count arrivals (the host checks both fields' ranges,
-    //      launch_pairw_bits_ranges) — so there is nothing to order and nothing to wait for at the end of an item. The
-    //      workgroup dispatched LAST folds: behind its own item it polls the slots until the arrival fields add up to
-    //      every wave of the grid (a snapshot in which they do holds every sum as well: the fields only grow), writes the
-    //      total and leaves the slots zeroed for the next pass. It holds one workgroup slot while it polls, when the list
-    //      has run dry anyway; every other workgroup is running or done by then and needs nothing from it.
-    //      (Round 4's form — a ticket word that every workgroup hits with a RETURNING atomic — cost 1 ms at this grid size:
-    //       atomics on one address serialise at ~14 M/s, and a returning atomic holds the workgroup's slot for ~2 us.)
-    // (fold_slots: a power of two <= kSlots — short launches use few slots, one per polling thread)
-    if (lane_e == 0)
-        atomicAdd(&slots[(blockIdx.x * (uint32_t)kStripWaves + wave) & (fold_slots - 1u)],
-                  (unsigned long long)mine + (1ull << 48));
-    if (blockIdx.x != gridDim.x - 1u) return;
-    const unsigned long long expected = (unsigned long long)gridDim.x * (unsigned long long)kStripWaves;
-    unsigned long long* wsum = reinterpret_cast<unsigned long long*>(lds_raw);   // [0..3] arrivals, [4..7] sums per wave
-    unsigned long long total = 0;
-    for (;;) {
-        unsigned long long cnt = 0, sum = 0;
-        for (uint32_t i = tid_e; i < fold_slots; i += (uint32_t)kStripThreads) {
-            const unsigned long long v = __hip_atomic_load(&slots[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cnt += v >> 48;
-            sum += v & ((1ull << 48) - 1ull);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            cnt += __shfl_down(cnt, o, 64);
-            sum += __shfl_down(sum, o, 64);
-        }
-        __syncthreads();   // (the previous round's reads of wsum are done)
-        if (lane_e == 0) {
-            wsum[wave] = cnt;
-            wsum[4 + wave] = sum;
-        }
-        __syncthreads();
-        cnt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        total = wsum[4] + wsum[5] + wsum[6] + wsum[7];
-        if (cnt == expected) break;
-        if (fold_slots > (uint32_t)kStripThreads) __builtin_amdgcn_s_sleep(8);   // (long launches: poll gently)
-    }
-    for (uint32_t i = tid_e; i < fold_slots; i += (uint32_t)kStripThreads)
-        __hip_atomic_store(&slots[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid_e == 0) out[0] = total;
-}
+#define STORM_SB16_WAVES 4
+#define STORM_SB16_NAME strip16_bits_kernel
+#include "strip16_bits_kernel.inc"
+#undef STORM_SB16_WAVES
+#undef STORM_SB16_NAME
+// [r6] The same with 8 waves and 512-row A tiles: waves w and w + 4 multiply different A rows by the SAME image and share
+// its construction — each holds the piece of wave w & 3 (its own LDS-DMA copy: no cross-wave wait) and writes one of the
+// two k-steps. Option k2_strip_operands = 6; measured against the default in profiles/r06_c_k2b_two_a_tiles.txt.
+#define STORM_SB16_WAVES 8
+#define STORM_SB16_NAME strip16_bits2_kernel
+#include "strip16_bits_kernel.inc"
+#undef STORM_SB16_WAVES
+#undef STORM_SB16_NAME
 
 // ------------------------------------------------------------------------------------------
 // K2t16: write-mode tile kernel on v_mfma_scale_f32_16x16x128_f8f6f4 (materialised XX^T, AND /
@@ -3700,17 +3383,18 @@ int launch_pairw_bitstream(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t pit
 // sparse container: the pool rows of its block columns.
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,
-                             uint32_t shard_count, uint64_t* d_total, bool slots_hold_sums) {
+                             uint32_t shard_count, uint64_t* d_total, bool slots_hold_sums, uint32_t a_tile) {
     if (pitch * (uint64_t)kStripBRows >= (1ull << 32)) {
         set_error("K2b: rows of %llu bytes are beyond the strips' 32-bit DMA offsets", (unsigned long long)pitch);
         return STORM_HIP_EINVAL;
     }
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
-    if (int rc = ensure_strip_items(ctx, ranges, n_kslices2, shard_rank, shard_count, (uint32_t)kStripATile, 2))
+    if (int rc = ensure_strip_items(ctx, ranges, n_kslices2, shard_rank, shard_count, a_tile, 2))
         return rc;
     const uint32_t n_strip = ctx->n_strip_items;
-    ctx->k2_operands_used = 5;
+    const uint32_t waves = a_tile / (uint32_t)kStripBRows;   // 4, or 8 for the 512-row form (strip16_bits2_kernel)
+    ctx->k2_operands_used = waves == 8u ? 6 : 5;
     if (n_strip > 0) {
         ctx->pass_report[0] |= STORM_HIP_RAN_BIT_STRIPS;
         ctx->pass_report[1] += ranges_word_pairs(ranges, (uint64_t)n_kslices2 * 4u, shard_count);  // a slice = 256 bit-MACs per pair = 4 words
@@ -3727,16 +3411,21 @@ int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pi
     // one gains nothing (profiles/r05_c_fold_ab.jsonl) and keeps the fold launch unless the option is 1
     const uint32_t fold_slots = n_strip <= 4096u ? 256u : (uint32_t)kSlots;
     const bool fold_wanted = ctx->k2_fold_inline > 0 || (ctx->k2_fold_inline < 0 && n_strip <= 4096u);
-    const uint64_t arrivals_per_slot = (uint64_t)n_strip * (uint64_t)kStripWaves / (uint64_t)fold_slots + 1u;
+    const uint64_t arrivals_per_slot = (uint64_t)n_strip * (uint64_t)waves / (uint64_t)fold_slots + 1u;
     const uint64_t wave_sum_max = 64ull * (4096ull * 64ull + 256ull) * 256ull;   // (runs are capped at 4096 stages)
     // (slots_hold_sums: another kernel of this pass — the list-probe kernel — has added sums of unknown size: fold launch)
     const bool fold_inline = fold_wanted && !slots_hold_sums && n_strip > 0 && arrivals_per_slot < 65535u &&
                              arrivals_per_slot * wave_sum_max < (1ull << 48);
     if (n_strip > 0) {
         kernel_time_mark(ctx);
-        hipLaunchKernelGGL(strip16_bits_kernel, dim3(n_strip), dim3(kStripThreads), (size_t)ctx->k2_lds_pad,
-                           ctx->stream, X, pitch, static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots,
-                           fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr, fold_slots);
+        if (waves == 8u)
+            hipLaunchKernelGGL(strip16_bits2_kernel, dim3(n_strip), dim3(512), (size_t)ctx->k2_lds_pad,
+                               ctx->stream, X, pitch, static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots,
+                               fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr, fold_slots);
+        else
+            hipLaunchKernelGGL(strip16_bits_kernel, dim3(n_strip), dim3(kStripThreads), (size_t)ctx->k2_lds_pad,
+                               ctx->stream, X, pitch, static_cast<const StripItem*>(ctx->d_strip_items), ctx->d_slots,
+                               fold_inline ? reinterpret_cast<unsigned long long*>(d_total) : nullptr, fold_slots);
         kernel_time_mark(ctx);
         STORM_HIP_TRY(hipGetLastError());
     }
@@ -3765,9 +3454,9 @@ static int launch_pairw_bits(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, 
 #endif
     ctx->n_items = 0;  // the strip items carry the diagonal tiles themselves
     memset(ctx->items_key, 0xff, sizeof(ctx->items_key));
-    if (operands == 5)
+    if (operands == 5 || operands == 6)
         return launch_pairw_bits_ranges(ctx, reinterpret_cast<const uint8_t*>(m->d), pitch, ranges, n_kslices * 2u,
-                                        shard_rank, shard_count, d_total);
+                                        shard_rank, shard_count, d_total, false, operands == 6 ? 512u : (uint32_t)kStripATile);
     if (int rc = ensure_strip_items(ctx, ranges, n_kslices, shard_rank, shard_count, (uint32_t)kStripATile))
         return rc;
 #ifndef STORM_HIP_PROBES
@@ -3907,6 +3596,7 @@ static int pairw_bits_upload_queue(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, 
 // Which strips an all-pairs pass runs (option k2_strip_operands; 0 = the default: K2b unless a non-default ring or MFMA
 // shape asks for the FP4 strips): ONE rule for the dense matrix and for the pool rows of a sparse container.
 int strip_operands_of(const storm_hip_ctx_t* ctx) {
+    if (ctx->k2_strip_operands == 6) return 5;   // (K2b with 512-row A tiles: a form of K2b; launch_pairw_mfma takes it where the matrix allows)
     if (ctx->k2_strip_operands != 0) return ctx->k2_strip_operands;
     return (ctx->k2_ring == kStripRingDefault && ctx->k2_shape == 16) ? 5 : 4;
 }
@@ -3925,8 +3615,10 @@ int launch_pairw_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* m, uint32_
         (m->n_rows + kStripATile - 1) / kStripATile * kStripATile <= m->n_rows_pad &&
         m->stride_words * 8 * (uint64_t)kStripBRows < (1ull << 32))
     {
-        ctx->k2_operands_used = operands;
-        return launch_pairw_bits(ctx, m, shard_rank, shard_count, operands, d_total);
+        // (6: 512-row A tiles want the zero rows up to a multiple of 512)
+        const bool wide = operands == 5 && ctx->k2_strip_operands == 6 && (m->n_rows + 511u) / 512u * 512u <= m->n_rows_pad;
+        ctx->k2_operands_used = wide ? 6 : operands;
+        return launch_pairw_bits(ctx, m, shard_rank, shard_count, wide ? 6 : operands, d_total);
     }
     ctx->k2_operands_used = 4;
     const uint64_t tile = strip_mode == 2 ? 512 : kStripATile;

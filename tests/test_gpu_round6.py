@@ -281,3 +281,40 @@ def test_first_matrix_call_on_the_row_lists_equals_the_steady_calls_and_the_orac
     finally:
         lib.STORM_hip_set_option(b"matrix_lists", -1)
         lib.STORM_hip_set_option(b"matrix_lists_kernel", 0)
+
+
+def test_bit_operand_strips_with_512_row_tiles_against_the_oracle(hip_ctx, orc):
+    """K2b's second form (k2_strip_operands = 6: strip16_bits2_kernel, 8 waves, 512-row A tiles, waves w and w + 4 behind one
+    B image of which each writes one k-step): an option. Shapes around the edges of its decomposition — one tile (only the
+    diagonal phase of eight blocks runs), 2 .. 5 tiles, ragged last blocks, one k-slice, ragged last chunks, an empty row,
+    runs of 1 .. 3 stages — for one device and for shards, with the fold in the launch and behind it. A matrix whose zero
+    rows do not reach the next multiple of 512 runs the 256-row form (k2_operands_used says which)."""
+    shapes = ((64, 300), (100, 448), (4096, 511), (4096, 512), (640, 1000), (4096, 769), (8192, 1500), (4160, 2000),
+              (9000, 1300), (30000, 1536), (12345, 2500), (1000, 3000), (65536, 1024))
+    try:
+        for M, N in shapes:
+            for d in (M // 2, max(1, M // 50)):
+                mat = synth.dense_matrix_c(M, N, d, seed=N + M)
+                mat[N // 2] = 0
+                want = orc.wrapper_diag_blocked(mat, 31)
+                m = hip_ctx.matrix_from_host(mat)
+                hip_ctx.set_option("k2_strip_operands", 6)
+                for fold in (-1, 0, 1):
+                    hip_ctx.set_option("k2_fold_inline", fold)
+                    got = [m.pairw() for _ in range(3)]
+                    assert got == [want] * 3, (M, N, d, fold, got, want)
+                    assert hip_ctx.get_option("k2_operands_used") == 6
+                hip_ctx.set_option("k2_fold_inline", -1)
+                for world in (2, 3):
+                    assert sum(m.pairw(r, world) for r in range(world)) == want, (M, N, d, world)
+                hip_ctx.set_option("k2_strip_operands", 0)
+                assert m.pairw() == want and hip_ctx.get_option("k2_operands_used") == 5
+                m.close()
+        mat = synth.dense_matrix_c(2048, 700, 300, seed=5)     # 700 rows: zero rows up to 768 only
+        m = hip_ctx.matrix_from_host(mat)
+        hip_ctx.set_option("k2_strip_operands", 6)
+        assert m.pairw() == orc.wrapper_diag_blocked(mat, 31) and hip_ctx.get_option("k2_operands_used") == 5
+        m.close()
+    finally:
+        hip_ctx.set_option("k2_strip_operands", 0)
+        hip_ctx.set_option("k2_fold_inline", -1)
