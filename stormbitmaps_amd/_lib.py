@@ -202,14 +202,14 @@ def check(rc: int, what: str) -> None:
 
 
 def kernel_source_hash() -> str:
-    """Fingerprint of the device sources (csrc/*.hip + the shared internal header): what a
+    """Fingerprint of the device sources (csrc/*.hip, csrc/*.inc + the shared internal header): what a
     profile summary under profiles/ was measured on. bench.py only quotes measured HBM traffic
     whose fingerprint equals the current one."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith(".hip") or name == "storm_hip_internal.h":
+        if name.endswith((".hip", ".inc")) or name == "storm_hip_internal.h":
             with open(os.path.join(csrc, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -636,6 +636,8 @@ void storm_hip_ctx_destroy(storm_hip_ctx_t* ctx) {
     if (ctx->h_scalar) (void)hipHostFree(ctx->h_scalar);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     if (ctx->h_stage_ring) (void)hipHostFree(ctx->h_stage_ring);
+    for (hipEvent_t e : ctx->stage_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     release_mfma_state(ctx);
     for (hipEvent_t ev : ctx->kernel_events) (void)hipEventDestroy(ev);

@@ -98,6 +98,9 @@ struct storm_hip_ctx_s {
     // arena build) is put off until the call AFTER the one that made them obsolete, or the context's end
     std::vector<void*> deferred_free, deferred_host_free;
     uint32_t deferred_age = 0;
+    hipEvent_t stage_ev[3] = {nullptr, nullptr, nullptr};   // the ring's rotation lives in the context: one Stager after another continues it and waits for the copy that last left a buffer
+    bool stage_used[3] = {false, false, false};
+    int stage_next = 0;
     void* h_stage_ring = nullptr;            // pinned staging ring of the sparse arena builder (storm_hip_sparse.hip: Stager), allocated on first use
     storm::Seg* d_segs = nullptr;            // segment table of the last geometry
     size_t segs_capacity = 0;
@@ -283,14 +286,10 @@ struct Stager {
     static constexpr size_t kBuf = 8u << 20;  // 8 MiB per buffer: 0.16 ms of PCIe time each
     static constexpr int kBufs = 3;
     storm_hip_ctx_t* ctx;
-    hipEvent_t ev[kBufs] = {nullptr, nullptr, nullptr};
-    bool used[kBufs] = {false, false, false};
-    int next = 0;
-    explicit Stager(storm_hip_ctx_t* c) : ctx(c) {}
-    ~Stager() {
-        for (hipEvent_t e : ev)
-            if (e) (void)hipEventDestroy(e);
-    }
+    hipEvent_t (&ev)[kBufs];   // (state of the context: see stage_ev)
+    bool (&used)[kBufs];
+    int& next;
+    explicit Stager(storm_hip_ctx_t* c) : ctx(c), ev(c->stage_ev), used(c->stage_used), next(c->stage_next) {}
     static_assert(kBuf * kBufs == ((size_t)24 << 20), "storm_hip_ctx_reserve_staging allocates the same ring");
     int init() {
         if (!ctx->h_stage_ring) {
@@ -301,7 +300,7 @@ struct Stager {
             }
         }
         for (int i = 0; i < kBufs; ++i)
-            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return STORM_HIP_EHIP;
+            if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return STORM_HIP_EHIP;
         return STORM_HIP_OK;
     }
     // pieces[p0, p1): consecutive in the device destination (dst_off ascending from 0, no gaps beyond `span`)
@@ -373,6 +372,18 @@ struct Stager {
         return flush();
     }
 };
+
+// A host table -> device memory on the context's stream. Small ones as they are (the runtime stages them); from 512 KiB on
+// through the pinned ring when the context has one: a large pageable source that is unmapped soon after an asynchronous copy —
+// a std::vector freed at the end of a build — made the next wide kernel start 10 - 30 ms late (LAB_NOTES "the late kernel").
+inline int upload_bytes(storm_hip_ctx_t* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (bytes == 0) return STORM_HIP_OK;
+    if (bytes < (512u << 10) || !ctx->h_stage_ring)
+        return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? STORM_HIP_OK : STORM_HIP_EHIP;
+    Stager stager(ctx);
+    if (int rc = stager.init()) return rc;
+    return stager.send_run(static_cast<uint8_t*>(d_dst), {{h_src, bytes}});
+}
 
 
 }  // namespace storm

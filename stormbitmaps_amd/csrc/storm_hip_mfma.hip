@@ -2090,9 +2090,7 @@ static int ensure_strip_items(storm_hip_ctx_t* ctx, const std::vector<RowRange>&
         ctx->strip_capacity = cap;
     }
     if (!items.empty()) {
-        STORM_HIP_TRY(hipMemcpyAsync(ctx->d_strip_items, items.data(),
-                                     items.size() * sizeof(StripItem), hipMemcpyHostToDevice,
-                                     ctx->stream));
+        if (int rc_up = upload_bytes(ctx, ctx->d_strip_items, items.data(), items.size() * sizeof(StripItem))) return rc_up;
         STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     ctx->n_strip_items = (uint32_t)items.size();
@@ -2362,8 +2360,7 @@ int launch_square_mfma(storm_hip_ctx_t* ctx, const storm_hip_matrix_s* a,
     }
     memset(ctx->strip_key, 0xff, sizeof(ctx->strip_key));  // the cached all-pairs table is gone
     ctx->n_strip_items = 0;
-    STORM_HIP_TRY(hipMemcpyAsync(ctx->d_strip_items, items.data(), items.size() * sizeof(StripItem),
-                                 hipMemcpyHostToDevice, ctx->stream));
+    if (int rc_up = upload_bytes(ctx, ctx->d_strip_items, items.data(), items.size() * sizeof(StripItem))) return rc_up;
     STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));  // `items` leaves scope
     for (int side = 0; side < 2; ++side) {
         const storm_hip_matrix_s* m = side ? b : a;
@@ -3572,7 +3569,7 @@ static int pairw_bits_upload_queue(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, 
             }
             l.n = (uint32_t)items.size();
             if (l.n) {
-                STORM_HIP_TRY(hipMemcpyAsync(l.d, items.data(), items.size() * sizeof(StripItem), hipMemcpyHostToDevice, ctx->stream));
+                if (int rc_up = upload_bytes(ctx, l.d, items.data(), items.size() * sizeof(StripItem))) return rc_up;
                 STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));   // `items` leaves scope
             }
             memcpy(l.key, key, sizeof(key));

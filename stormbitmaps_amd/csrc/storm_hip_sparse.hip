@@ -582,12 +582,11 @@ __global__ __launch_bounds__(kThreads) void probe_deal_kernel(const uint32_t* __
 // (Piece / Stager: the pinned staging ring, shared with the row lists of storm_hip_lists.hip: storm_hip_internal.h)
 
 template <typename T>
-int upload(T** d, const T* h, size_t n, hipStream_t stream) {
+int upload(storm_hip_ctx_t* ctx, T** d, const T* h, size_t n) {
     *d = nullptr;
     if (n == 0) return STORM_HIP_OK;
     STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), n * sizeof(T)));
-    STORM_HIP_TRY(hipMemcpyAsync(*d, h, n * sizeof(T), hipMemcpyHostToDevice, stream));
-    return STORM_HIP_OK;
+    return upload_bytes(ctx, *d, h, n * sizeof(T));
 }
 
 }  // namespace
@@ -958,8 +957,8 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             pllen.push_back(block_n[b]);
         }
         run_end.assign(probe_blocks.size() * kProbeOctants, 0);
-        if (int rc0 = upload(&dt.ploff, ploff.data(), ploff.size(), ctx->stream)) return rc0;
-        if (int rc0 = upload(&dt.pllen, pllen.data(), pllen.size(), ctx->stream)) return rc0;
+        if (int rc0 = upload(ctx, &dt.ploff, ploff.data(), ploff.size())) return rc0;
+        if (int rc0 = upload(ctx, &dt.pllen, pllen.data(), pllen.size())) return rc0;
         STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dt.rend), run_end.size() * sizeof(uint32_t)));
         const uint32_t n_threads = (uint32_t)run_end.size();
         hipLaunchKernelGGL(probe_run_end_kernel, dim3((n_threads + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
@@ -1279,7 +1278,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 }
                 if (hipMemcpyAsync(stage->d_chunk_table, stage->chunks.data(), stage->chunks.size() * sizeof(uint8_t*),
                                    hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                    hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                    upload_bytes(ctx, d_table, table.data(), table.size() * sizeof(uint64_t)) != STORM_HIP_OK) {
                     (void)hipFree(d_table);
                     rc = STORM_HIP_EHIP;
                     break;
@@ -1318,9 +1317,9 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         if (!list_row.empty()) {
             loff.reserve(list_blk.size());
             for (uint64_t b : list_blk) loff.push_back(dev_off[b]);
-            if ((rc = upload(&dt.lrow, list_row.data(), list_row.size(), ctx->stream)) ||
-                (rc = upload(&dt.loff, loff.data(), loff.size(), ctx->stream)) ||
-                (rc = upload(&dt.llen, list_len.data(), list_len.size(), ctx->stream)))
+            if ((rc = upload(ctx, &dt.lrow, list_row.data(), list_row.size())) ||
+                (rc = upload(ctx, &dt.loff, loff.data(), loff.size())) ||
+                (rc = upload(ctx, &dt.llen, list_len.data(), list_len.size())))
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
                                dim3(kThreads), 0, ctx->stream, s->d_pool, s->pitch, dt.lrow, dt.loff, dt.llen,
@@ -1349,9 +1348,9 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             tags.reserve(probe_blocks.size());
             for (size_t pb = 0; pb < probe_blocks.size(); ++pb) tags.push_back(block_local[pb] << 16);
             // (the lists' offsets, their lengths and the run ends are on the device since the start)
-            if ((rc = upload(&dt.tags, tags.data(), tags.size(), ctx->stream)) ||
-                (rc = upload(&dt.rdst, run_dst.data(), run_dst.size(), ctx->stream)) ||
-                (rc = upload(&dt.atoms, atoms.data(), atoms.size(), ctx->stream)))
+            if ((rc = upload(ctx, &dt.tags, tags.data(), tags.size())) ||
+                (rc = upload(ctx, &dt.rdst, run_dst.data(), run_dst.size())) ||
+                (rc = upload(ctx, &dt.atoms, atoms.data(), atoms.size())))
                 break;
             if (!probe_blocks.empty())
                 hipLaunchKernelGGL(probe_fill_kernel, dim3((uint32_t)probe_blocks.size()), dim3(kThreads), 0, ctx->stream,
@@ -1400,8 +1399,8 @@ static int ensure_full_pool(storm_hip_ctx_t* ctx, storm_hip_sparse_t* s) {
         }
         if (!s->probe_regions.empty()) {
             static_assert(sizeof(storm_hip_sparse_s::ProbeRegion) == 16, "four uint32 per region");
-            if ((rc = upload(&d_regions, reinterpret_cast<const uint32_t*>(s->probe_regions.data()),
-                             s->probe_regions.size() * 4, ctx->stream)))
+            if ((rc = upload(ctx, &d_regions, reinterpret_cast<const uint32_t*>(s->probe_regions.data()),
+                             s->probe_regions.size() * 4)))
                 break;
             hipLaunchKernelGGL(expand_probe_kernel, dim3((uint32_t)s->probe_regions.size()), dim3(kThreads), 0,
                                ctx->stream, np, s->pitch, s->d_probe_elems, d_regions);
