@@ -384,11 +384,15 @@ int storm_hip_sparse_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64
  * the reference's harness times, benchmark.cpp:605-613 — does not carry them over the bus. storm_hip_stage_add copies
  * the block's 1024 words into a pinned ring (sent 4 MiB at a time into 64 MiB device chunks) and returns its token;
  * storm_hip_sparse_create_blocks_staged builds the arena of storm_hip_sparse_create_blocks with the pool rows gathered
- * from the stage when EVERY bitmap block carries a valid token (token[b] < storm_hip_stage_count; list blocks: any
- * value), and from block_ptr otherwise. The stage may be destroyed once the arena exists. */
+ * from the stage when EVERY bitmap block carries a valid token (token[b] < storm_hip_stage_count), and from block_ptr
+ * otherwise; list blocks: a token of storm_hip_stage_add_list or ~0 (from block_ptr). The stage may be destroyed once the arena exists. */
 typedef struct storm_hip_stage_s storm_hip_stage_t;
 int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out);
 int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage, const uint64_t* words, uint64_t* token);
+/* The same for a LIST block (kind 0: n ascending 16-bit positions, 1 <= n <= 65536): the token is the list's place in the
+ * stage and goes into token[b] of storm_hip_sparse_create_blocks_staged; a list block whose token is ~0 travels from
+ * block_ptr[b] at build time, as in storm_hip_sparse_create_blocks (list and bitmap tokens are separate sequences). */
+int storm_hip_stage_add_list(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage, const uint16_t* list, uint32_t n, uint64_t* token);
 uint64_t storm_hip_stage_count(const storm_hip_stage_t* stage);
 void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage);
 int storm_hip_sparse_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "storm_hip_ctx_reserve_staging": (C.c_int, [vp]),
     "storm_hip_stage_create": (C.c_int, [vp, vp]),
     "storm_hip_stage_add": (C.c_int, [vp, vp, vp, vp]),
+    "storm_hip_stage_add_list": (C.c_int, [vp, vp, vp, u32, vp]),
     "storm_hip_stage_count": (u64, [vp]),
     "storm_hip_stage_destroy": (None, [vp, vp]),
     "storm_hip_sparse_create_blocks_staged": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -609,6 +609,17 @@ struct storm_hip_stage_s {
     uint32_t fill = 0;              // blocks in the current buffer
     uint64_t base = 0;              // token of the current buffer's first block
     const uint8_t** d_chunk_table = nullptr;   // the chunks' addresses on the device (rebuilt per gather)
+    // the LIST blocks: a byte stream of its own ("list space": position p = chunk p / 64 MiB, offset p % 64 MiB; a list never
+    // straddles a chunk), through two pinned buffers of kListBuf bytes behind the bitmaps' ring in the same allocation
+    static constexpr size_t kListBuf = 4u << 20, kListChunk = 64u << 20;
+    std::vector<uint8_t*> lchunks;
+    uint8_t* h_lring = nullptr;
+    hipEvent_t lev[2] = {nullptr, nullptr};
+    bool lused[2] = {false, false};
+    int lcur = 0;
+    uint32_t lfill = 0;             // bytes in the current buffer
+    uint64_t lbase = 0;             // list-space position of the current buffer's first byte
+    const uint8_t** d_lchunk_table = nullptr;
 };
 
 namespace {
@@ -643,6 +654,39 @@ int stage_send(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
     return STORM_HIP_OK;
 }
 
+// the current list buffer -> its chunk (a buffer never runs across a chunk boundary: storm_hip_stage_add_list)
+int stage_send_lists(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
+    if (st->lfill == 0) return STORM_HIP_OK;
+    const uint64_t chunk = st->lbase / storm_hip_stage_s::kListChunk, off = st->lbase % storm_hip_stage_s::kListChunk;
+    while (st->lchunks.size() <= chunk) {
+        uint8_t* c = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&c), storm_hip_stage_s::kListChunk) != hipSuccess) {
+            set_error("block stage: hipMalloc of a 64 MiB list chunk failed");
+            return STORM_HIP_ENOMEM;
+        }
+        st->lchunks.push_back(c);
+    }
+    STORM_HIP_TRY(hipMemcpyAsync(st->lchunks[chunk] + off, st->h_lring + (size_t)st->lcur * storm_hip_stage_s::kListBuf, st->lfill,
+                                 hipMemcpyHostToDevice, ctx->stream));
+    STORM_HIP_TRY(hipEventRecord(st->lev[st->lcur], ctx->stream));
+    st->lused[st->lcur] = true;
+    st->lcur ^= 1;
+    st->lbase += st->lfill;
+    st->lfill = 0;
+    if (st->lused[st->lcur]) STORM_HIP_TRY(hipEventSynchronize(st->lev[st->lcur]));
+    return STORM_HIP_OK;
+}
+
+// lists[dst ..) <- the staged list at list-space position `token`: one workgroup per block, 2 bytes per thread and trip
+__global__ __launch_bounds__(256) void gather_staged_lists_kernel(const uint8_t* const* __restrict__ lchunks,
+                                                                  const uint64_t* __restrict__ table, uint16_t* __restrict__ lists) {
+    const uint64_t dst = table[3 * blockIdx.x], token = table[3 * blockIdx.x + 1];
+    const uint32_t n = (uint32_t)table[3 * blockIdx.x + 2];
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(lchunks[token / storm_hip_stage_s::kListChunk] +
+                                                            token % storm_hip_stage_s::kListChunk);
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) lists[dst + i] = src[i];
+}
+
 // pool row `dst` <- staged block `token`: one workgroup per block, 32 bytes per thread
 __global__ __launch_bounds__(256) void gather_staged_kernel(const uint8_t* const* __restrict__ chunks,
                                                             const uint64_t* __restrict__ table, uint64_t* __restrict__ pool,
@@ -666,14 +710,17 @@ int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out) {
         *out = nullptr;
         STORM_HIP_TRY(hipSetDevice(ctx->device));
         std::unique_ptr<storm_hip_stage_t> st(new storm_hip_stage_t());
-        if (hipHostMalloc(reinterpret_cast<void**>(&st->h_ring), 2 * storm_hip_stage_s::kBufBlocks * storm_hip_stage_s::kBlockBytes,
+        const size_t ring_bytes = 2 * storm_hip_stage_s::kBufBlocks * storm_hip_stage_s::kBlockBytes;
+        if (hipHostMalloc(reinterpret_cast<void**>(&st->h_ring), ring_bytes + 2 * storm_hip_stage_s::kListBuf,
                           hipHostMallocDefault) != hipSuccess) {
-            set_error("stage_create: hipHostMalloc of the 8 MiB ring failed");
+            set_error("stage_create: hipHostMalloc of the 16 MiB of rings failed");
             return STORM_HIP_ENOMEM;
         }
+        st->h_lring = st->h_ring + ring_bytes;
         (void)storm_hip_ctx_reserve_staging(ctx);   // the arena builder's ring, too, while nobody is waiting
         for (int i = 0; i < 2; ++i)
-            if (hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming) != hipSuccess) {
+            if (hipEventCreateWithFlags(&st->ev[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&st->lev[i], hipEventDisableTiming) != hipSuccess) {
                 storm_hip_stage_destroy(ctx, st.release());
                 return STORM_HIP_EHIP;
             }
@@ -699,6 +746,27 @@ int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint6
     });
 }
 
+int storm_hip_stage_add_list(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint16_t* list, uint32_t n, uint64_t* token) {
+    return guarded("storm_hip_stage_add_list", [&]() -> int {
+        if (!ctx || !st || !list || !token || n == 0 || n > 65536u) {
+            set_error("stage_add_list: NULL argument or a list of %u positions", n);
+            return STORM_HIP_EINVAL;
+        }
+        const uint32_t bytes = n * 2u;
+        const uint64_t at = st->lbase + st->lfill;
+        const bool over_chunk = at % storm_hip_stage_s::kListChunk + bytes > storm_hip_stage_s::kListChunk;
+        if (over_chunk || st->lfill + bytes > storm_hip_stage_s::kListBuf) {
+            STORM_HIP_TRY(hipSetDevice(ctx->device));
+            if (int rc = stage_send_lists(ctx, st)) return rc;
+            if (over_chunk) st->lbase = (st->lbase / storm_hip_stage_s::kListChunk + 1u) * storm_hip_stage_s::kListChunk;
+        }
+        memcpy(st->h_lring + (size_t)st->lcur * storm_hip_stage_s::kListBuf + st->lfill, list, bytes);
+        *token = st->lbase + st->lfill;
+        st->lfill += bytes;
+        return STORM_HIP_OK;
+    });
+}
+
 uint64_t storm_hip_stage_count(const storm_hip_stage_t* st) { return st ? st->n_blocks : 0; }
 
 void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
@@ -712,15 +780,22 @@ void storm_hip_stage_destroy(storm_hip_ctx_t* ctx, storm_hip_stage_t* st) {
         if (ctx) ctx->deferred_free.push_back(c);
         else (void)hipFree(c);
     }
-    if (st->d_chunk_table) {
-        if (ctx) ctx->deferred_free.push_back(st->d_chunk_table);
-        else (void)hipFree(st->d_chunk_table);
+    for (uint8_t* c : st->lchunks) {
+        if (ctx) ctx->deferred_free.push_back(c);
+        else (void)hipFree(c);
     }
+    for (const uint8_t** t : {st->d_chunk_table, st->d_lchunk_table})
+        if (t) {
+            if (ctx) ctx->deferred_free.push_back(t);
+            else (void)hipFree(t);
+        }
     if (st->h_ring) {
         if (ctx) ctx->deferred_host_free.push_back(st->h_ring);
         else (void)hipHostFree(st->h_ring);
     }
     for (hipEvent_t e : st->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : st->lev)
         if (e) (void)hipEventDestroy(e);
     delete st;
 }
@@ -903,11 +978,12 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         uint32_t *atoms = nullptr, *bad = nullptr, *pllen = nullptr;
         uint64_t *loff = nullptr, *ploff = nullptr;
         uint16_t *lists = nullptr, *pos_tmp = nullptr;
+        uint64_t* ltable = nullptr;
         storm_hip_ctx_t* ctx = nullptr;
         ~DevTemps() {
             // (the build has waited for its last kernel; a hipFree waits for the device once more and costs ~0.2 ms: put off)
             for (void* p : {(void*)lrow, (void*)loff, (void*)llen, (void*)lists, (void*)tags, (void*)rend, (void*)rdst,
-                            (void*)atoms, (void*)bad, (void*)pllen, (void*)ploff, (void*)pos_tmp})
+                            (void*)atoms, (void*)bad, (void*)pllen, (void*)ploff, (void*)pos_tmp, (void*)ltable})
                 if (p) {
                     if (ctx) ctx->deferred_free.push_back(p);
                     else (void)hipFree(p);
@@ -930,13 +1006,33 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         std::vector<uint8_t> wanted(n_blocks, 0);
         for (uint64_t b : probe_blocks) wanted[b] = 1;
         for (uint64_t b : list_blk) wanted[b] = 1;
+        // [r6] lists the caller staged while it built the container (storm_hip_stage_add_list: a token that is not ~0) are
+        // gathered from the stage's chunks by one kernel; the others travel now, through the pinned ring. Both kinds lie in
+        // dt.lists in block order: first the run from the host, behind it the staged ones.
         std::vector<std::pair<const void*, size_t>> run;
+        std::vector<uint64_t> staged;   // blocks whose list is in the stage
+        const uint64_t list_space = stage ? stage->lbase + stage->lfill : 0;
         for (uint64_t b = 0; b < n_blocks; ++b)
             if (wanted[b] && block_n[b]) {
+                if (stage && stage_token && stage_token[b] != ~0ull) {
+                    if ((stage_token[b] & 1u) || stage_token[b] + (uint64_t)block_n[b] * 2u > list_space) {
+                        set_error("sparse_create: block %llu carries a list token outside the stage", (unsigned long long)b);
+                        return STORM_HIP_EINVAL;
+                    }
+                    staged.push_back(b);
+                    continue;
+                }
                 dev_off[b] = n_list_elems;
                 n_list_elems += block_n[b];
                 run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
             }
+        std::vector<uint64_t> ltable;
+        ltable.reserve(3 * staged.size());
+        for (uint64_t b : staged) {
+            dev_off[b] = n_list_elems;
+            ltable.insert(ltable.end(), {n_list_elems, stage_token[b], (uint64_t)block_n[b]});
+            n_list_elems += block_n[b];
+        }
         if (n_list_elems) {
             if (hipMalloc(reinterpret_cast<void**>(&dt.lists), n_list_elems * sizeof(uint16_t)) != hipSuccess) {
                 set_error("sparse_create: hipMalloc of %llu bytes for the lists failed",
@@ -944,6 +1040,20 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 return STORM_HIP_ENOMEM;
             }
             if (int rc0 = stager.send_run(reinterpret_cast<uint8_t*>(dt.lists), run)) return rc0;
+        }
+        if (!staged.empty()) {
+            if (int rc0 = stage_send_lists(ctx, stage)) return rc0;   // what is still in the ring
+            if (stage->d_lchunk_table) ctx->deferred_free.push_back(stage->d_lchunk_table);
+            stage->d_lchunk_table = nullptr;
+            STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage->d_lchunk_table), stage->lchunks.size() * sizeof(uint8_t*)));
+            STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dt.ltable), ltable.size() * sizeof(uint64_t)));
+            STORM_HIP_TRY(hipMemcpyAsync(stage->d_lchunk_table, stage->lchunks.data(), stage->lchunks.size() * sizeof(uint8_t*),
+                                         hipMemcpyHostToDevice, ctx->stream));
+            if (int rc0 = upload_bytes(ctx, dt.ltable, ltable.data(), ltable.size() * sizeof(uint64_t))) return rc0;
+            hipLaunchKernelGGL(gather_staged_lists_kernel, dim3((uint32_t)staged.size()), dim3(256), 0, ctx->stream,
+                               stage->d_lchunk_table, dt.ltable, dt.lists);
+            STORM_HIP_TRY(hipGetLastError());
+            STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`ltable` and the chunk table are pageable)
         }
     }
     lap("lists -> device");

@@ -1703,19 +1703,21 @@ typedef struct {
 /* [r6] Streaming for the sparse container. STORM_add hands every bitmap block it finishes to a block stage on the device
  * (storm_hip_stage_*: 8 KiB into a pinned ring, on its way 4 MiB at a time), so that the first all-pairs call — the one
  * call the reference's harness times, benchmark.cpp:605-613 — builds its arena from blocks that are already in HBM (one
- * gather kernel) instead of carrying 8 KiB per block over the bus: 655 MB and 91 ms at BASELINE c4's 50 % load. The lists
- * stay on the host until the arena is built (2 - 21 MB at the sparse loads). The first add also creates the context (the
+ * gather kernel) instead of carrying 8 KiB per block over the bus: 655 MB and 91 ms at BASELINE c4's 50 % load. The list
+ * blocks go the same way (storm_hip_stage_add_list: 2 bytes per position; 420 MB and 14 ms of the first call at 20971
+ * draws per row). The first add also creates the context (the
  * process's HIP initialisation: 150 - 250 ms that the first call used to pay). Same switch as the dense container's
  * streaming (STORM_HIP_STREAM_ROWS). What was staged is remembered per block as (row, index, id, set-bit count): a block
  * edited behind STORM_add's back (the public per-row / per-block adders) no longer matches at build time and the arena is
  * then built from the host's blocks as before. The stage is given up once the arena exists. */
-typedef struct { uint32_t row, b, id, bits; } stage_blk_t;
+typedef struct { uint32_t row, b, id, bits; uint64_t token; } stage_blk_t; /* bits: set bits of a bitmap block, length of a list block */
 typedef struct {
     storm_hip_stage_t* stage;
     int slot;                 /* the device slot the stage lives on */
     uint32_t generation;      /* the device configuration it was made under */
     stage_blk_t* blk;
     uint64_t n_blk, m_blk;
+    uint64_t n_bitmaps_staged; /* (bitmap tokens count up from 0) */
     int off;                  /* 1: staging was given up for this handle (until STORM_clear) */
 } storm_stage_t;
 
@@ -1727,6 +1729,7 @@ static void storm_stage_drop(STORM_t* h, int keep_off) {
     free(sg->blk);
     sg->blk = NULL;
     sg->n_blk = sg->m_blk = 0;
+    sg->n_bitmaps_staged = 0;
     if (keep_off) {
         sg->off = 1;
     } else {
@@ -1749,7 +1752,8 @@ static void storm_stage_row_locked(STORM_t* h, uint32_t row) {
     if (row == 0) (void)storm_hip_ctx_reserve_staging(ctx); /* the arena builder's pinned ring: now, not inside the first call */
     for (uint32_t b = 0; b < r->n_bitmaps; ++b) {
         const STORM_bitmap_t* blk = &r->bitmaps[b];
-        if (!blk->n_bitmap || !blk->data) continue;
+        const int is_list = !blk->n_bitmap;
+        if (is_list ? (!blk->n_scalar || !blk->scalar) : !blk->data) continue;
         if (!sg) {
             sg = (storm_stage_t*)calloc(1, sizeof(*sg));
             if (!sg) return;
@@ -1769,8 +1773,14 @@ static void storm_stage_row_locked(STORM_t* h, uint32_t row) {
             sg->m_blk = m;
         }
         uint64_t token = 0;
-        if (storm_hip_stage_add(ctx, sg->stage, blk->data, &token) != STORM_HIP_OK || token != sg->n_blk) goto give_up;
-        sg->blk[sg->n_blk++] = (stage_blk_t){row, b, blk->id, blk->n_bits_set};
+        if (is_list) { /* (lists too since round 6: 420 MB and 14 ms of the first call at c4's 20971 draws per row) */
+            if (storm_hip_stage_add_list(ctx, sg->stage, blk->scalar, blk->n_scalar, &token) != STORM_HIP_OK) goto give_up;
+            sg->blk[sg->n_blk++] = (stage_blk_t){row, b, blk->id, blk->n_scalar, token};
+        } else {
+            if (storm_hip_stage_add(ctx, sg->stage, blk->data, &token) != STORM_HIP_OK || token != sg->n_bitmaps_staged) goto give_up;
+            ++sg->n_bitmaps_staged;
+            sg->blk[sg->n_blk++] = (stage_blk_t){row, b, blk->id, blk->n_bits_set, token};
+        }
     }
     return;
 give_up:
@@ -2184,10 +2194,10 @@ static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
                 for (uint32_t b = 0; b < h->conts[i].n_bitmaps; ++b, ++at) {
                     const STORM_bitmap_t* blk = &h->conts[i].bitmaps[b];
                     tokens[at] = ~0ull;
-                    if (!blk->n_bitmap) continue;
+                    if (blk->n_bitmap ? !blk->data : (!blk->n_scalar || !blk->scalar)) continue; /* (never staged) */
                     if (k < sg->n_blk && sg->blk[k].row == i && sg->blk[k].b == b && sg->blk[k].id == blk->id &&
-                        sg->blk[k].bits == blk->n_bits_set) {
-                        tokens[at] = k++;
+                        sg->blk[k].bits == (blk->n_bitmap ? blk->n_bits_set : blk->n_scalar)) {
+                        tokens[at] = sg->blk[k++].token;
                     } else {
                         ok = 0;
                         break;

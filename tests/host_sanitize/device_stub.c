@@ -161,7 +161,7 @@ int storm_hip_sparse_create(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_bl
     return STORM_HIP_OK;
 }
 /* the block stage: a host copy of every staged block (ASan checks the 8 KiB read), tokens in order */
-struct storm_hip_stage_s { uint64_t n; uint64_t sum; };
+struct storm_hip_stage_s { uint64_t n; uint64_t sum; uint64_t list_bytes; };
 int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out) {
     (void)ctx;
     *out = (storm_hip_stage_t*)calloc(1, sizeof(**out));
@@ -171,6 +171,14 @@ int storm_hip_stage_add(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint6
     (void)ctx;
     for (int k = 0; k < 1024; ++k) st->sum += (uint64_t)__builtin_popcountll(words[k]);
     *token = st->n++;
+    return STORM_HIP_OK;
+}
+int storm_hip_stage_add_list(storm_hip_ctx_t* ctx, storm_hip_stage_t* st, const uint16_t* list, uint32_t n, uint64_t* token) {
+    (void)ctx;
+    if (n == 0 || n > 65536u) return STORM_HIP_EINVAL;
+    for (uint32_t k = 0; k < n; ++k) st->sum += list[k];   /* (ASan checks the list's extent) */
+    *token = st->list_bytes;
+    st->list_bytes += 2ull * n;
     return STORM_HIP_OK;
 }
 uint64_t storm_hip_stage_count(const storm_hip_stage_t* st) { return st ? st->n : 0; }
@@ -183,11 +191,17 @@ int storm_hip_sparse_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows,
                                           const uint64_t* row_block_offset, const uint32_t* block_id,
                                           const uint8_t* block_kind, const uint32_t* block_n, const void* const* block_ptr,
                                           storm_hip_stage_t* stage, const uint64_t* token, storm_hip_sparse_t** out) {
-    /* every bitmap block must carry the token of a staged block, in staging order */
-    uint64_t next = 0;
-    for (uint64_t b = 0; b < n_blocks; ++b)
+    /* every bitmap block must carry the token of a staged block, in staging order; a list block a place inside the staged
+     * lists, ascending, or ~0 */
+    uint64_t next = 0, lnext = 0;
+    for (uint64_t b = 0; b < n_blocks; ++b) {
         if (block_kind[b] && token[b] != next++) return STORM_HIP_EINVAL;
-    if (next != stage->n) return STORM_HIP_EINVAL;
+        if (!block_kind[b] && block_n[b] && token[b] != ~0ull) {
+            if (token[b] != lnext) return STORM_HIP_EINVAL;
+            lnext += 2ull * block_n[b];
+        }
+    }
+    if (next != stage->n || lnext > stage->list_bytes) return STORM_HIP_EINVAL;
     return storm_hip_sparse_create_blocks(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out);
 }
 /* reads every list entry and bitmap word through the pointers handed over (ASan checks their extents) */
