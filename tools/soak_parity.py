@@ -41,10 +41,15 @@ def main():
                 "k2_persistent": int(rng.choice([0, 0, 1 if probes else 0])),
                 "k2_pitch_pad": int(rng.choice([-1, -1, 0, 128, 640])),
                 "k2_shape": int(rng.choice([16, 16, 32 if probes else 16])),
-                "k2_tile_shape": int(rng.choice([0, 5, 5, 2, 2, 1, 16, 32] if probes else [0, 5, 5, 2, 2, 3, 4, 32])),
+                "k2_tile_shape": int(rng.choice([0, 5, 5, 2, 2, 1, 16, 32] if probes else [0, 5, 5, 2, 2, 3, 4, 32, 6, 6, 6])),
+                "k2_part_slots": int(rng.choice([0, 0, 1, 2])),
+                "k2_part_min_chunks": int(rng.choice([8, 8, 1, 3, 40])),
+                "k2_part_narrow": int(rng.choice([1, 1, 0])),
+                "k2_wave_below": int(rng.choice([400, 400, 0, 100000])),
+                "probe_bundle": int(rng.choice([-1, -1, 1, 4, 4])),
                 "k2_ring_sync": int(rng.choice([0, 0, 1])),
                 "k2_matrix_parts": int(rng.choice([0, 0, 1])),
-                "k2_strip_operands": int(rng.choice([0, 0, 5, 4, 1 if probes else 2, 2])),
+                "k2_strip_operands": int(rng.choice([0, 0, 5, 4, 1 if probes else 2, 2, 6, 6])),
                 "k2_matrix_pad": int(rng.choice([2, 2, 1, 0, 3])),
                 "k2_fold_inline": int(rng.choice([-1, -1, 0, 1])),
                 "k2_stream_groups_per_cu": int(rng.choice([0, 0, 1, 2, 3, 7])),
@@ -195,7 +200,7 @@ def main():
                 s.free()
         finally:
             for k, v in {"variant": -1, "k2_max_run": 0, "k2_tail_slices": 3, "k2_tail_run": 32,
-                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 0, "k2_ring_sync": 0, "k2_matrix_parts": 0, "k2_fold_inline": -1, "k2_strip_operands": 0,
+                         "k2_persistent": 0, "k2_pitch_pad": -1, "k2_matrix_pad": -1, "k2_shape": 16, "k2_tile_shape": 0, "k2_part_slots": 0, "k2_part_min_chunks": 8, "k2_part_narrow": 1, "k2_wave_below": 400, "probe_bundle": -1, "k2_ring_sync": 0, "k2_matrix_parts": 0, "k2_fold_inline": -1, "k2_strip_operands": 0,
                          "k2_stream_groups_per_cu": 0, "k2_stream_min_piece": 6, "k2_stream_min_run": 2,
                          "k2_stream_w3_1": 120, "k2_stream_w3_2": 60, "k2_shadow_budget_mb": 98304, "sparse_probe": -1}.items():
                 ctx.set_option(k, v)
