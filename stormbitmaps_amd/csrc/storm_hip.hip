@@ -582,6 +582,8 @@ int storm_hip_ctx_create(int device, void* stream, storm_hip_ctx_t** out) {
         warm_lists_code(ctx->stream);
         (void)result_target(ctx);
         ctx->mail_armed = false;
+        // (the second stream of the raw-buffer wrappers: creating it took 6.7 ms of their first call)
+        (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
         // ... and the runtime's path for copies out of pageable host memory: the first such copy of a process (a work list on
         // its way to the device) took 7.5 ms — the whole first-call penalty of a 1024-row matrix (rocprofv3 --hip-trace)
         {
