@@ -318,3 +318,35 @@ def test_bit_operand_strips_with_512_row_tiles_against_the_oracle(hip_ctx, orc):
     finally:
         hip_ctx.set_option("k2_strip_operands", 0)
         hip_ctx.set_option("k2_fold_inline", -1)
+
+
+def test_blocks_edited_between_the_adds_and_the_first_call_do_not_come_from_the_stage(orc):
+    """STORM_add stages every block it finishes (bitmaps and, since round 6, lists) on the device; the first all-pairs call
+    gathers the arena from the stage ONLY while every block still is what was staged. A row extended through the public
+    per-row adder (the reference's structs are public, storm.h:157-200) before that call — a list block more, a bitmap block
+    more — must be seen as it is now (storm.c:790-814 per pair on the container's present state)."""
+    import ctypes as C
+    lib = sb._lib.load()
+    lib.STORM_bitmap_cont_add.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    M, N, d = 3 * 65536, 260, 700
+    for grow in (300, 9000):                                   # the new block: a list of 300, a bitmap of 9000 positions
+        rows = [np.asarray(r, dtype=np.uint32) for r in synth.positions(2 * 65536, N, d, seed=80 + grow)]
+        s = sb.Storm()
+        for r in rows:
+            s.add(r)
+        for victim in (3, N - 1):                              # (the per-row adder appends blocks: the new positions lie beyond the row's last block)
+            extra = np.arange(2 * 65536 + 17, 2 * 65536 + 17 + grow, dtype=np.uint32)
+            conts = C.cast(s._h, C.POINTER(C.c_void_p))[0]     # STORM_s.conts
+            assert lib.STORM_bitmap_cont_add(C.c_void_p(conts + victim * 32), extra.ctypes.data_as(C.c_void_p), extra.size) == 1
+            rows[victim] = np.concatenate([rows[victim], extra])
+        want = orc.storm(rows).pairw()
+        assert [s.pairw_intersect_cardinality(), s.pairw_intersect_cardinality_blocked(0)] == [want, want], grow
+        s.free()
+    # ... and the untouched container does come out right through the stage (lists only; lists and bitmaps)
+    for d2 in (700, 30000):
+        rows = synth.positions(M, N, d2, seed=5 + d2)
+        s = sb.Storm()
+        for r in rows:
+            s.add(r)
+        assert s.pairw_intersect_cardinality() == orc.storm(rows).pairw(), d2
+        s.free()
