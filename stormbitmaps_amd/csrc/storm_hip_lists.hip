@@ -153,7 +153,11 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     // each are slower still (3.1 ms: one wave per SIMD covers no latency; eight waves: 1.64). The steps are the cost of this formulation:
     // lists_hash_kernel below has none and takes over where the rows are short.
     constexpr uint32_t kInvalid = 0xffffffffu;
-    constexpr uint32_t kFarRegs = 8u;
+    // [r6] kFarRegs 8 -> 24, in three groups of 8 that a step only touches while its window holds that many far elements
+    // (a test on scalars: every wave takes the same way): at 2096 positions per row a step looks up 24 elements per thread,
+    // and two thirds of them used to be loaded inside the step, the thread waiting for every batch of 8
+    constexpr uint32_t kFarGroup = 8u;
+    constexpr uint32_t kFarRegs = 3u * kFarGroup;
     constexpr uint32_t kARegs = 1u;
     constexpr uint32_t kBatch = 8u;      // loads in flight per thread in the remainder loops
     constexpr uint32_t kT = (uint32_t)kLmThreads;
@@ -173,16 +177,30 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     };
     // the masks of a batch are read together (one LDS round trip per batch, not per element); an invalid element reads
     // entry 0 and drops what it gets
-    auto lookup_batch = [&](const uint32_t* v, uint32_t n) {
-        uint2 m[kFarRegs];
+    auto lookup_batch = [&](const uint32_t* v) {
+        uint2 m[kFarGroup];
 #pragma unroll
-        for (uint32_t q = 0; q < kFarRegs; ++q)
-            if (q < n) m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 2u]);
+        for (uint32_t q = 0; q < kFarGroup; ++q)
+            m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 2u]);
 #pragma unroll
-        for (uint32_t q = 0; q < kFarRegs; ++q)
-            if (q < n && v[q] != kInvalid && (m[q].x | m[q].y)) count_bits(v[q], m[q]);
+        for (uint32_t q = 0; q < kFarGroup; ++q)
+            if (v[q] != kInvalid && (m[q].x | m[q].y)) count_bits(v[q], m[q]);
     };
     auto load_at = [&](uint32_t i, uint32_t e) -> uint32_t { return (i < e && !(dbg & 1u)) ? elems[i] : kInvalid; };
+    // the far elements a step holds in registers: group g only while the window lists more than g * 8 * threads of them
+    auto lookup_regs = [&](const uint32_t (&v)[kFarRegs], uint32_t count) {
+#pragma unroll
+        for (uint32_t g = 0; g < kFarRegs / kFarGroup; ++g)
+            if (count > g * kFarGroup * kT) lookup_batch(&v[g * kFarGroup]);
+    };
+    auto load_regs = [&](uint32_t (&v)[kFarRegs], uint32_t b, uint32_t e, bool ok) {
+#pragma unroll
+        for (uint32_t g = 0; g < kFarRegs / kFarGroup; ++g)
+            if (ok && e - b > g * kFarGroup * kT) {
+#pragma unroll
+                for (uint32_t q = g * kFarGroup; q < (g + 1u) * kFarGroup; ++q) v[q] = load_at(b + tid + q * kT, e);
+            }
+    };
     // the elements of [b, e) from the `skip`-th per thread on, kBatch loads in flight
     auto toggle_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
         for (uint32_t i = b + tid + skip * kT; i < e; i += kBatch * kT) {
@@ -193,12 +211,29 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
             for (uint32_t q = 0; q < kBatch; ++q) toggle1(v[q]);
         }
     };
+    // (beyond the registers: batches of 8 per thread, the next batch's loads in flight while this one is looked up)
     auto lookup_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
-        for (uint32_t i = b + tid + skip * kT; i < e; i += kFarRegs * kT) {
-            uint32_t v[kFarRegs];
+        const uint32_t first = b + skip * kT;
+        if (first >= e) return;
+        uint32_t va[kFarGroup], vb[kFarGroup];
 #pragma unroll
-            for (uint32_t q = 0; q < kFarRegs; ++q) v[q] = load_at(i + q * kT, e);
-            lookup_batch(v, kFarRegs);
+        for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_at(first + tid + q * kT, e);
+        for (uint32_t base = first;;) {   // (`base` is a scalar: the loop's exits are the same for every wave)
+            const uint32_t nb = base + kFarGroup * kT;
+            if (nb < e) {
+#pragma unroll
+                for (uint32_t q = 0; q < kFarGroup; ++q) vb[q] = load_at(nb + tid + q * kT, e);
+            }
+            lookup_batch(va);
+            if (nb >= e) break;
+            const uint32_t nc = nb + kFarGroup * kT;
+            if (nc < e) {
+#pragma unroll
+                for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_at(nc + tid + q * kT, e);
+            }
+            lookup_batch(vb);
+            if (nc >= e) break;
+            base = nc;
         }
     };
     // (a barrier for the LDS alone: __syncthreads() also waits for every global load in flight — the loads that were
@@ -224,10 +259,8 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
         a_next[q] = w1.ok ? load_at(w1.ab + tid + q * kT, w1.ae) : kInvalid;
     }
 #pragma unroll
-    for (uint32_t q = 0; q < kFarRegs; ++q) {
-        f_cur[q] = w0.ok ? load_at(w0.fb + tid + q * kT, w0.fe) : kInvalid;
-        f_next[q] = kInvalid;
-    }
+    for (uint32_t q = 0; q < kFarRegs; ++q) f_cur[q] = f_next[q] = kInvalid;
+    load_regs(f_cur, w0.fb, w0.fe, w0.ok);
     lds_barrier();   // the zeroed table
 #pragma unroll
     for (uint32_t q = 0; q < kARegs; ++q) toggle1(a_cur[q]);
@@ -239,9 +272,8 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     auto step = [&](uint32_t (&fc)[kFarRegs], uint32_t (&fn)[kFarRegs], uint32_t (&an)[kARegs], uint32_t (&an2)[kARegs]) {
 #pragma unroll
         for (uint32_t q = 0; q < kARegs; ++q) an2[q] = w2.ok ? load_at(w2.ab + tid + q * kT, w2.ae) : kInvalid;
-#pragma unroll
-        for (uint32_t q = 0; q < kFarRegs; ++q) fn[q] = w1.ok ? load_at(w1.fb + tid + q * kT, w1.fe) : kInvalid;
-        lookup_batch(fc, kFarRegs);
+        load_regs(fn, w1.fb, w1.fe, w1.ok);
+        lookup_regs(fc, w0.fe - w0.fb);
         if (w0.fe - w0.fb > kFarRegs * kT) lookup_rest(w0.fb, w0.fe, kFarRegs);
         lds_barrier();
 #pragma unroll
