@@ -49,9 +49,14 @@ constexpr int kLmThreads = 1024;
 constexpr uint32_t kLmGroup = 64;        // A rows per tile
 constexpr uint32_t kLmChunkGroups = 12;  // far rows per tile: 12 groups = 768
 constexpr uint32_t kLmChunk = kLmGroup * kLmChunkGroups;
-constexpr uint32_t kLmWinBits = 13;
-constexpr uint32_t kLmWin = 1u << kLmWinBits;
-constexpr uint32_t kLmTableBytes = kLmWin * 8u;                  // a 64-bit row mask per position
+// [r6] A window is 8191 positions, not 8192: entry 0 of the table is nobody's, and an ELEMENT is
+//     (row % 768) << 16 | 8 * (position % 8191 + 1)     — its row in the chunk and the BYTE OFFSET of its table entry —
+// so that 0 means "no element" (what a buffer load beyond a range returns: no bounds test, no select) and a lookup is one
+// v_and + ds_read_b64. The window kernel issues ~25 vector instructions per 64 lookups and the vector ALU is what it waits
+// for (profiles/r06_d_lists_matrix_counters.txt): the old encoding (row << 13 | position) cost five more per lookup.
+constexpr uint32_t kLmWin = 8191u;
+constexpr uint32_t kLmTableBytes = (kLmWin + 1u) * 8u;           // a 64-bit row mask per position, entry 0 unused
+constexpr uint32_t kLmRowShift = 16u;
 constexpr uint32_t kLmCountBytes = kLmGroup * kLmChunk * 2u;     // 16-bit counters
 static_assert(kLmTableBytes + kLmCountBytes <= 160u * 1024u, "LDS of a gfx950 CU");
 
@@ -65,7 +70,7 @@ __device__ __forceinline__ uint32_t lists_run_end(const uint32_t* __restrict__ p
     uint32_t lo = e + 1u, hi = r1;
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((pos[mid] >> kLmWinBits) == w) lo = mid + 1u;
+        if (pos[mid] / kLmWin == w) lo = mid + 1u;
         else hi = mid;
     }
     return lo;
@@ -76,8 +81,8 @@ __global__ __launch_bounds__(256) void lists_count_kernel(const uint32_t* __rest
     if (row >= n_rows) return;
     const uint32_t g = row / kLmGroup, r0 = row_off[row], r1 = row_off[row + 1];
     for (uint32_t e = r0 + threadIdx.x; e < r1; e += 256u) {
-        const uint32_t w = pos[e] >> kLmWinBits;
-        if (e != r0 && (pos[e - 1u] >> kLmWinBits) == w) continue;
+        const uint32_t w = pos[e] / kLmWin;
+        if (e != r0 && pos[e - 1u] / kLmWin == w) continue;
         atomicAdd(&cells[(uint64_t)g * n_windows + w], lists_run_end(pos, e, r1, w) - e);
     }
 }
@@ -87,13 +92,13 @@ __global__ __launch_bounds__(256) void lists_place_kernel(const uint32_t* __rest
     const uint32_t row = blockIdx.x;
     if (row >= n_rows) return;
     const uint32_t g = row / kLmGroup, r0 = row_off[row], r1 = row_off[row + 1];
-    const uint32_t tag = (row % kLmChunk) << kLmWinBits;
+    const uint32_t tag = (row % kLmChunk) << kLmRowShift;
     for (uint32_t e = r0 + threadIdx.x; e < r1; e += 256u) {
-        const uint32_t w = pos[e] >> kLmWinBits;
-        if (e != r0 && (pos[e - 1u] >> kLmWinBits) == w) continue;
+        const uint32_t w = pos[e] / kLmWin;
+        if (e != r0 && pos[e - 1u] / kLmWin == w) continue;
         const uint32_t end = lists_run_end(pos, e, r1, w);
         const uint32_t at = atomicAdd(&cursor[(uint64_t)g * n_windows + w], end - e);
-        for (uint32_t k = e; k < end; ++k) elems[at + (k - e)] = tag | (pos[k] & (kLmWin - 1u));
+        for (uint32_t k = e; k < end; ++k) elems[at + (k - e)] = tag | ((pos[k] % kLmWin + 1u) << 3);
     }
 }
 
@@ -103,8 +108,10 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     const uint32_t* __restrict__ elems, const uint32_t* __restrict__ off, uint32_t n_windows,
     const uint32_t* __restrict__ rowlen, const LmItem* __restrict__ items, uint32_t n_rows, int op,
     uint32_t* __restrict__ out, uint64_t ld, uint32_t dbg) {
-    __shared__ __attribute__((aligned(16))) uint32_t table[kLmTableBytes / 4u];   // [position][2 words]
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[kLmCountBytes / 4u];     // [a][j / 2]: two 16-bit counters per word
+    // (one array, the table first: its entries are addressed by the elements' own 16-bit byte offsets)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[(kLmTableBytes + kLmCountBytes) / 4u];
+    uint32_t* const table = lds;                          // [1 + position][2 words]
+    uint32_t* const cnt = lds + kLmTableBytes / 4u;       // [a][j / 2]: two 16-bit counters per word
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const LmItem it = items[blockIdx.x];
     if (it.gi == 0xffffffffu) return;   // (a filler: see the item order)
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     // ~130 vector instructions on sixteen waves: the CU's instruction issue), and four waves that carry four times as much
     // each are slower still (3.1 ms: one wave per SIMD covers no latency; eight waves: 1.64). The steps are the cost of this formulation:
     // lists_hash_kernel below has none and takes over where the rows are short.
-    constexpr uint32_t kInvalid = 0xffffffffu;
+    constexpr uint32_t kInvalid = 0u;
     // [r6] kFarRegs 8 -> 24, in three groups of 8 that a step only touches while its window holds that many far elements
     // (a test on scalars: every wave takes the same way): at 2096 positions per row a step looks up 24 elements per thread,
     // and two thirds of them used to be loaded inside the step, the thread waiting for every batch of 8
@@ -163,30 +170,39 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     constexpr uint32_t kT = (uint32_t)kLmThreads;
     auto toggle1 = [&](uint32_t v) {
         if (v != kInvalid) {
-            const uint32_t a = (v >> kLmWinBits) & (kLmGroup - 1u), p = v & (kLmWin - 1u);
-            atomicXor(&table[p * 2u + (a >> 5)], 1u << (a & 31u));
+            const uint32_t a = (v >> kLmRowShift) & (kLmGroup - 1u);
+            atomicXor(&table[((v & 0xffffu) >> 2) + (a >> 5)], 1u << (a & 31u));
         }
     };
     auto count_bits = [&](uint32_t v, uint2 m) {
-        const uint32_t j = v >> kLmWinBits;   // row in chunk: < 768
+        const uint32_t j = v >> kLmRowShift;   // row in chunk: < 768
         const uint32_t inc = 1u << (16u * (j & 1u));
-        for (uint32_t x = m.x; x; x &= x - 1u)
-            atomicAdd(&cnt[((uint32_t)__builtin_ctz(x) * kLmChunk + j) >> 1], inc);
-        for (uint32_t x = m.y; x; x &= x - 1u)
-            atomicAdd(&cnt[((32u + (uint32_t)__builtin_ctz(x)) * kLmChunk + j) >> 1], inc);
+        uint32_t* const cj = cnt + (j >> 1);   // counters of far row j: row a's word is kLmChunk / 2 words further per a
+        // one loop over the 64 rows' bits (two loops, one per word, ran max(bits of x) + max(bits of y) trips per wave and
+        // paid for two loop heads per element)
+        for (uint64_t x = (uint64_t)m.x | (uint64_t)m.y << 32; x; x &= x - 1ull)
+            atomicAdd(cj + (uint32_t)__builtin_ctzll(x) * (kLmChunk / 2u), inc);
     };
-    // the masks of a batch are read together (one LDS round trip per batch, not per element); an invalid element reads
-    // entry 0 and drops what it gets
+    // the masks of a batch are read together (one LDS round trip per batch, not per element); "no element" reads entry 0,
+    // which no position owns and which stays zero
     auto lookup_batch = [&](const uint32_t* v) {
         uint2 m[kFarGroup];
 #pragma unroll
         for (uint32_t q = 0; q < kFarGroup; ++q)
-            m[q] = *reinterpret_cast<const uint2*>(&table[(v[q] != kInvalid ? (v[q] & (kLmWin - 1u)) : 0u) * 2u]);
+            m[q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(table) + (v[q] & 0xffffu));
 #pragma unroll
         for (uint32_t q = 0; q < kFarGroup; ++q)
-            if (v[q] != kInvalid && (m[q].x | m[q].y)) count_bits(v[q], m[q]);
+            if (m[q].x | m[q].y) count_bits(v[q], m[q]);
     };
-    auto load_at = [&](uint32_t i, uint32_t e) -> uint32_t { return (i < e && !(dbg & 1u)) ? elems[i] : kInvalid; };
+    // elems[b, e) as a buffer: what is read beyond its end is 0 = no element (matrix_lists_debug & 1: an empty buffer)
+    auto range = [&](uint32_t b, uint32_t e) -> __amdgpu_buffer_rsrc_t {
+        const uint32_t bytes = (dbg & 1u) || e <= b ? 0u : (e - b) * 4u;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(elems) + __builtin_amdgcn_readfirstlane((int)b), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    auto load_el = [&](__amdgpu_buffer_rsrc_t rs, uint32_t idx) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(idx * 4u), 0, 0);
+    };
     // the far elements a step holds in registers: group g only while the window lists more than g * 8 * threads of them
     auto lookup_regs = [&](const uint32_t (&v)[kFarRegs], uint32_t count) {
 #pragma unroll
@@ -194,45 +210,48 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
             if (count > g * kFarGroup * kT) lookup_batch(&v[g * kFarGroup]);
     };
     auto load_regs = [&](uint32_t (&v)[kFarRegs], uint32_t b, uint32_t e, bool ok) {
+        const __amdgpu_buffer_rsrc_t rs = range(b, ok ? e : b);
 #pragma unroll
         for (uint32_t g = 0; g < kFarRegs / kFarGroup; ++g)
             if (ok && e - b > g * kFarGroup * kT) {
 #pragma unroll
-                for (uint32_t q = g * kFarGroup; q < (g + 1u) * kFarGroup; ++q) v[q] = load_at(b + tid + q * kT, e);
+                for (uint32_t q = g * kFarGroup; q < (g + 1u) * kFarGroup; ++q) v[q] = load_el(rs, tid + q * kT);
             }
     };
     // the elements of [b, e) from the `skip`-th per thread on, kBatch loads in flight
     auto toggle_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
-        for (uint32_t i = b + tid + skip * kT; i < e; i += kBatch * kT) {
+        const __amdgpu_buffer_rsrc_t rs = range(b, e);
+        for (uint32_t i = skip * kT; i < e - b; i += kBatch * kT) {   // (scalars: the same trips for every wave)
             uint32_t v[kBatch];
 #pragma unroll
-            for (uint32_t q = 0; q < kBatch; ++q) v[q] = load_at(i + q * kT, e);
+            for (uint32_t q = 0; q < kBatch; ++q) v[q] = load_el(rs, i + tid + q * kT);
 #pragma unroll
             for (uint32_t q = 0; q < kBatch; ++q) toggle1(v[q]);
         }
     };
     // (beyond the registers: batches of 8 per thread, the next batch's loads in flight while this one is looked up)
     auto lookup_rest = [&](uint32_t b, uint32_t e, uint32_t skip) {
-        const uint32_t first = b + skip * kT;
-        if (first >= e) return;
+        const uint32_t first = skip * kT, n = e - b;
+        if (first >= n) return;
+        const __amdgpu_buffer_rsrc_t rs = range(b, e);
         uint32_t va[kFarGroup], vb[kFarGroup];
 #pragma unroll
-        for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_at(first + tid + q * kT, e);
+        for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_el(rs, first + tid + q * kT);
         for (uint32_t base = first;;) {   // (`base` is a scalar: the loop's exits are the same for every wave)
             const uint32_t nb = base + kFarGroup * kT;
-            if (nb < e) {
+            if (nb < n) {
 #pragma unroll
-                for (uint32_t q = 0; q < kFarGroup; ++q) vb[q] = load_at(nb + tid + q * kT, e);
+                for (uint32_t q = 0; q < kFarGroup; ++q) vb[q] = load_el(rs, nb + tid + q * kT);
             }
             lookup_batch(va);
-            if (nb >= e) break;
+            if (nb >= n) break;
             const uint32_t nc = nb + kFarGroup * kT;
-            if (nc < e) {
+            if (nc < n) {
 #pragma unroll
-                for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_at(nc + tid + q * kT, e);
+                for (uint32_t q = 0; q < kFarGroup; ++q) va[q] = load_el(rs, nc + tid + q * kT);
             }
             lookup_batch(vb);
-            if (nc >= e) break;
+            if (nc >= n) break;
             base = nc;
         }
     };
@@ -255,8 +274,8 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
 #pragma unroll
     for (uint32_t q = 0; q < kARegs; ++q) {
         a_next2[q] = kInvalid;
-        a_cur[q] = w0.ok ? load_at(w0.ab + tid + q * kT, w0.ae) : kInvalid;
-        a_next[q] = w1.ok ? load_at(w1.ab + tid + q * kT, w1.ae) : kInvalid;
+        a_cur[q] = load_el(range(w0.ab, w0.ok ? w0.ae : w0.ab), tid + q * kT);
+        a_next[q] = load_el(range(w1.ab, w1.ok ? w1.ae : w1.ab), tid + q * kT);
     }
 #pragma unroll
     for (uint32_t q = 0; q < kFarRegs; ++q) f_cur[q] = f_next[q] = kInvalid;
@@ -271,7 +290,7 @@ __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
     // that rotated the names with v_mov at the end of a step waited there for every load it had just issued).
     auto step = [&](uint32_t (&fc)[kFarRegs], uint32_t (&fn)[kFarRegs], uint32_t (&an)[kARegs], uint32_t (&an2)[kARegs]) {
 #pragma unroll
-        for (uint32_t q = 0; q < kARegs; ++q) an2[q] = w2.ok ? load_at(w2.ab + tid + q * kT, w2.ae) : kInvalid;
+        for (uint32_t q = 0; q < kARegs; ++q) an2[q] = load_el(range(w2.ab, w2.ok ? w2.ae : w2.ab), tid + q * kT);
         load_regs(fn, w1.fb, w1.fe, w1.ok);
         lookup_regs(fc, w0.fe - w0.fb);
         if (w0.fe - w0.fb > kFarRegs * kT) lookup_rest(w0.fb, w0.fe, kFarRegs);
