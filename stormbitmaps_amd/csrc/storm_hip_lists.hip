@@ -102,6 +102,39 @@ __global__ __launch_bounds__(256) void lists_place_kernel(const uint32_t* __rest
     }
 }
 
+// [r6] The elements of a (group, window) cell, re-ordered so that the window kernel's lookups meet fewer bank conflicts: 32
+// consecutive lanes of a ds_read_b64 are served together, one 8-byte entry per pair of banks, and positions that are random
+// collide (0.70 of the kernel's LDS cycles were conflict cycles, profiles/r06_d_lists_matrix_counters.txt). Dealt here: the
+// elements are bucketed by the bank pair of their entry and emitted round by round, one of every bucket that still has one —
+// any 32 consecutive elements of the first rounds read 32 different bank pairs. One workgroup per cell, in place; a cell
+// beyond kDealMax elements stays as the atomics of lists_place_kernel left it (the order inside a cell carries no meaning).
+constexpr uint32_t kDealMax = 12288u;
+__global__ __launch_bounds__(256) void lists_deal_kernel(uint32_t* __restrict__ elems, const uint32_t* __restrict__ off,
+                                                         uint32_t n_windows) {
+    __shared__ uint32_t buf[kDealMax];
+    __shared__ uint32_t count[32], cursor[32];
+    const uint32_t g = blockIdx.x / n_windows, w = blockIdx.x % n_windows;
+    const uint32_t b = off[(uint64_t)g * n_windows + w], e = off[(uint64_t)(g + 1u) * n_windows + w];
+    const uint32_t n = e - b;
+    if (n < 64u || n > kDealMax) return;
+    if (threadIdx.x < 32u) count[threadIdx.x] = cursor[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        const uint32_t v = elems[b + i];
+        buf[i] = v;
+        atomicAdd(&count[(v >> 3) & 31u], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256u) {
+        const uint32_t v = buf[i], bk = (v >> 3) & 31u;
+        const uint32_t r = atomicAdd(&cursor[bk], 1u);   // the element's round
+        uint32_t at = 0;                                 // elements of earlier rounds + of this round in buckets before bk
+#pragma unroll
+        for (uint32_t k = 0; k < 32u; ++k) at += min(count[k], r) + (k < bk && count[k] > r ? 1u : 0u);
+        elems[b + at] = v;
+    }
+}
+
 struct LmWin { uint32_t ab, ae, fb, fe; bool ok; };
 
 __global__ __launch_bounds__(kLmThreads, 1) void lists_matrix_kernel(
@@ -700,6 +733,9 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
         STORM_HIP_TRY(hipMemcpyAsync(t.cursor, l->d_off, n_cells * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
         hipLaunchKernelGGL(lists_place_kernel, dim3((uint32_t)n_rows), dim3(256), 0, ctx->stream, t.pos, t.row_off,
                            (uint32_t)n_rows, n_windows, t.cursor, l->d_elems);
+        STORM_HIP_TRY(hipGetLastError());
+        if (getenv("STORM_HIP_LISTS_NO_DEAL") == nullptr)
+            hipLaunchKernelGGL(lists_deal_kernel, dim3(n_groups * n_windows), dim3(256), 0, ctx->stream, l->d_elems, l->d_off, n_windows);
         STORM_HIP_TRY(hipGetLastError());
         lap("offsets, place launched");
         const std::vector<LmItem> items = tile_order(n_rows, kLmGroup, kLmChunk);
