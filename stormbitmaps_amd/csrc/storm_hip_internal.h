@@ -118,7 +118,7 @@ struct storm_hip_ctx_s {
     int matrix_lists_kernel = 0;  // K5: 0 = by the row length, 1 = lists_matrix_kernel (windows), 2 = lists_hash_kernel where a group fits the table
     int matrix_lists_hash_min_log2 = 6;  // ... the hash kernel from this group size on (log2 of 8 .. 64 rows)
     int matrix_lists_debug = 0;   // timing ablations of lists_matrix_kernel (wrong results): 1 no element loads, 4 no barriers, 8 no stores, 16 no steps
-    int matrix_lists_permille_x10 = 60;  // ... the crossover density in 1/10000 of the dense replica's bits
+    int matrix_lists_permille_x10 = 80;  // ... the crossover density in 1/10000 of the dense replica's bits ([r6] 60 -> 80: the window kernel takes 5.2 ms at 0.8 % where the dense replica takes 6.4; level at 0.95 %)
     int seg_rows = 256;
     int chunks_per_item = 0;
     // info of the last dense launch
