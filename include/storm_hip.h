@@ -426,6 +426,13 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
                                      const uint64_t* row_block_offset, const uint32_t* block_id,
                                      const uint8_t* block_kind, const uint32_t* block_n,
                                      const void* const* block_ptr, storm_hip_rowlists_t** out);
+/* ... with the lists taken from a block stage (storm_hip_stage_add_list) when EVERY non-empty block carries a token
+ * (token[b] != ~0); from block_ptr otherwise. The stage is only read. */
+int storm_hip_rowlists_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                            const uint64_t* row_block_offset, const uint32_t* block_id,
+                                            const uint8_t* block_kind, const uint32_t* block_n,
+                                            const void* const* block_ptr, storm_hip_stage_t* stage, const uint64_t* token,
+                                            storm_hip_rowlists_t** out);
 void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l);
 int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l);
 /* the same rule from the counts alone (rows, listed positions, bits per row), BEFORE anything is built: a container the

@@ -96,6 +96,7 @@ SIGNATURES = {
     "storm_hip_sparse_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_matrix_create_from_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_rowlists_create_blocks": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, P(vp)]),
+    "storm_hip_rowlists_create_blocks_staged": (C.c_int, [vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, P(vp)]),
     "storm_hip_rowlists_destroy": (None, [vp, vp]),
     "storm_hip_rowlists_worthwhile": (C.c_int, [vp, vp]),
     "storm_hip_rowlists_worthwhile_counts": (C.c_int, [vp, u64, u64, u64]),

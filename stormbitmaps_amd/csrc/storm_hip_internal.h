@@ -239,6 +239,8 @@ int launch_pairw_mfma_ranges(storm_hip_ctx_t* ctx, const uint64_t* X, uint64_t s
                              uint64_t shadow_generation = 0, uint32_t n_words_logical = 0);
 int launch_pairw_bits_upload(storm_hip_ctx_t* ctx, storm_hip_matrix_s* m, const uint64_t* host_rows,
                              uint64_t src_stride_words, uint64_t* d_total);   // storm_hip_mfma.hip
+int stage_gather_lists(storm_hip_ctx_t* ctx, storm_hip_stage_s* stage, const std::vector<uint64_t>& ltable, uint16_t* d_lists,
+                       uint64_t** d_table);   // storm_hip_sparse.hip: staged list blocks -> a block-ordered list buffer
 int strip_operands_of(const storm_hip_ctx_t* ctx);   // 5 = K2b, 4 = FP4 strips, ... (storm_hip_mfma.hip)
 int launch_pairw_bits_ranges(storm_hip_ctx_t* ctx, const uint8_t* X, uint64_t pitch_bytes,
                              const std::vector<RowRange>& ranges, uint32_t n_kslices2, uint32_t shard_rank,

@@ -701,6 +701,36 @@ __global__ __launch_bounds__(256) void gather_staged_kernel(const uint8_t* const
 
 }  // namespace
 
+namespace storm {
+// lists[dst ..) <- the staged lists of `ltable` (three words per block: destination element, list token, length): what is
+// still in the stage's ring goes first; the table's device copy is handed back for the caller to free. Waits for the stream
+// (the tables are pageable). Tokens are checked against what the stage holds.
+int stage_gather_lists(storm_hip_ctx_t* ctx, storm_hip_stage_t* stage, const std::vector<uint64_t>& ltable, uint16_t* d_lists,
+                       uint64_t** d_table) {
+    *d_table = nullptr;
+    if (ltable.empty()) return STORM_HIP_OK;
+    const uint64_t list_space = stage->lbase + stage->lfill;
+    for (size_t k = 0; k < ltable.size(); k += 3)
+        if ((ltable[k + 1] & 1u) || ltable[k + 1] + ltable[k + 2] * 2u > list_space) {
+            set_error("block stage: a list token lies outside the stage");
+            return STORM_HIP_EINVAL;
+        }
+    if (int rc0 = stage_send_lists(ctx, stage)) return rc0;
+    if (stage->d_lchunk_table) ctx->deferred_free.push_back(stage->d_lchunk_table);
+    stage->d_lchunk_table = nullptr;
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage->d_lchunk_table), stage->lchunks.size() * sizeof(uint8_t*)));
+    STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(d_table), ltable.size() * sizeof(uint64_t)));
+    STORM_HIP_TRY(hipMemcpyAsync(stage->d_lchunk_table, stage->lchunks.data(), stage->lchunks.size() * sizeof(uint8_t*),
+                                 hipMemcpyHostToDevice, ctx->stream));
+    if (int rc0 = upload_bytes(ctx, *d_table, ltable.data(), ltable.size() * sizeof(uint64_t))) return rc0;
+    hipLaunchKernelGGL(gather_staged_lists_kernel, dim3((uint32_t)(ltable.size() / 3)), dim3(256), 0, ctx->stream,
+                       stage->d_lchunk_table, *d_table, d_lists);
+    STORM_HIP_TRY(hipGetLastError());
+    STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return STORM_HIP_OK;
+}
+}  // namespace storm
+
 int storm_hip_stage_create(storm_hip_ctx_t* ctx, storm_hip_stage_t** out) {
     return guarded("storm_hip_stage_create", [&]() -> int {
         if (!ctx || !out) {
@@ -1041,20 +1071,8 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
             }
             if (int rc0 = stager.send_run(reinterpret_cast<uint8_t*>(dt.lists), run)) return rc0;
         }
-        if (!staged.empty()) {
-            if (int rc0 = stage_send_lists(ctx, stage)) return rc0;   // what is still in the ring
-            if (stage->d_lchunk_table) ctx->deferred_free.push_back(stage->d_lchunk_table);
-            stage->d_lchunk_table = nullptr;
-            STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&stage->d_lchunk_table), stage->lchunks.size() * sizeof(uint8_t*)));
-            STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dt.ltable), ltable.size() * sizeof(uint64_t)));
-            STORM_HIP_TRY(hipMemcpyAsync(stage->d_lchunk_table, stage->lchunks.data(), stage->lchunks.size() * sizeof(uint8_t*),
-                                         hipMemcpyHostToDevice, ctx->stream));
-            if (int rc0 = upload_bytes(ctx, dt.ltable, ltable.data(), ltable.size() * sizeof(uint64_t))) return rc0;
-            hipLaunchKernelGGL(gather_staged_lists_kernel, dim3((uint32_t)staged.size()), dim3(256), 0, ctx->stream,
-                               stage->d_lchunk_table, dt.ltable, dt.lists);
-            STORM_HIP_TRY(hipGetLastError());
-            STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));   // (`ltable` and the chunk table are pageable)
-        }
+        if (!staged.empty())
+            if (int rc0 = stage_gather_lists(ctx, stage, ltable, dt.lists, &dt.ltable)) return rc0;
     }
     lap("lists -> device");
     std::vector<uint64_t> ploff;

@@ -2184,7 +2184,7 @@ static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
         rc = 0;
         /* [r6] the bitmap blocks STORM_add has already sent to this device: a token per block while every bitmap block of
          * the container still is the block that was staged, in the order it was staged (else: from the host, as before) */
-        storm_stage_t* sg = dense == 0 ? (storm_stage_t*)h->hip_stage : NULL;
+        storm_stage_t* sg = dense != 1 ? (storm_stage_t*)h->hip_stage : NULL; /* (the arena and, for its lists, K5) */
         uint64_t* tokens = NULL;
         if (sg && sg->stage && !sg->off && sg->generation == VIEW_GENERATION && sg->slot >= V0 && sg->slot < V1 &&
             (tokens = (uint64_t*)malloc((n_blocks + 1) * sizeof(uint64_t))) != NULL) {
@@ -2211,8 +2211,11 @@ static int storm_build_device(STORM_t* h, sparse_state_t* st, int dense) {
         for (int d = V0; d < V1 && rc == 0; ++d) {
             storm_hip_ctx_t* ctx = device_ctx(d);
             const int r = !ctx ? -1
-                          : dense == 2 ? storm_hip_rowlists_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
-                                                                          lens, ptrs, &st->l[d])
+                          : dense == 2 ? ((tokens && d == sg->slot)
+                                              ? storm_hip_rowlists_create_blocks_staged(ctx, h->n_conts, n_blocks, row_off, ids,
+                                                                                        kinds, lens, ptrs, sg->stage, tokens, &st->l[d])
+                                              : storm_hip_rowlists_create_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
+                                                                                 lens, ptrs, &st->l[d]))
                           : dense ? storm_hip_matrix_create_from_blocks(ctx, h->n_conts, n_blocks, row_off, ids, kinds,
                                                                         lens, ptrs, &st->m[d])
                           : (tokens && d == sg->slot)

@@ -315,6 +315,14 @@ int storm_hip_rowlists_create_blocks(storm_hip_ctx_t* ctx, uint64_t n_rows, uint
     *out = NULL;
     return STORM_HIP_OK;
 }
+int storm_hip_rowlists_create_blocks_staged(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
+                                            const uint64_t* row_block_offset, const uint32_t* block_id,
+                                            const uint8_t* block_kind, const uint32_t* block_n, const void* const* block_ptr,
+                                            storm_hip_stage_t* stage, const uint64_t* token, storm_hip_rowlists_t** out) {
+    (void)stage;
+    for (uint64_t b = 0; token && b < n_blocks; ++b) (void)token[b];   /* (ASan checks the token array's extent) */
+    return storm_hip_rowlists_create_blocks(ctx, n_rows, n_blocks, row_block_offset, block_id, block_kind, block_n, block_ptr, out);
+}
 void storm_hip_rowlists_destroy(storm_hip_ctx_t* ctx, storm_hip_rowlists_t* l) { (void)ctx; (void)l; }
 int storm_hip_rowlists_worthwhile(storm_hip_ctx_t* ctx, const storm_hip_rowlists_t* l) { (void)ctx; return l == NULL; }
 int storm_hip_rowlists_worthwhile_counts(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_elems, uint64_t n_bits) {
