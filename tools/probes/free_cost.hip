@@ -9,14 +9,17 @@ int main() {
     hipStreamCreate(&s);
     hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, s);
     hipStreamSynchronize(s);
-    for (int mode = 0; mode < 3; ++mode)
+    for (int mode = 0; mode < 4; ++mode)
         for (size_t bytes : {(size_t)1 << 16, (size_t)1 << 24, (size_t)64 << 20}) {
             void* p[10];
+            const double ta = now_ms();
             for (auto& q : p) {
-                if (mode == 2) { if (hipMallocAsync(&q, bytes, s) != hipSuccess) { printf("hipMallocAsync failed\n"); return 1; } }
+                if (mode >= 2) { if (hipMallocAsync(&q, bytes, s) != hipSuccess) { printf("hipMallocAsync failed\n"); return 1; } }
                 else if (hipMalloc(&q, bytes) != hipSuccess) return 1;
             }
+            const double tb = now_ms();
             hipStreamSynchronize(s);
+            printf("{\"alloc\": \"%s\", \"bytes\": %zu, \"ten_allocs_ms\": %.3f}\n", mode >= 2 ? "hipMallocAsync" : "hipMalloc", bytes, tb - ta);
             const double t0 = now_ms();
             int rc = 0;
             for (auto& q : p) rc |= (mode == 0 ? hipFree(q) : hipFreeAsync(q, s));
@@ -25,7 +28,7 @@ int main() {
             hipStreamSynchronize(s);
             const double t2 = now_ms();
             printf("{\"alloc\": \"%s\", \"free\": \"%s\", \"bytes\": %zu, \"ten_frees_ms\": %.3f, \"next_launch_and_wait_ms\": %.3f, \"rc\": %d}\n",
-                   mode == 2 ? "hipMallocAsync" : "hipMalloc", mode == 0 ? "hipFree" : "hipFreeAsync", bytes, t1 - t0, t2 - t1, rc);
+                   mode >= 2 ? "hipMallocAsync" : "hipMalloc", mode == 0 ? "hipFree" : "hipFreeAsync", bytes, t1 - t0, t2 - t1, rc);
         }
     return 0;
 }
