@@ -350,3 +350,73 @@ def test_blocks_edited_between_the_adds_and_the_first_call_do_not_come_from_the_
             s.add(r)
         assert s.pairw_intersect_cardinality() == orc.storm(rows).pairw(), d2
         s.free()
+
+
+def test_block_stage_through_the_c_abi_with_some_lists_staged_and_some_from_the_host(hip_ctx, orc):
+    """storm_hip_stage_* + storm_hip_sparse_create_blocks_staged / storm_hip_rowlists_create_blocks_staged called directly
+    (storm.h hands over all of a container's blocks or none): every bitmap block staged, every SECOND list block staged and the
+    others with token ~0 (they travel from block_ptr at build time), lists long enough to cross a ring buffer; then every list
+    staged for the row lists' build. Totals and per-pair counts against the oracle's STORM_t restatement (storm.c:790-814)."""
+    import ctypes as C
+    import torch
+    lib = sb._lib.load()
+    rng = np.random.default_rng(41)
+    M, N = 4 * 65536, 330
+    rows = []
+    for r in range(N):
+        d = 40000 if r % 9 == 0 else (2500 if r % 2 else 300)       # some blocks become bitmaps (> 4096 positions in one block)
+        rows.append(np.unique(rng.integers(0, M, size=d, dtype=np.uint64)).astype(np.uint32))
+    for only_lists in (False, True):
+        if only_lists:
+            rows = [r[:3000] if len(r) > 3000 else r for r in rows]
+            rows = [np.unique((r.astype(np.uint64) * 7919) % M).astype(np.uint32) for r in rows]   # spread: no block beyond 4096
+        want_total = orc.storm(rows).pairw()
+        stage = C.c_void_p()
+        assert lib.storm_hip_stage_create(hip_ctx._h, C.byref(stage)) == 0
+        off, ids, kinds, lens, ptrs, toks, keep = [0], [], [], [], [], [], []
+        n_list = 0
+        for r in rows:
+            for b in np.unique(r // 65536):
+                v = r[r // 65536 == b] % 65536
+                tok = C.c_uint64(0)
+                if len(v) >= 4096 and not only_lists:                 # a bitmap block: 1024 words
+                    words = np.zeros(1024, dtype=np.uint64)
+                    np.bitwise_or.at(words, v // 64, np.uint64(1) << (v % 64).astype(np.uint64))
+                    keep.append(words)
+                    assert lib.storm_hip_stage_add(hip_ctx._h, stage, words.ctypes.data_as(C.c_void_p), C.byref(tok)) == 0
+                    kinds.append(1); lens.append(0)
+                else:
+                    lst = np.ascontiguousarray(v, dtype=np.uint16)
+                    keep.append(lst)
+                    n_list += 1
+                    if only_lists or n_list % 2 == 0:
+                        assert lib.storm_hip_stage_add_list(hip_ctx._h, stage, lst.ctypes.data_as(C.c_void_p), len(lst), C.byref(tok)) == 0
+                    else:
+                        tok = C.c_uint64(2 ** 64 - 1)
+                    kinds.append(0); lens.append(len(lst))
+                ids.append(int(b)); ptrs.append(keep[-1].ctypes.data); toks.append(tok.value)
+            off.append(len(ids))
+        a_off, a_id = np.array(off, dtype=np.uint64), np.array(ids, dtype=np.uint32)
+        a_kind, a_len = np.array(kinds, dtype=np.uint8), np.array(lens, dtype=np.uint32)
+        a_ptr, a_tok = np.array(ptrs, dtype=np.uint64), np.array(toks, dtype=np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        assert lib.storm_hip_sparse_create_blocks_staged(hip_ctx._h, N, len(ids), p(a_off), p(a_id), p(a_kind), p(a_len), p(a_ptr),
+                                                         stage, p(a_tok), C.byref(h)) == 0, lib.storm_hip_last_error()
+        out = C.c_uint64()
+        for _ in range(2):
+            assert lib.storm_hip_pairw_sparse(hip_ctx._h, h, 0, 1, C.byref(out)) == 0 and out.value == want_total
+        lib.storm_hip_sparse_destroy(hip_ctx._h, h)
+        if only_lists:
+            l = C.c_void_p()
+            assert lib.storm_hip_rowlists_create_blocks_staged(hip_ctx._h, N, len(ids), p(a_off), p(a_id), p(a_kind), p(a_len), p(a_ptr),
+                                                               stage, p(a_tok), C.byref(l)) == 0 and l.value, lib.storm_hip_last_error()
+            dev = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+            assert lib.storm_hip_rowlists_pairw_matrix_device(hip_ctx._h, l, 0, C.c_void_p(dev.data_ptr()), N) == 0
+            assert np.array_equal(np.triu(dev.cpu().numpy(), k=1), np.triu(orc.storm(rows).pair_counts().astype(np.int32), k=1))
+            lib.storm_hip_rowlists_destroy(hip_ctx._h, l)
+        bad = a_tok.copy()
+        bad[np.flatnonzero(a_kind == 0)[0]] = 1 << 40                # a list token beyond what was staged: refused, not read
+        assert lib.storm_hip_sparse_create_blocks_staged(hip_ctx._h, N, len(ids), p(a_off), p(a_id), p(a_kind), p(a_len), p(a_ptr),
+                                                         stage, p(bad), C.byref(h)) != 0
+        lib.storm_hip_stage_destroy(hip_ctx._h, stage)
