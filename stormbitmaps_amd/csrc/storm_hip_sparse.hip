@@ -1032,6 +1032,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         if (block_kind[b] == 0 && probe_c[block_id[b]]) probe_blocks.push_back(b);
     std::vector<uint64_t> dev_off(n_blocks + 1, ~0ull);
     uint64_t n_list_elems = 0;
+    const uint16_t* lists_view = nullptr;   // where the kernels below find the raw lists: dt.lists, or the stage's one chunk
     {
         std::vector<uint8_t> wanted(n_blocks, 0);
         for (uint64_t b : probe_blocks) wanted[b] = 1;
@@ -1056,6 +1057,14 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 n_list_elems += block_n[b];
                 run.emplace_back(block_ptr[b], (size_t)block_n[b] * sizeof(uint16_t));
             }
+        // ... unless EVERY wanted list is staged and the stage's lists fit one chunk (up to 32 M positions: every sparse
+        // load of c4): the builder then reads them where they lie — dev_off = the token, no table, no gather, no copy
+        if (run.empty() && !staged.empty() && list_space <= storm_hip_stage_s::kListChunk) {
+            if (int rc0 = stage_send_lists(ctx, stage)) return rc0;   // what is still in the ring
+            for (uint64_t b : staged) dev_off[b] = stage_token[b] / 2u;
+            lists_view = reinterpret_cast<const uint16_t*>(stage->lchunks[0]);
+            staged.clear();
+        }
         std::vector<uint64_t> ltable;
         ltable.reserve(3 * staged.size());
         for (uint64_t b : staged) {
@@ -1073,6 +1082,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         }
         if (!staged.empty())
             if (int rc0 = stage_gather_lists(ctx, stage, ltable, dt.lists, &dt.ltable)) return rc0;
+        if (!lists_view) lists_view = dt.lists;
     }
     lap("lists -> device");
     std::vector<uint64_t> ploff;
@@ -1090,7 +1100,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
         STORM_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dt.rend), run_end.size() * sizeof(uint32_t)));
         const uint32_t n_threads = (uint32_t)run_end.size();
         hipLaunchKernelGGL(probe_run_end_kernel, dim3((n_threads + kThreads - 1) / kThreads), dim3(kThreads), 0, ctx->stream,
-                           dt.lists, dt.ploff, dt.pllen, (uint32_t)probe_blocks.size(), dt.rend);
+                           lists_view, dt.ploff, dt.pllen, (uint32_t)probe_blocks.size(), dt.rend);
         STORM_HIP_TRY(hipGetLastError());
         STORM_HIP_TRY(hipMemcpyAsync(run_end.data(), dt.rend, run_end.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         STORM_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1451,7 +1461,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 break;
             hipLaunchKernelGGL(expand_lists_kernel, dim3((uint32_t)list_row.size()),
                                dim3(kThreads), 0, ctx->stream, s->d_pool, s->pitch, dt.lrow, dt.loff, dt.llen,
-                               dt.lists);
+                               lists_view);
             if (hipGetLastError() != hipSuccess) { rc = STORM_HIP_EHIP; break; }
         }
         // probe columns: element layout on the device
@@ -1482,7 +1492,7 @@ static int build_arena(storm_hip_ctx_t* ctx, uint64_t n_rows, uint64_t n_blocks,
                 break;
             if (!probe_blocks.empty())
                 hipLaunchKernelGGL(probe_fill_kernel, dim3((uint32_t)probe_blocks.size()), dim3(kThreads), 0, ctx->stream,
-                                   dt.lists, dt.ploff, dt.pllen, dt.tags, dt.rend, dt.rdst, s->d_probe_elems, dt.pos_tmp, dt.bad);
+                                   lists_view, dt.ploff, dt.pllen, dt.tags, dt.rend, dt.rdst, s->d_probe_elems, dt.pos_tmp, dt.bad);
             if (!atoms.empty())
                 hipLaunchKernelGGL(probe_deal_kernel, dim3((uint32_t)(atoms.size() / 2)), dim3(kThreads), 0, ctx->stream,
                                    dt.atoms, dt.pos_tmp, s->d_probe_pos16);
