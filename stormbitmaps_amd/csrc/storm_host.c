@@ -2270,6 +2270,19 @@ static int sparse_job(int d, int phase, void* arg) {
     return storm_hip_pairw_sparse_end(g_ctx[d], &j->part[d]);
 }
 
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+#define HOST_LAP(what)                                                                        \
+    do {                                                                                      \
+        if (lap_on) {                                                                         \
+            const double t_ = now_ms();                                                       \
+            fprintf(stderr, "[storm_host] %-34s %8.2f ms\n", what, t_ - lap_t0);              \
+            lap_t0 = t_;                                                                      \
+        }                                                                                     \
+    } while (0)
 static uint64_t storm_pairw_device_locked(STORM_t* h);
 static uint64_t storm_pairw_device(STORM_t* h) {
     device_lock();
@@ -2290,6 +2303,8 @@ static int always_fingerprint(void) {
 static uint64_t storm_pairw_device_locked(STORM_t* h) {
     if (h->n_conts < 2) return 0;
     configure_from_env();
+    const int lap_on = getenv("STORM_HIP_TIMING") != NULL;
+    double lap_t0 = lap_on ? now_ms() : 0;
     /* A cached arena is checked against the container (storm_fingerprint, O(blocks): 0.1 - 0.3 ms at c4) WHILE the
      * pass runs on it: the pass is launched first, the fingerprint is computed on the caller's thread behind the
      * launches, and only a mismatch — a caller edited rows through the public adders — throws the total away,
@@ -2297,11 +2312,13 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
     int verified = 0; /* 1: the state was started from the container as it is now */
     sparse_state_t* st = storm_state(h, &verified);
     if (!st) return across_ranks(ALL_PAIRS_FAILED);
+    HOST_LAP("state, fingerprint");
     for (;;) {
         if (!st->have_arena && storm_build_device(h, st, 0)) {
             storm_drop_device(h);
             return across_ranks(ALL_PAIRS_FAILED);
         }
+        HOST_LAP("arena (built or kept)");
         sparse_job_t j;
         j.st = st;
         const uint64_t epoch = storm_epoch(); /* read before the pass: a mutator running meanwhile makes the next call check again */
@@ -2311,6 +2328,7 @@ static uint64_t storm_pairw_device_locked(STORM_t* h) {
         j.count = VN;
         memset(j.part, 0, sizeof(j.part));
         if (run_on_devices(sparse_job, &j, "all-pairs pass (STORM_t)")) return across_ranks(ALL_PAIRS_FAILED);
+        HOST_LAP("pass");
         if (j.check && j.fingerprint != h->hip_fingerprint) {
             storm_drop_device(h);
             if (!(st = storm_state(h, &verified))) return across_ranks(ALL_PAIRS_FAILED);
@@ -2394,19 +2412,6 @@ static int storm_lists_worthwhile(const STORM_t* h) {
     return storm_hip_rowlists_worthwhile_counts(g_ctx[V0], h->n_conts, n_elems, (max_id + 1) * 65536ull);
 }
 
-static double now_ms(void) {
-    struct timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
-#define HOST_LAP(what)                                                                        \
-    do {                                                                                      \
-        if (lap_on) {                                                                         \
-            const double t_ = now_ms();                                                       \
-            fprintf(stderr, "[storm_host] %-34s %8.2f ms\n", what, t_ - lap_t0);              \
-            lap_t0 = t_;                                                                      \
-        }                                                                                     \
-    } while (0)
 int STORM_pairw_matrix_device(STORM_t* h, int op, uint32_t* d_out, uint64_t out_rows, uint64_t out_ld) {
     if (!h) return -1;
     if (!d_out) return -2;
