@@ -81,6 +81,31 @@ def worker(kind, seconds):
         call = lambda: m.pairw_launch(d_total.data_ptr())
         name = "storm::strip16_bits_kernel (+ fold_slots_kernel), whole pass"
         flop = N * (N - 1) // 2 * (M // 64) * 128.0
+    elif kind == "k2h":      # [r6] the per-pair matrix of 4096 rows: tile128_kernel
+        m.close()
+        N = 4096
+        m = ctx.matrix(N, M // 64)
+        m.fill_synthetic(M, M // 2, seed=42)
+        ctx.set_option("k2_tile_shape", 6)
+        dst = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        call = lambda: m.pairw_matrix_device(dst.data_ptr(), N, "and")
+        name = "storm::tile128_kernel (per-pair matrix of 4096 rows), whole call"
+        flop = N * (N - 1) // 2 * (M // 64) * 128.0
+    elif kind == "ring":     # [r6] the c2 triangle on the ring kernel
+        ctx.set_option("k2_tile_shape", 5)
+        dst = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        call = lambda: m.pairw_matrix_device(dst.data_ptr(), N, "and")
+        name = "storm::tilering_kernel (materialised upper triangle at c2), whole call"
+        flop = N * (N - 1) // 2 * (M // 64) * 128.0
+    elif kind == "k5":       # [r6] the window kernel of the row lists at the c4 shape, 2096 positions per row
+        s = sb.Storm()
+        s.add_synthetic(524288, N, 2096, seed=42)
+        lib.STORM_hip_set_option(b"matrix_lists", 1)
+        lib.STORM_hip_set_option(b"matrix_lists_kernel", 1)
+        dst = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
+        call = lambda: s.pairw_matrix_device(dst.data_ptr(), N, N)
+        name = "lists_matrix_kernel (K5, c4 shape, 2096 positions per row), whole call"
+        flop = 0.0
     else:
         dst = torch.zeros((N, N), dtype=torch.int32, device="cuda:0")
         call = lambda: m.pairw_matrix_device(dst.data_ptr(), N, "and")
@@ -162,7 +187,9 @@ def main():
     try:
         for k in args.kernels.split(","):
             env = dict(os.environ)
-            if k.split("_")[0] in ("k2b", "tile"):   # k2b_shipped / tile_shipped: the shipped library (no stamps, no in-kernel clock)
+            if k in ("k2h", "ring", "k5"):            # [r6] shipped library: tile128_kernel at 4096 rows, tilering_kernel at c2, K5 at 2096 per row
+                cmd = [sys.executable, os.path.abspath(__file__), "--worker", k, "--seconds", str(args.seconds)]
+            elif k.split("_")[0] in ("k2b", "tile"):   # k2b_shipped / tile_shipped: the shipped library (no stamps, no in-kernel clock)
                 if os.path.exists(probes_lib) and not k.endswith("_shipped"):
                     env["STORM_HIP_LIB"] = probes_lib
                 cmd = [sys.executable, os.path.abspath(__file__), "--worker", k.split("_")[0], "--seconds", str(args.seconds)]
